@@ -1,0 +1,338 @@
+"""CPU oracle for the MusicAttrRegGMVAE hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this file.  The shipped path (``music-fader-nets_amd``) never calls it and fails loudly when the
+HIP library is missing.
+
+It is a from-scratch fp32 restatement (plain torch-CPU tensor maths, explicit GRU recurrences,
+autograd only for the gradients) of what the reference executes on this path:
+
+    forward        gmm_model.py:220-259   (encode :82-98, repar :229-235, approx_qy_x :194-218,
+                                           sub_decoders :100-117, global_decoder :119-149)
+    losses         trainer_gmm.py:109-196 (loss_function), :199-217 (latent regulariser)
+    step           trainer_gmm.py:220-258 (zero_grad, backward, clip_grad_norm_(.,1), Adam)
+    helpers        trainer_gmm.py:296-303 (convert_to_one_hot), test_class.py:44-50 (clean_output)
+
+Parity pin: checked against ``tests/golden/{small,c0,hand}.npz`` which were produced by importing
+the reference itself (``tests/golden/make_golden.py``) - see ``tests/test_oracle_golden.py``.
+All hot arithmetic of the reference lives in PyTorch (nn.GRU / GRUCell / Linear / log_softmax /
+nll_loss / kl_divergence / Adam, torch 2.10.0 here); the GRU convention restated below is
+r=sig(W_ir x+b_ir+W_hr h+b_hr), z=sig(..), n=tanh(W_in x+b_in+r*(W_hn h+b_hn)), h'=(1-z)n+z h.
+
+Tensors are addressed by the reference's ``state_dict`` key names.
+"""
+import math
+
+import numpy as np
+import torch
+
+E, R, N, C = 342, 3, 16, 24          # trainer_gmm.py:35-38
+START_TOKEN = E - 1                  # gmm_model.py:120-121  (out[:, -1] = 1)
+LOG_2PI = math.log(2.0 * math.pi)
+
+
+# ----------------------------------------------------------------------------------------------
+# parameters
+# ----------------------------------------------------------------------------------------------
+
+def init_state_dict(hidden, zdim, n_component=2, seed=1234):
+    """Seeded random init that reproduces ``torch.manual_seed(seed); MusicAttrRegGMVAE(...)``.
+
+    The reference builds its parameters through torch's module constructors in the order of
+    gmm_model.py:33-71; reproducing the same draws needs the same constructors in the same
+    order (nn.GRU / nn.GRUCell: every tensor U(-1/sqrt(H), 1/sqrt(H)); nn.Linear: kaiming-uniform
+    weight then bias; nn.Embedding: N(0,1) then xavier_uniform_/constant_ over-write).  We call
+    the torch constructors directly - they ARE the algorithm here - and only harvest the tensors.
+    """
+    from torch import nn
+    torch.manual_seed(seed)
+    H, Z = hidden, zdim
+    mods = [
+        ("gru_r", nn.GRU(E, H, batch_first=True, bidirectional=True)),
+        ("gru_n", nn.GRU(E, H, batch_first=True, bidirectional=True)),
+        ("gru_c", nn.GRU(E, H, batch_first=True, bidirectional=True)),
+        ("c_r", nn.Linear(Z, 3)), ("c_n", nn.Linear(Z, 3)),
+        ("gru_d_r", nn.GRU(Z + R, H, batch_first=True)),
+        ("gru_d_n", nn.GRU(Z + N, H, batch_first=True)),
+        ("gru_d_c", nn.GRU(Z + C, H, batch_first=True)),
+        ("mu_r", nn.Linear(2 * H, Z)), ("var_r", nn.Linear(2 * H, Z)),
+        ("mu_n", nn.Linear(2 * H, Z)), ("var_n", nn.Linear(2 * H, Z)),
+        ("mu_c", nn.Linear(2 * H, Z)), ("var_c", nn.Linear(2 * H, Z)),
+        ("linear_init_global", nn.Linear(2 * Z + 24, H)),
+        ("grucell_g", nn.GRUCell(2 * Z + 24 + E, H)),
+        ("grucell_g_2", nn.GRUCell(H, H)),
+        ("linear_init_r", nn.Linear(Z, H)), ("linear_init_n", nn.Linear(Z, H)),
+        ("linear_init_c", nn.Linear(Z, H)),
+        ("linear_out_r", nn.Linear(H, R)), ("linear_out_n", nn.Linear(H, N)),
+        ("linear_out_c", nn.Linear(Z, C)), ("linear_out_g", nn.Linear(H, E)),
+    ]
+    for name in ("mu_r_lookup", "mu_n_lookup"):          # gmm_model.py:151-165
+        emb = nn.Embedding(n_component, Z)
+        nn.init.xavier_uniform_(emb.weight)
+        mods.append((name, emb))
+    for name in ("logvar_r_lookup", "logvar_n_lookup"):  # gmm_model.py:167-183 (pow_exp=-2)
+        emb = nn.Embedding(n_component, Z)
+        nn.init.constant_(emb.weight, float(np.log(np.exp(-2.0) ** 2)))
+        mods.append((name, emb))
+    sd = {}
+    for name, m in mods:
+        for k, v in m.state_dict().items():
+            sd[name + "." + k] = v.detach().clone()
+    return sd
+
+
+#: parameters that exist in the state_dict but never take part in forward
+UNUSED_PREFIXES = ("gru_c.", "gru_d_c.", "mu_c.", "var_c.", "c_r.", "c_n.", "linear_init_c.",
+                   "linear_out_c.")
+FROZEN = ("logvar_r_lookup.weight", "logvar_n_lookup.weight")     # gmm_model.py:175,182
+
+
+def trainable_used_keys(sd):
+    return [k for k in sd if not k.startswith(UNUSED_PREFIXES) and k not in FROZEN]
+
+
+# ----------------------------------------------------------------------------------------------
+# helpers
+# ----------------------------------------------------------------------------------------------
+def convert_to_one_hot(idx, dims):
+    """trainer_gmm.py:296-303."""
+    idx = torch.as_tensor(idx).long()
+    oh = torch.zeros(tuple(idx.shape) + (dims,))
+    return oh.scatter_(-1, idx.unsqueeze(-1), 1.0)
+
+
+def clean_output(out):
+    """test_class.py:44-50: argmax -> trim zeros both ends -> cut at first EOS(1)."""
+    recon = np.trim_zeros(torch.argmax(out, dim=-1).cpu().numpy().squeeze())
+    if 1 in recon:
+        last = np.argwhere(recon == 1)[0][0]
+        recon[recon == 1] = 0
+        recon = recon[:last]
+    return recon
+
+
+def gru_cell(x_proj, h, w_hh, b_hh):
+    """One GRU step given the input-side pre-activation x_proj = W_ih x + b_ih (B,3H)."""
+    H = h.shape[1]
+    gh = h @ w_hh.t() + b_hh
+    r = torch.sigmoid(x_proj[:, :H] + gh[:, :H])
+    z = torch.sigmoid(x_proj[:, H:2 * H] + gh[:, H:2 * H])
+    n = torch.tanh(x_proj[:, 2 * H:] + r * gh[:, 2 * H:])
+    return (1.0 - z) * n + z * h
+
+
+def _gru_final(x, sd, pfx, sfx, reverse):
+    """Final hidden state of one direction of a batch_first GRU over x (B,T,in)."""
+    w_ih, w_hh = sd[pfx + "weight_ih_l0" + sfx], sd[pfx + "weight_hh_l0" + sfx]
+    b_ih, b_hh = sd[pfx + "bias_ih_l0" + sfx], sd[pfx + "bias_hh_l0" + sfx]
+    B, T, _ = x.shape
+    h = torch.zeros(B, w_hh.shape[1])
+    xp = x @ w_ih.t() + b_ih
+    order = range(T - 1, -1, -1) if reverse else range(T)
+    for t in order:
+        h = gru_cell(xp[:, t], h, w_hh, b_hh)
+    return h
+
+
+def encode(sd, x):
+    """gmm_model.py:82-98 -> (mu_r, sigma_r, mu_n, sigma_n); 'var' heads are used as std-devs."""
+    res = []
+    for e in ("r", "n"):
+        hf = _gru_final(x, sd, "gru_%s." % e, "", False)
+        hb = _gru_final(x, sd, "gru_%s." % e, "_reverse", True)
+        xe = torch.cat([hf, hb], dim=1)           # h_n.transpose(0,1).view(B,-1) = [fwd | bwd]
+        mu = xe @ sd["mu_%s.weight" % e].t() + sd["mu_%s.bias" % e]
+        sg = torch.exp(xe @ sd["var_%s.weight" % e].t() + sd["var_%s.bias" % e])
+        res += [mu, sg]
+    return tuple(res)
+
+
+def approx_qy_x(z, mu_lookup, logvar_lookup):
+    """gmm_model.py:194-218 (logvar is treated as a *variance* log here)."""
+    K = mu_lookup.shape[0]
+    cols = []
+    for k in range(K):
+        llh = -0.5 * ((z - mu_lookup[k]) ** 2 / torch.exp(logvar_lookup[k]) + logvar_lookup[k] + LOG_2PI)
+        cols.append(llh.sum(dim=1) + math.log(1.0 / K))
+    ll = torch.stack(cols, dim=1)
+    return ll, torch.softmax(ll, dim=1)
+
+
+def sub_decoder(sd, e, attr_oh, z):
+    """gmm_model.py:100-117 for one attribute; log_softmax over dim=1 = the TIME axis."""
+    B, Tr, _ = attr_oh.shape
+    inp = torch.cat([attr_oh, z.unsqueeze(1).expand(B, Tr, z.shape[1])], dim=-1)
+    h = z @ sd["linear_init_%s.weight" % e].t() + sd["linear_init_%s.bias" % e]
+    p = "gru_d_%s." % e
+    xp = inp @ sd[p + "weight_ih_l0"].t() + sd[p + "bias_ih_l0"]
+    hs = []
+    for t in range(Tr):
+        h = gru_cell(xp[:, t], h, sd[p + "weight_hh_l0"], sd[p + "bias_hh_l0"])
+        hs.append(h)
+    hs = torch.stack(hs, dim=1)
+    logits = hs @ sd["linear_out_%s.weight" % e].t() + sd["linear_out_%s.bias" % e]
+    return torch.log_softmax(logits, dim=1)
+
+
+def global_decoder(sd, z, steps, teacher=None):
+    """gmm_model.py:119-149.  teacher=(B,T) int tokens -> teacher forcing (train mode,
+    eps=100 makes `p < eps` always true, :139-142); None -> greedy argmax feedback (:147-148)."""
+    B = z.shape[0]
+    tok = torch.full((B,), START_TOKEN, dtype=torch.long)
+    hx0 = z @ sd["linear_init_global.weight"].t() + sd["linear_init_global.bias"]
+    hx1 = None
+    outs = []
+    for i in range(steps):
+        inp = torch.cat([convert_to_one_hot(tok, E), z], dim=1)
+        xp = inp @ sd["grucell_g.weight_ih"].t() + sd["grucell_g.bias_ih"]
+        hx0 = gru_cell(xp, hx0, sd["grucell_g.weight_hh"], sd["grucell_g.bias_hh"])
+        if i == 0:
+            hx1 = hx0
+        xp2 = hx0 @ sd["grucell_g_2.weight_ih"].t() + sd["grucell_g_2.bias_ih"]
+        hx1 = gru_cell(xp2, hx1, sd["grucell_g_2.weight_hh"], sd["grucell_g_2.bias_hh"])
+        out = torch.log_softmax(hx1 @ sd["linear_out_g.weight"].t() + sd["linear_out_g.bias"], dim=1)
+        outs.append(out)
+        tok = teacher[:, i] if teacher is not None else out.max(1)[1]
+    return torch.stack(outs, dim=1)
+
+
+def forward(sd, d, r, n, c, eps_r, eps_n):
+    """gmm_model.py:220-259 in train mode.  d/r/n are int token tensors (the one-hot tensors the
+    reference receives are exactly convert_to_one_hot of these)."""
+    x = convert_to_one_hot(d, E)
+    mu_r, sg_r, mu_n, sg_n = encode(sd, x)
+    z_r = mu_r + sg_r * eps_r
+    z_n = mu_n + sg_n * eps_n
+    ll_r, qy_r = approx_qy_x(z_r, sd["mu_r_lookup.weight"], sd["logvar_r_lookup.weight"])
+    ll_n, qy_n = approx_qy_x(z_n, sd["mu_n_lookup.weight"], sd["logvar_n_lookup.weight"])
+    r_out = sub_decoder(sd, "r", convert_to_one_hot(r, R), z_r)
+    n_out = sub_decoder(sd, "n", convert_to_one_hot(n, N), z_n)
+    zc = torch.cat([z_r, z_n, c], dim=1)
+    out = global_decoder(sd, zc, d.shape[1], teacher=d)
+    return dict(out=out, r_out=r_out, n_out=n_out, mu_r=mu_r, sigma_r=sg_r, mu_n=mu_n, sigma_n=sg_n,
+                z_r=z_r, z_n=z_n, ll_r=ll_r, ll_n=ll_n, qy_r=qy_r, qy_n=qy_n,
+                y_r=qy_r.max(1)[1], y_n=qy_n.max(1)[1])
+
+
+# ----------------------------------------------------------------------------------------------
+# losses
+# ----------------------------------------------------------------------------------------------
+def beta_schedule(step, beta):
+    """trainer_gmm.py:125-128 (negative for 1000 <= step < 10000 - reproduced as is)."""
+    return 0.0 if step < 1000 else min((step - 10000) / 10000 * beta, beta)
+
+
+def _nll_mean(logp, target):
+    return -logp.reshape(-1, logp.shape[-1]).gather(1, target.reshape(-1, 1)).mean()
+
+
+def _kl_normal(mu_q, sg_q, mu_p, sg_p):
+    """KL(N(mu_q,sg_q) || N(mu_p,sg_p)) per dimension (torch.distributions.kl._kl_normal_normal)."""
+    var_ratio = (sg_q / sg_p) ** 2
+    t1 = ((mu_q - mu_p) / sg_p) ** 2
+    return 0.5 * (var_ratio + t1 - 1.0 - torch.log(var_ratio))
+
+
+def loss_function(sd, fw, d, r, n, step, beta=0.1, is_supervised=False, y_label=None):
+    """trainer_gmm.py:109-196 -> (loss, CE_X, CE_R, CE_N, kld_lat_r, kld_lat_n, kld_cls_r, kld_cls_n)."""
+    beta0 = beta_schedule(step, beta)
+    ce_x = _nll_mean(fw["out"], d)
+    ce_r = _nll_mean(fw["r_out"], r)
+    ce_n = _nll_mean(fw["n_out"], n)
+    ce = 5 * ce_x + ce_r + ce_n
+    zero = torch.zeros(())
+    res = {}
+    for e in ("r", "n"):
+        mu_q, sg_q, qy, ll = fw["mu_" + e], fw["sigma_" + e], fw["qy_" + e], fw["ll_" + e]
+        mu_lk, lv_lk = sd["mu_%s_lookup.weight" % e], sd["logvar_%s_lookup.weight" % e]
+        K = qy.shape[-1]
+        if not is_supervised:
+            tot = zero
+            for k in range(K):
+                kl = _kl_normal(mu_q, sg_q, mu_lk[k], torch.exp(lv_lk[k])).mean(dim=-1)  # exp(logvar) as STD
+                tot = tot + (kl * qy[:, k]).mean()
+            ent = (qy * torch.log_softmax(ll, dim=1)).mean(dim=1)
+            cls = (ent - math.log(1.0 / K)).mean()
+            res[e] = (tot, cls, zero)
+        else:
+            y = y_label.long()
+            kl = _kl_normal(mu_q, sg_q, mu_lk[y], torch.exp(lv_lk[y])).mean(dim=-1)
+            clf = -torch.log_softmax(qy, dim=1).gather(1, y.view(-1, 1)).mean()     # CE on probabilities
+            res[e] = (kl.mean(), zero, clf)
+    if not is_supervised:
+        loss = ce + beta0 * (res["r"][0] + res["n"][0] + res["r"][1] + res["n"][1])
+    else:
+        loss = ce + beta0 * (res["r"][0] + res["n"][0]) + (res["r"][2] + res["n"][2])
+    return loss, ce_x, ce_r, ce_n, res["r"][0], res["n"][0], res["r"][1], res["n"][1]
+
+
+def latent_regularized_loss(z_r, z_n, r_density, n_density):
+    """trainer_gmm.py:199-217 (uses latent dim 0 only; D_attr is float64 -> float32)."""
+    out = []
+    for z, a in ((z_r, r_density), (z_n, n_density)):
+        a = np.asarray(a, np.float64)
+        d_attr = torch.from_numpy(np.subtract.outer(a, a)).float()
+        d_z = z[:, 0].reshape(-1, 1) - z[:, 0]
+        out.append(((torch.tanh(d_z) - torch.sign(d_attr)) ** 2).mean())
+    return tuple(out)
+
+
+def total_loss(sd, batch, eps_r, eps_n, step, beta, is_supervised=False):
+    """forward + all loss terms of trainer_gmm.py:224-247; returns (loss, tuple8, fw)."""
+    d, r, n = (torch.as_tensor(batch[k]).long() for k in ("d", "r", "n"))
+    c = torch.as_tensor(batch["c"]).float()
+    fw = forward(sd, d, r, n, c, eps_r, eps_n)
+    y = torch.as_tensor(batch["a"]).long() if is_supervised else None
+    ls = loss_function(sd, fw, d, r, n, step, beta=beta, is_supervised=is_supervised, y_label=y)
+    l_r, l_n = latent_regularized_loss(fw["z_r"], fw["z_n"], batch["r_density"], batch["n_density"])
+    loss = ls[0] + l_r + l_n
+    tup = (loss, ls[1], ls[2], ls[3], l_r, l_n, ls[4] + ls[5], ls[6] + ls[7])
+    return loss, tup, fw
+
+
+# ----------------------------------------------------------------------------------------------
+# training step
+# ----------------------------------------------------------------------------------------------
+class AdamState:
+    """torch.optim.Adam defaults (lr=1e-3, betas=(0.9,0.999), eps=1e-8, no weight decay)."""
+
+    def __init__(self, keys):
+        self.t = 0
+        self.m = {k: None for k in keys}
+        self.v = {k: None for k in keys}
+
+
+def gradients(sd, batch, eps_r, eps_n, step, beta, is_supervised=False):
+    keys = trainable_used_keys(sd)
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in keys}
+    p = dict(sd)
+    p.update(leaves)
+    loss, tup, fw = total_loss(p, batch, eps_r, eps_n, step, beta, is_supervised)
+    grads = torch.autograd.grad(loss, [leaves[k] for k in keys])
+    return {k: g for k, g in zip(keys, grads)}, tup, fw
+
+
+def train_step(sd, opt, batch, eps_r, eps_n, step, beta=0.2, lr=1e-3, is_supervised=False, max_norm=1.0):
+    """trainer_gmm.py:220-258.  Mutates sd / opt in place; returns (step+1, 8 floats, grad_norm)."""
+    grads, tup, _ = gradients(sd, batch, eps_r, eps_n, step, beta, is_supervised)
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()
+    coef = min(1.0, float(max_norm / (total + 1e-6)))             # clip_grad_norm_
+    opt.t += 1
+    b1, b2, eps = 0.9, 0.999, 1e-8
+    bc1, bc2 = 1 - b1 ** opt.t, 1 - b2 ** opt.t
+    for k, g in grads.items():
+        g = g * coef
+        if opt.m[k] is None:
+            opt.m[k], opt.v[k] = torch.zeros_like(g), torch.zeros_like(g)
+        opt.m[k].mul_(b1).add_(g, alpha=1 - b1)
+        opt.v[k].mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = (opt.v[k].sqrt() / math.sqrt(bc2)).add_(eps)
+        sd[k] = sd[k] - (lr / bc1) * opt.m[k] / denom
+    return step + 1, tuple(float(x.detach()) for x in tup), float(total)
+
+
+def greedy_decode(sd, z, steps):
+    """eval-mode global_decoder (gmm_model.py:147-148) -> (log-probs (B,steps,E), tokens (B,steps))."""
+    with torch.no_grad():
+        lp = global_decoder(sd, z, steps, teacher=None)
+    return lp, lp.argmax(-1)
