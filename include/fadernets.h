@@ -1,0 +1,200 @@
+/*
+ * fadernets.h - C ABI of libfadernets_hip.so: the MI355X (gfx950) kernels behind the
+ * MusicAttrRegGMVAE training / inference path of Music FaderNets.
+ *
+ * The reference has no FFI: the path is PyTorch module code (gmm_model.py:10-259) driven by
+ * trainer_gmm.py:109-303.  Each entry point below replaces the torch operator(s) the reference
+ * executes at the cited lines; the Python class in music-fader-nets_amd/gmm_model.py keeps the
+ * reference's class surface and calls these through ctypes.
+ *
+ * Conventions
+ *   - every function returns int: 0 = OK, <0 = FN_E_* argument error, >0 = hipError_t;
+ *   - all pointers are DEVICE pointers (fp32 unless stated, int32 for token ids), owned by the
+ *     caller; nothing is allocated, freed or synchronised inside (graph-capture safe);
+ *   - `stream` is a hipStream_t passed as void*; work is stream-ordered;
+ *   - functions are re-entrant; the library keeps no mutable global state;
+ *   - per-step tensors are TIME-MAJOR: [T][B][...] so that one step is one contiguous slab;
+ *     token tensors are batch-major [B][T] int32 exactly as the data loader yields them.
+ */
+#ifndef FADERNETS_H
+#define FADERNETS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FN_OK 0
+#define FN_E_NULL (-1)      /* required pointer is NULL                     */
+#define FN_E_SHAPE (-2)     /* unsupported / inconsistent sizes             */
+#define FN_E_ALIGN (-3)     /* pointer or leading dimension not aligned     */
+#define FN_E_WORKSPACE (-4) /* workspace too small                          */
+#define FN_E_COUNT (-5)     /* too many scans in one call                   */
+
+#define FN_MAX_SCANS 8
+
+int fn_version(void);                 /* ABI version, currently 1 */
+const char* fn_strerror(int code);    /* static string for FN_E_* / hipError_t */
+
+/* ------------------------------------------------------------------------------------------
+ * Dense fp32 GEMM on the f32 MFMA (v_mfma_f32_16x16x4_f32), exact-f32 fma chains.
+ *   C[M,N] = alpha * opA(A) * opB(B) + beta * C + bias[N]
+ *   a_kmajor=1: A is [M,K] row-major (lda)      a_kmajor=0: A is stored [K,M] row-major (lda)
+ *   b_kmajor=1: B is [N,K] row-major (ldb) i.e. a torch Linear weight; 0: B is [K,N] row-major
+ * Replaces nn.Linear forward (gmm_model.py:86,91,108,113,123,137: a_k=1,b_k=1), its input
+ * gradient (a_k=1,b_k=0) and its weight gradient dW = dY^T X (a_k=0,b_k=0).
+ * splitk>1 needs ws of fn_gemm_ws_bytes(M,N,splitk) bytes (deterministic slab reduction).
+ * ------------------------------------------------------------------------------------------ */
+size_t fn_gemm_ws_bytes(int M, int N, int splitk);
+int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha,
+                const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc,
+                const float* bias, int splitk, float* ws, size_t ws_bytes, void* stream);
+
+/* dst[c*dst_ld + r] = src[r*src_ld + c]  for r < R, c < C */
+int fn_transpose_f32(const float* src, int R, int C, int src_ld, float* dst, int dst_ld, void* stream);
+/* out[n] = beta*out[n] + sum_m X[m*ld + n]; ws >= fn_colsum_ws_bytes(M,N) */
+size_t fn_colsum_ws_bytes(int M, int N);
+int fn_colsum_f32(const float* X, int M, int N, int ld, float beta, float* out, float* ws, size_t ws_bytes,
+                  void* stream);
+/* y[i] += alpha * x[i] */
+int fn_axpy_f32(int64_t n, float alpha, const float* x, float* y, void* stream);
+/* out[0] = sum x[0..n) (single workgroup, deterministic order) */
+int fn_sum_f32(const float* x, int64_t n, float scale, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GRU sequence scans (replace nn.GRU / nn.GRUCell loops: gmm_model.py:84,89,109,114,131-136).
+ *
+ * One call runs up to FN_MAX_SCANS independent scans concurrently: every time step is ONE
+ * launch whose grid covers all scans (fused  h W_hh^T  MFMA GEMM + gate epilogue).
+ * Gate order r,z,n (torch).  Input-side pre-activation of step p for batch row b:
+ *    gx[b,:] = b_ih + gx_dense[p][b,:] + gx_table[tok][:] + gx_rowbias[b,:]     (each optional)
+ *    tok = (tau < 0) ? start_token : idx[b*idx_ld + tau],  tau = (reverse ? T-1-p : p) + idx_shift
+ * Storage is in PROCESSING order p = 0..T-1 (for reverse scans p=0 is the last time step).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct FnGruFwd {
+    int32_t B, T, H;
+    int32_t reverse;          /* 1: consume tokens from the end (the *_reverse direction)      */
+    const float* w_hh;        /* [3H][H]                                                       */
+    const float* b_hh;        /* [3H]                                                          */
+    const float* b_ih;        /* [3H] or NULL                                                  */
+    const float* h0;          /* [B][H] or NULL (= zeros)                                      */
+    const float* gx_dense;    /* [T][B][3H] or NULL                                            */
+    const float* gx_table;    /* [V][3H] (= W_ih[:, :V]^T) or NULL                             */
+    const int32_t* idx;       /* [B][idx_ld] token ids, required with gx_table                 */
+    int32_t idx_ld;
+    int32_t idx_shift;        /* -1 for the global decoder (input of step i is token i-1)      */
+    int32_t start_token;      /* used when tau < 0                                             */
+    const float* gx_rowbias;  /* [B][3H] or NULL (per-sequence constant part, W_ih[:,V:] z)    */
+    float* h_all;             /* [T][B][H] state after each step                               */
+    float* gates;             /* [T][B][4][H] saved r,z,n,(W_hn h + b_hn); NULL = inference    */
+} FnGruFwd;
+
+int fn_gru_seq_fwd(const FnGruFwd* scans, int n_scans, void* stream);
+
+/* Backward of the same scans (autograd of nn.GRU / GRUCell in loss.backward(), trainer_gmm.py:249).
+ *   dh_p = dh_ext[p] (+ dh_last at p = T-1) + carried gradient
+ *   outputs: dgx_all [T][B][3H] = d(pre-activations r,z,n) (= d gx, also d(W_hh h + b_hh) for r,z)
+ *            dghn_all[T][B][H]  = d(W_hn h + b_hn)
+ *            dh0 [B][H]  gradient wrt h0 (NULL = not needed)
+ *            dgx_rowsum [B][3H] += sum_p dgx_all[p]  (NULL = not needed; caller zero-fills)
+ * w_hh_t is W_hh transposed: [H][3H].  scratch: [B][H] floats per scan. */
+typedef struct FnGruBwd {
+    int32_t B, T, H;
+    const float* w_hh_t;      /* [H][3H]                                                       */
+    const float* h0;          /* [B][H] or NULL                                                */
+    const float* h_all;       /* [T][B][H]  from forward                                       */
+    const float* gates;       /* [T][B][4][H] from forward                                     */
+    const float* dh_last;     /* [B][H] or NULL                                                */
+    const float* dh_ext;      /* [T][B][H] or NULL                                             */
+    float* dgx_all;           /* [T][B][3H]                                                    */
+    float* dghn_all;          /* [T][B][H]                                                     */
+    float* dh0;               /* [B][H] or NULL                                                */
+    float* dgx_rowsum;        /* [B][3H] or NULL                                               */
+    float* scratch;           /* [B][H]                                                        */
+} FnGruBwd;
+
+int fn_gru_seq_bwd(const FnGruBwd* scans, int n_scans, void* stream);
+
+/* dTable[v][:] = sum over (p,b) with tok(p,b)==v of dgx_all[p][b][:]   (W_ih one-hot columns' grad;
+ * tok defined as in FnGruFwd).  out is [V][N3]; ws >= fn_embed_grad_ws_bytes(T*B, V, N3). */
+size_t fn_embed_grad_ws_bytes(int64_t rows, int V, int N3);
+int fn_embed_grad_f32(const float* dgx_all, int B, int T, int N3, const int32_t* idx, int idx_ld, int idx_shift,
+                      int start_token, int reverse, int V, float* out, float* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Output heads
+ * ------------------------------------------------------------------------------------------ */
+/* vocab-axis log_softmax (+ optional fused NLL and its gradient): gmm_model.py:137 + trainer_gmm.py:131.
+ * logits [T*B][ld] time-major rows (row = t*B + b), E valid columns.
+ *   logp_bt  [B][T][E] or NULL   log-probabilities in the reference's (B,T,E) layout
+ *   target   [B][T] int32 or NULL
+ *   nll_rows [T*B] or NULL       -logp[target] per row
+ *   dlogits  [T*B][ld] or NULL   grad_scale * (softmax - onehot(target))   (may alias logits)  */
+int fn_vocab_logsoftmax(const float* logits, int B, int T, int E, int ld, float* logp_bt, const int32_t* target,
+                        float* nll_rows, float grad_scale, float* dlogits, void* stream);
+/* generic backward of the same log_softmax: dlogits[row] = g - softmax * sum(g), g = gout_bt[b][t][:] */
+int fn_vocab_logsoftmax_bwd(const float* logp_bt, const float* gout_bt, int B, int T, int E, int ld, float* dlogits,
+                            void* stream);
+/* greedy head for inference (gmm_model.py:73-80,137,147-148): log_softmax + argmax (first index on ties)
+ * logits [B][ld] -> logp_out [B][E] (row stride logp_ld) or NULL, tok_out[b*tok_ld] */
+int fn_vocab_argmax(const float* logits, int B, int E, int ld, float* logp_out, int64_t logp_ld, int32_t* tok_out,
+                    int tok_ld, void* stream);
+
+/* TIME-axis log_softmax of the sub-decoders (gmm_model.py:110,115; the reference's dim=1 quirk).
+ * logits [Tr][B][Cc] time-major.  logp_bt [B][Tr][Cc].  target [B][Tr] or NULL.
+ * nll_bc [B][Cc] (sum over t with target==c of -logp) ; dlogits [Tr][B][Cc] = grad_scale * dNLLsum/dlogits. */
+int fn_time_logsoftmax(const float* logits, int B, int Tr, int Cc, float* logp_bt, const int32_t* target, float* nll_bc,
+                       float grad_scale, float* dlogits, void* stream);
+int fn_time_logsoftmax_bwd(const float* logp_bt, const float* gout_bt, int B, int Tr, int Cc, float* dlogits,
+                           void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Latent block: reparameterised sample + Gaussian-mixture posterior (gmm_model.py:86,91,229-242,
+ * 194-218) and the KL / class terms of trainer_gmm.py:150-194.  One wavefront per batch row.
+ *   pre [B][2Z]: columns [0,Z) = mu, [Z,2Z) = v (sigma = exp(v));  eps [B][Z]
+ *   mu_lk, lv_lk [K][Z] component means / log-variances
+ * fwd outputs: sigma [B][Z], z [B][Z], ll [B][K], qy [B][K], y [B] int32,
+ *   terms [B][4]: {sum_k qy_k KLmean_k, mean_k(qy log qy), KLmean_{label}, -log softmax(qy)[label]}
+ *   (label terms only when labels != NULL).  K <= 8.
+ * ------------------------------------------------------------------------------------------ */
+int fn_latent_fwd(const float* pre, const float* eps, const float* mu_lk, const float* lv_lk, int B, int Z, int K,
+                  const int32_t* labels, float* sigma, float* z, float* ll, float* qy, int32_t* y, float* terms,
+                  void* stream);
+/* Backward. Upstream gradients (any may be NULL): g_z, g_mu, g_sigma [B][Z]; g_ll, g_qy [B][K].
+ * Fused loss gradient (trainer_gmm.py:150-194) when w_lat/w_cls/w_clf != 0:
+ *    L += w_lat * sum_b sum_k qy KLmean_k  + w_cls * sum_b mean_k(qy log qy)          (unsupervised)
+ *    L += w_lat * sum_b KLmean_label       + w_clf * sum_b CE(softmax(qy), label)     (labels != NULL)
+ * outputs: dpre [B][2Z]; dmu_lk_rows [B][K][Z] per-row contributions to d mu_lookup (reduce with
+ * fn_colsum_f32 over B). */
+int fn_latent_bwd(const float* pre, const float* eps, const float* mu_lk, const float* lv_lk, int B, int Z, int K,
+                  const int32_t* labels, const float* z, const float* qy, const float* g_z, const float* g_mu,
+                  const float* g_sigma, const float* g_ll, const float* g_qy, float w_lat, float w_cls, float w_clf,
+                  float* dpre, float* dmu_lk_rows, void* stream);
+
+/* Pairwise latent regulariser (trainer_gmm.py:199-217): rows [row0,row0+nrows) of the global batch.
+ *   attr_all is float64 like the reference's numpy densities (only the sign of a_i - a_j is used).
+ *   loss_rows[i] = sum_j (tanh(z0[row0+i]-z0[j]) - sign(a[row0+i]-a[j]))^2
+ *   dz0[i]       = grad_scale * 4 * sum_j (tanh(D)-S)(1-tanh(D)^2)     (the exact d/dz0 of sum_ij, by antisymmetry) */
+int fn_pairwise_reg(const float* z0_all, const double* attr_all, int n_all, int row0, int nrows, float* loss_rows,
+                    float grad_scale, float* dz0, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * clip_grad_norm_(., max_norm) + Adam (trainer_gmm.py:250-251, torch.optim.Adam defaults) over a
+ * flat fp32 buffer.  fn_sumsq writes sum(g^2) to out[0]; fn_clip_adam reads the (all-reduced)
+ * total from sumsq[0] on device, so no host sync is needed.
+ * ------------------------------------------------------------------------------------------ */
+int fn_sumsq_f32(const float* g, int64_t n, float* out, float* ws, size_t ws_bytes, void* stream);
+size_t fn_sumsq_ws_bytes(int64_t n);
+int fn_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, float max_norm, float lr,
+                 float beta1, float beta2, float eps, int step, void* stream);
+
+/* one-hot (B,T,V) -> int32 indices (argmax along the last axis); used at the class boundary where callers
+ * hand over convert_to_one_hot tensors (trainer_gmm.py:296-303) */
+int fn_onehot_to_index(const float* oh, int64_t rows, int V, int32_t* idx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FADERNETS_H */

@@ -1,0 +1,11 @@
+"""music-fader-nets_amd: MI355X-native GM-VAE (MusicAttrRegGMVAE) training / inference path of Music FaderNets.
+
+The directory name contains '-' (it follows the upstream repo name), so import it through
+``mfn_import.load_package()`` at the repo root, which registers it as ``music_fader_nets_amd``.
+"""
+from .gmm_model import MusicAttrRegGMVAE  # noqa: F401
+from .trainer import GMVAETrainer, beta_schedule, convert_to_one_hot  # noqa: F401
+from .decode import clean_output, fader_sweep, greedy_decode  # noqa: F401
+
+__all__ = ["MusicAttrRegGMVAE", "GMVAETrainer", "beta_schedule", "convert_to_one_hot", "clean_output", "fader_sweep",
+           "greedy_decode"]

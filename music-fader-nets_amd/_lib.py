@@ -1,0 +1,90 @@
+"""ctypes binding of libfadernets_hip.so (the C ABI in include/fadernets.h).
+
+The product path has NO fallback: if the library is missing or a symbol is absent this module
+raises, and every op in hipops.py raises on a non-zero return code.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfadernets_hip.so")
+
+FN_MAX_SCANS = 8
+_f = C.POINTER(C.c_float)
+_i = C.POINTER(C.c_int32)
+vp = C.c_void_p
+
+
+class FnGruFwd(C.Structure):
+    _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("H", C.c_int32), ("reverse", C.c_int32),
+                ("w_hh", vp), ("b_hh", vp), ("b_ih", vp), ("h0", vp), ("gx_dense", vp), ("gx_table", vp),
+                ("idx", vp), ("idx_ld", C.c_int32), ("idx_shift", C.c_int32), ("start_token", C.c_int32),
+                ("gx_rowbias", vp), ("h_all", vp), ("gates", vp)]
+
+
+class FnGruBwd(C.Structure):
+    _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("H", C.c_int32),
+                ("w_hh_t", vp), ("h0", vp), ("h_all", vp), ("gates", vp), ("dh_last", vp), ("dh_ext", vp),
+                ("dgx_all", vp), ("dghn_all", vp), ("dh0", vp), ("dgx_rowsum", vp), ("scratch", vp)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/fadernets.h
+SIGNATURES = {
+    "fn_version": (C.c_int, []),
+    "fn_strerror": (C.c_char_p, [C.c_int]),
+    "fn_gemm_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "fn_gemm_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, C.c_int, vp, C.c_int,
+                              C.c_float, vp, C.c_int, vp, C.c_int, vp, C.c_size_t, vp]),
+    "fn_transpose_f32": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
+    "fn_colsum_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "fn_colsum_f32": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, C.c_size_t, vp]),
+    "fn_axpy_f32": (C.c_int, [C.c_int64, C.c_float, vp, vp, vp]),
+    "fn_sum_f32": (C.c_int, [vp, C.c_int64, C.c_float, vp, vp]),
+    "fn_gru_seq_fwd": (C.c_int, [C.POINTER(FnGruFwd), C.c_int, vp]),
+    "fn_gru_seq_bwd": (C.c_int, [C.POINTER(FnGruBwd), C.c_int, vp]),
+    "fn_embed_grad_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
+    "fn_embed_grad_f32": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    vp, vp, C.c_size_t, vp]),
+    "fn_vocab_logsoftmax": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_float, vp, vp]),
+    "fn_vocab_logsoftmax_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "fn_vocab_argmax": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp, C.c_int, vp]),
+    "fn_time_logsoftmax": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_float, vp, vp]),
+    "fn_time_logsoftmax_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "fn_latent_fwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "fn_latent_bwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
+                                C.c_float, C.c_float, C.c_float, vp, vp, vp]),
+    "fn_pairwise_reg": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_float, vp, vp]),
+    "fn_sumsq_ws_bytes": (C.c_size_t, [C.c_int64]),
+    "fn_sumsq_f32": (C.c_int, [vp, C.c_int64, vp, vp, C.c_size_t, vp]),
+    "fn_clip_adam": (C.c_int, [vp, vp, vp, vp, C.c_int64, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                               C.c_int, vp]),
+    "fn_onehot_to_index": (C.c_int, [vp, C.c_int64, C.c_int, vp, vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libfadernets_hip.so not found at %s - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C music-fader-nets_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.fn_version() != 1:
+        raise RuntimeError("libfadernets_hip.so ABI version %d != 1" % lib.fn_version())
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().fn_strerror(code)
+        raise RuntimeError("%s failed: %s (code %d)" % (what, msg.decode() if msg else "?", code))

@@ -1,0 +1,248 @@
+// gemm.hip - dense fp32 GEMM on the f32 MFMA + small dense helpers (transpose, column sums, axpy, sum).
+// Replaces nn.Linear forward / backward of the reference (gmm_model.py:86,91,108,113,123,137 and their
+// autograd), see include/fadernets.h.
+#include "common.h"
+#include "mma_core.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// C tile BM x BN, 4 waves laid out WM x WN, each wave TM x TN MFMA tiles (16x16).
+template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC>
+__global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alpha, const float* __restrict__ A, long lda,
+                                                  const float* __restrict__ B, long ldb, float beta, float* __restrict__ C,
+                                                  long ldc, const float* __restrict__ bias, int ksplit_len,
+                                                  float* __restrict__ slabs) {
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    using SA = Stage<BM, BK, AKC, NT>;
+    using SB = Stage<BN, BK, BKC, NT>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BUFW = SA::WORDS + SB::WORDS;   // buffer b: A at smem + b*BUFW, B right behind it
+
+    const int ntn = (N + BN - 1) / BN, ntm = (M + BM - 1) / BM;
+    const int tile = fn_xcd_remap(blockIdx.x, ntn * ntm);
+    const int tm = tile / ntn, tn = tile % ntn;   // consecutive virtual tiles share the A row panel
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = blockIdx.z * ksplit_len;
+    const int kend = min(K, kbeg + ksplit_len);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const bool vecA = fn_aligned16(A, lda), vecB = fn_aligned16(B, ldb);
+    const RowsPlain ra{m0, M}, rb{n0, N};
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    SA sa;
+    SB sb;
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        sa.load(A, lda, ra, kbeg, kend, vecA);
+        sb.load(B, ldb, rb, kbeg, kend, vecB);
+        sa.store(smem);
+        sb.store(smem + SA::WORDS);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            sa.load(A, lda, ra, kbeg + (kt + 1) * BK, kend, vecA);
+            sb.load(B, ldb, rb, kbeg + (kt + 1) * BK, kend, vecB);
+        }
+        mma_slab<TM, TN, BK, SA, SB>(smem + cur * BUFW, smem + cur * BUFW + SA::WORDS, wm * TM * 16, wn * TN * 16, lane, acc);
+        if (kt + 1 < nk) {
+            sa.store(smem + (cur ^ 1) * BUFW);
+            sb.store(smem + (cur ^ 1) * BUFW + SA::WORDS);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: D[row = (lane>>4)*4 + reg][col = lane&15]
+    const int cj = lane & 15, rq = (lane >> 4) * 4;
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const int col = n0 + (wn * TN + n) * 16 + cj;
+            if (col >= N) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = m0 + (wm * TM + m) * 16 + rq + i;
+                if (row >= M) continue;
+                const float v = acc[m][n][i];
+                if (slabs) {
+                    slabs[((long)blockIdx.z * M + row) * N + col] = v;
+                } else {
+                    float o = alpha * v;
+                    if (bias) o += bias[col];
+                    if (beta != 0.f) o += beta * C[(long)row * ldc + col];
+                    C[(long)row * ldc + col] = o;
+                }
+            }
+        }
+}
+
+// C = alpha * sum_s slabs[s] + beta*C + bias
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, int S, int M, int N, float alpha, float beta,
+                                   float* __restrict__ C, long ldc, const float* __restrict__ bias) {
+    const long total = (long)M * N;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < S; ++k) s += slabs[k * total + i];
+        const int row = i / N, col = i % N;
+        float o = alpha * s;
+        if (bias) o += bias[col];
+        if (beta != 0.f) o += beta * C[(long)row * ldc + col];
+        C[(long)row * ldc + col] = o;
+    }
+}
+
+__global__ void transpose_kernel(const float* __restrict__ src, int R, int Cc, long src_ld, float* __restrict__ dst, long dst_ld) {
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + threadIdx.x;
+        t[j][threadIdx.x] = (r < R && c < Cc) ? src[(long)r * src_ld + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + threadIdx.x;
+        if (r < R && c < Cc) dst[(long)c * dst_ld + r] = t[threadIdx.x][j];
+    }
+}
+
+// partial[chunk][n] = sum over rows of the chunk
+__global__ void colsum_partial_kernel(const float* __restrict__ X, int M, int N, long ld, int rows_per_chunk,
+                                      float* __restrict__ partial) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
+    float s = 0.f;
+    for (int m = m0; m < m1; ++m) s += X[(long)m * ld + n];
+    partial[(long)blockIdx.y * N + n] = s;
+}
+__global__ void colsum_final_kernel(const float* __restrict__ partial, int chunks, int N, float beta, float* __restrict__ out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += partial[(long)c * N + n];
+    out[n] = (beta != 0.f ? beta * out[n] : 0.f) + s;
+}
+
+__global__ void axpy_kernel(long n, float alpha, const float* __restrict__ x, float* __restrict__ y) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] += alpha * x[i];
+}
+
+__global__ void sum_kernel(const float* __restrict__ x, long n, float scale, float* __restrict__ out) {
+    __shared__ float red[1024 / 64];
+    float s = 0.f;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) s += x[i];
+    s = fn_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+        out[0] = t * scale;
+    }
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+int launch_gemm(int ak, int bk, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb, float beta,
+                float* C, int ldc, const float* bias, int splitk, float* ws, hipStream_t st) {
+    const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
+    int klen = K;
+    if (splitk > 1) {
+        klen = ((K + splitk - 1) / splitk + BK - 1) / BK * BK;
+        splitk = (K + klen - 1) / klen;
+    }
+    dim3 grid(ntm * ntn, 1, splitk > 1 ? splitk : 1);
+    float* slabs = splitk > 1 ? ws : nullptr;
+#define FN_GEMM_LAUNCH(AK, BKK)                                                                                            \
+    {                                                                                                                      \
+        using SA = Stage<BM, BK, AK, NT>;                                                                                  \
+        using SB = Stage<BN, BK, BKK, NT>;                                                                                 \
+        const size_t sh = 2 * (SA::WORDS + SB::WORDS) * sizeof(float);                                                     \
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, AK, BKK>), grid, dim3(NT), sh, st, M, N, K, alpha, A, (long)lda, \
+                           B, (long)ldb, beta, C, (long)ldc, bias, klen, slabs);                                           \
+    }
+    if (ak && bk) FN_GEMM_LAUNCH(true, true)
+    else if (ak && !bk) FN_GEMM_LAUNCH(true, false)
+    else if (!ak && !bk) FN_GEMM_LAUNCH(false, false)
+    else FN_GEMM_LAUNCH(false, true)
+#undef FN_GEMM_LAUNCH
+    FN_CHECK_LAUNCH();
+    if (splitk > 1) {
+        const long total = (long)M * N;
+        const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, slabs, splitk, M, N, alpha, beta, C, (long)ldc, bias);
+        FN_CHECK_LAUNCH();
+    }
+    return FN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t fn_gemm_ws_bytes(int M, int N, int splitk) { return splitk > 1 ? (size_t)splitk * M * N * sizeof(float) : 0; }
+
+int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb,
+                float beta, float* C, int ldc, const float* bias, int splitk, float* ws, size_t ws_bytes, void* stream) {
+    if (!A || !B || !C) return FN_E_NULL;
+    if (M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return FN_E_SHAPE;
+    if (splitk > 1 && (!ws || ws_bytes < fn_gemm_ws_bytes(M, N, splitk))) return FN_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    if (tiles128 * (splitk > 1 ? splitk : 1) >= 96)
+        return launch_gemm<128, 128, 16, 2, 2>(a_kmajor, b_kmajor, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, splitk, ws, st);
+    return launch_gemm<64, 64, 16, 2, 2>(a_kmajor, b_kmajor, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, splitk, ws, st);
+}
+
+int fn_transpose_f32(const float* src, int R, int C, int src_ld, float* dst, int dst_ld, void* stream) {
+    if (!src || !dst) return FN_E_NULL;
+    if (R <= 0 || C <= 0 || src_ld < C || dst_ld < R) return FN_E_SHAPE;
+    hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(32, 8), 0, (hipStream_t)stream, src, R, C,
+                       (long)src_ld, dst, (long)dst_ld);
+    FN_CHECK_LAUNCH();
+    return FN_OK;
+}
+
+static int colsum_chunks(int M) { return M >= 4096 ? 64 : (M >= 256 ? 16 : 1); }
+size_t fn_colsum_ws_bytes(int M, int N) { return (size_t)colsum_chunks(M) * N * sizeof(float); }
+
+int fn_colsum_f32(const float* X, int M, int N, int ld, float beta, float* out, float* ws, size_t ws_bytes, void* stream) {
+    if (!X || !out || !ws) return FN_E_NULL;
+    if (M <= 0 || N <= 0 || ld < N) return FN_E_SHAPE;
+    if (ws_bytes < fn_colsum_ws_bytes(M, N)) return FN_E_WORKSPACE;
+    const int chunks = colsum_chunks(M), rpc = (M + chunks - 1) / chunks;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, chunks), dim3(256), 0, (hipStream_t)stream, X, M, N, (long)ld, rpc, ws);
+    FN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, chunks, N, beta, out);
+    FN_CHECK_LAUNCH();
+    return FN_OK;
+}
+
+int fn_axpy_f32(int64_t n, float alpha, const float* x, float* y, void* stream) {
+    if (!x || !y) return FN_E_NULL;
+    if (n <= 0) return FN_E_SHAPE;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(axpy_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long)n, alpha, x, y);
+    FN_CHECK_LAUNCH();
+    return FN_OK;
+}
+
+int fn_sum_f32(const float* x, int64_t n, float scale, float* out, void* stream) {
+    if (!x || !out) return FN_E_NULL;
+    if (n <= 0) return FN_E_SHAPE;
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, (long)n, scale, out);
+    FN_CHECK_LAUNCH();
+    return FN_OK;
+}
+
+}  // extern "C"

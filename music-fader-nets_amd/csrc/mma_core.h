@@ -1,0 +1,149 @@
+// mma_core.h - LDS-staged operand tiles + f32 MFMA micro-kernel shared by the GEMM and GRU kernels.
+//
+// gfx950 only.  Arithmetic is v_mfma_f32_16x16x4_f32 (f32 in / f32 accumulate: bit-for-bit an fmaf
+// chain, 32-cycle issue per SIMD, needs >= 2 independent accumulators per wave to reach the issue rate).
+//
+// Operand fragment convention of the instruction: lane l supplies A[i = l&15][k = l>>4] and
+// B[k = l>>4][j = l&15]; D[row = (l>>4)*4 + reg][col = l&15].
+// We permute K inside every 8-wide block so that one lane's two k-values are adjacent:
+//   MFMA s (s=0,1) of block kb uses k = 8*kb + 2*(l>>4) + s       (same permutation for A and B)
+// which lets a K-contiguous LDS tile be read with ONE ds_read_b64 per two MFMAs.
+//
+// LDS layouts (conflict-free by construction, see MI355X_MICROARCH.md LDS table):
+//   KC (source is K-contiguous): tile[ROWS][BK+4] ; fragment = ds_read_b64 at row i, word 8kb+2g.
+//        64-bank b64 slots: slot = i*(BK+4)/2 + g = 2i + g (mod 32) for BK%64==28.. (BK=32: 18i+g) ->
+//        distinct over the 32 lanes of a half-wave for BK = 16 or 32.
+//   RC (source is row-contiguous, i.e. the operand is stored transposed): tile[BK][ROWS+8];
+//        fragment = two ds_read_b32 at k = 8kb+2g+s, word i: banks i and i+16 for g even/odd.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define FN_DEVINL __device__ __forceinline__
+
+FN_DEVINL bool fn_aligned16(const void* p, long ld) { return ((((uintptr_t)p) & 15) == 0) && ((ld & 3) == 0); }
+
+// Plain contiguous row window [row0, row0+nrows_valid)
+struct RowsPlain {
+    int row0, nrows;
+    FN_DEVINL long operator()(int r) const { return (row0 + r < nrows) ? (long)(row0 + r) : -1; }
+};
+
+// ROWS x BK operand tile staged through registers into LDS by NT threads.
+template <int ROWS, int BK, bool KC, int NT>
+struct Stage {
+    static constexpr int NV = ROWS * BK / 4;
+    static constexpr int NPT = (NV + NT - 1) / NT;
+    static constexpr int LDW = KC ? (BK + 4) : (ROWS + 8);
+    static constexpr int WORDS = KC ? ROWS * LDW : BK * LDW;
+    float4 r[NPT];
+
+    // KC : element (row, k) at src[rowmap(row)*ld + k]          rows bounded by rowmap (<0 = zero row)
+    // RC : element (row, k) at src[k*ld + row0 + row], row0+row < nrows
+    template <class RowMap>
+    FN_DEVINL void load(const float* __restrict__ src, long ld, const RowMap& rowmap, int k0, int K, bool vec) {
+#pragma unroll
+        for (int q = 0; q < NPT; ++q) {
+            const int i = threadIdx.x + q * NT;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((NV % NT == 0) || i < NV) {
+                if (KC) {
+                    const int row = i / (BK / 4), c = (i % (BK / 4)) * 4;
+                    const long gr = rowmap(row);
+                    const int gk = k0 + c;
+                    if (gr >= 0 && gk < K) {
+                        const float* p = src + gr * ld + gk;
+                        if (vec && gk + 3 < K) {
+                            v = *reinterpret_cast<const float4*>(p);
+                        } else {
+                            v.x = p[0];
+                            if (gk + 1 < K) v.y = p[1];
+                            if (gk + 2 < K) v.z = p[2];
+                            if (gk + 3 < K) v.w = p[3];
+                        }
+                    }
+                } else {
+                    const int k = i / (ROWS / 4), c = (i % (ROWS / 4)) * 4;
+                    const int gk = k0 + k;
+                    if (gk < K) {
+                        const long g0 = rowmap(c), g3 = rowmap(c + 3);
+                        if (g0 >= 0) {
+                            const float* p = src + (long)gk * ld + g0;
+                            if (vec && g3 >= 0) {
+                                v = *reinterpret_cast<const float4*>(p);
+                            } else {
+                                v.x = p[0];
+                                if (rowmap(c + 1) >= 0) v.y = p[1];
+                                if (rowmap(c + 2) >= 0) v.z = p[2];
+                                if (g3 >= 0) v.w = p[3];
+                            }
+                        }
+                    }
+                }
+            }
+            r[q] = v;
+        }
+    }
+
+    FN_DEVINL void store(float* __restrict__ lds) const {
+#pragma unroll
+        for (int q = 0; q < NPT; ++q) {
+            const int i = threadIdx.x + q * NT;
+            if ((NV % NT == 0) || i < NV) {
+                if (KC) {
+                    const int row = i / (BK / 4), c = (i % (BK / 4)) * 4;
+                    *reinterpret_cast<float4*>(lds + row * LDW + c) = r[q];
+                } else {
+                    const int k = i / (ROWS / 4), c = (i % (ROWS / 4)) * 4;
+                    *reinterpret_cast<float4*>(lds + k * LDW + c) = r[q];
+                }
+            }
+        }
+    }
+
+    // fragment pair (s = 0,1) for the 16 tile rows starting at tr0, k-block kb
+    static FN_DEVINL float2 frag(const float* __restrict__ lds, int tr0, int kb, int lane) {
+        const int i = lane & 15, g = lane >> 4;
+        if (KC) {
+            return *reinterpret_cast<const float2*>(lds + (tr0 + i) * LDW + 8 * kb + 2 * g);
+        } else {
+            float2 f;
+            f.x = lds[(8 * kb + 2 * g) * LDW + tr0 + i];
+            f.y = lds[(8 * kb + 2 * g + 1) * LDW + tr0 + i];
+            return f;
+        }
+    }
+};
+
+// One BK-deep slab of MFMAs for a wave computing TM x TN tiles of 16x16.
+template <int TM, int TN, int BK, class SA, class SB>
+FN_DEVINL void mma_slab(const float* __restrict__ ldsA, const float* __restrict__ ldsB, int arow0, int brow0, int lane,
+                        f32x4 (&acc)[TM][TN]) {
+#pragma unroll
+    for (int kb = 0; kb < BK / 8; ++kb) {
+        float2 a[TM], b[TN];
+#pragma unroll
+        for (int m = 0; m < TM; ++m) a[m] = SA::frag(ldsA, arow0 + 16 * m, kb, lane);
+#pragma unroll
+        for (int n = 0; n < TN; ++n) b[n] = SB::frag(ldsB, brow0 + 16 * n, kb, lane);
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].x, b[n].x, acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].y, b[n].y, acc[m][n], 0, 0, 0);
+    }
+}
+
+FN_DEVINL float fn_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// XCD-aware block remap: consecutive virtual ids land on the same XCD (block b runs on XCD b % 8),
+// so tiles that share weight rows share one L2.  Bijective for any n.
+FN_DEVINL int fn_xcd_remap(int b, int n) {
+    const int q = n >> 3, r = n & 7, x = b & 7, s = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
+}

@@ -1,0 +1,330 @@
+"""Forward / backward orchestration of the MusicAttrRegGMVAE path on top of the HIP ops.
+
+This is the host-side schedule: which C-ABI kernel runs on which buffer, in which order.  All
+arithmetic happens in the kernels (``ops`` = hipops.HipOps); torch is used for buffer ownership and
+a few strided copies.  Reference semantics reproduced (file:line = /root/reference):
+
+  encode            gmm_model.py:82-98      4 concurrent GRU scans + mu/var heads
+  repar / q(y|x)    gmm_model.py:229-242    fn_latent_fwd (one wavefront per sample)
+  sub_decoders      gmm_model.py:100-117    2 scans + TIME-axis log_softmax
+  global_decoder    gmm_model.py:119-149    teacher forced (eps=100): L1 scan, batched W_ih2 GEMM, L2 scan,
+                                            batched 512->342 output GEMM + log_softmax
+  backward          autograd of the above   reverse scans, batched dW GEMMs, token-segment sums
+
+Layouts: per-step tensors are time-major [T][B][..]; token tensors are [B][T] int32.
+"""
+import math
+
+import torch
+
+E_VOCAB, R_DIMS, N_DIMS, C_DIMS = 342, 3, 16, 24
+LOGIT_LD = 344            # 342 padded to a 16-byte multiple so that the logits rows stay float4-aligned
+
+
+class Engine:
+    def __init__(self, ops, params, hidden, zdim, n_component, device):
+        self.ops = ops
+        self.p = params                 # name -> device tensor (the nn.Parameter storage)
+        self.H, self.Z, self.K = hidden, zdim, n_component
+        self.ZG = 2 * zdim + C_DIMS
+        self.dev = torch.device(device)
+        self._bufs = {}
+        self.tab = {}                   # transposed one-hot columns of W_ih:  key -> [V][3H]
+        self.whh_t = {}                 # transposed W_hh: key -> [H][3H]
+        self.saved = None
+        if hidden % 16 != 0:
+            raise ValueError("hidden_dims must be a multiple of 16 for the MFMA tiles")
+        if n_component > 8:
+            raise ValueError("n_component > 8 not supported by fn_latent_*")
+
+    # ------------------------------------------------------------------------------------------
+    def buf(self, name, shape, dtype=torch.float32):
+        shape = tuple(int(s) for s in shape)
+        t = self._bufs.get(name)
+        if t is None or tuple(t.shape) != shape or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.dev)
+            self._bufs[name] = t
+        return t
+
+    def zbuf(self, name, shape):
+        t = self.buf(name, shape)
+        t.zero_()
+        return t
+
+    # GRU parameter sets on the path: key -> (prefix, suffix, one-hot width V)
+    def _gru_sets(self):
+        return {
+            "r": ("gru_r.", "_l0", E_VOCAB), "r_reverse": ("gru_r.", "_l0_reverse", E_VOCAB),
+            "n": ("gru_n.", "_l0", E_VOCAB), "n_reverse": ("gru_n.", "_l0_reverse", E_VOCAB),
+            "d_r": ("gru_d_r.", "_l0", R_DIMS), "d_n": ("gru_d_n.", "_l0", N_DIMS),
+            "g": ("grucell_g.", "", E_VOCAB), "g2": ("grucell_g_2.", "", 0),
+        }
+
+    def refresh_weights(self, need_backward=True):
+        """Re-derive the transposed weight images after the parameters changed (once per optimiser step)."""
+        H = self.H
+        for key, (pfx, sfx, V) in self._gru_sets().items():
+            w_ih = self.p[pfx + "weight_ih" + sfx]
+            if V > 0:
+                tab = self.buf("tab_" + key, (V, 3 * H))
+                self.ops.transpose(w_ih[:, :V], tab)
+                self.tab[key] = tab
+            if need_backward:
+                wt = self.buf("whht_" + key, (H, 3 * H))
+                self.ops.transpose(self.p[pfx + "weight_hh" + sfx], wt)
+                self.whh_t[key] = wt
+
+    # ------------------------------------------------------------------------------------------
+    # forward
+    # ------------------------------------------------------------------------------------------
+    def encode(self, d, save=True):
+        """4 concurrent scans (gru_r / gru_n x fwd / reverse) + mu|var heads -> pre_e [B][2Z] (mu | log-sigma)."""
+        ops, P, H, Z = self.ops, self.p, self.H, self.Z
+        B, T = d.shape
+        scans, hall = [], {}
+        for e in ("r", "n"):
+            for key, sfx, rev in ((e, "_l0", 0), (e + "_reverse", "_l0_reverse", 1)):
+                pfx = "gru_%s." % e
+                hall[key] = self.buf("enc_h_" + key, (T, B, H))
+                scans.append(dict(B=B, T=T, H=H, reverse=rev, w_hh=P[pfx + "weight_hh" + sfx], b_hh=P[pfx + "bias_hh" + sfx],
+                                  b_ih=P[pfx + "bias_ih" + sfx], gx_table=self.tab[key], idx=d, idx_shift=0,
+                                  h_all=hall[key], gates=self.buf("enc_g_" + key, (T, B, 4, H)) if save else None))
+        ops.gru_seq_fwd(scans)
+        pre = {}
+        for e in ("r", "n"):
+            hf, hb = hall[e][T - 1], hall[e + "_reverse"][T - 1]
+            pre[e] = self.buf("pre_" + e, (B, 2 * Z))
+            for head, c0 in (("mu_", 0), ("var_", Z)):
+                W, bias = P[head + e + ".weight"], P[head + e + ".bias"]
+                ops.gemm(hf, W[:, :H], pre[e][:, c0:c0 + Z], bias=bias)
+                ops.gemm(hb, W[:, H:], pre[e][:, c0:c0 + Z], beta=1.0)
+        return pre
+
+    def latent(self, pre, eps, labels=None):
+        ops, P, Z, K = self.ops, self.p, self.Z, self.K
+        out = {}
+        for e in ("r", "n"):
+            B = pre[e].shape[0]
+            o = dict(sigma=self.buf("sigma_" + e, (B, Z)), z=self.buf("z_" + e, (B, Z)), ll=self.buf("ll_" + e, (B, K)),
+                     qy=self.buf("qy_" + e, (B, K)), y=self.buf("y_" + e, (B,), torch.int32), terms=self.buf("terms_" + e, (B, 4)))
+            ops.latent_fwd(pre[e], eps[e], P["mu_%s_lookup.weight" % e], P["logvar_%s_lookup.weight" % e], labels,
+                           o["sigma"], o["z"], o["ll"], o["qy"], o["y"], o["terms"])
+            out[e] = o
+        return out
+
+    def decoders(self, d, r, n, c, z_r, z_n):
+        """sub-decoders + teacher-forced global decoder up to the (pre-softmax) logits."""
+        ops, P, H, Z, ZG = self.ops, self.p, self.H, self.Z, self.ZG
+        B, T = d.shape
+        Tr = r.shape[1]
+        scans = []
+        sd = {}
+        for e, attr, Ce, z in (("r", r, R_DIMS, z_r), ("n", n, N_DIMS, z_n)):
+            h0 = self.buf("sd_h0_" + e, (B, H))
+            ops.gemm(z, P["linear_init_%s.weight" % e], h0, bias=P["linear_init_%s.bias" % e])
+            w_ih = P["gru_d_%s.weight_ih_l0" % e]
+            rb = self.buf("sd_rb_" + e, (B, 3 * H))
+            ops.gemm(z, w_ih[:, Ce:], rb)
+            sd[e] = dict(h0=h0, rb=rb, h_all=self.buf("sd_h_" + e, (Tr, B, H)), gates=self.buf("sd_g_" + e, (Tr, B, 4, H)))
+            scans.append(dict(B=B, T=Tr, H=H, w_hh=P["gru_d_%s.weight_hh_l0" % e], b_hh=P["gru_d_%s.bias_hh_l0" % e],
+                              b_ih=P["gru_d_%s.bias_ih_l0" % e], h0=h0, gx_table=self.tab["d_" + e], idx=attr, gx_rowbias=rb,
+                              h_all=sd[e]["h_all"], gates=sd[e]["gates"]))
+        zc = self.buf("zc", (B, ZG))
+        zc[:, :Z].copy_(z_r)
+        zc[:, Z:2 * Z].copy_(z_n)
+        zc[:, 2 * Z:].copy_(c)
+        h0g = self.buf("g_h0", (B, H))
+        ops.gemm(zc, P["linear_init_global.weight"], h0g, bias=P["linear_init_global.bias"])
+        rbg = self.buf("g_rb", (B, 3 * H))
+        ops.gemm(zc, P["grucell_g.weight_ih"][:, E_VOCAB:], rbg)
+        hx0 = self.buf("g_hx0", (T, B, H))
+        g1 = self.buf("g_gates1", (T, B, 4, H))
+        scans.append(dict(B=B, T=T, H=H, w_hh=P["grucell_g.weight_hh"], b_hh=P["grucell_g.bias_hh"], b_ih=P["grucell_g.bias_ih"],
+                          h0=h0g, gx_table=self.tab["g"], idx=d, idx_shift=-1, start_token=E_VOCAB - 1, gx_rowbias=rbg,
+                          h_all=hx0, gates=g1))
+        ops.gru_seq_fwd(scans)        # layer-1 scan and both sub-decoder scans run concurrently
+        # layer 2: input projections for all steps in one GEMM, then the recurrent scan (h_init = hx0[0], gmm_model.py:134-135)
+        gx2 = self.buf("g_gx2", (T, B, 3 * H))
+        ops.gemm(hx0.view(T * B, H), P["grucell_g_2.weight_ih"], gx2.view(T * B, 3 * H), bias=P["grucell_g_2.bias_ih"])
+        hx1 = self.buf("g_hx1", (T, B, H))
+        g2 = self.buf("g_gates2", (T, B, 4, H))
+        ops.gru_seq_fwd([dict(B=B, T=T, H=H, w_hh=P["grucell_g_2.weight_hh"], b_hh=P["grucell_g_2.bias_hh"], h0=hx0[0],
+                              gx_dense=gx2, h_all=hx1, gates=g2)])
+        logits = self.buf("g_logits", (T * B, LOGIT_LD))
+        ops.gemm(hx1.view(T * B, H), P["linear_out_g.weight"], logits[:, :E_VOCAB], bias=P["linear_out_g.bias"])
+        for e, Ce in (("r", R_DIMS), ("n", N_DIMS)):
+            sd[e]["logits"] = self.buf("sd_logits_" + e, (Tr, B, Ce))
+            ops.gemm(sd[e]["h_all"].view(Tr * B, H), P["linear_out_%s.weight" % e], sd[e]["logits"].view(Tr * B, Ce),
+                     bias=P["linear_out_%s.bias" % e])
+        return dict(sd=sd, zc=zc, h0g=h0g, rbg=rbg, hx0=hx0, g1=g1, gx2=gx2, hx1=hx1, g2=g2, logits=logits)
+
+    def forward(self, d, r, n, c, eps_r, eps_n, labels=None):
+        """Full training-mode forward up to logits; everything backward needs stays in named buffers."""
+        pre = self.encode(d)
+        lat = self.latent(pre, {"r": eps_r, "n": eps_n}, labels)
+        dec = self.decoders(d, r, n, c, lat["r"]["z"], lat["n"]["z"])
+        self.saved = dict(d=d, r=r, n=n, c=c, eps={"r": eps_r, "n": eps_n}, labels=labels, pre=pre, lat=lat, dec=dec)
+        return self.saved
+
+    # ------------------------------------------------------------------------------------------
+    # backward
+    # ------------------------------------------------------------------------------------------
+    def _gru_weight_grads(self, key, pfx, sfx, T, B, dgx, dghn, h_all, h0, G, splitk):
+        """dW_hh / db_hh of one scan from the saved per-step gate gradients (batched over all steps)."""
+        ops, H = self.ops, self.H
+        dW = G[pfx + "weight_hh" + sfx]
+        dgx2 = dgx.view(T * B, 3 * H)
+        dgn2 = dghn.view(T * B, H)
+        if T > 1:
+            hprev = h_all.view(T * B, H)[: (T - 1) * B]
+            ops.gemm(dgx2[B:, : 2 * H], hprev, dW[: 2 * H], a_k=False, b_k=False, splitk=splitk)
+            ops.gemm(dgn2[B:], hprev, dW[2 * H:], a_k=False, b_k=False, splitk=splitk)
+        else:
+            dW.zero_()
+        if h0 is not None:
+            ops.gemm(dgx2[:B, : 2 * H], h0, dW[: 2 * H], a_k=False, b_k=False, beta=1.0)
+            ops.gemm(dgn2[:B], h0, dW[2 * H:], a_k=False, b_k=False, beta=1.0)
+        db = G[pfx + "bias_hh" + sfx]
+        ops.colsum(dgx2[:, : 2 * H], db[: 2 * H])
+        ops.colsum(dgn2, db[2 * H:])
+
+    @staticmethod
+    def _splitk(rows):
+        return 16 if rows >= 32768 else (8 if rows >= 4096 else (4 if rows >= 1024 else 1))
+
+    def backward(self, G, dlogits_sd, lat_up, w_lat, w_cls, w_clf, after_decoders=None):
+        """Backward of forward().
+
+        G            name -> gradient tensor to FILL (views of the flat gradient buffer)
+        (dlogits of the global decoder must already be in saved['dec']['logits'], in place)
+        dlogits_sd   {'r','n'} -> [Tr][B][Ce] gradient wrt the sub-decoder pre-softmax logits
+        lat_up       {'r','n'} -> dict(g_z, g_mu, g_sigma, g_ll, g_qy) upstream gradients (entries may be None;
+                     g_z is a REQUIRED zero-or-filled [B][Z] buffer that decoder gradients are accumulated into)
+        w_*          fused loss weights for fn_latent_bwd (0 = only the upstream gradients)
+        after_decoders  optional callback fired once every decoder-side parameter gradient is enqueued
+                     (data parallel: start reducing that bucket while the encoder scans run)
+        """
+        ops, P, H, Z, ZG, K = self.ops, self.p, self.H, self.Z, self.ZG, self.K
+        S = self.saved
+        d, r, n = S["d"], S["r"], S["n"]
+        dec, lat, pre = S["dec"], S["lat"], S["pre"]
+        B, T = d.shape
+        Tr = r.shape[1]
+        sk_T, sk_Tr = self._splitk(T * B), self._splitk(Tr * B)
+
+        # ---- global decoder output layer ----------------------------------------------------------
+        dlog = dec["logits"]                                   # [T*B][344], holds dlogits
+        hx1f, hx0f = dec["hx1"].view(T * B, H), dec["hx0"].view(T * B, H)
+        ops.gemm(dlog[:, :E_VOCAB], hx1f, G["linear_out_g.weight"], a_k=False, b_k=False, splitk=sk_T)
+        ops.colsum(dlog[:, :E_VOCAB], G["linear_out_g.bias"])
+        dhx1 = self.buf("g_dhx1", (T, B, H))
+        ops.gemm(dlog[:, :E_VOCAB], P["linear_out_g.weight"], dhx1.view(T * B, H), a_k=True, b_k=False)
+        # ---- layer 2 scan -------------------------------------------------------------------------
+        dgx2 = self.buf("g_dgx2", (T, B, 3 * H))
+        dghn2 = self.buf("g_dghn2", (T, B, H))
+        dh0_l2 = self.buf("g_dh0_l2", (B, H))
+        ops.gru_seq_bwd([dict(B=B, T=T, H=H, w_hh_t=self.whh_t["g2"], h0=dec["hx0"][0], h_all=dec["hx1"], gates=dec["g2"],
+                              dh_ext=dhx1, dgx_all=dgx2, dghn_all=dghn2, dh0=dh0_l2, scratch=self.buf("g_scr2", (B, H)))])
+        self._gru_weight_grads("g2", "grucell_g_2.", "", T, B, dgx2, dghn2, dec["hx1"], dec["hx0"][0], G, sk_T)
+        dgx2f = dgx2.view(T * B, 3 * H)
+        ops.gemm(dgx2f, hx0f, G["grucell_g_2.weight_ih"], a_k=False, b_k=False, splitk=sk_T)
+        ops.colsum(dgx2f, G["grucell_g_2.bias_ih"])
+        dhx0 = self.buf("g_dhx0", (T, B, H))
+        ops.gemm(dgx2f, P["grucell_g_2.weight_ih"], dhx0.view(T * B, H), a_k=True, b_k=False)
+        ops.axpy(1.0, dh0_l2, dhx0[0])                        # hx1 was initialised with hx0[0]
+        # ---- sub-decoder output layers ------------------------------------------------------------
+        sd = dec["sd"]
+        dh_sd = {}
+        for e, Ce in (("r", R_DIMS), ("n", N_DIMS)):
+            dl = dlogits_sd[e].view(Tr * B, Ce)
+            hf = sd[e]["h_all"].view(Tr * B, H)
+            ops.gemm(dl, hf, G["linear_out_%s.weight" % e], a_k=False, b_k=False, splitk=sk_Tr)
+            ops.colsum(dl, G["linear_out_%s.bias" % e])
+            dh_sd[e] = self.buf("sd_dh_" + e, (Tr, B, H))
+            ops.gemm(dl, P["linear_out_%s.weight" % e], dh_sd[e].view(Tr * B, H), a_k=True, b_k=False)
+        # ---- layer 1 scan + both sub-decoder scans (concurrent) -----------------------------------
+        dgx1 = self.buf("g_dgx1", (T, B, 3 * H))
+        dghn1 = self.buf("g_dghn1", (T, B, H))
+        dh0_g = self.buf("g_dh0", (B, H))
+        drb_g = self.zbuf("g_drb", (B, 3 * H))
+        scans = [dict(B=B, T=T, H=H, w_hh_t=self.whh_t["g"], h0=dec["h0g"], h_all=dec["hx0"], gates=dec["g1"], dh_ext=dhx0,
+                      dgx_all=dgx1, dghn_all=dghn1, dh0=dh0_g, dgx_rowsum=drb_g, scratch=self.buf("g_scr1", (B, H)))]
+        sdb = {}
+        for e in ("r", "n"):
+            sdb[e] = dict(dgx=self.buf("sd_dgx_" + e, (Tr, B, 3 * H)), dghn=self.buf("sd_dghn_" + e, (Tr, B, H)),
+                          dh0=self.buf("sd_dh0_" + e, (B, H)), drb=self.zbuf("sd_drb_" + e, (B, 3 * H)))
+            scans.append(dict(B=B, T=Tr, H=H, w_hh_t=self.whh_t["d_" + e], h0=sd[e]["h0"], h_all=sd[e]["h_all"], gates=sd[e]["gates"],
+                              dh_ext=dh_sd[e], dgx_all=sdb[e]["dgx"], dghn_all=sdb[e]["dghn"], dh0=sdb[e]["dh0"],
+                              dgx_rowsum=sdb[e]["drb"], scratch=self.buf("sd_scr_" + e, (B, H))))
+        ops.gru_seq_bwd(scans)
+        # layer-1 parameter gradients
+        self._gru_weight_grads("g", "grucell_g.", "", T, B, dgx1, dghn1, dec["hx0"], dec["h0g"], G, sk_T)
+        dWg = G["grucell_g.weight_ih"]                          # [3H][E+ZG]
+        dtab = self.buf("dtab_E", (E_VOCAB, 3 * H))
+        ops.embed_grad(dgx1, d, -1, E_VOCAB - 1, 0, E_VOCAB, dtab)
+        ops.transpose(dtab, dWg[:, :E_VOCAB])
+        ops.gemm(drb_g, dec["zc"], dWg[:, E_VOCAB:], a_k=False, b_k=False)
+        ops.colsum(drb_g, G["grucell_g.bias_ih"])
+        # d zc -> accumulated straight into the two latent gradients (the chroma columns need no gradient)
+        Wz_g, Wig = P["grucell_g.weight_ih"], P["linear_init_global.weight"]
+        for e, c0 in (("r", 0), ("n", Z)):
+            gz = lat_up[e]["g_z"]
+            ops.gemm(drb_g, Wz_g[:, E_VOCAB + c0:E_VOCAB + c0 + Z], gz, a_k=True, b_k=False, beta=1.0)
+            ops.gemm(dh0_g, Wig[:, c0:c0 + Z], gz, a_k=True, b_k=False, beta=1.0)
+        ops.gemm(dh0_g, dec["zc"], G["linear_init_global.weight"], a_k=False, b_k=False)
+        ops.colsum(dh0_g, G["linear_init_global.bias"])
+        # sub-decoder parameter gradients and their contribution to dz
+        for e, attr, Ce in (("r", r, R_DIMS), ("n", n, N_DIMS)):
+            pfx = "gru_d_%s." % e
+            z = lat[e]["z"]
+            gz = lat_up[e]["g_z"]
+            self._gru_weight_grads("d_" + e, pfx, "_l0", Tr, B, sdb[e]["dgx"], sdb[e]["dghn"], sd[e]["h_all"], sd[e]["h0"], G, sk_Tr)
+            dW = G[pfx + "weight_ih_l0"]                        # [3H][Ce+Z]
+            dt = self.buf("dtab_" + e, (Ce, 3 * H))
+            ops.embed_grad(sdb[e]["dgx"], attr, 0, 0, 0, Ce, dt)
+            ops.transpose(dt, dW[:, :Ce])
+            ops.gemm(sdb[e]["drb"], z, dW[:, Ce:], a_k=False, b_k=False)
+            ops.colsum(sdb[e]["drb"], G[pfx + "bias_ih_l0"])
+            ops.gemm(sdb[e]["drb"], P[pfx + "weight_ih_l0"][:, Ce:], gz, a_k=True, b_k=False, beta=1.0)
+            ops.gemm(sdb[e]["dh0"], P["linear_init_%s.weight" % e], gz, a_k=True, b_k=False, beta=1.0)
+            ops.gemm(sdb[e]["dh0"], z, G["linear_init_%s.weight" % e], a_k=False, b_k=False)
+            ops.colsum(sdb[e]["dh0"], G["linear_init_%s.bias" % e])
+        if after_decoders is not None:
+            after_decoders()
+        # ---- latent block + heads -----------------------------------------------------------------
+        scans = []
+        encb = {}
+        for e in ("r", "n"):
+            up = lat_up[e]
+            dpre = self.buf("dpre_" + e, (B, 2 * Z))
+            dmu_rows = self.buf("dmulk_rows_" + e, (B, K * Z))
+            ops.latent_bwd(pre[e], S["eps"][e], P["mu_%s_lookup.weight" % e], P["logvar_%s_lookup.weight" % e], S["labels"],
+                           lat[e]["z"], lat[e]["qy"], up["g_z"], up.get("g_mu"), up.get("g_sigma"), up.get("g_ll"), up.get("g_qy"),
+                           w_lat, w_cls, w_clf, dpre, dmu_rows)
+            ops.colsum(dmu_rows, G["mu_%s_lookup.weight" % e].view(-1))
+            hf = self._bufs["enc_h_" + e][T - 1]
+            hb = self._bufs["enc_h_" + e + "_reverse"][T - 1]
+            dhf, dhb = self.buf("enc_dhf_" + e, (B, H)), self.buf("enc_dhb_" + e, (B, H))
+            for i, (head, c0) in enumerate((("mu_", 0), ("var_", Z))):
+                W = P[head + e + ".weight"]                     # [Z][2H]
+                dp = dpre[:, c0:c0 + Z]
+                ops.gemm(dp, W[:, :H], dhf, a_k=True, b_k=False, beta=float(i))
+                ops.gemm(dp, W[:, H:], dhb, a_k=True, b_k=False, beta=float(i))
+                dW = G[head + e + ".weight"]
+                ops.gemm(dp, hf, dW[:, :H], a_k=False, b_k=False)
+                ops.gemm(dp, hb, dW[:, H:], a_k=False, b_k=False)
+                ops.colsum(dp, G[head + e + ".bias"])
+            for key, dh in ((e, dhf), (e + "_reverse", dhb)):
+                encb[key] = dict(dgx=self.buf("enc_dgx_" + key, (T, B, 3 * H)), dghn=self.buf("enc_dghn_" + key, (T, B, H)))
+                scans.append(dict(B=B, T=T, H=H, w_hh_t=self.whh_t[key], h0=None, h_all=self._bufs["enc_h_" + key],
+                                  gates=self._bufs["enc_g_" + key], dh_last=dh, dgx_all=encb[key]["dgx"], dghn_all=encb[key]["dghn"],
+                                  scratch=self.buf("enc_scr_" + key, (B, H))))
+        ops.gru_seq_bwd(scans)        # 4 concurrent reverse scans
+        for e in ("r", "n"):
+            for key, sfx, rev in ((e, "_l0", 0), (e + "_reverse", "_l0_reverse", 1)):
+                pfx = "gru_%s." % e
+                self._gru_weight_grads(key, pfx, sfx, T, B, encb[key]["dgx"], encb[key]["dghn"], self._bufs["enc_h_" + key], None, G, sk_T)
+                dtab = self.buf("dtab_E", (E_VOCAB, 3 * H))
+                ops.embed_grad(encb[key]["dgx"], d, 0, 0, rev, E_VOCAB, dtab)
+                ops.transpose(dtab, G[pfx + "weight_ih" + sfx])
+                ops.colsum(encb[key]["dgx"].view(T * B, 3 * H), G[pfx + "bias_ih" + sfx])

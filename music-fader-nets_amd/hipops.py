@@ -1,0 +1,227 @@
+"""Tensor-level wrappers over the C ABI (include/fadernets.h).
+
+PyTorch is only the owner of device memory and of the current HIP stream here: each method checks
+dtype / device / layout, takes ``data_ptr()`` and calls the HIP kernel on
+``torch.cuda.current_stream()``.  No method has a CPU or eager-torch fallback; a missing library or
+a non-zero return code raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk(t, dtype=torch.float32, name="tensor"):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU (got %s): the HIP path has no CPU fallback" % (name, t.device))
+    if t.dtype != dtype:
+        raise RuntimeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+
+
+def _mat(t, name):
+    """2-D view with unit inner stride -> (ptr, rows, cols, ld)."""
+    _chk(t, name=name)
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise RuntimeError("%s must be 2-D with contiguous rows, got shape %s strides %s" % (name, tuple(t.shape), t.stride()))
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+    return _p(t), t.shape[0], t.shape[1], ld
+
+
+def _dense(t, dtype=torch.float32, name="tensor"):
+    _chk(t, dtype, name)
+    if t is not None and not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+    return _p(t)
+
+
+class HipOps:
+    """The product backend: every method is one C-ABI call on the current stream."""
+
+    name = "hip"
+
+    def __init__(self, device):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("HipOps needs a GPU device")
+        self._ws = {}
+
+    # -- plumbing -------------------------------------------------------------------------------
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def workspace(self, nbytes, tag="ws"):
+        """Grow-only scratch buffer per tag (stable pointer once warm -> graph friendly)."""
+        cur = self._ws.get(tag)
+        if cur is None or cur.numel() * 4 < nbytes:
+            cur = torch.empty((max(nbytes, 4) + 3) // 4, dtype=torch.float32, device=self.device)
+            self._ws[tag] = cur
+        return cur
+
+    # -- dense ----------------------------------------------------------------------------------
+    def gemm(self, A, B, Cm, a_k=True, b_k=True, alpha=1.0, beta=0.0, bias=None, splitk=1):
+        pa, ar, ac, lda = _mat(A, "A")
+        pb, br, bc, ldb = _mat(B, "B")
+        pc, M, N, ldc = _mat(Cm, "C")
+        K = ac if a_k else ar
+        if (ar if a_k else ac) != M or (br if b_k else bc) != N or (bc if b_k else br) != K:
+            raise RuntimeError("gemm shape mismatch A%s B%s C%s a_k=%s b_k=%s" % (tuple(A.shape), tuple(B.shape), tuple(Cm.shape), a_k, b_k))
+        _chk(bias, name="bias")
+        ws, wsb = None, 0
+        if splitk > 1:
+            wsb = self.lib.fn_gemm_ws_bytes(M, N, splitk)
+            ws = self.workspace(wsb, "gemm")
+        _lib.check(self.lib.fn_gemm_f32(int(a_k), int(b_k), M, N, K, alpha, pa, lda, pb, ldb, beta, pc, ldc, _p(bias), splitk,
+                                        _p(ws), wsb, self.stream()), "fn_gemm_f32")
+
+    def transpose(self, src, dst):
+        ps, R, Cc, sld = _mat(src, "src")
+        pd, dr, dc, dld = _mat(dst, "dst")
+        if (dr, dc) != (Cc, R):
+            raise RuntimeError("transpose shape mismatch %s -> %s" % (tuple(src.shape), tuple(dst.shape)))
+        _lib.check(self.lib.fn_transpose_f32(ps, R, Cc, sld, pd, dld, self.stream()), "fn_transpose_f32")
+
+    def colsum(self, X, out, beta=0.0):
+        px, M, N, ld = _mat(X, "X")
+        _dense(out, name="out")
+        if out.numel() != N:
+            raise RuntimeError("colsum: out has %d elements, expected %d" % (out.numel(), N))
+        wsb = self.lib.fn_colsum_ws_bytes(M, N)
+        ws = self.workspace(wsb, "colsum")
+        _lib.check(self.lib.fn_colsum_f32(px, M, N, ld, beta, _p(out), _p(ws), wsb, self.stream()), "fn_colsum_f32")
+
+    def axpy(self, alpha, x, y):
+        _dense(x, name="x"), _dense(y, name="y")
+        if x.numel() != y.numel():
+            raise RuntimeError("axpy size mismatch")
+        _lib.check(self.lib.fn_axpy_f32(x.numel(), alpha, _p(x), _p(y), self.stream()), "fn_axpy_f32")
+
+    def sum(self, x, out, scale=1.0):
+        _dense(x, name="x"), _chk(out, name="out")
+        _lib.check(self.lib.fn_sum_f32(_p(x), x.numel(), scale, _p(out), self.stream()), "fn_sum_f32")
+
+    # -- GRU scans ------------------------------------------------------------------------------
+    def gru_seq_fwd(self, scans):
+        arr = (_lib.FnGruFwd * len(scans))()
+        for d, s in zip(arr, scans):
+            for k in ("w_hh", "b_hh", "b_ih", "h0", "gx_dense", "gx_table", "gx_rowbias", "h_all", "gates"):
+                _dense(s.get(k), name=k)
+            _dense(s.get("idx"), torch.int32, "idx")
+            d.B, d.T, d.H, d.reverse = s["B"], s["T"], s["H"], int(s.get("reverse", 0))
+            d.w_hh, d.b_hh, d.b_ih, d.h0 = _p(s["w_hh"]), _p(s["b_hh"]), _p(s.get("b_ih")), _p(s.get("h0"))
+            d.gx_dense, d.gx_table, d.idx = _p(s.get("gx_dense")), _p(s.get("gx_table")), _p(s.get("idx"))
+            d.idx_ld = s["idx"].shape[1] if s.get("idx") is not None else 0
+            d.idx_shift, d.start_token = int(s.get("idx_shift", 0)), int(s.get("start_token", 0))
+            d.gx_rowbias, d.h_all, d.gates = _p(s.get("gx_rowbias")), _p(s["h_all"]), _p(s.get("gates"))
+        _lib.check(self.lib.fn_gru_seq_fwd(arr, len(scans), self.stream()), "fn_gru_seq_fwd")
+
+    def gru_seq_bwd(self, scans):
+        arr = (_lib.FnGruBwd * len(scans))()
+        for d, s in zip(arr, scans):
+            for k in ("w_hh_t", "h0", "h_all", "gates", "dh_last", "dh_ext", "dgx_all", "dghn_all", "dh0", "dgx_rowsum", "scratch"):
+                _dense(s.get(k), name=k)
+            d.B, d.T, d.H = s["B"], s["T"], s["H"]
+            d.w_hh_t, d.h0, d.h_all, d.gates = _p(s["w_hh_t"]), _p(s.get("h0")), _p(s["h_all"]), _p(s["gates"])
+            d.dh_last, d.dh_ext = _p(s.get("dh_last")), _p(s.get("dh_ext"))
+            d.dgx_all, d.dghn_all, d.dh0 = _p(s["dgx_all"]), _p(s["dghn_all"]), _p(s.get("dh0"))
+            d.dgx_rowsum, d.scratch = _p(s.get("dgx_rowsum")), _p(s["scratch"])
+        _lib.check(self.lib.fn_gru_seq_bwd(arr, len(scans), self.stream()), "fn_gru_seq_bwd")
+
+    def embed_grad(self, dgx_all, idx, idx_shift, start_token, reverse, V, out):
+        _dense(dgx_all, name="dgx_all"), _dense(idx, torch.int32, "idx"), _dense(out, name="out")
+        T, B, N3 = dgx_all.shape
+        wsb = self.lib.fn_embed_grad_ws_bytes(T * B, V, N3)
+        ws = self.workspace(wsb, "embed")
+        _lib.check(self.lib.fn_embed_grad_f32(_p(dgx_all), B, T, N3, _p(idx), idx.shape[1], idx_shift, start_token, int(reverse), V,
+                                              _p(out), _p(ws), wsb, self.stream()), "fn_embed_grad_f32")
+
+    # -- heads ----------------------------------------------------------------------------------
+    def vocab_logsoftmax(self, logits, B, T, E, logp_bt=None, target=None, nll_rows=None, grad_scale=0.0, dlogits=None):
+        pl, rows, _, ld = _mat(logits, "logits")
+        _dense(logp_bt, name="logp_bt"), _dense(target, torch.int32, "target"), _dense(nll_rows, name="nll_rows")
+        if dlogits is not None and _mat(dlogits, "dlogits")[3] != ld:
+            raise RuntimeError("dlogits must share the leading dimension of logits")
+        _lib.check(self.lib.fn_vocab_logsoftmax(pl, B, T, E, ld, _p(logp_bt), _p(target), _p(nll_rows), grad_scale, _p(dlogits),
+                                                self.stream()), "fn_vocab_logsoftmax")
+
+    def vocab_logsoftmax_bwd(self, logp_bt, gout_bt, dlogits):
+        _dense(logp_bt, name="logp_bt"), _dense(gout_bt, name="gout_bt")
+        B, T, E = logp_bt.shape
+        pd, _, _, ld = _mat(dlogits, "dlogits")
+        _lib.check(self.lib.fn_vocab_logsoftmax_bwd(_p(logp_bt), _p(gout_bt), B, T, E, ld, pd, self.stream()), "fn_vocab_logsoftmax_bwd")
+
+    def vocab_argmax(self, logits, E, logp_out, tok_out):
+        """logits [B][ld]; logp_out: 2-D view [B][E] (any row stride) or None; tok_out: int32 1-D view (any stride)."""
+        pl, B, _, ld = _mat(logits, "logits")
+        _chk(tok_out, torch.int32, "tok_out")
+        lp_ld = 0
+        if logp_out is not None:
+            _chk(logp_out, name="logp_out")
+            lp_ld = logp_out.stride(0)
+        _lib.check(self.lib.fn_vocab_argmax(pl, B, E, ld, _p(logp_out), lp_ld, _p(tok_out), tok_out.stride(0) if tok_out.dim() else 1,
+                                            self.stream()), "fn_vocab_argmax")
+
+    def time_logsoftmax(self, logits, logp_bt=None, target=None, nll_bc=None, grad_scale=0.0, dlogits=None):
+        _dense(logits, name="logits"), _dense(logp_bt, name="logp_bt"), _dense(target, torch.int32, "target")
+        _dense(nll_bc, name="nll_bc"), _dense(dlogits, name="dlogits")
+        Tr, B, Cc = logits.shape
+        _lib.check(self.lib.fn_time_logsoftmax(_p(logits), B, Tr, Cc, _p(logp_bt), _p(target), _p(nll_bc), grad_scale, _p(dlogits),
+                                               self.stream()), "fn_time_logsoftmax")
+
+    def time_logsoftmax_bwd(self, logp_bt, gout_bt, dlogits):
+        _dense(logp_bt, name="logp_bt"), _dense(gout_bt, name="gout_bt"), _dense(dlogits, name="dlogits")
+        B, Tr, Cc = logp_bt.shape
+        _lib.check(self.lib.fn_time_logsoftmax_bwd(_p(logp_bt), _p(gout_bt), B, Tr, Cc, _p(dlogits), self.stream()), "fn_time_logsoftmax_bwd")
+
+    # -- latent ---------------------------------------------------------------------------------
+    def latent_fwd(self, pre, eps, mu_lk, lv_lk, labels, sigma, z, ll, qy, y, terms):
+        for t, n in ((pre, "pre"), (eps, "eps"), (mu_lk, "mu_lk"), (lv_lk, "lv_lk"), (sigma, "sigma"), (z, "z"), (ll, "ll"), (qy, "qy"),
+                     (terms, "terms")):
+            _dense(t, name=n)
+        _dense(labels, torch.int32, "labels"), _dense(y, torch.int32, "y")
+        B, Z = eps.shape
+        K = mu_lk.shape[0]
+        _lib.check(self.lib.fn_latent_fwd(_p(pre), _p(eps), _p(mu_lk), _p(lv_lk), B, Z, K, _p(labels), _p(sigma), _p(z), _p(ll), _p(qy),
+                                          _p(y), _p(terms), self.stream()), "fn_latent_fwd")
+
+    def latent_bwd(self, pre, eps, mu_lk, lv_lk, labels, z, qy, g_z, g_mu, g_sigma, g_ll, g_qy, w_lat, w_cls, w_clf, dpre, dmu_lk_rows):
+        for t, n in ((pre, "pre"), (eps, "eps"), (mu_lk, "mu_lk"), (lv_lk, "lv_lk"), (z, "z"), (qy, "qy"), (g_z, "g_z"), (g_mu, "g_mu"),
+                     (g_sigma, "g_sigma"), (g_ll, "g_ll"), (g_qy, "g_qy"), (dpre, "dpre"), (dmu_lk_rows, "dmu_lk_rows")):
+            _dense(t, name=n)
+        _dense(labels, torch.int32, "labels")
+        B, Z = eps.shape
+        K = mu_lk.shape[0]
+        _lib.check(self.lib.fn_latent_bwd(_p(pre), _p(eps), _p(mu_lk), _p(lv_lk), B, Z, K, _p(labels), _p(z), _p(qy), _p(g_z), _p(g_mu),
+                                          _p(g_sigma), _p(g_ll), _p(g_qy), w_lat, w_cls, w_clf, _p(dpre), _p(dmu_lk_rows),
+                                          self.stream()), "fn_latent_bwd")
+
+    def pairwise_reg(self, z0_all, attr_all, row0, nrows, loss_rows, grad_scale=0.0, dz0=None):
+        _dense(z0_all, name="z0_all"), _dense(attr_all, torch.float64, "attr_all"), _dense(loss_rows, name="loss_rows"), _dense(dz0, name="dz0")
+        _lib.check(self.lib.fn_pairwise_reg(_p(z0_all), _p(attr_all), z0_all.numel(), row0, nrows, _p(loss_rows), grad_scale, _p(dz0),
+                                            self.stream()), "fn_pairwise_reg")
+
+    # -- optimiser ------------------------------------------------------------------------------
+    def sumsq(self, g, out):
+        _dense(g, name="g"), _chk(out, name="out")
+        wsb = self.lib.fn_sumsq_ws_bytes(g.numel())
+        ws = self.workspace(wsb, "sumsq")
+        _lib.check(self.lib.fn_sumsq_f32(_p(g), g.numel(), _p(out), _p(ws), wsb, self.stream()), "fn_sumsq_f32")
+
+    def clip_adam(self, p, g, m, v, sumsq, max_norm, lr, beta1, beta2, eps, step):
+        for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+            _dense(t, name=n)
+        _chk(sumsq, name="sumsq")
+        _lib.check(self.lib.fn_clip_adam(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(sumsq), max_norm, lr, beta1, beta2, eps, step,
+                                         self.stream()), "fn_clip_adam")
+
+    def onehot_to_index(self, oh, idx):
+        _dense(oh, name="oh"), _dense(idx, torch.int32, "idx")
+        V = oh.shape[-1]
+        _lib.check(self.lib.fn_onehot_to_index(_p(oh), oh.numel() // V, V, _p(idx), self.stream()), "fn_onehot_to_index")

@@ -1,0 +1,220 @@
+"""Fused training / evaluation step of the GM-VAE, mirroring trainer_gmm.py:220-293.
+
+``GMVAETrainer.train(step, d_oh, r_oh, n_oh, d, r, n, c, r_density, n_density, is_supervised, y_label)`` keeps
+the reference's argument list and returns ``(step + 1, (loss, CE_X, CE_R, CE_N, l_r, l_n, kld_latent, kld_class))``
+(trainer_gmm.py:252-258) but runs without autograd: forward kernels -> fused loss / gradient-seed kernels ->
+backward kernels -> clip + Adam kernel over one flat parameter buffer.
+
+Loss terms (trainer_gmm.py:109-217); every reduction is normalised by the GLOBAL batch so that data-parallel
+ranks simply SUM their gradients and statistics:
+  CE = 5*CE_X + CE_R + CE_N (means over B*T / B*Tr incl. pad, :131-138)
+  beta0 schedule :125-128 (negative between step 1000 and 10000 - reproduced)
+  unsupervised: + beta0 * (sum_k mean_b q_k KL_k  [r,n]  +  mean_b(mean_k q log q) - log(1/K)  [r,n])  (:150-178)
+  supervised:   + beta0 * mean_b KL_label [r,n] + CrossEntropy(softmax(qy), label) [r,n]            (:181-194)
+  + pairwise tanh/sign regulariser on z[:,0] for r and n                                             (:199-217)
+"""
+import math
+
+import numpy as np
+import torch
+
+from .engine import E_VOCAB
+
+# parameters whose gradient is complete once the decoder backward has run (first all-reduce bucket)
+DECODER_PREFIXES = ("linear_out_g.", "grucell_g_2.", "grucell_g.", "linear_init_global.", "gru_d_r.", "gru_d_n.",
+                    "linear_out_r.", "linear_out_n.", "linear_init_r.", "linear_init_n.")
+
+# layout of the device-side statistics vector
+S_CE_X, S_CE_R, S_CE_N, S_L_R, S_L_N, S_TERMS_R, S_TERMS_N, S_LEN = 0, 1, 2, 3, 4, 5, 9, 16
+
+
+def beta_schedule(step, beta):
+    """trainer_gmm.py:125-128."""
+    return 0.0 if step < 1000 else min((step - 10000) / 10000 * beta, beta)
+
+
+class FlatParams:
+    """Flat fp32 images of the trainable, used parameters: parameter / gradient / Adam m, v.
+
+    The module's parameters are re-pointed at views of the flat parameter buffer (``state_dict`` keeps
+    working, one kernel updates everything) and the gradient buffer is what data-parallel all-reduces.
+    Decoder-side parameters come first so that their gradient bucket can be reduced while the encoder
+    backward scans still run."""
+
+    def __init__(self, model):
+        named = model.used_parameters()
+        named = [kp for kp in named if kp[0].startswith(DECODER_PREFIXES)] + \
+                [kp for kp in named if not kp[0].startswith(DECODER_PREFIXES)]
+        dev = named[0][1].device
+        self.offsets, off = {}, 0
+        self.bucket_split = 0
+        for k, p in named:
+            if not k.startswith(DECODER_PREFIXES) and self.bucket_split == 0:
+                self.bucket_split = off
+            self.offsets[k] = off
+            off += (p.numel() + 3) // 4 * 4          # 16-byte aligned segment starts
+        self.n = off
+        self.param = torch.zeros(off, device=dev)
+        self.grad = torch.zeros(off, device=dev)
+        self.m = torch.zeros(off, device=dev)
+        self.v = torch.zeros(off, device=dev)
+        self.names = [k for k, _ in named]
+        self.G = {}
+        for k, p in named:
+            o, s = self.offsets[k], p.numel()
+            self.param[o:o + s].copy_(p.data.reshape(-1))
+            p.data = self.param[o:o + s].view_as(p.data)
+            self.G[k] = self.grad[o:o + s].view_as(p.data)
+        self.t = 0
+        model._engine = None           # parameter storage moved: rebuild the engine's pointer table
+        model.weights_changed()
+
+
+class GMVAETrainer:
+    def __init__(self, model, lr=1e-3, beta=0.2, max_norm=1.0, dist_ctx=None):
+        self.model = model
+        self.lr, self.beta, self.max_norm = lr, beta, max_norm
+        self.flat = FlatParams(model)
+        self.dist = dist_ctx                         # parallel.DataParallelContext or None
+        dev = self.flat.param.device
+        self.stats = torch.zeros(S_LEN, device=dev)  # partial sums of the loss terms (device side)
+        self.sumsq = torch.zeros(1, device=dev)
+        self.last_grad_sumsq = None
+        model.train()
+
+    # ------------------------------------------------------------------------------------------
+    def prepare_batch(self, d, r, n, c, r_density, n_density, y_label=None):
+        """Upload one batch: token tensors -> int32 [B][T]; densities stay float64 (only the SIGN of their
+        pairwise float64 differences is used, trainer_gmm.py:208-210)."""
+        m = self.model
+        dev = self.flat.param.device
+        d = m._indices(torch.as_tensor(d).to(dev), 342)
+        r = m._indices(torch.as_tensor(r).to(dev), 3)
+        n = m._indices(torch.as_tensor(n).to(dev), 16)
+        c = torch.as_tensor(c).to(dev).float().contiguous()
+        rd = torch.as_tensor(np.asarray(r_density, dtype=np.float64)).to(dev).contiguous()
+        nd = torch.as_tensor(np.asarray(n_density, dtype=np.float64)).to(dev).contiguous()
+        lab = None if y_label is None else torch.as_tensor(y_label).to(dev).to(torch.int32).contiguous()
+        return d, r, n, c, rd, nd, lab
+
+    def draw_eps(self, B, T):
+        """eps in the reference's CPU-generator order (see MusicAttrRegGMVAE._draw_eps)."""
+        return self.model._draw_eps(B, T, self.flat.param.device)
+
+    def _forward_losses(self, step, batch, eps, want_grads):
+        m = self.model
+        eng = m.engine()
+        ops = eng.ops
+        d, r, n, c, rd, nd, labels = batch
+        B, T = d.shape
+        Tr = r.shape[1]
+        Bg = B if self.dist is None else self.dist.global_batch(B)
+        Z = eng.Z
+        beta0 = beta_schedule(step, self.beta)
+        S = eng.forward(d, r, n, c, eps[0], eps[1], labels)
+        dec, lat = S["dec"], S["lat"]
+        st = self.stats
+        # reconstruction terms; the gradient seeds overwrite the logits in place
+        nll = eng.buf("nll_rows", (T * B,))
+        ops.vocab_logsoftmax(dec["logits"], B, T, E_VOCAB, target=d, nll_rows=nll,
+                             grad_scale=5.0 / (Bg * T) if want_grads else 0.0, dlogits=dec["logits"] if want_grads else None)
+        ops.sum(nll, st[S_CE_X:S_CE_X + 1], 1.0 / (Bg * T))
+        dl_sd = {}
+        for slot, e, attr, Ce in ((S_CE_R, "r", r, 3), (S_CE_N, "n", n, 16)):
+            nbc = eng.buf("nll_bc_" + e, (B, Ce))
+            dl_sd[e] = eng.buf("sd_dlogits_" + e, (Tr, B, Ce)) if want_grads else None
+            ops.time_logsoftmax(dec["sd"][e]["logits"], target=attr, nll_bc=nbc, grad_scale=1.0 / (Bg * Tr), dlogits=dl_sd[e])
+            ops.sum(nbc, st[slot:slot + 1], 1.0 / (Bg * Tr))
+        # latent terms: column sums of the per-row terms written by fn_latent_fwd
+        for slot, e in ((S_TERMS_R, "r"), (S_TERMS_N, "n")):
+            ops.colsum(lat[e]["terms"], st[slot:slot + 4])
+        # pairwise regulariser on z[:, 0] against the GLOBAL batch
+        lat_up = {}
+        for slot, e, attr in ((S_L_R, "r", rd), (S_L_N, "n", nd)):
+            z0 = eng.buf("reg_z0_" + e, (B,))
+            z0.copy_(lat[e]["z"][:, 0])
+            if self.dist is not None:
+                z0_all, a_all, row0 = self.dist.gather_rows(z0, attr)
+            else:
+                z0_all, a_all, row0 = z0, attr, 0
+            lrow = eng.buf("reg_rows_" + e, (B,))
+            dz0 = eng.buf("reg_dz0_" + e, (B,)) if want_grads else None
+            ops.pairwise_reg(z0_all, a_all, row0, B, lrow, 1.0 / (Bg * Bg), dz0)
+            ops.sum(lrow, st[slot:slot + 1], 1.0 / (Bg * Bg))
+            if want_grads:
+                gz = eng.zbuf("g_z_" + e, (B, Z))
+                gz[:, 0].copy_(dz0)
+                lat_up[e] = dict(g_z=gz)
+        w = (beta0 / Bg, beta0 / Bg, 0.0) if labels is None else (beta0 / Bg, 0.0, 1.0 / Bg)
+        return dl_sd, lat_up, w, beta0, Bg
+
+    def _tuple8(self, beta0, Bg, supervised):
+        """device partial sums -> the reference's 8 numbers (ONE D2H copy; the reference does 8 .item() calls, :257)."""
+        if self.dist is not None:
+            self.dist.all_reduce_sum(self.stats)
+        s = self.stats.tolist()
+        K = self.model.n_component
+        ce_x, ce_r, ce_n, l_r, l_n = s[S_CE_X], s[S_CE_R], s[S_CE_N], s[S_L_R], s[S_L_N]
+        tr_, tn_ = s[S_TERMS_R:S_TERMS_R + 4], s[S_TERMS_N:S_TERMS_N + 4]
+        if not supervised:
+            kld_lat = tr_[0] / Bg + tn_[0] / Bg
+            kld_cls = (tr_[1] / Bg - math.log(1.0 / K)) + (tn_[1] / Bg - math.log(1.0 / K))
+            loss = 5 * ce_x + ce_r + ce_n + beta0 * (kld_lat + kld_cls)
+        else:
+            kld_lat = tr_[2] / Bg + tn_[2] / Bg
+            kld_cls = 0.0
+            loss = 5 * ce_x + ce_r + ce_n + beta0 * kld_lat + (tr_[3] / Bg + tn_[3] / Bg)
+        loss += l_r + l_n
+        return (loss, ce_x, ce_r, ce_n, l_r, l_n, kld_lat, kld_cls)
+
+    # ------------------------------------------------------------------------------------------
+    def step_device(self, step, batch, eps):
+        """One optimisation step, fully asynchronous (no host sync): returns nothing; statistics stay on the device."""
+        m = self.model
+        eng = m.engine()
+        dl_sd, lat_up, w, beta0, Bg = self._forward_losses(step, batch, eps, want_grads=True)
+        hook = None
+        if self.dist is not None:
+            hook = lambda: self.dist.start_bucket(self.flat.grad[:self.flat.bucket_split])
+        eng.backward(self.flat.G, dl_sd, lat_up, *w, after_decoders=hook)
+        if self.dist is not None:
+            self.dist.start_bucket(self.flat.grad[self.flat.bucket_split:])
+            self.dist.finish_buckets()
+        ops = eng.ops
+        ops.sumsq(self.flat.grad, self.sumsq)      # norm of the (all-reduced) gradient: identical on every rank
+        self.flat.t += 1
+        ops.clip_adam(self.flat.param, self.flat.grad, self.flat.m, self.flat.v, self.sumsq, self.max_norm, self.lr,
+                      0.9, 0.999, 1e-8, self.flat.t)
+        m.weights_changed()
+        return beta0, Bg
+
+    def train(self, step, d_oh, r_oh, n_oh, d, r, n, c, r_density, n_density, is_supervised=False, y_label=None, eps=None):
+        """trainer_gmm.py:220-258 (same argument order; the one-hot arguments are accepted and ignored when the
+        integer tensors are given, since convert_to_one_hot(d) carries no more information than d)."""
+        batch = self.prepare_batch(d if d is not None else d_oh, r if r is not None else r_oh, n if n is not None else n_oh,
+                                   c, r_density, n_density, y_label if is_supervised else None)
+        if eps is None:
+            eps = self.draw_eps(*batch[0].shape)
+        beta0, Bg = self.step_device(step, batch, eps)
+        return step + 1, self._tuple8(beta0, Bg, is_supervised)
+
+    @torch.no_grad()
+    def evaluate(self, step, d_oh, r_oh, n_oh, d, r, n, c, r_density, n_density, is_supervised=False, y_label=None, eps=None):
+        """trainer_gmm.py:261-293: the same forward + losses (still train mode, as the reference), no update."""
+        batch = self.prepare_batch(d if d is not None else d_oh, r if r is not None else r_oh, n if n is not None else n_oh,
+                                   c, r_density, n_density, y_label if is_supervised else None)
+        if eps is None:
+            eps = self.draw_eps(*batch[0].shape)
+        _, _, _, beta0, Bg = self._forward_losses(step, batch, eps, want_grads=False)
+        return self._tuple8(beta0, Bg, is_supervised)
+
+    def grad_norm(self):
+        """L2 norm of the last (all-reduced, unclipped) gradient - one host sync."""
+        return math.sqrt(float(self.sumsq.item()))
+
+
+def convert_to_one_hot(input, dims):
+    """trainer_gmm.py:296-303 (kept for callers that still build one-hot tensors; the kernels read indices)."""
+    input = input.long()
+    oh = torch.zeros(tuple(input.shape) + (dims,), device=input.device)
+    return oh.scatter_(-1, input.unsqueeze(-1), 1.0)

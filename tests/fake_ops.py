@@ -1,0 +1,241 @@
+"""TEST-ONLY stand-in for music-fader-nets_amd/hipops.HipOps.
+
+Implements the *documented semantics* of every C-ABI entry point (include/fadernets.h) with plain torch on
+the CPU, so that the host-side schedule (engine.py / trainer.py / parallel.py: which op runs on which buffer
+in which order, gradient routing, data-parallel reductions) can be checked against the oracle without a GPU.
+It is never imported by the product; the product path fails loudly without the HIP library.
+"""
+import math
+
+import torch
+
+LOG_2PI = math.log(2 * math.pi)
+
+
+class FakeOps:
+    name = "fake-cpu"
+
+    def __init__(self):
+        self.calls = []
+
+    # -- dense --------------------------------------------------------------------------------------
+    def gemm(self, A, B, Cm, a_k=True, b_k=True, alpha=1.0, beta=0.0, bias=None, splitk=1):
+        self.calls.append("gemm")
+        a = A if a_k else A.t()
+        b = B.t() if b_k else B
+        assert a.shape[0] == Cm.shape[0] and b.shape[1] == Cm.shape[1] and a.shape[1] == b.shape[0], "gemm shapes"
+        res = alpha * (a @ b)
+        if bias is not None:
+            res = res + bias
+        if beta != 0.0:
+            res = res + beta * Cm
+        Cm.copy_(res)
+
+    def transpose(self, src, dst):
+        assert tuple(dst.shape) == (src.shape[1], src.shape[0])
+        dst.copy_(src.t())
+
+    def colsum(self, X, out, beta=0.0):
+        assert out.numel() == X.shape[1] and out.is_contiguous()
+        s = X.sum(dim=0)
+        out.copy_((beta * out if beta != 0.0 else 0) + s.view_as(out))
+
+    def axpy(self, alpha, x, y):
+        assert x.is_contiguous() and y.is_contiguous()
+        y.add_(alpha * x)
+
+    def sum(self, x, out, scale=1.0):
+        out.copy_((x.sum() * scale).view_as(out))
+
+    # -- GRU ----------------------------------------------------------------------------------------
+    @staticmethod
+    def _tok(s, p):
+        tau = (s["T"] - 1 - p if s.get("reverse", 0) else p) + s.get("idx_shift", 0)
+        if tau < 0:
+            return torch.full((s["B"],), s.get("start_token", 0), dtype=torch.long)
+        return s["idx"][:, tau].long()
+
+    def gru_seq_fwd(self, scans):
+        self.calls.append("gru_seq_fwd")
+        for s in scans:
+            B, T, H = s["B"], s["T"], s["H"]
+            h = s["h0"] if s.get("h0") is not None else torch.zeros(B, H)
+            for p in range(T):
+                gx = torch.zeros(B, 3 * H)
+                if s.get("b_ih") is not None:
+                    gx = gx + s["b_ih"]
+                if s.get("gx_dense") is not None:
+                    gx = gx + s["gx_dense"][p]
+                if s.get("gx_table") is not None:
+                    gx = gx + s["gx_table"][self._tok(s, p)]
+                if s.get("gx_rowbias") is not None:
+                    gx = gx + s["gx_rowbias"]
+                gh = h @ s["w_hh"].t() + s["b_hh"]
+                r = torch.sigmoid(gx[:, :H] + gh[:, :H])
+                z = torch.sigmoid(gx[:, H:2 * H] + gh[:, H:2 * H])
+                n = torch.tanh(gx[:, 2 * H:] + r * gh[:, 2 * H:])
+                h = (1 - z) * n + z * h
+                s["h_all"][p].copy_(h)
+                if s.get("gates") is not None:
+                    g = s["gates"][p]
+                    g[:, 0].copy_(r), g[:, 1].copy_(z), g[:, 2].copy_(n), g[:, 3].copy_(gh[:, 2 * H:])
+
+    def gru_seq_bwd(self, scans):
+        self.calls.append("gru_seq_bwd")
+        for s in scans:
+            B, T, H = s["B"], s["T"], s["H"]
+            carry = torch.zeros(B, H)
+            if s.get("dh_last") is not None:
+                carry = carry + s["dh_last"]
+            for q in range(T - 1, -1, -1):
+                dh = carry + (s["dh_ext"][q] if s.get("dh_ext") is not None else 0)
+                g = s["gates"][q]
+                r, z, n, hn = g[:, 0], g[:, 1], g[:, 2], g[:, 3]
+                hp = (s["h0"] if s.get("h0") is not None else torch.zeros(B, H)) if q == 0 else s["h_all"][q - 1]
+                dn = dh * (1 - z)
+                dz = dh * (hp - n)
+                dnp = dn * (1 - n * n)
+                dr = dnp * hn
+                dzp = dz * z * (1 - z)
+                drp = dr * r * (1 - r)
+                dgx = torch.cat([drp, dzp, dnp], dim=1)
+                s["dgx_all"][q].copy_(dgx)
+                s["dghn_all"][q].copy_(dnp * r)
+                if s.get("dgx_rowsum") is not None:
+                    s["dgx_rowsum"].add_(dgx)
+                dgh = torch.cat([drp, dzp, dnp * r], dim=1)
+                carry = dh * z + dgh @ s["w_hh_t"].t()
+            if s.get("dh0") is not None:
+                s["dh0"].copy_(carry)
+
+    def embed_grad(self, dgx_all, idx, idx_shift, start_token, reverse, V, out):
+        T, B, N3 = dgx_all.shape
+        out.zero_()
+        fake = dict(T=T, B=B, reverse=reverse, idx_shift=idx_shift, start_token=start_token, idx=idx)
+        for p in range(T):
+            out.index_add_(0, self._tok(fake, p), dgx_all[p])
+
+    # -- heads --------------------------------------------------------------------------------------
+    def vocab_logsoftmax(self, logits, B, T, E, logp_bt=None, target=None, nll_rows=None, grad_scale=0.0, dlogits=None):
+        x = logits[:, :E].view(T, B, E)
+        lp = torch.log_softmax(x, dim=-1)
+        if logp_bt is not None:
+            logp_bt.copy_(lp.permute(1, 0, 2))
+        if target is not None:
+            tg = target.long().t().contiguous()            # [T][B]
+            if nll_rows is not None:
+                nll_rows.copy_(-lp.gather(2, tg.unsqueeze(-1)).reshape(-1))
+            if dlogits is not None:
+                g = lp.exp()
+                g.scatter_add_(2, tg.unsqueeze(-1), -torch.ones(T, B, 1))
+                dlogits[:, :E].copy_((grad_scale * g).view(T * B, E))
+
+    def vocab_logsoftmax_bwd(self, logp_bt, gout_bt, dlogits):
+        B, T, E = logp_bt.shape
+        g = gout_bt - logp_bt.exp() * gout_bt.sum(-1, keepdim=True)
+        dlogits[:, :E].copy_(g.permute(1, 0, 2).reshape(T * B, E))
+
+    def vocab_argmax(self, logits, E, logp_out, tok_out):
+        lp = torch.log_softmax(logits[:, :E], dim=-1)
+        if logp_out is not None:
+            logp_out.copy_(lp)
+        tok_out.copy_(logits[:, :E].max(1)[1].to(torch.int32))
+
+    def time_logsoftmax(self, logits, logp_bt=None, target=None, nll_bc=None, grad_scale=0.0, dlogits=None):
+        Tr, B, Cc = logits.shape
+        lp = torch.log_softmax(logits, dim=0)              # over time
+        if logp_bt is not None:
+            logp_bt.copy_(lp.permute(1, 0, 2))
+        if target is not None:
+            oh = torch.zeros(Tr, B, Cc).scatter_(2, target.long().t().unsqueeze(-1), 1.0)
+            if nll_bc is not None:
+                nll_bc.copy_(-(lp * oh).sum(0))
+            if dlogits is not None:
+                dlogits.copy_(grad_scale * (lp.exp() * oh.sum(0, keepdim=True) - oh))
+
+    def time_logsoftmax_bwd(self, logp_bt, gout_bt, dlogits):
+        g = gout_bt - logp_bt.exp() * gout_bt.sum(1, keepdim=True)
+        dlogits.copy_(g.permute(1, 0, 2))
+
+    # -- latent -------------------------------------------------------------------------------------
+    @staticmethod
+    def _latent_math(pre, eps, mu_lk, lv_lk):
+        Z = eps.shape[1]
+        K = mu_lk.shape[0]
+        mu, s = pre[:, :Z], torch.exp(pre[:, Z:])
+        z = mu + s * eps
+        ll = torch.stack([(-0.5 * ((z - mu_lk[k]) ** 2 / torch.exp(lv_lk[k]) + lv_lk[k] + LOG_2PI)).sum(1) + math.log(1.0 / K)
+                          for k in range(K)], dim=1)
+        qy = torch.softmax(ll, dim=1)
+        sp = torch.exp(lv_lk)                              # [K][Z] used as STD
+        vr = (s.unsqueeze(1) / sp) ** 2
+        t1 = ((mu.unsqueeze(1) - mu_lk) / sp) ** 2
+        klm = (0.5 * (vr + t1 - 1 - torch.log(vr))).mean(-1)      # [B][K]
+        return mu, s, z, ll, qy, klm
+
+    def latent_fwd(self, pre, eps, mu_lk, lv_lk, labels, sigma, z, ll, qy, y, terms):
+        mu, s, zz, l, q, klm = self._latent_math(pre, eps, mu_lk, lv_lk)
+        sigma.copy_(s), z.copy_(zz), ll.copy_(l), qy.copy_(q)
+        y.copy_(q.max(1)[1].to(torch.int32))
+        terms.zero_()
+        terms[:, 0] = (q * klm).sum(1)
+        terms[:, 1] = (q * torch.log_softmax(l, dim=1)).mean(1)
+        if labels is not None:
+            lb = labels.long().view(-1, 1)
+            terms[:, 2] = klm.gather(1, lb).view(-1)
+            terms[:, 3] = -torch.log_softmax(q, dim=1).gather(1, lb).view(-1)
+
+    def latent_bwd(self, pre, eps, mu_lk, lv_lk, labels, z, qy, g_z, g_mu, g_sigma, g_ll, g_qy, w_lat, w_cls, w_clf, dpre, dmu_lk_rows):
+        # gradients by autograd of the documented forward + fused loss: checks the schedule AND documents the maths
+        with torch.enable_grad():
+            self._latent_bwd(pre, eps, mu_lk, lv_lk, labels, g_z, g_mu, g_sigma, g_ll, g_qy, w_lat, w_cls, w_clf, dpre, dmu_lk_rows)
+
+    def _latent_bwd(self, pre, eps, mu_lk, lv_lk, labels, g_z, g_mu, g_sigma, g_ll, g_qy, w_lat, w_cls, w_clf, dpre, dmu_lk_rows):
+        B, Z = eps.shape
+        K = mu_lk.shape[0]
+        pre_ = pre.clone().requires_grad_(True)
+        mlk = mu_lk.unsqueeze(0).repeat(B, 1, 1).clone().requires_grad_(True)   # per-row copy -> per-row gradient
+        tot = torch.zeros(())
+        rows = []
+        for b in range(B):
+            mu, s, zz, l, q, klm = self._latent_math(pre_[b:b + 1], eps[b:b + 1], mlk[b], lv_lk)
+            rows.append((mu, s, zz, l, q, klm))
+        mu = torch.cat([r[0] for r in rows]); s = torch.cat([r[1] for r in rows]); zz = torch.cat([r[2] for r in rows])
+        l = torch.cat([r[3] for r in rows]); q = torch.cat([r[4] for r in rows]); klm = torch.cat([r[5] for r in rows])
+        for g, t in ((g_z, zz), (g_mu, mu), (g_sigma, s), (g_ll, l), (g_qy, q)):
+            if g is not None:
+                tot = tot + (g * t).sum()
+        if labels is None:
+            tot = tot + w_lat * (q * klm).sum() + w_cls * (q * torch.log_softmax(l, dim=1)).mean(1).sum()
+        else:
+            lb = labels.long().view(-1, 1)
+            tot = tot + w_lat * klm.gather(1, lb).sum() + w_clf * (-torch.log_softmax(q, dim=1).gather(1, lb)).sum()
+        gp, gm = torch.autograd.grad(tot, [pre_, mlk], allow_unused=True)
+        dpre.copy_(gp if gp is not None else torch.zeros_like(pre))
+        if dmu_lk_rows is not None:
+            dmu_lk_rows.copy_((gm if gm is not None else torch.zeros_like(mlk)).reshape(B, K * Z))
+
+    def pairwise_reg(self, z0_all, attr_all, row0, nrows, loss_rows, grad_scale=0.0, dz0=None):
+        assert attr_all.dtype == torch.float64
+        zi = z0_all[row0:row0 + nrows].view(-1, 1)
+        ai = attr_all[row0:row0 + nrows].view(-1, 1)
+        th = torch.tanh(zi - z0_all.view(1, -1))
+        sg = torch.sign(ai - attr_all.view(1, -1)).float()
+        loss_rows.copy_(((th - sg) ** 2).sum(1))
+        if dz0 is not None:
+            dz0.copy_(grad_scale * 4.0 * ((th - sg) * (1 - th * th)).sum(1))
+
+    # -- optimiser ----------------------------------------------------------------------------------
+    def sumsq(self, g, out):
+        out.copy_((g.double() ** 2).sum().float().view_as(out))
+
+    def clip_adam(self, p, g, m, v, sumsq, max_norm, lr, beta1, beta2, eps, step):
+        coef = min(1.0, max_norm / (math.sqrt(float(sumsq[0])) + 1e-6))
+        gg = g * coef
+        m.mul_(beta1).add_(gg, alpha=1 - beta1)
+        v.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
+        bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+        p.sub_((lr / bc1) * m / (v.sqrt() / math.sqrt(bc2) + eps))
+
+    def onehot_to_index(self, oh, idx):
+        idx.copy_(oh.max(-1)[1].to(torch.int32))

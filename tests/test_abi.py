@@ -1,0 +1,31 @@
+"""The C-ABI library loads and exports every symbol include/fadernets.h declares (no compute without a GPU)."""
+import os
+import re
+
+from mfn_import import ROOT, load_package
+
+
+def test_header_symbols_exported():
+    load_package()
+    from music_fader_nets_amd import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "fadernets.h")).read()
+    declared = set(re.findall(r"\b(fn_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.fn_version() == 1
+    assert lib.fn_strerror(-2) == b"unsupported or inconsistent sizes"
+
+
+def test_argument_errors_without_gpu():
+    """Argument validation happens before any launch, so it is testable on the CPU box."""
+    load_package()
+    from music_fader_nets_amd import _lib
+    lib = _lib.load()
+    assert lib.fn_gemm_f32(1, 1, 4, 4, 4, 1.0, None, 4, None, 4, 0.0, None, 4, None, 1, None, 0, None) == -1
+    assert lib.fn_gru_seq_fwd(None, 1, None) == -1
+    assert lib.fn_gemm_ws_bytes(128, 64, 4) == 4 * 128 * 64 * 4
+    arr = (_lib.FnGruFwd * 9)()
+    assert lib.fn_gru_seq_fwd(arr, 9, None) == -5

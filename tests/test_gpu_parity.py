@@ -1,0 +1,491 @@
+"""Parity of the HIP path (through the C ABI) against the oracle / golden fixtures on a real MI355X.
+
+Tolerances (fp32): kernel outputs vs an fp64/CPU restatement of the same op: 2e-5 relative to the tensor's max;
+end-to-end gradients vs the reference's autograd: 5e-4 relative to each tensor's max; greedy-decode token ids
+bit-exact wherever the reference's own top-2 log-prob gap exceeds 1e-4 (a flipped near-tie changes every later token,
+so rows are compared up to the first sub-threshold gap).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from fake_ops import FakeOps
+from helpers import NOISE_PARAMS, batch_of, load_golden, make_model, relerr, sd_from
+from mfn_import import load_package
+from oracle import gmvae_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    load_package()
+    from music_fader_nets_amd.hipops import HipOps
+    return HipOps(torch.device(DEV))
+
+
+@pytest.fixture(scope="module")
+def small():
+    return load_golden("small")
+
+
+@pytest.fixture(scope="module")
+def c0():
+    return load_golden("c0")
+
+
+def g(t):
+    return None if t is None else t.to(DEV)
+
+
+def close(a, b, tol=2e-5, msg=""):
+    e = relerr(a.detach().cpu().numpy() if torch.is_tensor(a) else a, b.detach().cpu().numpy() if torch.is_tensor(b) else b)
+    assert e < tol, "%s rel err %.3e" % (msg, e)
+
+
+# ----------------------------------------------------------------------------------------------
+# kernels one by one, against the documented semantics (tests/fake_ops.py) or fp64 torch
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("a_k,b_k", [(True, True), (True, False), (False, False), (False, True)])
+@pytest.mark.parametrize("M,N,K,splitk", [(64, 48, 32, 1), (256, 1536, 512, 1), (130, 342, 75, 1), (7, 3, 513, 1),
+                                          (300, 200, 4100, 8), (1536, 512, 2048, 4)])
+def test_gemm(ops, a_k, b_k, M, N, K, splitk):
+    torch.manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn((M, K) if a_k else (K, M))
+    B = torch.randn((N, K) if b_k else (K, N))
+    C0 = torch.randn(M, N)
+    bias = torch.randn(N)
+    ref = 0.5 * ((A if a_k else A.t()).double() @ (B.t() if b_k else B).double()) + 2.0 * C0.double() + bias.double()
+    Cd = g(C0.clone())
+    ops.gemm(g(A), g(B), Cd, a_k=a_k, b_k=b_k, alpha=0.5, beta=2.0, bias=g(bias), splitk=splitk)
+    close(Cd, ref.float(), 1e-5, "gemm")
+
+
+def test_gemm_is_transpose_detecting(ops):
+    """identity A with an ASYMMETRIC B: catches a swapped C-write (cdna guide rule 16)."""
+    n = 96
+    A = torch.eye(n)
+    B = torch.arange(n * n, dtype=torch.float32).view(n, n) / 7.0          # B[k][j], asymmetric
+    C = torch.zeros(n, n, device=DEV)
+    ops.gemm(g(A), g(B), C, a_k=True, b_k=False)
+    assert torch.equal(C.cpu(), B)
+
+
+def test_gemm_strided_views(ops):
+    """sub-matrix views with odd leading dimensions (W_ih[:, 342:], logits[:, :342]) take the scalar-load path."""
+    torch.manual_seed(3)
+    W = torch.randn(192, 622)
+    z = torch.randn(37, 280)
+    out = torch.zeros(37, 200, device=DEV)
+    ops.gemm(g(z), g(W)[:, 342:], out[:, :192])
+    close(out[:, :192], (z.double() @ W[:, 342:].double().t()).float(), 1e-5)
+    assert float(out[:, 192:].abs().max()) == 0.0
+    dl = torch.randn(50, 344)
+    Wo = torch.randn(342, 64)
+    dh = torch.zeros(50, 64, device=DEV)
+    ops.gemm(g(dl)[:, :342], g(Wo), dh, a_k=True, b_k=False)
+    close(dh, (dl[:, :342].double() @ Wo.double()).float(), 1e-5)
+
+
+def test_small_dense_helpers(ops):
+    torch.manual_seed(5)
+    X = torch.randn(1000, 342)
+    dst = torch.zeros(342, 1004, device=DEV)
+    ops.transpose(g(X), dst[:, :1000])
+    assert torch.equal(dst[:, :1000].cpu(), X.t())
+    out = torch.ones(342, device=DEV)
+    ops.colsum(g(X), out, beta=1.0)
+    close(out, (X.double().sum(0) + 1).float(), 1e-5)
+    big = torch.randn(70000, 96)
+    out = torch.zeros(96, device=DEV)
+    ops.colsum(g(big), out)
+    close(out, big.double().sum(0).float(), 2e-5)
+    y = torch.randn(5000, device=DEV)
+    x = torch.randn(5000, device=DEV)
+    y0 = y.clone()
+    ops.axpy(0.25, x, y)
+    close(y, y0 + 0.25 * x, 1e-6)
+    s = torch.zeros(3, device=DEV)
+    ops.sum(x, s[1:2], 0.5)
+    close(s[1], 0.5 * x.double().sum().float(), 1e-5)
+    gbuf = torch.randn(1234567, device=DEV)
+    ss = torch.zeros(1, device=DEV)
+    ops.sumsq(gbuf, ss)
+    close(ss, (gbuf.double() ** 2).sum().float().view(1), 1e-6)
+    oh = torch.zeros(40, 342)
+    ids = torch.randint(0, 342, (40,))
+    oh[torch.arange(40), ids] = 1
+    idx = torch.zeros(40, dtype=torch.int32, device=DEV)
+    ops.onehot_to_index(g(oh), idx)
+    assert torch.equal(idx.cpu().long(), ids)
+
+
+def _scan_inputs(B, T, H, V, seed, with_table=True, reverse=0, shift=0):
+    torch.manual_seed(seed)
+    s = dict(B=B, T=T, H=H, reverse=reverse, w_hh=torch.randn(3 * H, H) / math.sqrt(H), b_hh=torch.randn(3 * H) * 0.1,
+             b_ih=torch.randn(3 * H) * 0.1, h0=torch.randn(B, H) * 0.5, gx_rowbias=torch.randn(B, 3 * H) * 0.3,
+             idx_shift=shift, start_token=V - 1)
+    if with_table:
+        s["gx_table"] = torch.randn(V, 3 * H) * 0.5
+        s["idx"] = torch.randint(0, V, (B, T), dtype=torch.int32)
+    else:
+        s["gx_dense"] = torch.randn(T, B, 3 * H) * 0.5
+    s["h_all"] = torch.zeros(T, B, H)
+    s["gates"] = torch.zeros(T, B, 4, H)
+    return s
+
+
+def _to_dev(s):
+    return {k: (g(v) if torch.is_tensor(v) else v) for k, v in s.items()}
+
+
+@pytest.mark.parametrize("B,T,H", [(6, 5, 64), (70, 9, 48), (256, 4, 512)])
+def test_gru_scan_fwd_bwd_kernels(ops, B, T, H):
+    """fn_gru_seq_fwd / fn_gru_seq_bwd: three concurrent scans (table+reverse, table+shift, dense; different T)."""
+    fake = FakeOps()
+    cpu = [_scan_inputs(B, T, H, 21, 1, True, reverse=1), _scan_inputs(B, T + 2, H, 21, 2, True, shift=-1),
+           _scan_inputs(B, max(1, T - 2), H, 21, 3, False)]
+    cpu[2]["h0"] = None
+    dev = [_to_dev(s) for s in cpu]
+    fake.gru_seq_fwd(cpu)
+    ops.gru_seq_fwd(dev)
+    for i, (c, d) in enumerate(zip(cpu, dev)):
+        close(d["h_all"], c["h_all"], 2e-5, "h_all[%d]" % i)
+        close(d["gates"], c["gates"], 2e-5, "gates[%d]" % i)
+    bc, bd = [], []
+    for i, c in enumerate(cpu):
+        Ti = c["T"]
+        torch.manual_seed(10 + i)
+        b = dict(B=B, T=Ti, H=H, w_hh_t=c["w_hh"].t().contiguous(), h0=c.get("h0"), h_all=c["h_all"], gates=c["gates"],
+                 dh_last=torch.randn(B, H) if i != 1 else None, dh_ext=torch.randn(Ti, B, H) if i != 0 else None,
+                 dgx_all=torch.zeros(Ti, B, 3 * H), dghn_all=torch.zeros(Ti, B, H), dh0=torch.zeros(B, H) if i != 2 else None,
+                 dgx_rowsum=torch.zeros(B, 3 * H) if i == 1 else None, scratch=torch.zeros(B, H))
+        bc.append(b)
+        bd.append(_to_dev(b))
+    fake.gru_seq_bwd(bc)
+    ops.gru_seq_bwd(bd)
+    for i, (c, d) in enumerate(zip(bc, bd)):
+        for k in ("dgx_all", "dghn_all", "dh0", "dgx_rowsum"):
+            if c[k] is not None:
+                close(d[k], c[k], 5e-5, "%s[%d]" % (k, i))
+    # token-segment sums of dgx (one-hot W_ih columns)
+    for i in (0, 1):
+        out_c, out_d = torch.zeros(21, 3 * H), torch.zeros(21, 3 * H, device=DEV)
+        fake.embed_grad(bc[i]["dgx_all"], cpu[i]["idx"], cpu[i]["idx_shift"], 20, cpu[i]["reverse"], 21, out_c)
+        ops.embed_grad(bd[i]["dgx_all"], dev[i]["idx"], cpu[i]["idx_shift"], 20, cpu[i]["reverse"], 21, out_d)
+        close(out_d, out_c, 5e-5, "embed_grad[%d]" % i)
+
+
+def test_embed_grad_full_vocab(ops):
+    torch.manual_seed(8)
+    T, B, N3, V = 33, 130, 200, 342
+    dgx = torch.randn(T, B, N3)
+    idx = torch.randint(0, V, (B, T), dtype=torch.int32)
+    idx[:, T // 2:] = 0                                        # heavy padding token, like real batches
+    ref, out = torch.zeros(V, N3), torch.zeros(V, N3, device=DEV)
+    FakeOps().embed_grad(dgx, idx, 0, 0, 0, V, ref)
+    ops.embed_grad(g(dgx), g(idx), 0, 0, 0, V, out)
+    close(out, ref, 2e-5)
+
+
+def test_head_kernels(ops):
+    fake = FakeOps()
+    torch.manual_seed(11)
+    B, T, E = 9, 7, 342
+    logits = torch.randn(T * B, 344) * 3
+    target = torch.randint(0, E, (B, T), dtype=torch.int32)
+    lp_c, nll_c, dl_c = torch.zeros(B, T, E), torch.zeros(T * B), torch.zeros(T * B, 344)
+    fake.vocab_logsoftmax(logits, B, T, E, lp_c, target, nll_c, 0.37, dl_c)
+    ld = g(logits)
+    lp_d, nll_d = torch.zeros(B, T, E, device=DEV), torch.zeros(T * B, device=DEV)
+    ops.vocab_logsoftmax(ld, B, T, E, lp_d, g(target), nll_d, 0.37, ld)       # dlogits in place
+    close(lp_d, lp_c), close(nll_d, nll_c), close(ld[:, :E], dl_c[:, :E], 2e-5)
+    gout = torch.randn(B, T, E)
+    d1c, d1d = torch.zeros(T * B, 344), torch.zeros(T * B, 344, device=DEV)
+    fake.vocab_logsoftmax_bwd(lp_c, gout, d1c)
+    ops.vocab_logsoftmax_bwd(lp_d, g(gout), d1d)
+    close(d1d[:, :E], d1c[:, :E], 2e-5)
+    # time axis
+    Tr, Cc = 8, 16
+    lg = torch.randn(Tr, B, Cc) * 2
+    tg = torch.randint(0, Cc, (B, Tr), dtype=torch.int32)
+    lpc, nc, dc = torch.zeros(B, Tr, Cc), torch.zeros(B, Cc), torch.zeros(Tr, B, Cc)
+    lpd, nd, dd = (torch.zeros_like(x, device=DEV) for x in (lpc, nc, dc))
+    fake.time_logsoftmax(lg, lpc, tg, nc, 0.11, dc)
+    ops.time_logsoftmax(g(lg), lpd, g(tg), nd, 0.11, dd)
+    close(lpd, lpc), close(nd, nc), close(dd, dc, 2e-5)
+    go = torch.randn(B, Tr, Cc)
+    d2c, d2d = torch.zeros(Tr, B, Cc), torch.zeros(Tr, B, Cc, device=DEV)
+    fake.time_logsoftmax_bwd(lpc, go, d2c)
+    ops.time_logsoftmax_bwd(lpd, g(go), d2d)
+    close(d2d, d2c, 2e-5)
+    # greedy head incl. exact ties -> first index
+    lg2 = torch.randn(13, 344)
+    lg2[3, 100] = lg2[3, 200] = 50.0
+    lg2[5, 0] = lg2[5, 341] = 60.0
+    tok = torch.zeros(13, 4, dtype=torch.int32, device=DEV)
+    lp2 = torch.zeros(13, 4, E, device=DEV)
+    ops.vocab_argmax(g(lg2), E, lp2[:, 2, :], tok[:, 2])
+    assert torch.equal(tok[:, 2].cpu().long(), lg2[:, :E].max(1)[1])
+    assert int(tok[3, 2]) == 100 and int(tok[5, 2]) == 0
+    close(lp2[:, 2, :], torch.log_softmax(lg2[:, :E].double(), -1).float())
+
+
+@pytest.mark.parametrize("sup", [False, True])
+def test_latent_kernels(ops, sup):
+    fake = FakeOps()
+    torch.manual_seed(21)
+    B, Z, K = 11, 128, 2
+    pre = torch.randn(B, 2 * Z) * 0.3
+    eps = torch.randn(B, Z)
+    mu_lk = torch.randn(K, Z) * 0.2
+    lv_lk = torch.full((K, Z), -4.0) + torch.randn(K, Z) * 0.01
+    labels = torch.randint(0, K, (B,), dtype=torch.int32) if sup else None
+    names = ("sigma", "z", "ll", "qy", "y", "terms")
+    oc = dict(sigma=torch.zeros(B, Z), z=torch.zeros(B, Z), ll=torch.zeros(B, K), qy=torch.zeros(B, K),
+              y=torch.zeros(B, dtype=torch.int32), terms=torch.zeros(B, 4))
+    od = {k: g(v.clone()) for k, v in oc.items()}
+    fake.latent_fwd(pre, eps, mu_lk, lv_lk, labels, *[oc[k] for k in names])
+    ops.latent_fwd(g(pre), g(eps), g(mu_lk), g(lv_lk), g(labels), *[od[k] for k in names])
+    for k in ("sigma", "z", "ll", "qy"):
+        close(od[k], oc[k], 2e-5, k)
+    assert torch.equal(od["y"].cpu(), oc["y"])
+    cols = (0, 1, 2, 3) if sup else (0, 1)
+    close(od["terms"][:, cols], oc["terms"][:, cols], 5e-5, "terms")
+    ups = [torch.randn(B, Z), torch.randn(B, Z), torch.randn(B, Z), torch.randn(B, K), torch.randn(B, K)]
+    w = (0.3, 0.0, 0.7) if sup else (0.3, 0.2, 0.0)
+    dc, mc = torch.zeros(B, 2 * Z), torch.zeros(B, K * Z)
+    dd, md = g(dc.clone()), g(mc.clone())
+    fake.latent_bwd(pre, eps, mu_lk, lv_lk, labels, oc["z"], oc["qy"], *ups, *w, dc, mc)
+    ops.latent_bwd(g(pre), g(eps), g(mu_lk), g(lv_lk), g(labels), od["z"], od["qy"], *[g(u) for u in ups], *w, dd, md)
+    close(dd, dc, 1e-4, "dpre")
+    close(md, mc, 1e-4, "dmu_lk_rows")
+
+
+def test_latent_kernel_saturated_posterior(ops):
+    """q(y|x) underflows to exactly (1, 0) at initialisation (KL terms ~1500): gradients must stay finite."""
+    torch.manual_seed(2)
+    B, Z, K = 5, 128, 2
+    pre, eps = torch.randn(B, 2 * Z) * 0.1, torch.randn(B, Z)
+    mu_lk, lv_lk = torch.randn(K, Z) * 0.2, torch.full((K, Z), -4.0)
+    o = [torch.zeros(B, Z, device=DEV), torch.zeros(B, Z, device=DEV), torch.zeros(B, K, device=DEV), torch.zeros(B, K, device=DEV),
+         torch.zeros(B, dtype=torch.int32, device=DEV), torch.zeros(B, 4, device=DEV)]
+    ops.latent_fwd(g(pre), g(eps), g(mu_lk), g(lv_lk), None, *o)
+    assert float(o[3].min()) == 0.0                                # saturated
+    dd, md = torch.zeros(B, 2 * Z, device=DEV), torch.zeros(B, K * Z, device=DEV)
+    ops.latent_bwd(g(pre), g(eps), g(mu_lk), g(lv_lk), None, o[1], o[3], None, None, None, None, None, 0.1, 0.1, 0.0, dd, md)
+    assert bool(torch.isfinite(dd).all()) and bool(torch.isfinite(md).all())
+
+
+def test_pairwise_and_adam_kernels(ops):
+    fake = FakeOps()
+    torch.manual_seed(31)
+    n_all = 300
+    z0 = torch.randn(n_all)
+    attr = torch.randint(0, 17, (n_all,)).double() / 16.0            # many exact ties -> sign 0
+    lc, gc = torch.zeros(100), torch.zeros(100)
+    ld_, gd = torch.zeros(100, device=DEV), torch.zeros(100, device=DEV)
+    fake.pairwise_reg(z0, attr, 150, 100, lc, 1e-3, gc)
+    ops.pairwise_reg(g(z0), g(attr), 150, 100, ld_, 1e-3, gd)
+    close(ld_, lc, 2e-5), close(gd, gc, 5e-5)
+    n = 100003
+    p, gr, m, v = torch.randn(n), torch.randn(n) * 3, torch.rand(n) * 0.1, torch.rand(n) * 0.01
+    pc, mc, vc = p.clone(), m.clone(), v.clone()
+    pd, md, vd = g(p.clone()), g(m.clone()), g(v.clone())
+    ssc = torch.zeros(1)
+    fake.sumsq(gr, ssc)
+    fake.clip_adam(pc, gr, mc, vc, ssc, 1.0, 1e-3, 0.9, 0.999, 1e-8, 7)
+    ops.clip_adam(pd, g(gr), md, vd, g(ssc), 1.0, 1e-3, 0.9, 0.999, 1e-8, 7)
+    close(pd, pc, 1e-6), close(md, mc, 1e-5), close(vd, vc, 1e-5)
+
+
+# ----------------------------------------------------------------------------------------------
+# end to end against the golden fixtures (small: stored weights; c0: seeded H=512 weights)
+# ----------------------------------------------------------------------------------------------
+def _fw_check(res, gold, tol):
+    (out, r_out, n_out, _, _), (dis_r, dis_n), (z_r, z_n), (ll_r, ll_n), (qy_r, qy_n), (y_r, y_n) = res
+    got = dict(out=out, r_out=r_out, n_out=n_out, mu_r=dis_r.mean, sigma_r=dis_r.stddev, mu_n=dis_n.mean, sigma_n=dis_n.stddev,
+               z_r=z_r, z_n=z_n, ll_r=ll_r, ll_n=ll_n, qy_r=qy_r, qy_n=qy_n)
+    for k, v in got.items():
+        np.testing.assert_allclose(v.detach().cpu().numpy(), gold["fw_" + k], rtol=tol, atol=tol, err_msg=k)
+    assert np.array_equal(y_r.cpu().numpy(), gold["fw_y_r"]) and np.array_equal(y_n.cpu().numpy(), gold["fw_y_n"])
+    return got
+
+
+@pytest.mark.parametrize("case", ["small", "c0"])
+def test_dropin_forward_backward_vs_reference(case, small, c0):
+    gold = small if case == "small" else c0
+    H, Z = int(gold["meta_dims"][0]), int(gold["meta_dims"][1])
+    m = make_model(H, Z, sd_from(gold, "w0/") if case == "small" else None, device=DEV)
+    pkg = load_package()
+    b = batch_of(gold)
+    d, r, n = (torch.from_numpy(b[k]).to(DEV) for k in ("d", "r", "n"))
+    c = torch.from_numpy(b["c"]).to(DEV)
+    eps = (torch.from_numpy(gold["eps_r"]).to(DEV), torch.from_numpy(gold["eps_n"]).to(DEV))
+    res = m(pkg.convert_to_one_hot(d, 342), pkg.convert_to_one_hot(r, 3), pkg.convert_to_one_hot(n, 16), c, eps=eps)
+    got = _fw_check(res, gold, 1e-4)
+    # the reference's torch loss code on top of our outputs, then autograd through the fused node
+    sd = {k: p for k, p in m.named_parameters()}
+    got_cpu_free = {k: v for k, v in got.items()}
+    import oracle.gmvae_oracle as o
+    ls = o.loss_function(sd, got_cpu_free, d.long(), r.long(), n.long(), 20000, beta=0.2)
+    zr, zn = got["z_r"], got["z_n"]
+    l_r, l_n = [((torch.tanh(z[:, 0].reshape(-1, 1) - z[:, 0]) -
+                  torch.sign(torch.from_numpy(np.subtract.outer(a, a)).float().to(DEV))) ** 2).mean()
+                for z, a in ((zr, b["r_density"]), (zn, b["n_density"]))]
+    loss = ls[0] + l_r + l_n
+    np.testing.assert_allclose(float(loss.detach()), gold["total_loss_unsup_20000"][0], rtol=2e-5)
+    loss.backward()
+    sq = 0.0
+    for k, p in m.named_parameters():
+        if k.startswith(orc.UNUSED_PREFIXES) or k in orc.FROZEN:
+            assert p.grad is None, k
+            continue
+        gcpu = p.grad.detach().cpu().double()
+        sq += float((gcpu ** 2).sum())
+        if case == "small":
+            ref = gold["grad_unsup/" + k]
+            e = relerr(gcpu.numpy(), ref)
+            assert e < 5e-4 or np.abs(ref).max() < 1e-6, (k, e)
+        else:
+            ref = gold["gradsum_unsup/" + k]
+            np.testing.assert_allclose(float(gcpu.abs().sum()), ref[1], rtol=5e-4, atol=1e-5, err_msg=k)
+    np.testing.assert_allclose(math.sqrt(sq), gold["gradnorm_unsup_20000"][0], rtol=1e-4)
+
+
+@pytest.mark.parametrize("case,sup", [("small", False), ("small", True), ("c0", False)])
+def test_fused_gradients_vs_reference(case, sup, small, c0):
+    gold = small if case == "small" else c0
+    H, Z = int(gold["meta_dims"][0]), int(gold["meta_dims"][1])
+    pkg = load_package()
+    m = make_model(H, Z, sd_from(gold, "w0/") if case == "small" else None, device=DEV)
+    tr = pkg.GMVAETrainer(m, lr=1e-3, beta=0.2)
+    b = batch_of(gold)
+    batch = tr.prepare_batch(b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"], b["a"] if sup else None)
+    eps = (torch.from_numpy(gold["eps_r"]).to(DEV), torch.from_numpy(gold["eps_n"]).to(DEV))
+    dl_sd, lat_up, w, beta0, Bg = tr._forward_losses(20000, batch, eps, want_grads=True)
+    m.engine().backward(tr.flat.G, dl_sd, lat_up, *w)
+    tag = "sup" if sup else "unsup"
+    tup = tr._tuple8(beta0, Bg, sup)
+    np.testing.assert_allclose(tup[0], gold["total_loss_%s_20000" % tag][0], rtol=2e-5)
+    for k in tr.flat.names:
+        gk = tr.flat.G[k].cpu().double()
+        if case == "small":
+            ref = gold["grad_%s/%s" % (tag, k)]
+            e = relerr(gk.numpy(), ref)
+            assert e < 5e-4 or np.abs(ref).max() < 1e-6, (k, e)
+        else:
+            ref = gold["gradsum_%s/%s" % (tag, k)]
+            np.testing.assert_allclose(float(gk.abs().sum()), ref[1], rtol=5e-4, atol=1e-5, err_msg=k)
+    m.engine().ops.sumsq(tr.flat.grad, tr.sumsq)
+    np.testing.assert_allclose(tr.grad_norm(), gold["gradnorm_%s_20000" % tag][0], rtol=1e-4)
+
+
+@pytest.mark.parametrize("case", ["small", "c0"])
+def test_three_train_steps_vs_reference_train(case, small, c0):
+    """GMVAETrainer.train vs the reference's own train() (trainer_gmm.py:220-258), 3 steps from step 19999."""
+    gold = small if case == "small" else c0
+    H, Z = int(gold["meta_dims"][0]), int(gold["meta_dims"][1])
+    pkg = load_package()
+    m = make_model(H, Z, sd_from(gold, "w0/") if case == "small" else None, device=DEV)
+    tr = pkg.GMVAETrainer(m, lr=1e-3, beta=0.2)
+    b = batch_of(gold)
+    step = 19999
+    for it in range(3):
+        torch.manual_seed(99 + it)
+        step, tup = tr.train(step, None, None, None, b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"])
+        np.testing.assert_allclose(tup, gold["train_tuples"][it], rtol=5e-4, err_msg="step %d" % it)
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    if case == "small":
+        for k, v in sd_from(gold, "w3/").items():
+            if k not in NOISE_PARAMS:
+                np.testing.assert_allclose(sd[k].numpy(), v.numpy(), rtol=0, atol=1e-4, err_msg=k)
+    else:
+        for k, v in sd.items():
+            if k not in NOISE_PARAMS:
+                vd = v.double()
+                np.testing.assert_allclose([vd.abs().sum().item(), (vd * vd).sum().item()], gold["w3sum/" + k][1:], rtol=2e-5, err_msg=k)
+    torch.manual_seed(123)
+    ev = tr.evaluate(step - 1, None, None, None, b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"])
+    np.testing.assert_allclose(ev, gold["eval_tuple"], rtol=5e-4)
+
+
+@pytest.mark.parametrize("case", ["small", "c0"])
+def test_greedy_decode_tokens(case, small, c0):
+    gold = small if case == "small" else c0
+    H, Z = int(gold["meta_dims"][0]), int(gold["meta_dims"][1])
+    m = make_model(H, Z, sd_from(gold, "w0/") if case == "small" else None, device=DEV)
+    m.eval()
+    z = torch.from_numpy(gold["dec_z"]).to(DEV)
+    steps = gold["dec_tokens"].shape[1]
+    lp = m.global_decoder(z, steps)
+    np.testing.assert_allclose(lp[:, 0].cpu().numpy(), gold["dec_logp_first"], rtol=1e-4, atol=1e-4)
+    tok = lp.argmax(-1).cpu().numpy()
+    ref, gap = gold["dec_tokens"], gold["dec_gap"]
+    checked = 0
+    for i in range(tok.shape[0]):
+        tight = np.nonzero(gap[i] < 1e-4)[0]
+        upto = int(tight[0]) if len(tight) else steps        # exact up to the first near-tie of the reference itself
+        assert np.array_equal(tok[i, :upto], ref[i, :upto]), (i, upto)
+        checked += upto
+    assert checked >= 0.9 * tok.size
+    pkg = load_package()
+    d = torch.from_numpy(gold["d"]).to(DEV)
+    c = torch.from_numpy(gold["c"]).to(DEV)
+    eps = (torch.from_numpy(gold["eps_r"]), torch.from_numpy(gold["eps_n"]))
+    tk, _ = pkg.fader_sweep(m, d, c, [0.75, -0.5], steps=steps, which="r", eps=eps)
+    assert np.array_equal(tk[:, 0].cpu().numpy()[:, :8], ref[:, :8])
+
+
+# ----------------------------------------------------------------------------------------------
+# BASELINE size (B=256, T=256, Tr=64, H=512): size-independent properties
+# ----------------------------------------------------------------------------------------------
+def test_full_size_properties():
+    pkg = load_package()
+    from music_fader_nets_amd.synth import synth_batch
+    B, T, Tr = 256, 256, 64
+    m = make_model(512, 128, device=DEV)
+    tr = pkg.GMVAETrainer(m, lr=1e-3, beta=0.2)
+    b = synth_batch(np.random.RandomState(0), B, T, Tr)
+    batch = tr.prepare_batch(b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"])
+    torch.manual_seed(99)
+    eps = tr.draw_eps(B, T)
+    # (1) determinism: the same step twice from the same state gives bit-identical gradients
+    dl_sd, lat_up, w, beta0, Bg = tr._forward_losses(20000, batch, eps, True)
+    m.engine().backward(tr.flat.G, dl_sd, lat_up, *w)
+    g1 = tr.flat.grad.clone()
+    t1 = tr._tuple8(beta0, Bg, False)
+    dl_sd, lat_up, w, beta0, Bg = tr._forward_losses(20000, batch, eps, True)
+    m.engine().backward(tr.flat.G, dl_sd, lat_up, *w)
+    assert torch.equal(g1, tr.flat.grad)
+    assert bool(torch.isfinite(g1).all())
+    # (2) batch-row independence: the loss of the first 64 rows alone equals the same rows' share
+    #     (CE terms are per-row means) -> CE_X of a sub-batch computed separately matches the row-slice mean
+    nll = m.engine()._bufs["nll_rows"].view(T, B)
+    sub = tr.prepare_batch(b["d"][:64], b["r"][:64], b["n"][:64], b["c"][:64], b["r_density"][:64], b["n_density"][:64])
+    full_rows = float(nll[:, :64].double().sum()) / (64 * T)        # before: computed inside the full batch
+    tr._forward_losses(20000, sub, (eps[0][:64].contiguous(), eps[1][:64].contiguous()), False)
+    t_sub = tr._tuple8(beta0, 64, False)
+    np.testing.assert_allclose(t_sub[1], full_rows, rtol=1e-5)
+    # (3) directional derivative: loss(w + h*g/|g|) - loss(w - h*g/|g|) ~ 2h|g|
+    gn = float(g1.double().norm())
+    hstep = 2e-3
+    p0 = tr.flat.param.clone()
+    vals = []
+    for sgn in (+1, -1):
+        tr.flat.param.copy_(p0 + sgn * hstep * g1 / gn)
+        m.weights_changed()
+        tr._forward_losses(20000, batch, eps, False)
+        vals.append(tr._tuple8(beta0, Bg, False)[0])
+    tr.flat.param.copy_(p0)
+    m.weights_changed()
+    np.testing.assert_allclose((vals[0] - vals[1]) / (2 * hstep), gn, rtol=2e-2)
+    # (4) a few optimisation steps reduce the reconstruction loss
+    step, first = 20000, None
+    for it in range(6):
+        step, tup = tr.train(step, None, None, None, b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"], eps=eps)
+        first = first or tup
+    assert tup[1] < first[1] and all(math.isfinite(x) for x in tup)

@@ -1,0 +1,149 @@
+"""Host-side schedule (engine / trainer / decode) checked WITHOUT a GPU: the C-ABI ops are replaced by their documented
+semantics (tests/fake_ops.py) and results are compared with the golden fixtures / the oracle.  The same assertions
+run against the real HIP kernels in test_gpu_parity.py."""
+import numpy as np
+import pytest
+import torch
+
+from fake_ops import FakeOps
+from helpers import NOISE_PARAMS, batch_of, load_golden, make_model, relerr, sd_from
+from mfn_import import load_package
+from oracle import gmvae_oracle as orc
+
+
+@pytest.fixture(scope="module")
+def small():
+    return load_golden("small")
+
+
+def _tensors(g):
+    b = batch_of(g)
+    return (torch.from_numpy(b["d"]), torch.from_numpy(b["r"]), torch.from_numpy(b["n"]), torch.from_numpy(b["c"]),
+            torch.from_numpy(g["eps_r"]), torch.from_numpy(g["eps_n"]))
+
+
+def test_cpu_model_without_library_hook_raises(small):
+    m = make_model(64, 32, sd_from(small, "w0/"))
+    d, r, n, c, er, en = _tensors(small)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(d, r, n, c, eps=(er, en))
+
+
+def test_state_dict_contract(small):
+    m = make_model(64, 32)
+    ref = sd_from(small, "w0/")
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(ref.keys()) or set(sd.keys()) == set(ref.keys())
+    for k, v in ref.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+        assert torch.equal(sd[k], v), k          # seeded construction == the reference's seeded construction
+    assert not m.logvar_r_lookup.weight.requires_grad and m.mu_r_lookup.weight.requires_grad
+
+
+def test_dropin_forward_and_autograd(small):
+    """model(...) returns the reference's nested tuple; the reference-style torch loss on top of it back-propagates
+    through the single fused autograd node into .grad of exactly the parameters the reference gives a gradient."""
+    m = make_model(64, 32, sd_from(small, "w0/"), ops=FakeOps())
+    d, r, n, c, er, en = _tensors(small)
+    pkg = load_package()
+    res = m(pkg.convert_to_one_hot(d, 342), pkg.convert_to_one_hot(r, 3), pkg.convert_to_one_hot(n, 16), c, eps=(er, en))
+    (out, r_out, n_out, z0, z1), (dis_r, dis_n), (z_r, z_n), (ll_r, ll_n), (qy_r, qy_n), (y_r, y_n) = res
+    assert z0 == 0 and z1 == 0
+    got = dict(out=out, r_out=r_out, n_out=n_out, mu_r=dis_r.mean, sigma_r=dis_r.stddev, mu_n=dis_n.mean, sigma_n=dis_n.stddev,
+               z_r=z_r, z_n=z_n, ll_r=ll_r, ll_n=ll_n, qy_r=qy_r, qy_n=qy_n)
+    for k, v in got.items():
+        np.testing.assert_allclose(v.detach().numpy(), small["fw_" + k], rtol=2e-5, atol=2e-5, err_msg=k)
+    assert np.array_equal(y_r.numpy(), small["fw_y_r"]) and np.array_equal(y_n.numpy(), small["fw_y_n"])
+    # reference-style loss in torch on OUR outputs (what trainer_gmm.py would do after `from gmm_model import *`)
+    sd = {k: p for k, p in m.named_parameters()}
+    ls = orc.loss_function(sd, got, d, r, n, 20000, beta=0.2)
+    l_r, l_n = orc.latent_regularized_loss(z_r, z_n, small["r_density"], small["n_density"])
+    loss = ls[0] + l_r + l_n
+    np.testing.assert_allclose(float(loss.detach()), small["total_loss_unsup_20000"][0], rtol=1e-5)
+    loss.backward()
+    for k, p in m.named_parameters():
+        ref = small.get("grad_unsup/" + k)
+        if ref is None:
+            assert p.grad is None, k
+            continue
+        assert p.grad is not None, k
+        assert relerr(p.grad.numpy(), ref) < 3e-4 or np.abs(ref).max() < 1e-6, (k, relerr(p.grad.numpy(), ref))
+
+
+@pytest.mark.parametrize("sup", [False, True])
+def test_fused_step_gradients(small, sup):
+    pkg = load_package()
+    m = make_model(64, 32, sd_from(small, "w0/"), ops=FakeOps())
+    tr = pkg.GMVAETrainer(m, lr=1e-3, beta=0.2)
+    b = batch_of(small)
+    batch = tr.prepare_batch(b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"], b["a"] if sup else None)
+    eps = (torch.from_numpy(small["eps_r"]), torch.from_numpy(small["eps_n"]))
+    dl_sd, lat_up, w, beta0, Bg = tr._forward_losses(20000, batch, eps, want_grads=True)
+    m.engine().backward(tr.flat.G, dl_sd, lat_up, *w)
+    tag = "sup" if sup else "unsup"
+    tup = tr._tuple8(beta0, Bg, sup)
+    np.testing.assert_allclose(tup[0], small["total_loss_%s_20000" % tag][0], rtol=1e-5)
+    for k in tr.flat.names:
+        ref = small["grad_%s/%s" % (tag, k)]
+        e = relerr(tr.flat.G[k].numpy(), ref)
+        assert e < 3e-4 or np.abs(ref).max() < 1e-6, (k, e)
+    tr.model.engine().ops.sumsq(tr.flat.grad, tr.sumsq)
+    np.testing.assert_allclose(tr.grad_norm(), small["gradnorm_%s_20000" % tag][0], rtol=1e-4)
+
+
+def test_three_fused_train_steps(small):
+    """GMVAETrainer.train == the reference's train() (trainer_gmm.py:220) for 3 steps from step 19999."""
+    pkg = load_package()
+    m = make_model(64, 32, sd_from(small, "w0/"), ops=FakeOps())
+    tr = pkg.GMVAETrainer(m, lr=1e-3, beta=0.2)
+    b = batch_of(small)
+    step = 19999
+    for it in range(3):
+        torch.manual_seed(99 + it)
+        step, tup = tr.train(step, None, None, None, b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"])
+        np.testing.assert_allclose(tup, small["train_tuples"][it], rtol=3e-4, err_msg="step %d" % it)
+    sd = m.state_dict()
+    for k, v in sd_from(small, "w3/").items():
+        if k in NOISE_PARAMS:
+            continue
+        np.testing.assert_allclose(sd[k].numpy(), v.numpy(), rtol=0, atol=1e-4, err_msg=k)   # Adam step = 1e-3; near-zero gradients carry rounding noise
+    torch.manual_seed(123)
+    ev = tr.evaluate(step - 1, None, None, None, b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"])
+    np.testing.assert_allclose(ev, small["eval_tuple"], rtol=3e-4)
+
+
+def test_greedy_decode_and_clean_output(small):
+    pkg = load_package()
+    m = make_model(64, 32, sd_from(small, "w0/"), ops=FakeOps())
+    m.eval()
+    z = torch.from_numpy(small["dec_z"])
+    steps = small["dec_tokens"].shape[1]
+    lp = m.global_decoder(z, steps)
+    assert tuple(lp.shape) == (z.shape[0], steps, 342)
+    assert np.array_equal(lp.argmax(-1).numpy(), small["dec_tokens"])
+    np.testing.assert_allclose(lp[:, 0].numpy(), small["dec_logp_first"], rtol=1e-5, atol=1e-5)
+    hand = load_golden("hand")
+    for i in range(5):
+        got = pkg.clean_output(torch.from_numpy(hand["clean_in_%d" % i]))
+        assert np.array_equal(got, hand["clean_out_%d" % i])
+    with pytest.raises(NotImplementedError):
+        m.train()
+        m.global_decoder(z, 3)
+
+
+def test_encode_and_fader_sweep_shapes(small):
+    pkg = load_package()
+    m = make_model(64, 32, sd_from(small, "w0/"), ops=FakeOps())
+    d, r, n, c, er, en = _tensors(small)
+    m.eval()
+    dis_r, dis_n = m.encode(pkg.convert_to_one_hot(d, 342))
+    np.testing.assert_allclose(dis_r.mean.numpy(), small["fw_mu_r"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(dis_n.stddev.numpy(), small["fw_sigma_n"], rtol=2e-5, atol=2e-5)
+    tok, z0 = pkg.fader_sweep(m, d, c, [0.75], steps=30, which="r", eps=(er, en))
+    assert np.array_equal(tok[:, 0].numpy(), small["dec_tokens"])          # golden decode used z_r[:,0] = 0.75
+    ll, qy = m.approx_qy_x(torch.from_numpy(small["fw_z_r"]), m.mu_r_lookup, m.logvar_r_lookup, 2)
+    np.testing.assert_allclose(ll.numpy(), small["fw_ll_r"], rtol=1e-5)
+    r_out, n_out, _, _ = m.sub_decoders(pkg.convert_to_one_hot(r, 3), torch.from_numpy(small["fw_z_r"]),
+                                        pkg.convert_to_one_hot(n, 16), torch.from_numpy(small["fw_z_n"]))
+    np.testing.assert_allclose(r_out.numpy(), small["fw_r_out"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(n_out.numpy(), small["fw_n_out"], rtol=2e-5, atol=2e-5)
