@@ -43,6 +43,9 @@ struct RowsGate {   // local row r of the 48-row weight tile -> row of W_hh ([3H
     FN_DEVINL long operator()(int r) const { return (long)(r >> 4) * H + h0 + (r & 15); }
 };
 
+// NS = number of scans covered by this launch (a distinct kernel symbol per phase: 4 = the encoder step,
+// 3 = decoder layer 1 + both sub-decoders, 1 = a single scan), so per-phase durations show up separately in rocprof.
+template <int NS>
 __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
     using SA = Stage<64, BK, true, NT>;
     using SB = Stage<48, BK, true, NT>;
@@ -52,8 +55,8 @@ __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
     const int v = fn_xcd_remap(blockIdx.x, args.total);
     int si = 0;
 #pragma unroll
-    for (int k = 1; k < FN_MAX_SCANS; ++k)
-        if (k < args.n && v >= args.s[k].tile0) si = k;
+    for (int k = 1; k < NS; ++k)
+        if (v >= args.s[k].tile0) si = k;
     const FwdStep& S = args.s[si];
     const int local = v - S.tile0;
     const int tn = local / S.ntm, tm = local % S.ntm;     // row tiles fastest: neighbours share weight rows
@@ -152,6 +155,7 @@ struct BwdArgs {
     int n, total;
 };
 
+template <int NS>
 __global__ __launch_bounds__(NT) void gru_bwd_step_kernel(const BwdArgs args) {
     using SA = Stage<64, BK, true, NT>;
     using SB = Stage<32, BK, true, NT>;
@@ -161,8 +165,8 @@ __global__ __launch_bounds__(NT) void gru_bwd_step_kernel(const BwdArgs args) {
     const int v = fn_xcd_remap(blockIdx.x, args.total);
     int si = 0;
 #pragma unroll
-    for (int k = 1; k < FN_MAX_SCANS; ++k)
-        if (k < args.n && v >= args.s[k].tile0) si = k;
+    for (int k = 1; k < NS; ++k)
+        if (v >= args.s[k].tile0) si = k;
     const BwdStep& S = args.s[si];
     const int local = v - S.tile0;
     const int tn = local / S.ntm, tm = local % S.ntm;
@@ -320,7 +324,11 @@ int fn_gru_seq_fwd(const FnGruFwd* scans, int n_scans, void* stream) {
             tiles += f.ntm * (d.H / 16);
         }
         a.total = tiles;
-        hipLaunchKernelGGL(gru_fwd_step_kernel, dim3(tiles), dim3(NT), 0, st, a);
+        switch (a.n) {
+#define FN_CASE(N) case N: hipLaunchKernelGGL(gru_fwd_step_kernel<N>, dim3(tiles), dim3(NT), 0, st, a); break;
+            FN_CASE(1) FN_CASE(2) FN_CASE(3) FN_CASE(4) FN_CASE(5) FN_CASE(6) FN_CASE(7) FN_CASE(8)
+#undef FN_CASE
+        }
         FN_CHECK_LAUNCH();
     }
     return FN_OK;
@@ -375,7 +383,11 @@ int fn_gru_seq_bwd(const FnGruBwd* scans, int n_scans, void* stream) {
         }
         if (tiles == 0) continue;
         a.total = tiles;
-        hipLaunchKernelGGL(gru_bwd_step_kernel, dim3(tiles), dim3(NT), 0, st, a);
+        switch (a.n) {
+#define FN_CASE(N) case N: hipLaunchKernelGGL(gru_bwd_step_kernel<N>, dim3(tiles), dim3(NT), 0, st, a); break;
+            FN_CASE(1) FN_CASE(2) FN_CASE(3) FN_CASE(4) FN_CASE(5) FN_CASE(6) FN_CASE(7) FN_CASE(8)
+#undef FN_CASE
+        }
         FN_CHECK_LAUNCH();
     }
     return FN_OK;

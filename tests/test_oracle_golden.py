@@ -167,3 +167,20 @@ def test_greedy_decode_tokens_bit_exact(case, small, c0):
     lp, tok = orc.greedy_decode(sd, torch.from_numpy(g["dec_z"]), steps)
     np.testing.assert_allclose(lp[:, 0].numpy(), g["dec_logp_first"], rtol=1e-5, atol=1e-5)
     assert np.array_equal(tok.numpy(), g["dec_tokens"])
+
+
+def test_cpu_baseline_model_matches_reference_train(c0):
+    """oracle/cpu_baseline.py (the timed torch.nn restatement of the reference's CPU path) reproduces the
+    reference's own train() numbers on BASELINE config 0 (B=8, T=64, hidden 512)."""
+    from mfn_import import load_package
+    load_package()
+    from oracle import cpu_baseline
+    sd = orc.init_state_dict(512, 128)
+    model = cpu_baseline.build(sd, 512, 128)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    B, Z = c0["eps_r"].shape
+    for it in range(2):
+        torch.manual_seed(99 + it)
+        eps_r, eps_n = torch.randn(B, Z), torch.randn(B, Z)
+        tup = cpu_baseline.train_step(model, opt, _batch(c0), eps_r, eps_n, 19999 + it, beta=0.2)
+        np.testing.assert_allclose(tup, c0["train_tuples"][it], rtol=3e-4)
