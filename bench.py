@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--cpu-sample-batch", type=int, default=32)
     args = ap.parse_args()
 
+    t_start = time.perf_counter()
     from mfn_import import load_package
     pkg = load_package()
     from music_fader_nets_amd import parallel
@@ -92,6 +93,11 @@ def main():
     torch.manual_seed(99 + rank)
     eps = (torch.randn(B, Z).to(dev), torch.randn(B, Z).to(dev))
 
+    def log(msg):
+        if rank == 0:
+            print("[bench %.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
+
+    log("model + batch ready on %s" % dev)
     step = 20000
     for _ in range(args.warmup):
         trainer.step_device(step, batch, eps)
@@ -117,7 +123,9 @@ def main():
     assert all(np.isfinite(tup)), tup
 
     tokens_per_s = world * B * T * args.steps / dt
+    log("timed region done: %.3f ms/step" % (dt / args.steps * 1e3))
     roof = measure_dominant_kernel(trainer, batch, eps)
+    log("dominant-kernel timing done")
     roof["step_frac"] = round(tokens_per_s / world * F_ALG_PER_TOKEN / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
     out = {
         "metric": "event-tokens/sec GM-VAE train, seq256 b256", "value": round(tokens_per_s, 1), "unit": "event-tokens/s",

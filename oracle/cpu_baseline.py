@@ -93,11 +93,20 @@ def train_step(model, opt, batch, eps_r, eps_n, step, beta=0.2):
     return tuple(float(v.detach()) for v in (loss, ls[1], ls[2], ls[3], l_r, l_n, ls[4] + ls[5], ls[6] + ls[7]))
 
 
-def time_baseline(H, Z, B, T, Tr, seed=0, steps=1, threads=None):
-    """tokens/s of the CPU path on a bounded sample (B rows of the benchmark's T-step sequences)."""
+def host_threads():
+    """usable host cores: the scheduler affinity of this process (os.cpu_count() over-reports inside containers)."""
     import os
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def time_baseline(H, Z, B, T, Tr, seed=0, steps=1, threads=None, budget_s=30.0):
+    """tokens/s of the CPU path on a BOUNDED sample: B rows of the benchmark's T-step sequences, shrunk (halving B) until
+    a probe step predicts at most `budget_s` seconds of CPU work."""
     from importlib import import_module
-    threads = threads or os.cpu_count()
+    threads = threads or min(host_threads(), 64)
     torch.set_num_threads(threads)
     sd = orc.init_state_dict(H, Z)
     model = build(sd, H, Z)
@@ -108,6 +117,14 @@ def time_baseline(H, Z, B, T, Tr, seed=0, steps=1, threads=None):
     eps_r, eps_n = torch.randn(B, Z), torch.randn(B, Z)
     warm = synth.synth_batch(np.random.RandomState(1), 4, 16, 4)
     train_step(model, opt, warm, torch.randn(4, Z), torch.randn(4, Z), 20000)          # thread-pool / allocator warm-up
+    probe = synth.synth_batch(np.random.RandomState(2), 2, T, Tr)                       # 2 full-length rows: cost scales ~linearly in B
+    t0 = time.perf_counter()
+    train_step(model, opt, probe, torch.randn(2, Z), torch.randn(2, Z), 20000)
+    per_row = (time.perf_counter() - t0) / 2
+    while B > 2 and per_row * B * steps > budget_s:
+        B //= 2
+    b = synth.synth_batch(np.random.RandomState(seed), B, T, Tr)
+    eps_r, eps_n = torch.randn(B, Z), torch.randn(B, Z)
     t0 = time.perf_counter()
     for s in range(steps):
         train_step(model, opt, b, eps_r, eps_n, 20000 + s)
