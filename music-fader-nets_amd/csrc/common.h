@@ -22,3 +22,8 @@ __device__ __forceinline__ float fn_wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+__device__ __forceinline__ double fn_wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

@@ -138,6 +138,13 @@ __device__ __forceinline__ float kl_dim(float mu, float s, float mk, float lvk) 
     return 0.5f * (vr + t1 - 1.0f - logf(vr));
 }
 
+__device__ __forceinline__ double kl_dim_f64(double mu, double s, double mk, double lvk) {
+    const double sp = exp(lvk);
+    const double vr = (s / sp) * (s / sp);
+    const double t1 = ((mu - mk) / sp) * ((mu - mk) / sp);
+    return 0.5 * (vr + t1 - 1.0 - log(vr));
+}
+
 __global__ __launch_bounds__(256) void latent_fwd_kernel(const float* __restrict__ pre, const float* __restrict__ eps,
                                                          const float* __restrict__ mu_lk, const float* __restrict__ lv_lk, int B, int Z,
                                                          int K, const int* __restrict__ labels, float* __restrict__ sigma,
@@ -146,9 +153,12 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(const float* __restrict
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
-    float llk[KMAX], klk[KMAX];
+    // log-likelihoods are ~1e3 in magnitude while the posterior only depends on their DIFFERENCES: accumulate in
+    // double so that q(y|x) is not limited by the float32 ulp (~1e-4) of the sums (the reference's own float32
+    // sums carry that noise; we stay closer to the exact value than it does).
+    double llk[KMAX], klk[KMAX];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) { llk[k] = 0.f; klk[k] = 0.f; }
+    for (int k = 0; k < KMAX; ++k) { llk[k] = 0.0; klk[k] = 0.0; }
     for (int d = lane; d < Z; d += 64) {
         const float mu = pre[(long)b * 2 * Z + d];
         const float s = expf(pre[(long)b * 2 * Z + Z + d]);
@@ -159,26 +169,27 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(const float* __restrict
         for (int k = 0; k < KMAX; ++k) {
             if (k < K) {
                 const float mk = mu_lk[k * Z + d], lv = lv_lk[k * Z + d];
-                llk[k] += -0.5f * ((zz - mk) * (zz - mk) / expf(lv) + lv + LOG_2PI);
-                klk[k] += kl_dim(mu, s, mk, lv);
+                const double dzm = (double)zz - (double)mk;
+                llk[k] += -0.5 * (dzm * dzm * exp(-(double)lv) + (double)lv + (double)LOG_2PI);
+                klk[k] += kl_dim_f64(mu, s, mk, lv);
             }
         }
     }
-    const float logpk = logf(1.0f / (float)K);
-    float mx = -INFINITY;
+    const double logpk = log(1.0 / (double)K);
+    double mx = -INFINITY;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
         if (k < K) {
-            llk[k] = fn_wave_sum(llk[k]) + logpk;
-            klk[k] = fn_wave_sum(klk[k]) / (float)Z;
-            mx = fmaxf(mx, llk[k]);
+            llk[k] = fn_wave_sum_f64(llk[k]) + logpk;
+            klk[k] = fn_wave_sum_f64(klk[k]) / (double)Z;
+            mx = fmax(mx, llk[k]);
         }
     }
-    float den = 0.f;
+    double den = 0.0;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
-        if (k < K) den += expf(llk[k] - mx);
-    const float lse = mx + logf(den);
+        if (k < K) den += exp(llk[k] - mx);
+    const double lse = mx + log(den);
     if (lane == 0) {
         float qk[KMAX];
         float t_lat = 0.f, t_ent = 0.f, qmax = -1.f, qden = 0.f;
@@ -186,12 +197,12 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(const float* __restrict
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
             if (k < K) {
-                const float lq = llk[k] - lse;
-                const float q = expf(lq);
+                const float lq = (float)(llk[k] - lse);
+                const float q = (float)exp(llk[k] - lse);
                 qk[k] = q;
-                ll[(long)b * K + k] = llk[k];
+                ll[(long)b * K + k] = (float)llk[k];
                 qy[(long)b * K + k] = q;
-                t_lat += q * klk[k];
+                t_lat += q * (float)klk[k];
                 t_ent += q * lq;
                 if (q > qmax) { qmax = q; am = k; }
             }
@@ -204,7 +215,7 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(const float* __restrict
             for (int k = 0; k < KMAX; ++k)
                 if (k < K) {
                     qden += expf(qk[k] - qmax);
-                    if (k == lb) t_sup = klk[k];
+                    if (k == lb) t_sup = (float)klk[k];
                 }
 #pragma unroll
             for (int k = 0; k < KMAX; ++k)
@@ -230,28 +241,31 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
     const int lb = labels ? labels[b] : -1;
-    // pass 1: KLmean_k (needed for dL/dq)
-    float klk[KMAX];
+    // pass 1: KLmean_k for dL/dq.  The softmax backward q_k (dq_k - sum_j q_j dq_j) only sees DIFFERENCES of the dq_k while
+    // each KLmean_k is ~1e3: evaluate and accumulate them in double so that the float32 ulp of those sums (~1e-4) does
+    // not leak into the gradient.
+    double klk[KMAX];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) klk[k] = 0.f;
+    for (int k = 0; k < KMAX; ++k) klk[k] = 0.0;
     if (w_lat != 0.f && !labels) {
         for (int d = lane; d < Z; d += 64) {
             const float mu = pre[(long)b * 2 * Z + d];
             const float s = expf(pre[(long)b * 2 * Z + Z + d]);
 #pragma unroll
             for (int k = 0; k < KMAX; ++k)
-                if (k < K) klk[k] += kl_dim(mu, s, mu_lk[k * Z + d], lv_lk[k * Z + d]);
+                if (k < K) klk[k] += kl_dim_f64(mu, s, mu_lk[k * Z + d], lv_lk[k * Z + d]);
         }
 #pragma unroll
         for (int k = 0; k < KMAX; ++k)
-            if (k < K) klk[k] = fn_wave_sum(klk[k]) / (float)Z;
+            if (k < K) klk[k] = fn_wave_sum_f64(klk[k]) / (double)Z;
     }
-    // dL/dq_k then softmax backward -> dll_k (all lanes compute the same K-sized scalars)
-    float q[KMAX], dq[KMAX], dll[KMAX];
+    // dL/dq_k then softmax backward -> dll_k (all lanes compute the same K-sized scalars, in double)
+    float q[KMAX], dll[KMAX];
+    double dq[KMAX];
     float qmax = -1.f;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
-        q[k] = 0.f; dq[k] = 0.f; dll[k] = 0.f;
+        q[k] = 0.f; dq[k] = 0.0; dll[k] = 0.f;
         if (k < K) { q[k] = qy[(long)b * K + k]; qmax = fmaxf(qmax, q[k]); }
     }
     float qden = 0.f;
@@ -259,24 +273,24 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict
 #pragma unroll
         for (int k = 0; k < KMAX; ++k)
             if (k < K) qden += expf(q[k] - qmax);
-    float dot = 0.f;
+    double dot = 0.0;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
         if (k < K) {
-            float g = g_qy ? g_qy[(long)b * K + k] : 0.f;
+            double g = g_qy ? (double)g_qy[(long)b * K + k] : 0.0;
             if (!labels) {
-                g += w_lat * klk[k];
-                g += w_cls * (logf(fmaxf(q[k], 1e-37f)) + 1.0f) / (float)K;   // q==0 contributes 0 (as q*log_softmax does)
+                g += (double)w_lat * klk[k];
+                g += (double)w_cls * (log(fmax((double)q[k], 1e-300)) + 1.0) / (double)K;   // q==0 contributes 0 (as q*log_softmax does)
             } else if (w_clf != 0.f) {
-                g += w_clf * (expf(q[k] - qmax) / qden - (k == lb ? 1.0f : 0.0f));
+                g += (double)(w_clf * (expf(q[k] - qmax) / qden - (k == lb ? 1.0f : 0.0f)));
             }
             dq[k] = g;
-            dot += q[k] * g;
+            dot += (double)q[k] * g;
         }
     }
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
-        if (k < K) dll[k] = q[k] * (dq[k] - dot) + (g_ll ? g_ll[(long)b * K + k] : 0.f);
+        if (k < K) dll[k] = (float)((double)q[k] * (dq[k] - dot)) + (g_ll ? g_ll[(long)b * K + k] : 0.f);
     // pass 2: per-dimension gradients
     for (int d = lane; d < Z; d += 64) {
         const float mu = pre[(long)b * 2 * Z + d];
