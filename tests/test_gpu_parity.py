@@ -468,8 +468,9 @@ def test_full_size_properties():
     t1 = tr._tuple8(beta0, Bg, False)
     dl_sd, lat_up, w, beta0, Bg = tr._forward_losses(20000, batch, eps, True)
     m.engine().backward(tr.flat.G, dl_sd, lat_up, *w)
-    assert torch.equal(g1, tr.flat.grad)
     assert bool(torch.isfinite(g1).all())
+    # repeatability: identical up to the float32 summation order of the token-segment sums (LDS atomics)
+    assert float((g1 - tr.flat.grad).abs().max()) <= 1e-5 * float(g1.abs().max())
     # (2) batch-row independence: the loss of the first 64 rows alone equals the same rows' share
     #     (CE terms are per-row means) -> CE_X of a sub-batch computed separately matches the row-slice mean
     nll = m.engine()._bufs["nll_rows"].view(T, B)
