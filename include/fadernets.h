@@ -98,7 +98,8 @@ int fn_gru_seq_fwd(const FnGruFwd* scans, int n_scans, void* stream);
  *   outputs: dgx_all [T][B][3H] = d(pre-activations r,z,n) (= d gx, also d(W_hh h + b_hh) for r,z)
  *            dghn_all[T][B][H]  = d(W_hn h + b_hn)
  *            dh0 [B][H]  gradient wrt h0 (NULL = not needed)
- *            dgx_rowsum [B][3H] += sum_p dgx_all[p]  (NULL = not needed; caller zero-fills)
+ *            dgx_rowsum [B][3H] += sum_p dgx_all[p], dghn_rowsum [B][H] += sum_p dghn_all[p]
+ *                        (NULL = not needed; caller zero-fills; their column sums are the bias gradients)
  * w_hh_t is W_hh transposed: [H][3H].  scratch: [B][H] floats per scan. */
 typedef struct FnGruBwd {
     int32_t B, T, H;
@@ -112,6 +113,7 @@ typedef struct FnGruBwd {
     float* dghn_all;          /* [T][B][H]                                                     */
     float* dh0;               /* [B][H] or NULL                                                */
     float* dgx_rowsum;        /* [B][3H] or NULL                                               */
+    float* dghn_rowsum;       /* [B][H] or NULL                                                */
     float* scratch;           /* [B][H]                                                        */
 } FnGruBwd;
 

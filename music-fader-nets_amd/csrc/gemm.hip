@@ -7,6 +7,7 @@
 namespace {
 
 constexpr int NT = 256;
+constexpr int PF_DEPTH = 2;     // K tiles in flight ahead of the MFMAs
 
 // C tile BM x BN, 4 waves laid out WM x WN, each wave TM x TN MFMA tiles (16x16).
 template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC>
@@ -18,7 +19,6 @@ __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alp
     using SA = Stage<BM, BK, AKC, NT>;
     using SB = Stage<BN, BK, BKC, NT>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int BUFW = SA::WORDS + SB::WORDS;   // buffer b: A at smem + b*BUFW, B right behind it
 
     const int ntn = (N + BN - 1) / BN, ntm = (M + BM - 1) / BM;
     const int tile = fn_xcd_remap(blockIdx.x, ntn * ntm);
@@ -38,29 +38,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alp
 #pragma unroll
         for (int n = 0; n < TN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    SA sa;
-    SB sb;
     const int nk = (kend - kbeg + BK - 1) / BK;
-    if (nk > 0) {
-        sa.load(A, lda, ra, kbeg, kend, vecA);
-        sb.load(B, ldb, rb, kbeg, kend, vecB);
-        sa.store(smem);
-        sb.store(smem + SA::WORDS);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            sa.load(A, lda, ra, kbeg + (kt + 1) * BK, kend, vecA);
-            sb.load(B, ldb, rb, kbeg + (kt + 1) * BK, kend, vecB);
-        }
-        mma_slab<TM, TN, BK, SA, SB>(smem + cur * BUFW, smem + cur * BUFW + SA::WORDS, wm * TM * 16, wn * TN * 16, lane, acc);
-        if (kt + 1 < nk) {
-            sa.store(smem + (cur ^ 1) * BUFW);
-            sb.store(smem + (cur ^ 1) * BUFW + SA::WORDS);
-        }
-        __syncthreads();
-    }
+    auto loadA = [&](int k0, SA& st) { st.load(A, lda, ra, kbeg + k0, kend, vecA); };
+    auto loadB = [&](int k0, SB& st) { st.load(B, ldb, rb, kbeg + k0, kend, vecB); };
+    fn_kloop<PF_DEPTH, TM, TN, BK, SA, SB>(smem, nk, loadA, loadB, wm * TM * 16, wn * TN * 16, lane, acc);
 
     // epilogue: D[row = (lane>>4)*4 + reg][col = lane&15]
     const int cj = lane & 15, rq = (lane >> 4) * 4;
@@ -122,9 +103,16 @@ __global__ void colsum_partial_kernel(const float* __restrict__ X, int M, int N,
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
-    float s = 0.f;
-    for (int m = m0; m < m1; ++m) s += X[(long)m * ld + n];
-    partial[(long)blockIdx.y * N + n] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // 4 independent loads in flight per thread
+    int m = m0;
+    for (; m + 3 < m1; m += 4) {
+        s0 += X[(long)m * ld + n];
+        s1 += X[(long)(m + 1) * ld + n];
+        s2 += X[(long)(m + 2) * ld + n];
+        s3 += X[(long)(m + 3) * ld + n];
+    }
+    for (; m < m1; ++m) s0 += X[(long)m * ld + n];
+    partial[(long)blockIdx.y * N + n] = (s0 + s1) + (s2 + s3);
 }
 __global__ void colsum_final_kernel(const float* __restrict__ partial, int chunks, int N, float beta, float* __restrict__ out) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -213,7 +201,7 @@ int fn_transpose_f32(const float* src, int R, int C, int src_ld, float* dst, int
     return FN_OK;
 }
 
-static int colsum_chunks(int M) { return M >= 4096 ? 64 : (M >= 256 ? 16 : 1); }
+static int colsum_chunks(int M) { return M >= 16384 ? 256 : (M >= 4096 ? 64 : (M >= 256 ? 16 : 1)); }
 size_t fn_colsum_ws_bytes(int M, int N) { return (size_t)colsum_chunks(M) * N * sizeof(float); }
 
 int fn_colsum_f32(const float* X, int M, int N, int ld, float beta, float* out, float* ws, size_t ws_bytes, void* stream) {

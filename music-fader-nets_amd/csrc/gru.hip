@@ -14,6 +14,7 @@ namespace {
 
 constexpr int NT = 256;
 constexpr int BK = 32;
+constexpr int PF_DEPTH = 3;     // K tiles kept in flight ahead of the MFMAs (the scan steps are latency-bound)
 
 // ---------------------------------------------------------------------------------------------
 // forward step
@@ -50,7 +51,6 @@ __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
     using SA = Stage<64, BK, true, NT>;
     using SB = Stage<48, BK, true, NT>;
     __shared__ __attribute__((aligned(16))) float smem[2 * (SA::WORDS + SB::WORDS)];
-    constexpr int BUFW = SA::WORDS + SB::WORDS;   // buffer b: A at smem + b*BUFW, B right behind it
 
     const int v = fn_xcd_remap(blockIdx.x, args.total);
     int si = 0;
@@ -72,27 +72,12 @@ __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
         const RowsPlain ra{m0, B};
         const RowsGate rb{hh0, H};
         const bool vecA = fn_aligned16(S.h_prev, H), vecB = fn_aligned16(S.w_hh, H);
-        SA sa;
-        SB sb;
         const int nk = (H + BK - 1) / BK;
-        sa.load(S.h_prev, H, ra, 0, H, vecA);
-        sb.load(S.w_hh, H, rb, 0, H, vecB);
-        sa.store(smem);
-        sb.store(smem + SA::WORDS);
-        __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            if (kt + 1 < nk) {
-                sa.load(S.h_prev, H, ra, (kt + 1) * BK, H, vecA);
-                sb.load(S.w_hh, H, rb, (kt + 1) * BK, H, vecB);
-            }
-            mma_slab<1, 3, BK, SA, SB>(smem + cur * BUFW, smem + cur * BUFW + SA::WORDS, wave * 16, 0, lane, acc);
-            if (kt + 1 < nk) {
-                sa.store(smem + (cur ^ 1) * BUFW);
-                sb.store(smem + (cur ^ 1) * BUFW + SA::WORDS);
-            }
-            __syncthreads();
-        }
+        const float* hp = S.h_prev;
+        const float* wp = S.w_hh;
+        auto loadA = [&](int k0, SA& st) { st.load(hp, H, ra, k0, H, vecA); };
+        auto loadB = [&](int k0, SB& st) { st.load(wp, H, rb, k0, H, vecB); };
+        fn_kloop<PF_DEPTH, 1, 3, BK, SA, SB>(smem, nk, loadA, loadB, wave * 16, 0, lane, acc);
     }
 
     const int jj = hh0 + (lane & 15);
@@ -146,6 +131,7 @@ struct BwdStep {
     float* dghn_q;
     float* dhz_out;
     float* rowsum;
+    float* rowsum_n;
     float* dh0_out;
     int B, H;
     int tile0, ntm;
@@ -160,7 +146,6 @@ __global__ __launch_bounds__(NT) void gru_bwd_step_kernel(const BwdArgs args) {
     using SA = Stage<64, BK, true, NT>;
     using SB = Stage<32, BK, true, NT>;
     __shared__ __attribute__((aligned(16))) float smem[2 * (SA::WORDS + SB::WORDS)];
-    constexpr int BUFW = SA::WORDS + SB::WORDS;   // buffer b: A at smem + b*BUFW, B right behind it
 
     const int v = fn_xcd_remap(blockIdx.x, args.total);
     int si = 0;
@@ -181,32 +166,17 @@ __global__ __launch_bounds__(NT) void gru_bwd_step_kernel(const BwdArgs args) {
     if (S.a_rz) {
         const RowsPlain ra{m0, B}, rb{n0, H};
         const bool vecRZ = fn_aligned16(S.a_rz, 3 * H), vecN = fn_aligned16(S.a_n, H), vecB = fn_aligned16(S.w_hh_t, 3 * H);
-        SA sa;
-        SB sb;
         const int K = 3 * H, K2 = 2 * H;
         const int nk = (K + BK - 1) / BK;
-        auto loadA = [&](int k0) {
-            if (k0 < K2) sa.load(S.a_rz, 3 * H, ra, k0, K2, vecRZ);
-            else sa.load(S.a_n, H, ra, k0 - K2, H, vecN);
+        const float* arz = S.a_rz;
+        const float* an = S.a_n;
+        const float* wt = S.w_hh_t;
+        auto loadA = [&](int k0, SA& st) {
+            if (k0 < K2) st.load(arz, 3 * H, ra, k0, K2, vecRZ);
+            else st.load(an, H, ra, k0 - K2, H, vecN);
         };
-        loadA(0);
-        sb.load(S.w_hh_t, K, rb, 0, K, vecB);
-        sa.store(smem);
-        sb.store(smem + SA::WORDS);
-        __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            if (kt + 1 < nk) {
-                loadA((kt + 1) * BK);
-                sb.load(S.w_hh_t, K, rb, (kt + 1) * BK, K, vecB);
-            }
-            mma_slab<1, 2, BK, SA, SB>(smem + cur * BUFW, smem + cur * BUFW + SA::WORDS, wave * 16, 0, lane, acc);
-            if (kt + 1 < nk) {
-                sa.store(smem + (cur ^ 1) * BUFW);
-                sb.store(smem + (cur ^ 1) * BUFW + SA::WORDS);
-            }
-            __syncthreads();
-        }
+        auto loadB = [&](int k0, SB& st) { st.load(wt, K, rb, k0, K, vecB); };
+        fn_kloop<PF_DEPTH, 1, 2, BK, SA, SB>(smem, nk, loadA, loadB, wave * 16, 0, lane, acc);
     }
 
 #pragma unroll
@@ -242,6 +212,7 @@ __global__ __launch_bounds__(NT) void gru_bwd_step_kernel(const BwdArgs args) {
                 float* rs = S.rowsum + (long)b * 3 * H;
                 rs[jj] += drp; rs[H + jj] += dzp; rs[2 * H + jj] += dnp;
             }
+            if (S.rowsum_n) S.rowsum_n[o] += dnp * r;
         }
     }
 }
@@ -375,6 +346,7 @@ int fn_gru_seq_bwd(const FnGruBwd* scans, int n_scans, void* stream) {
             }
             f.dhz_out = d.scratch;
             f.rowsum = d.dgx_rowsum;
+            f.rowsum_n = d.dghn_rowsum;
             f.dh0_out = d.dh0;
             f.B = d.B; f.H = d.H;
             f.ntm = (d.B + 63) / 64;

@@ -139,6 +139,47 @@ FN_DEVINL void mma_slab(const float* __restrict__ ldsA, const float* __restrict_
     }
 }
 
+// Software-pipelined K loop shared by every MFMA kernel: D register-staged tiles are kept in flight ahead of the tile
+// being multiplied (the loop is latency-bound otherwise: one 14 KB tile per ~2 us round trip), LDS is double buffered,
+// one barrier per K tile.  loadA / loadB(k0, stage&) issue the global loads of the tile starting at k0.
+template <int D, int TM, int TN, int BK, class SA, class SB, class FA, class FB>
+FN_DEVINL void fn_kloop(float* __restrict__ smem, int nk, const FA& loadA, const FB& loadB, int arow0, int brow0, int lane,
+                        f32x4 (&acc)[TM][TN]) {
+    constexpr int BUFW = SA::WORDS + SB::WORDS;   // buffer b: A at smem + b*BUFW, B right behind it
+    SA sa[D];
+    SB sb[D];
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (s < nk) {
+            loadA(s * BK, sa[s]);
+            loadB(s * BK, sb[s]);
+        }
+    if (nk > 0) {
+        sa[0].store(smem);
+        sb[0].store(smem + SA::WORDS);
+    }
+    __syncthreads();
+    for (int base = 0; base < nk; base += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int kt = base + u;
+            if (kt < nk) {
+                const int cur = kt & 1;
+                if (kt + D < nk) {                      // set u held tile kt (now in LDS): refill it with tile kt + D
+                    loadA((kt + D) * BK, sa[u]);
+                    loadB((kt + D) * BK, sb[u]);
+                }
+                mma_slab<TM, TN, BK, SA, SB>(smem + cur * BUFW, smem + cur * BUFW + SA::WORDS, arow0, brow0, lane, acc);
+                if (kt + 1 < nk) {
+                    sa[(u + 1) % D].store(smem + (cur ^ 1) * BUFW);
+                    sb[(u + 1) % D].store(smem + (cur ^ 1) * BUFW + SA::WORDS);
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
 FN_DEVINL float fn_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // XCD-aware block remap: consecutive virtual ids land on the same XCD (block b runs on XCD b % 8),

@@ -169,8 +169,9 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     # backward
     # ------------------------------------------------------------------------------------------
-    def _gru_weight_grads(self, key, pfx, sfx, T, B, dgx, dghn, h_all, h0, G, splitk):
-        """dW_hh / db_hh of one scan from the saved per-step gate gradients (batched over all steps)."""
+    def _gru_weight_grads(self, key, pfx, sfx, T, B, dgx, dghn, h_all, h0, G, splitk, rs, rsn):
+        """dW_hh / db_hh of one scan from the saved per-step gate gradients (batched over all steps); the bias gradients
+        are column sums of the per-sequence row sums rs [B][3H] / rsn [B][H] accumulated by the backward scan."""
         ops, H = self.ops, self.H
         dW = G[pfx + "weight_hh" + sfx]
         dgx2 = dgx.view(T * B, 3 * H)
@@ -185,8 +186,8 @@ class Engine:
             ops.gemm(dgx2[:B, : 2 * H], h0, dW[: 2 * H], a_k=False, b_k=False, beta=1.0)
             ops.gemm(dgn2[:B], h0, dW[2 * H:], a_k=False, b_k=False, beta=1.0)
         db = G[pfx + "bias_hh" + sfx]
-        ops.colsum(dgx2[:, : 2 * H], db[: 2 * H])
-        ops.colsum(dgn2, db[2 * H:])
+        ops.colsum(rs[:, : 2 * H], db[: 2 * H])
+        ops.colsum(rsn, db[2 * H:])
 
     @staticmethod
     def _splitk(rows):
@@ -223,12 +224,14 @@ class Engine:
         dgx2 = self.buf("g_dgx2", (T, B, 3 * H))
         dghn2 = self.buf("g_dghn2", (T, B, H))
         dh0_l2 = self.buf("g_dh0_l2", (B, H))
+        rs2, rsn2 = self.zbuf("g_rs2", (B, 3 * H)), self.zbuf("g_rsn2", (B, H))
         ops.gru_seq_bwd([dict(B=B, T=T, H=H, w_hh_t=self.whh_t["g2"], h0=dec["hx0"][0], h_all=dec["hx1"], gates=dec["g2"],
-                              dh_ext=dhx1, dgx_all=dgx2, dghn_all=dghn2, dh0=dh0_l2, scratch=self.buf("g_scr2", (B, H)))])
-        self._gru_weight_grads("g2", "grucell_g_2.", "", T, B, dgx2, dghn2, dec["hx1"], dec["hx0"][0], G, sk_T)
+                              dh_ext=dhx1, dgx_all=dgx2, dghn_all=dghn2, dh0=dh0_l2, dgx_rowsum=rs2, dghn_rowsum=rsn2,
+                              scratch=self.buf("g_scr2", (B, H)))])
+        self._gru_weight_grads("g2", "grucell_g_2.", "", T, B, dgx2, dghn2, dec["hx1"], dec["hx0"][0], G, sk_T, rs2, rsn2)
         dgx2f = dgx2.view(T * B, 3 * H)
         ops.gemm(dgx2f, hx0f, G["grucell_g_2.weight_ih"], a_k=False, b_k=False, splitk=sk_T)
-        ops.colsum(dgx2f, G["grucell_g_2.bias_ih"])
+        ops.colsum(rs2, G["grucell_g_2.bias_ih"])
         dhx0 = self.buf("g_dhx0", (T, B, H))
         ops.gemm(dgx2f, P["grucell_g_2.weight_ih"], dhx0.view(T * B, H), a_k=True, b_k=False)
         ops.axpy(1.0, dh0_l2, dhx0[0])                        # hx1 was initialised with hx0[0]
@@ -247,18 +250,20 @@ class Engine:
         dghn1 = self.buf("g_dghn1", (T, B, H))
         dh0_g = self.buf("g_dh0", (B, H))
         drb_g = self.zbuf("g_drb", (B, 3 * H))
+        rsn_g = self.zbuf("g_rsn1", (B, H))
         scans = [dict(B=B, T=T, H=H, w_hh_t=self.whh_t["g"], h0=dec["h0g"], h_all=dec["hx0"], gates=dec["g1"], dh_ext=dhx0,
-                      dgx_all=dgx1, dghn_all=dghn1, dh0=dh0_g, dgx_rowsum=drb_g, scratch=self.buf("g_scr1", (B, H)))]
+                      dgx_all=dgx1, dghn_all=dghn1, dh0=dh0_g, dgx_rowsum=drb_g, dghn_rowsum=rsn_g, scratch=self.buf("g_scr1", (B, H)))]
         sdb = {}
         for e in ("r", "n"):
             sdb[e] = dict(dgx=self.buf("sd_dgx_" + e, (Tr, B, 3 * H)), dghn=self.buf("sd_dghn_" + e, (Tr, B, H)),
-                          dh0=self.buf("sd_dh0_" + e, (B, H)), drb=self.zbuf("sd_drb_" + e, (B, 3 * H)))
+                          dh0=self.buf("sd_dh0_" + e, (B, H)), drb=self.zbuf("sd_drb_" + e, (B, 3 * H)),
+                          rsn=self.zbuf("sd_rsn_" + e, (B, H)))
             scans.append(dict(B=B, T=Tr, H=H, w_hh_t=self.whh_t["d_" + e], h0=sd[e]["h0"], h_all=sd[e]["h_all"], gates=sd[e]["gates"],
                               dh_ext=dh_sd[e], dgx_all=sdb[e]["dgx"], dghn_all=sdb[e]["dghn"], dh0=sdb[e]["dh0"],
-                              dgx_rowsum=sdb[e]["drb"], scratch=self.buf("sd_scr_" + e, (B, H))))
+                              dgx_rowsum=sdb[e]["drb"], dghn_rowsum=sdb[e]["rsn"], scratch=self.buf("sd_scr_" + e, (B, H))))
         ops.gru_seq_bwd(scans)
         # layer-1 parameter gradients
-        self._gru_weight_grads("g", "grucell_g.", "", T, B, dgx1, dghn1, dec["hx0"], dec["h0g"], G, sk_T)
+        self._gru_weight_grads("g", "grucell_g.", "", T, B, dgx1, dghn1, dec["hx0"], dec["h0g"], G, sk_T, drb_g, rsn_g)
         dWg = G["grucell_g.weight_ih"]                          # [3H][E+ZG]
         dtab = self.buf("dtab_E", (E_VOCAB, 3 * H))
         ops.embed_grad(dgx1, d, -1, E_VOCAB - 1, 0, E_VOCAB, dtab)
@@ -278,7 +283,8 @@ class Engine:
             pfx = "gru_d_%s." % e
             z = lat[e]["z"]
             gz = lat_up[e]["g_z"]
-            self._gru_weight_grads("d_" + e, pfx, "_l0", Tr, B, sdb[e]["dgx"], sdb[e]["dghn"], sd[e]["h_all"], sd[e]["h0"], G, sk_Tr)
+            self._gru_weight_grads("d_" + e, pfx, "_l0", Tr, B, sdb[e]["dgx"], sdb[e]["dghn"], sd[e]["h_all"], sd[e]["h0"], G, sk_Tr,
+                                   sdb[e]["drb"], sdb[e]["rsn"])
             dW = G[pfx + "weight_ih_l0"]                        # [3H][Ce+Z]
             dt = self.buf("dtab_" + e, (Ce, 3 * H))
             ops.embed_grad(sdb[e]["dgx"], attr, 0, 0, 0, Ce, dt)
@@ -315,16 +321,18 @@ class Engine:
                 ops.gemm(dp, hb, dW[:, H:], a_k=False, b_k=False)
                 ops.colsum(dp, G[head + e + ".bias"])
             for key, dh in ((e, dhf), (e + "_reverse", dhb)):
-                encb[key] = dict(dgx=self.buf("enc_dgx_" + key, (T, B, 3 * H)), dghn=self.buf("enc_dghn_" + key, (T, B, H)))
+                encb[key] = dict(dgx=self.buf("enc_dgx_" + key, (T, B, 3 * H)), dghn=self.buf("enc_dghn_" + key, (T, B, H)),
+                                 rs=self.zbuf("enc_rs_" + key, (B, 3 * H)), rsn=self.zbuf("enc_rsn_" + key, (B, H)))
                 scans.append(dict(B=B, T=T, H=H, w_hh_t=self.whh_t[key], h0=None, h_all=self._bufs["enc_h_" + key],
                                   gates=self._bufs["enc_g_" + key], dh_last=dh, dgx_all=encb[key]["dgx"], dghn_all=encb[key]["dghn"],
-                                  scratch=self.buf("enc_scr_" + key, (B, H))))
+                                  dgx_rowsum=encb[key]["rs"], dghn_rowsum=encb[key]["rsn"], scratch=self.buf("enc_scr_" + key, (B, H))))
         ops.gru_seq_bwd(scans)        # 4 concurrent reverse scans
         for e in ("r", "n"):
             for key, sfx, rev in ((e, "_l0", 0), (e + "_reverse", "_l0_reverse", 1)):
                 pfx = "gru_%s." % e
-                self._gru_weight_grads(key, pfx, sfx, T, B, encb[key]["dgx"], encb[key]["dghn"], self._bufs["enc_h_" + key], None, G, sk_T)
+                self._gru_weight_grads(key, pfx, sfx, T, B, encb[key]["dgx"], encb[key]["dghn"], self._bufs["enc_h_" + key], None, G, sk_T,
+                                       encb[key]["rs"], encb[key]["rsn"])
                 dtab = self.buf("dtab_E", (E_VOCAB, 3 * H))
                 ops.embed_grad(encb[key]["dgx"], d, 0, 0, rev, E_VOCAB, dtab)
                 ops.transpose(dtab, G[pfx + "weight_ih" + sfx])
-                ops.colsum(encb[key]["dgx"].view(T * B, 3 * H), G[pfx + "bias_ih" + sfx])
+                ops.colsum(encb[key]["rs"], G[pfx + "bias_ih" + sfx])

@@ -125,13 +125,13 @@ class HipOps:
     def gru_seq_bwd(self, scans):
         arr = (_lib.FnGruBwd * len(scans))()
         for d, s in zip(arr, scans):
-            for k in ("w_hh_t", "h0", "h_all", "gates", "dh_last", "dh_ext", "dgx_all", "dghn_all", "dh0", "dgx_rowsum", "scratch"):
+            for k in ("w_hh_t", "h0", "h_all", "gates", "dh_last", "dh_ext", "dgx_all", "dghn_all", "dh0", "dgx_rowsum", "dghn_rowsum", "scratch"):
                 _dense(s.get(k), name=k)
             d.B, d.T, d.H = s["B"], s["T"], s["H"]
             d.w_hh_t, d.h0, d.h_all, d.gates = _p(s["w_hh_t"]), _p(s.get("h0")), _p(s["h_all"]), _p(s["gates"])
             d.dh_last, d.dh_ext = _p(s.get("dh_last")), _p(s.get("dh_ext"))
             d.dgx_all, d.dghn_all, d.dh0 = _p(s["dgx_all"]), _p(s["dghn_all"]), _p(s.get("dh0"))
-            d.dgx_rowsum, d.scratch = _p(s.get("dgx_rowsum")), _p(s["scratch"])
+            d.dgx_rowsum, d.dghn_rowsum, d.scratch = _p(s.get("dgx_rowsum")), _p(s.get("dghn_rowsum")), _p(s["scratch"])
         _lib.check(self.lib.fn_gru_seq_bwd(arr, len(scans), self.stream()), "fn_gru_seq_bwd")
 
     def embed_grad(self, dgx_all, idx, idx_shift, start_token, reverse, V, out):

@@ -103,6 +103,8 @@ class FakeOps:
                 s["dghn_all"][q].copy_(dnp * r)
                 if s.get("dgx_rowsum") is not None:
                     s["dgx_rowsum"].add_(dgx)
+                if s.get("dghn_rowsum") is not None:
+                    s["dghn_rowsum"].add_(dnp * r)
                 dgh = torch.cat([drp, dzp, dnp * r], dim=1)
                 carry = dh * z + dgh @ s["w_hh_t"].t()
             if s.get("dh0") is not None:

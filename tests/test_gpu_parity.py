@@ -162,13 +162,14 @@ def test_gru_scan_fwd_bwd_kernels(ops, B, T, H):
         b = dict(B=B, T=Ti, H=H, w_hh_t=c["w_hh"].t().contiguous(), h0=c.get("h0"), h_all=c["h_all"], gates=c["gates"],
                  dh_last=torch.randn(B, H) if i != 1 else None, dh_ext=torch.randn(Ti, B, H) if i != 0 else None,
                  dgx_all=torch.zeros(Ti, B, 3 * H), dghn_all=torch.zeros(Ti, B, H), dh0=torch.zeros(B, H) if i != 2 else None,
-                 dgx_rowsum=torch.zeros(B, 3 * H) if i == 1 else None, scratch=torch.zeros(B, H))
+                 dgx_rowsum=torch.zeros(B, 3 * H) if i == 1 else None, dghn_rowsum=torch.zeros(B, H) if i != 0 else None,
+                 scratch=torch.zeros(B, H))
         bc.append(b)
         bd.append(_to_dev(b))
     fake.gru_seq_bwd(bc)
     ops.gru_seq_bwd(bd)
     for i, (c, d) in enumerate(zip(bc, bd)):
-        for k in ("dgx_all", "dghn_all", "dh0", "dgx_rowsum"):
+        for k in ("dgx_all", "dghn_all", "dh0", "dgx_rowsum", "dghn_rowsum"):
             if c[k] is not None:
                 close(d[k], c[k], 5e-5, "%s[%d]" % (k, i))
     # token-segment sums of dgx (one-hot W_ih columns)
