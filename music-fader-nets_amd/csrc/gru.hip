@@ -39,9 +39,11 @@ struct FwdArgs {
     int n, total;
 };
 
-struct RowsGate {   // local row r of the 48-row weight tile -> row of W_hh ([3H][H])
+struct RowsGate {   // local row r of the 48-row weight tile -> row of W_hh ([3H][H]); always in range (H % 16 == 0)
     int h0, H;
-    FN_DEVINL long operator()(int r) const { return (long)(r >> 4) * H + h0 + (r & 15); }
+    FN_DEVINL bool valid(int) const { return true; }
+    FN_DEVINL long clamped(int r) const { return (long)(r >> 4) * H + h0 + (r & 15); }
+    FN_DEVINL bool all_valid(int) const { return true; }
 };
 
 // NS = number of scans covered by this launch (a distinct kernel symbol per phase: 4 = the encoder step,

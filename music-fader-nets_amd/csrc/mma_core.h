@@ -25,10 +25,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 FN_DEVINL bool fn_aligned16(const void* p, long ld) { return ((((uintptr_t)p) & 15) == 0) && ((ld & 3) == 0); }
 
-// Plain contiguous row window [row0, row0+nrows_valid)
+// Row maps: local tile row r -> source row.  valid(r) says whether the row exists; clamped(r) is always a legal row
+// (out-of-range rows are loaded from a legal address and zeroed by a select, so the fast path has NO branches).
 struct RowsPlain {
     int row0, nrows;
-    FN_DEVINL long operator()(int r) const { return (row0 + r < nrows) ? (long)(row0 + r) : -1; }
+    FN_DEVINL bool valid(int r) const { return row0 + r < nrows; }
+    FN_DEVINL long clamped(int r) const { return (long)min(row0 + r, nrows - 1); }
+    FN_DEVINL bool all_valid(int rows) const { return row0 + rows <= nrows; }
 };
 
 // ROWS x BK operand tile staged through registers into LDS by NT threads.
@@ -40,10 +43,28 @@ struct Stage {
     static constexpr int WORDS = KC ? ROWS * LDW : BK * LDW;
     float4 r[NPT];
 
-    // KC : element (row, k) at src[rowmap(row)*ld + k]          rows bounded by rowmap (<0 = zero row)
-    // RC : element (row, k) at src[k*ld + row0 + row], row0+row < nrows
+    // KC : element (row, k) at src[rowmap(row)*ld + k]
+    // RC : element (row, k) at src[k*ld + rowmap(row)]   (rows of one float4 are consecutive)
+    // Fast path (16-byte aligned source, tile fully inside K [and inside the rows for RC]): unconditional
+    // global_load_dwordx4, all issued back to back.  Anything else takes the element-wise bounds-checked path.
     template <class RowMap>
     FN_DEVINL void load(const float* __restrict__ src, long ld, const RowMap& rowmap, int k0, int K, bool vec) {
+        const bool fast = vec && (k0 + BK <= K) && (KC || rowmap.all_valid(ROWS));
+        if (fast) {
+#pragma unroll
+            for (int q = 0; q < NPT; ++q) {
+                const int i = min((int)threadIdx.x + q * NT, NV - 1);
+                if (KC) {
+                    const int row = i / (BK / 4), c = (i % (BK / 4)) * 4;
+                    const float4 v = *reinterpret_cast<const float4*>(src + rowmap.clamped(row) * ld + (k0 + c));
+                    r[q] = rowmap.valid(row) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+                    const int k = i / (ROWS / 4), c = (i % (ROWS / 4)) * 4;
+                    r[q] = *reinterpret_cast<const float4*>(src + (long)(k0 + k) * ld + rowmap.clamped(c));
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < NPT; ++q) {
             const int i = threadIdx.x + q * NT;
@@ -51,35 +72,23 @@ struct Stage {
             if ((NV % NT == 0) || i < NV) {
                 if (KC) {
                     const int row = i / (BK / 4), c = (i % (BK / 4)) * 4;
-                    const long gr = rowmap(row);
                     const int gk = k0 + c;
-                    if (gr >= 0 && gk < K) {
-                        const float* p = src + gr * ld + gk;
-                        if (vec && gk + 3 < K) {
-                            v = *reinterpret_cast<const float4*>(p);
-                        } else {
-                            v.x = p[0];
-                            if (gk + 1 < K) v.y = p[1];
-                            if (gk + 2 < K) v.z = p[2];
-                            if (gk + 3 < K) v.w = p[3];
-                        }
+                    if (rowmap.valid(row) && gk < K) {
+                        const float* p = src + rowmap.clamped(row) * ld + gk;
+                        v.x = p[0];
+                        if (gk + 1 < K) v.y = p[1];
+                        if (gk + 2 < K) v.z = p[2];
+                        if (gk + 3 < K) v.w = p[3];
                     }
                 } else {
                     const int k = i / (ROWS / 4), c = (i % (ROWS / 4)) * 4;
                     const int gk = k0 + k;
-                    if (gk < K) {
-                        const long g0 = rowmap(c), g3 = rowmap(c + 3);
-                        if (g0 >= 0) {
-                            const float* p = src + (long)gk * ld + g0;
-                            if (vec && g3 >= 0) {
-                                v = *reinterpret_cast<const float4*>(p);
-                            } else {
-                                v.x = p[0];
-                                if (rowmap(c + 1) >= 0) v.y = p[1];
-                                if (rowmap(c + 2) >= 0) v.z = p[2];
-                                if (g3 >= 0) v.w = p[3];
-                            }
-                        }
+                    if (gk < K && rowmap.valid(c)) {
+                        const float* p = src + (long)gk * ld + rowmap.clamped(c);
+                        v.x = p[0];
+                        if (rowmap.valid(c + 1)) v.y = p[1];
+                        if (rowmap.valid(c + 2)) v.z = p[2];
+                        if (rowmap.valid(c + 3)) v.w = p[3];
                     }
                 }
             }
