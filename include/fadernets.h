@@ -72,6 +72,7 @@ int fn_sum_f32(const float* x, int64_t n, float scale, float* out, void* stream)
  *    gx[b,:] = b_ih + gx_dense[p][b,:] + gx_table[tok][:] + gx_rowbias[b,:]     (each optional)
  *    tok = (tau < 0) ? start_token : idx[b*idx_ld + tau],  tau = (reverse ? T-1-p : p) + idx_shift
  * Storage is in PROCESSING order p = 0..T-1 (for reverse scans p=0 is the last time step).
+ * H must be a multiple of 32; w_hh, h0, h_all 16-byte aligned.
  * ------------------------------------------------------------------------------------------ */
 typedef struct FnGruFwd {
     int32_t B, T, H;
@@ -88,8 +89,12 @@ typedef struct FnGruFwd {
     int32_t start_token;      /* used when tau < 0                                             */
     const float* gx_rowbias;  /* [B][3H] or NULL (per-sequence constant part, W_ih[:,V:] z)    */
     float* h_all;             /* [T][B][H] state after each step                               */
-    float* gates;             /* [T][B][4][H] saved r,z,n,(W_hn h + b_hn); NULL = inference    */
+    float* gates;             /* [T][fn_gru_gates_floats(B,H)] saved r,z,n,(W_hn h + b_hn) in a    */
+                              /* private blocked layout (opaque to the caller); NULL = inference */
 } FnGruFwd;
+
+/* floats per time step of the saved-gates buffer (4*H*ceil16(B)) */
+size_t fn_gru_gates_floats(int B, int H);
 
 int fn_gru_seq_fwd(const FnGruFwd* scans, int n_scans, void* stream);
 
@@ -106,7 +111,7 @@ typedef struct FnGruBwd {
     const float* w_hh_t;      /* [H][3H]                                                       */
     const float* h0;          /* [B][H] or NULL                                                */
     const float* h_all;       /* [T][B][H]  from forward                                       */
-    const float* gates;       /* [T][B][4][H] from forward                                     */
+    const float* gates;       /* [T][fn_gru_gates_floats(B,H)] from forward                    */
     const float* dh_last;     /* [B][H] or NULL                                                */
     const float* dh_ext;      /* [T][B][H] or NULL                                             */
     float* dgx_all;           /* [T][B][3H]                                                    */

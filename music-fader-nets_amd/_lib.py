@@ -40,6 +40,7 @@ SIGNATURES = {
     "fn_colsum_f32": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, C.c_size_t, vp]),
     "fn_axpy_f32": (C.c_int, [C.c_int64, C.c_float, vp, vp, vp]),
     "fn_sum_f32": (C.c_int, [vp, C.c_int64, C.c_float, vp, vp]),
+    "fn_gru_gates_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "fn_gru_seq_fwd": (C.c_int, [C.POINTER(FnGruFwd), C.c_int, vp]),
     "fn_gru_seq_bwd": (C.c_int, [C.POINTER(FnGruBwd), C.c_int, vp]),
     "fn_embed_grad_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),

@@ -1,20 +1,37 @@
 // gru.hip - GRU sequence scans for the GM-VAE path (encoders gmm_model.py:84,89; sub-decoders :109,114;
-// global decoder cells :131-136) and their backward.
+// global decoder cells :131-136) and their backward (autograd of the same, trainer_gmm.py:249).
 //
-// One time step of ALL concurrently running scans is one launch: a fused  h_{p-1} W_hh^T  f32-MFMA GEMM
-// whose epilogue applies the gate maths and writes h_p (+ the saved gates).  The step boundary is a
-// dependent-kernel boundary (~1.5-1.9 us on MI355X), cheaper than an in-kernel grid barrier, and no
-// cross-workgroup visibility protocol is needed.  Workgroup tile: 64 batch rows x 16 hidden units x
-// {r,z,n}: each wave owns 16 rows and holds r/z/n pre-activations of the SAME (row, unit) in the same
-// lane, so the gate epilogue is lane-local.
+// One time step of ALL concurrently running scans is ONE launch (a dependent-kernel boundary, ~1.5-1.9 us on
+// MI355X, is cheaper than an in-kernel grid barrier and needs no cross-workgroup visibility protocol).
+//
+// Step kernel structure (forward: h_{p-1} W_hh^T -> gates; backward: dgh W_hh -> dh -> gate backward):
+//   * workgroup tile = (16*TM batch rows) x (16 hidden units [x r,z,n] forward / 16*TN units backward);
+//   * the 4 waves of a workgroup SPLIT K: wave w owns the 32-wide K chunks w, w+4, ...  and streams its
+//     operand fragments global -> VGPR directly in MFMA layout (no LDS staging, no barrier in the K loop):
+//     lane (i = l&15, g = l>>4) reads, per tile row i, two float4 at k0 + 4g and k0 + 16 + 4g, i.e. every
+//     dwordx4 instruction covers 16 rows x 64 contiguous bytes; MFMA step j of a chunk consumes k = 4g + j
+//     (j < 4) or 16 + 4g + (j-4)  - the same K permutation for A and B, so the product is unchanged;
+//   * D chunks are kept in flight per wave (register ring) - the step is latency-bound otherwise;
+//   * one LDS exchange + barrier at the end adds the 4 partial accumulators; wave m then owns M-tile m and
+//     holds r/z/n of the SAME (row, unit) in the same lane, so the gate epilogue is lane-local;
+//   * the saved gates use a private blocked layout in which every wave store / load instruction is one
+//     contiguous 256-byte run (see gate_off).
 #include "common.h"
 #include "mma_core.h"
 
 namespace {
 
 constexpr int NT = 256;
-constexpr int BK = 32;
-constexpr int PF_DEPTH = 3;     // K tiles kept in flight ahead of the MFMAs (the scan steps are latency-bound)
+
+// offset of (batch row b, gate q in {r,z,n,hn}, hidden unit u) inside one step's gate slab; nrt = ceil(B/16).
+// [unit tile][row tile][gate][i = b&3][quad = (b&15)>>2][j = u&15]: for fixed (tiles, gate, i) the 64 lanes
+// (quad, j) of a wave touch 64 consecutive floats.
+FN_DEVINL long gate_off(int b, int q, int u, int nrt) {
+    return ((((long)(u >> 4) * nrt + (b >> 4)) * 4 + q) * 4 + (b & 3)) * 64 + ((b & 15) >> 2) * 16 + (u & 15);
+}
+
+FN_DEVINL float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+FN_DEVINL float f4at(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
 
 // ---------------------------------------------------------------------------------------------
 // forward step
@@ -39,21 +56,11 @@ struct FwdArgs {
     int n, total;
 };
 
-struct RowsGate {   // local row r of the 48-row weight tile -> row of W_hh ([3H][H]); always in range (H % 16 == 0)
-    int h0, H;
-    FN_DEVINL bool valid(int) const { return true; }
-    FN_DEVINL long clamped(int r) const { return (long)(r >> 4) * H + h0 + (r & 15); }
-    FN_DEVINL bool all_valid(int) const { return true; }
-};
-
 // NS = number of scans covered by this launch (a distinct kernel symbol per phase: 4 = the encoder step,
 // 3 = decoder layer 1 + both sub-decoders, 1 = a single scan), so per-phase durations show up separately in rocprof.
-template <int NS>
+template <int NS, int TM, int D>
 __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
-    using SA = Stage<64, BK, true, NT>;
-    using SB = Stage<48, BK, true, NT>;
-    __shared__ __attribute__((aligned(16))) float smem[2 * (SA::WORDS + SB::WORDS)];
-
+    __shared__ __attribute__((aligned(16))) float red[4 * TM * 3 * 256];
     const int v = fn_xcd_remap(blockIdx.x, args.total);
     int si = 0;
 #pragma unroll
@@ -62,58 +69,121 @@ __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
     const FwdStep& S = args.s[si];
     const int local = v - S.tile0;
     const int tn = local / S.ntm, tm = local % S.ntm;     // row tiles fastest: neighbours share weight rows
-    const int m0 = tm * 64, hh0 = tn * 16;
+    const int m0 = tm * (16 * TM), hh0 = tn * 16;
     const int B = S.B, H = S.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int nrt = (B + 15) >> 4;
 
-    f32x4 acc[1][3];
+    // ---- epilogue operands of the M-tile this wave will finish: issued first, consumed last --------------
+    const int jj = hh0 + li;
+    float gx[4][3], hp[4];
+    float bh[3] = {0.f, 0.f, 0.f};
+    if (wave < TM) {
 #pragma unroll
-    for (int n = 0; n < 3; ++n) acc[0][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    if (S.h_prev) {
-        const RowsPlain ra{m0, B};
-        const RowsGate rb{hh0, H};
-        const bool vecA = fn_aligned16(S.h_prev, H), vecB = fn_aligned16(S.w_hh, H);
-        const int nk = (H + BK - 1) / BK;
-        const float* hp = S.h_prev;
-        const float* wp = S.w_hh;
-        auto loadA = [&](int k0, SA& st) { st.load(hp, H, ra, k0, H, vecA); };
-        auto loadB = [&](int k0, SB& st) { st.load(wp, H, rb, k0, H, vecB); };
-        fn_kloop<PF_DEPTH, 1, 3, BK, SA, SB>(smem, nk, loadA, loadB, wave * 16, 0, lane, acc);
+        for (int q = 0; q < 3; ++q) bh[q] = S.b_hh[q * H + jj];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int b = min(m0 + wave * 16 + lg * 4 + i, B - 1);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) gx[i][q] = S.b_ih ? S.b_ih[q * H + jj] : 0.f;
+            if (S.gx_dense) {
+                const float* row = S.gx_dense + (long)b * 3 * H;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) gx[i][q] += row[q * H + jj];
+            }
+            if (S.gx_table) {
+                const int tok = S.idx ? S.idx[(long)b * S.idx_ld] : S.tok_const;
+                const float* row = S.gx_table + (long)tok * 3 * H;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) gx[i][q] += row[q * H + jj];
+            }
+            if (S.gx_rowbias) {
+                const float* row = S.gx_rowbias + (long)b * 3 * H;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) gx[i][q] += row[q * H + jj];
+            }
+            hp[i] = S.h_prev ? S.h_prev[(long)b * H + jj] : 0.f;
+        }
     }
 
-    const int jj = hh0 + (lane & 15);
-    const float bhr = S.b_hh[jj], bhz = S.b_hh[H + jj], bhn = S.b_hh[2 * H + jj];
-    float bir = 0.f, biz = 0.f, bin = 0.f;
-    if (S.b_ih) { bir = S.b_ih[jj]; biz = S.b_ih[H + jj]; bin = S.b_ih[2 * H + jj]; }
+    f32x4 acc[TM][3];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (S.h_prev) {
+        const float* ap[TM];
+        const float* bp[3];
+#pragma unroll
+        for (int m = 0; m < TM; ++m) ap[m] = S.h_prev + (long)min(m0 + 16 * m + li, B - 1) * H + 4 * lg;
+#pragma unroll
+        for (int n = 0; n < 3; ++n) bp[n] = S.w_hh + ((long)n * H + hh0 + li) * H + 4 * lg;
+        const int nk = H >> 5;
+        const int nkw = wave < nk ? (nk - wave + 3) >> 2 : 0;        // chunks wave, wave+4, ...
+        float4 fa[D][TM][2], fb[D][3][2];
+        auto load = [&](int set, int it) {
+            const int k0 = (wave + 4 * it) << 5;
+#pragma unroll
+            for (int m = 0; m < TM; ++m) { fa[set][m][0] = ld4(ap[m] + k0); fa[set][m][1] = ld4(ap[m] + k0 + 16); }
+#pragma unroll
+            for (int n = 0; n < 3; ++n) { fb[set][n][0] = ld4(bp[n] + k0); fb[set][n][1] = ld4(bp[n] + k0 + 16); }
+        };
+#pragma unroll
+        for (int s = 0; s < D; ++s)
+            if (s < nkw) load(s, s);
+        for (int base = 0; base < nkw; base += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                const int it = base + u;
+                if (it < nkw) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int m = 0; m < TM; ++m)
+#pragma unroll
+                            for (int n = 0; n < 3; ++n)
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4at(fa[u][m][j >> 2], j & 3), f4at(fb[u][n][j >> 2], j & 3),
+                                                                                 acc[m][n], 0, 0, 0);
+                    if (it + D < nkw) load(u, it + D);
+                }
+            }
+        }
+        // ---- add the 4 K-partials: wave m ends up with M-tile m --------------------------------------------
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < 3; ++n)
+                *reinterpret_cast<f32x4*>(red + ((wave * TM + m) * 3 + n) * 256 + lane * 4) = acc[m][n];
+        __syncthreads();
+    }
+    if (wave >= TM) return;
+    f32x4 r3[3];
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+        r3[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (S.h_prev) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) r3[n] += *reinterpret_cast<const f32x4*>(red + ((w * TM + wave) * 3 + n) * 256 + lane * 4);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int b = m0 + wave * 16 + (lane >> 4) * 4 + i;
+        const int b = m0 + wave * 16 + lg * 4 + i;
         if (b >= B) continue;
-        float gxr = bir, gxz = biz, gxn = bin;
-        if (S.gx_dense) {
-            const float* row = S.gx_dense + (long)b * 3 * H;
-            gxr += row[jj]; gxz += row[H + jj]; gxn += row[2 * H + jj];
-        }
-        if (S.gx_table) {
-            const int tok = S.idx ? S.idx[(long)b * S.idx_ld] : S.tok_const;
-            const float* row = S.gx_table + (long)tok * 3 * H;
-            gxr += row[jj]; gxz += row[H + jj]; gxn += row[2 * H + jj];
-        }
-        if (S.gx_rowbias) {
-            const float* row = S.gx_rowbias + (long)b * 3 * H;
-            gxr += row[jj]; gxz += row[H + jj]; gxn += row[2 * H + jj];
-        }
-        const float ghr = acc[0][0][i] + bhr, ghz = acc[0][1][i] + bhz, ghn = acc[0][2][i] + bhn;
-        const float r = fn_sigmoid(gxr + ghr);
-        const float z = fn_sigmoid(gxz + ghz);
-        const float n = tanhf(gxn + r * ghn);
-        const float hp = S.h_prev ? S.h_prev[(long)b * H + jj] : 0.f;
-        const float h = (1.0f - z) * n + z * hp;
+        const float ghr = r3[0][i] + bh[0], ghz = r3[1][i] + bh[1], ghn = r3[2][i] + bh[2];
+        const float r = fn_sigmoid(gx[i][0] + ghr);
+        const float z = fn_sigmoid(gx[i][1] + ghz);
+        const float n = tanhf(gx[i][2] + r * ghn);
+        const float h = (1.0f - z) * n + z * hp[i];
         S.h_out[(long)b * H + jj] = h;
         if (S.gates) {
-            float* g = S.gates + (long)b * 4 * H;
-            g[jj] = r; g[H + jj] = z; g[2 * H + jj] = n; g[3 * H + jj] = ghn;
+            float* g = S.gates;
+            g[gate_off(b, 0, jj, nrt)] = r;
+            g[gate_off(b, 1, jj, nrt)] = z;
+            g[gate_off(b, 2, jj, nrt)] = n;
+            g[gate_off(b, 3, jj, nrt)] = ghn;
         }
     }
 }
@@ -143,12 +213,9 @@ struct BwdArgs {
     int n, total;
 };
 
-template <int NS>
+template <int NS, int TM, int TN, int D>
 __global__ __launch_bounds__(NT) void gru_bwd_step_kernel(const BwdArgs args) {
-    using SA = Stage<64, BK, true, NT>;
-    using SB = Stage<32, BK, true, NT>;
-    __shared__ __attribute__((aligned(16))) float smem[2 * (SA::WORDS + SB::WORDS)];
-
+    __shared__ __attribute__((aligned(16))) float red[4 * TM * TN * 256];
     const int v = fn_xcd_remap(blockIdx.x, args.total);
     int si = 0;
 #pragma unroll
@@ -157,48 +224,96 @@ __global__ __launch_bounds__(NT) void gru_bwd_step_kernel(const BwdArgs args) {
     const BwdStep& S = args.s[si];
     const int local = v - S.tile0;
     const int tn = local / S.ntm, tm = local % S.ntm;
-    const int m0 = tm * 64, n0 = tn * 32;
+    const int m0 = tm * (16 * TM), n0 = tn * (16 * TN);
     const int B = S.B, H = S.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int nrt = (B + 15) >> 4;
 
-    f32x4 acc[1][2];
-    acc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[0][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     if (S.a_rz) {
-        const RowsPlain ra{m0, B}, rb{n0, H};
-        const bool vecRZ = fn_aligned16(S.a_rz, 3 * H), vecN = fn_aligned16(S.a_n, H), vecB = fn_aligned16(S.w_hh_t, 3 * H);
-        const int K = 3 * H, K2 = 2 * H;
-        const int nk = (K + BK - 1) / BK;
-        const float* arz = S.a_rz;
-        const float* an = S.a_n;
-        const float* wt = S.w_hh_t;
-        auto loadA = [&](int k0, SA& st) {
-            if (k0 < K2) st.load(arz, 3 * H, ra, k0, K2, vecRZ);
-            else st.load(an, H, ra, k0 - K2, H, vecN);
-        };
-        auto loadB = [&](int k0, SB& st) { st.load(wt, K, rb, k0, K, vecB); };
-        fn_kloop<PF_DEPTH, 1, 2, BK, SA, SB>(smem, nk, loadA, loadB, wave * 16, 0, lane, acc);
-    }
-
+        const int K2 = 2 * H, K = 3 * H;
+        const float *arz[TM], *an[TM], *bp[TN];
 #pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2) {
-        const int jj = n0 + t2 * 16 + (lane & 15);
+        for (int m = 0; m < TM; ++m) {
+            const long row = min(m0 + 16 * m + li, B - 1);
+            arz[m] = S.a_rz + row * K + 4 * lg;
+            an[m] = S.a_n + row * H + 4 * lg - K2;          // indexed with the global k of the [rz | n] concatenation
+        }
+#pragma unroll
+        for (int n = 0; n < TN; ++n) bp[n] = S.w_hh_t + (long)min(n0 + 16 * n + li, H - 1) * K + 4 * lg;
+        const int nk = K >> 5;
+        const int nkw = wave < nk ? (nk - wave + 3) >> 2 : 0;
+        float4 fa[D][TM][2], fb[D][TN][2];
+        auto load = [&](int set, int it) {
+            const int k0 = (wave + 4 * it) << 5;
+            const bool rz = k0 < K2;                             // wave-uniform: a chunk never straddles 2H (H % 32 == 0)
+#pragma unroll
+            for (int m = 0; m < TM; ++m) {
+                const float* p = (rz ? arz[m] : an[m]) + k0;
+                fa[set][m][0] = ld4(p);
+                fa[set][m][1] = ld4(p + 16);
+            }
+#pragma unroll
+            for (int n = 0; n < TN; ++n) { fb[set][n][0] = ld4(bp[n] + k0); fb[set][n][1] = ld4(bp[n] + k0 + 16); }
+        };
+#pragma unroll
+        for (int s = 0; s < D; ++s)
+            if (s < nkw) load(s, s);
+        for (int base = 0; base < nkw; base += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                const int it = base + u;
+                if (it < nkw) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int m = 0; m < TM; ++m)
+#pragma unroll
+                            for (int n = 0; n < TN; ++n)
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4at(fa[u][m][j >> 2], j & 3), f4at(fb[u][n][j >> 2], j & 3),
+                                                                                 acc[m][n], 0, 0, 0);
+                    if (it + D < nkw) load(u, it + D);
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+                *reinterpret_cast<f32x4*>(red + ((wave * TM + m) * TN + n) * 256 + lane * 4) = acc[m][n];
+        __syncthreads();
+    }
+    if (wave >= TM) return;
+#pragma unroll
+    for (int t2 = 0; t2 < TN; ++t2) {
+        f32x4 a4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (S.a_rz) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a4 += *reinterpret_cast<const f32x4*>(red + ((w * TM + wave) * TN + t2) * 256 + lane * 4);
+        }
+        const int jj = n0 + t2 * 16 + li;
         if (jj >= H) continue;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int b = m0 + wave * 16 + (lane >> 4) * 4 + i;
+            const int b = m0 + wave * 16 + lg * 4 + i;
             if (b >= B) continue;
             const long o = (long)b * H + jj;
-            float dh = acc[0][t2][i];
+            float dh = a4[i];
             if (S.dh_in) dh += S.dh_in[o];
             if (S.dh_ext) dh += S.dh_ext[o];
             if (!S.gates_q) {
                 S.dh0_out[o] = dh;
                 continue;
             }
-            const float* g = S.gates_q + (long)b * 4 * H;
-            const float r = g[jj], z = g[H + jj], n = g[2 * H + jj], hn = g[3 * H + jj];
+            const float* g = S.gates_q;
+            const float r = g[gate_off(b, 0, jj, nrt)], z = g[gate_off(b, 1, jj, nrt)], n = g[gate_off(b, 2, jj, nrt)],
+                        hn = g[gate_off(b, 3, jj, nrt)];
             const float hp = S.hprev_q ? S.hprev_q[o] : 0.f;
             const float dn = dh * (1.0f - z);
             const float dz = dh * (hp - n);
@@ -219,45 +334,28 @@ __global__ __launch_bounds__(NT) void gru_bwd_step_kernel(const BwdArgs args) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// gradient of the one-hot columns of W_ih: segmented sum of dgx rows by token id
-// ---------------------------------------------------------------------------------------------
-constexpr int EG_COLS = 64;
-constexpr int EG_ROWS = 4096;
-
-__global__ __launch_bounds__(NT) void embed_grad_partial_kernel(const float* __restrict__ dgx, int B, int T, int N3,
-                                                                const int* __restrict__ idx, int idx_ld, int idx_shift,
-                                                                int start_token, int reverse, int V, float* __restrict__ ws) {
-    extern __shared__ __attribute__((aligned(16))) float tab[];   // [V][EG_COLS]
-    const int col0 = blockIdx.x * EG_COLS, c = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const long rows = (long)B * T;
-    const long r0 = (long)blockIdx.y * EG_ROWS, r1 = min(rows, r0 + (long)EG_ROWS);
-    for (int i = threadIdx.x; i < V * EG_COLS; i += NT) tab[i] = 0.f;
-    __syncthreads();
-    if (col0 + c < N3) {
-        for (long r = r0 + w; r < r1; r += 4) {
-            const int p = (int)(r / B), b = (int)(r % B);
-            const int tau = (reverse ? T - 1 - p : p) + idx_shift;
-            const int tok = tau < 0 ? start_token : idx[(long)b * idx_ld + tau];
-            atomicAdd(&tab[tok * EG_COLS + c], dgx[r * N3 + col0 + c]);
-        }
+template <int TM, int D>
+void launch_fwd(const FwdArgs& a, int tiles, hipStream_t st) {
+    switch (a.n) {
+#define FN_CASE(N) case N: hipLaunchKernelGGL((gru_fwd_step_kernel<N, TM, D>), dim3(tiles), dim3(NT), 0, st, a); break;
+        FN_CASE(1) FN_CASE(2) FN_CASE(3) FN_CASE(4) FN_CASE(5) FN_CASE(6) FN_CASE(7) FN_CASE(8)
+#undef FN_CASE
     }
-    __syncthreads();
-    if (col0 + c < N3)
-        for (int vv = w; vv < V; vv += 4) ws[((long)blockIdx.y * V + vv) * N3 + col0 + c] = tab[vv * EG_COLS + c];
 }
-
-__global__ void embed_grad_reduce_kernel(const float* __restrict__ ws, int chunks, long total, float* __restrict__ out) {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < chunks; ++k) s += ws[k * total + i];
-        out[i] = s;
+template <int TM, int TN, int D>
+void launch_bwd(const BwdArgs& a, int tiles, hipStream_t st) {
+    switch (a.n) {
+#define FN_CASE(N) case N: hipLaunchKernelGGL((gru_bwd_step_kernel<N, TM, TN, D>), dim3(tiles), dim3(NT), 0, st, a); break;
+        FN_CASE(1) FN_CASE(2) FN_CASE(3) FN_CASE(4) FN_CASE(5) FN_CASE(6) FN_CASE(7) FN_CASE(8)
+#undef FN_CASE
     }
 }
 
 }  // namespace
 
 extern "C" {
+
+size_t fn_gru_gates_floats(int B, int H) { return (size_t)4 * H * (((size_t)B + 15) / 16 * 16); }
 
 int fn_gru_seq_fwd(const FnGruFwd* scans, int n_scans, void* stream) {
     if (!scans) return FN_E_NULL;
@@ -266,12 +364,19 @@ int fn_gru_seq_fwd(const FnGruFwd* scans, int n_scans, void* stream) {
     for (int s = 0; s < n_scans; ++s) {
         const FnGruFwd& d = scans[s];
         if (!d.w_hh || !d.b_hh || !d.h_all) return FN_E_NULL;
-        if (d.B <= 0 || d.T <= 0 || d.H <= 0 || (d.H % 16) != 0) return FN_E_SHAPE;
+        if (d.B <= 0 || d.T <= 0 || d.H <= 0 || (d.H % 32) != 0) return FN_E_SHAPE;
         if (d.gx_table && !d.idx) return FN_E_NULL;
+        if ((((uintptr_t)d.w_hh) | ((uintptr_t)d.h_all) | ((uintptr_t)d.h0)) & 15) return FN_E_ALIGN;
         Tmax = d.T > Tmax ? d.T : Tmax;
     }
     hipStream_t st = (hipStream_t)stream;
     for (int p = 0; p < Tmax; ++p) {
+        // row-tile height: 64 rows when the launch already fills the chip, 32 otherwise (more workgroups)
+        long big_tiles = 0;
+        for (int s = 0; s < n_scans; ++s)
+            if (p < scans[s].T) big_tiles += (long)((scans[s].B + 63) / 64) * (scans[s].H / 16);
+        const bool big = big_tiles >= 256;
+        const int bm = big ? 64 : 32;
         FwdArgs a;
         a.n = 0;
         int tiles = 0;
@@ -283,7 +388,7 @@ int fn_gru_seq_fwd(const FnGruFwd* scans, int n_scans, void* stream) {
             f.w_hh = d.w_hh; f.b_hh = d.b_hh; f.b_ih = d.b_ih;
             f.h_prev = p == 0 ? d.h0 : d.h_all + (p - 1) * BH;
             f.h_out = d.h_all + p * BH;
-            f.gates = d.gates ? d.gates + p * 4 * BH : nullptr;
+            f.gates = d.gates ? d.gates + (long)p * fn_gru_gates_floats(d.B, d.H) : nullptr;
             f.gx_dense = d.gx_dense ? d.gx_dense + p * 3 * BH : nullptr;
             f.gx_table = d.gx_table;
             f.gx_rowbias = d.gx_rowbias;
@@ -292,16 +397,13 @@ int fn_gru_seq_fwd(const FnGruFwd* scans, int n_scans, void* stream) {
             f.idx_ld = d.idx_ld;
             f.tok_const = d.start_token;
             f.B = d.B; f.H = d.H;
-            f.ntm = (d.B + 63) / 64;
+            f.ntm = (d.B + bm - 1) / bm;
             f.tile0 = tiles;
             tiles += f.ntm * (d.H / 16);
         }
         a.total = tiles;
-        switch (a.n) {
-#define FN_CASE(N) case N: hipLaunchKernelGGL(gru_fwd_step_kernel<N>, dim3(tiles), dim3(NT), 0, st, a); break;
-            FN_CASE(1) FN_CASE(2) FN_CASE(3) FN_CASE(4) FN_CASE(5) FN_CASE(6) FN_CASE(7) FN_CASE(8)
-#undef FN_CASE
-        }
+        if (big) launch_fwd<4, 2>(a, tiles, st);
+        else launch_fwd<2, 3>(a, tiles, st);
         FN_CHECK_LAUNCH();
     }
     return FN_OK;
@@ -314,11 +416,21 @@ int fn_gru_seq_bwd(const FnGruBwd* scans, int n_scans, void* stream) {
     for (int s = 0; s < n_scans; ++s) {
         const FnGruBwd& d = scans[s];
         if (!d.w_hh_t || !d.h_all || !d.gates || !d.dgx_all || !d.dghn_all || !d.scratch) return FN_E_NULL;
-        if (d.B <= 0 || d.T <= 0 || d.H <= 0 || (d.H % 16) != 0) return FN_E_SHAPE;
+        if (d.B <= 0 || d.T <= 0 || d.H <= 0 || (d.H % 32) != 0) return FN_E_SHAPE;
+        if ((((uintptr_t)d.w_hh_t) | ((uintptr_t)d.dgx_all) | ((uintptr_t)d.dghn_all)) & 15) return FN_E_ALIGN;
         Tmax = d.T > Tmax ? d.T : Tmax;
     }
     hipStream_t st = (hipStream_t)stream;
     for (int it = 0; it <= Tmax; ++it) {
+        long big_tiles = 0;
+        for (int s = 0; s < n_scans; ++s) {
+            const FnGruBwd& d = scans[s];
+            if (it > d.T || (it == d.T && !d.dh0)) continue;
+            big_tiles += (long)((d.B + 63) / 64) * ((d.H + 31) / 32);
+        }
+        if (big_tiles == 0) continue;
+        const bool big = big_tiles >= 192;
+        const int bm = big ? 64 : 32, bn = big ? 32 : 16;
         BwdArgs a;
         a.n = 0;
         int tiles = 0;
@@ -327,6 +439,7 @@ int fn_gru_seq_bwd(const FnGruBwd* scans, int n_scans, void* stream) {
             if (it > d.T || (it == d.T && !d.dh0)) continue;
             BwdStep& f = a.s[a.n++];
             const long BH = (long)d.B * d.H;
+            const long GS = (long)fn_gru_gates_floats(d.B, d.H);
             const int q = d.T - 1 - it;                    // step whose gate backward runs now (-1 on the last)
             f.w_hh_t = d.w_hh_t;
             if (it > 0) {
@@ -339,7 +452,7 @@ int fn_gru_seq_bwd(const FnGruBwd* scans, int n_scans, void* stream) {
             }
             f.dh_ext = (d.dh_ext && q >= 0) ? d.dh_ext + (long)q * BH : nullptr;
             if (q >= 0) {
-                f.gates_q = d.gates + (long)q * 4 * BH;
+                f.gates_q = d.gates + (long)q * GS;
                 f.hprev_q = q == 0 ? d.h0 : d.h_all + (long)(q - 1) * BH;
                 f.dgx_q = d.dgx_all + (long)q * 3 * BH;
                 f.dghn_q = d.dghn_all + (long)q * BH;
@@ -351,46 +464,15 @@ int fn_gru_seq_bwd(const FnGruBwd* scans, int n_scans, void* stream) {
             f.rowsum_n = d.dghn_rowsum;
             f.dh0_out = d.dh0;
             f.B = d.B; f.H = d.H;
-            f.ntm = (d.B + 63) / 64;
+            f.ntm = (d.B + bm - 1) / bm;
             f.tile0 = tiles;
-            tiles += f.ntm * ((d.H + 31) / 32);
+            tiles += f.ntm * ((d.H + bn - 1) / bn);
         }
-        if (tiles == 0) continue;
         a.total = tiles;
-        switch (a.n) {
-#define FN_CASE(N) case N: hipLaunchKernelGGL(gru_bwd_step_kernel<N>, dim3(tiles), dim3(NT), 0, st, a); break;
-            FN_CASE(1) FN_CASE(2) FN_CASE(3) FN_CASE(4) FN_CASE(5) FN_CASE(6) FN_CASE(7) FN_CASE(8)
-#undef FN_CASE
-        }
+        if (big) launch_bwd<4, 2, 2>(a, tiles, st);
+        else launch_bwd<2, 1, 3>(a, tiles, st);
         FN_CHECK_LAUNCH();
     }
-    return FN_OK;
-}
-
-static int eg_chunks(int64_t rows) { return (int)((rows + EG_ROWS - 1) / EG_ROWS); }
-size_t fn_embed_grad_ws_bytes(int64_t rows, int V, int N3) { return (size_t)eg_chunks(rows) * V * N3 * sizeof(float); }
-
-int fn_embed_grad_f32(const float* dgx_all, int B, int T, int N3, const int32_t* idx, int idx_ld, int idx_shift,
-                      int start_token, int reverse, int V, float* out, float* ws, size_t ws_bytes, void* stream) {
-    if (!dgx_all || !idx || !out || !ws) return FN_E_NULL;
-    if (B <= 0 || T <= 0 || N3 <= 0 || V <= 0 || (size_t)V * EG_COLS * sizeof(float) > 160 * 1024) return FN_E_SHAPE;
-    const int64_t rows = (int64_t)B * T;
-    if (ws_bytes < fn_embed_grad_ws_bytes(rows, V, N3)) return FN_E_WORKSPACE;
-    const int chunks = eg_chunks(rows);
-    hipStream_t st = (hipStream_t)stream;
-    const size_t sh = (size_t)V * EG_COLS * sizeof(float);
-    static bool attr_set = false;   // idempotent, value never changes
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)embed_grad_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(embed_grad_partial_kernel, dim3((N3 + EG_COLS - 1) / EG_COLS, chunks), dim3(NT), sh, st, dgx_all, B, T, N3,
-                       idx, idx_ld, idx_shift, start_token, reverse, V, ws);
-    FN_CHECK_LAUNCH();
-    const long total = (long)V * N3;
-    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(embed_grad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, chunks, total, out);
-    FN_CHECK_LAUNCH();
     return FN_OK;
 }
 

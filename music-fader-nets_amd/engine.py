@@ -32,8 +32,8 @@ class Engine:
         self.tab = {}                   # transposed one-hot columns of W_ih:  key -> [V][3H]
         self.whh_t = {}                 # transposed W_hh: key -> [H][3H]
         self.saved = None
-        if hidden % 16 != 0:
-            raise ValueError("hidden_dims must be a multiple of 16 for the MFMA tiles")
+        if hidden % 32 != 0:
+            raise ValueError("hidden_dims must be a multiple of 32 (K chunks of the MFMA step kernels)")
         if n_component > 8:
             raise ValueError("n_component > 8 not supported by fn_latent_*")
 
@@ -88,7 +88,7 @@ class Engine:
                 hall[key] = self.buf("enc_h_" + key, (T, B, H))
                 scans.append(dict(B=B, T=T, H=H, reverse=rev, w_hh=P[pfx + "weight_hh" + sfx], b_hh=P[pfx + "bias_hh" + sfx],
                                   b_ih=P[pfx + "bias_ih" + sfx], gx_table=self.tab[key], idx=d, idx_shift=0,
-                                  h_all=hall[key], gates=self.buf("enc_g_" + key, (T, B, 4, H)) if save else None))
+                                  h_all=hall[key], gates=self.buf("enc_g_" + key, (T, ops.gates_floats(B, H))) if save else None))
         ops.gru_seq_fwd(scans)
         pre = {}
         for e in ("r", "n"):
@@ -125,7 +125,7 @@ class Engine:
             w_ih = P["gru_d_%s.weight_ih_l0" % e]
             rb = self.buf("sd_rb_" + e, (B, 3 * H))
             ops.gemm(z, w_ih[:, Ce:], rb)
-            sd[e] = dict(h0=h0, rb=rb, h_all=self.buf("sd_h_" + e, (Tr, B, H)), gates=self.buf("sd_g_" + e, (Tr, B, 4, H)))
+            sd[e] = dict(h0=h0, rb=rb, h_all=self.buf("sd_h_" + e, (Tr, B, H)), gates=self.buf("sd_g_" + e, (Tr, ops.gates_floats(B, H))))
             scans.append(dict(B=B, T=Tr, H=H, w_hh=P["gru_d_%s.weight_hh_l0" % e], b_hh=P["gru_d_%s.bias_hh_l0" % e],
                               b_ih=P["gru_d_%s.bias_ih_l0" % e], h0=h0, gx_table=self.tab["d_" + e], idx=attr, gx_rowbias=rb,
                               h_all=sd[e]["h_all"], gates=sd[e]["gates"]))
@@ -138,7 +138,7 @@ class Engine:
         rbg = self.buf("g_rb", (B, 3 * H))
         ops.gemm(zc, P["grucell_g.weight_ih"][:, E_VOCAB:], rbg)
         hx0 = self.buf("g_hx0", (T, B, H))
-        g1 = self.buf("g_gates1", (T, B, 4, H))
+        g1 = self.buf("g_gates1", (T, ops.gates_floats(B, H)))
         scans.append(dict(B=B, T=T, H=H, w_hh=P["grucell_g.weight_hh"], b_hh=P["grucell_g.bias_hh"], b_ih=P["grucell_g.bias_ih"],
                           h0=h0g, gx_table=self.tab["g"], idx=d, idx_shift=-1, start_token=E_VOCAB - 1, gx_rowbias=rbg,
                           h_all=hx0, gates=g1))
@@ -147,7 +147,7 @@ class Engine:
         gx2 = self.buf("g_gx2", (T, B, 3 * H))
         ops.gemm(hx0.view(T * B, H), P["grucell_g_2.weight_ih"], gx2.view(T * B, 3 * H), bias=P["grucell_g_2.bias_ih"])
         hx1 = self.buf("g_hx1", (T, B, H))
-        g2 = self.buf("g_gates2", (T, B, 4, H))
+        g2 = self.buf("g_gates2", (T, ops.gates_floats(B, H)))
         ops.gru_seq_fwd([dict(B=B, T=T, H=H, w_hh=P["grucell_g_2.weight_hh"], b_hh=P["grucell_g_2.bias_hh"], h0=hx0[0],
                               gx_dense=gx2, h_all=hx1, gates=g2)])
         logits = self.buf("g_logits", (T * B, LOGIT_LD))

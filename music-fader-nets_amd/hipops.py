@@ -108,6 +108,10 @@ class HipOps:
         _lib.check(self.lib.fn_sum_f32(_p(x), x.numel(), scale, _p(out), self.stream()), "fn_sum_f32")
 
     # -- GRU scans ------------------------------------------------------------------------------
+    def gates_floats(self, B, H):
+        """floats per time step of the (opaque, blocked) saved-gates buffer."""
+        return int(self.lib.fn_gru_gates_floats(B, H))
+
     def gru_seq_fwd(self, scans):
         arr = (_lib.FnGruFwd * len(scans))()
         for d, s in zip(arr, scans):

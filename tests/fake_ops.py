@@ -49,6 +49,15 @@ class FakeOps:
 
     # -- GRU ----------------------------------------------------------------------------------------
     @staticmethod
+    def gates_floats(B, H):
+        return 4 * H * ((B + 15) // 16 * 16)
+
+    @staticmethod
+    def _gview(gates, p, B, H):
+        """the gate buffer is opaque to callers; the fake keeps plain [B][4][H] in the head of each step's slab"""
+        return gates[p].reshape(-1)[: B * 4 * H].view(B, 4, H)
+
+    @staticmethod
     def _tok(s, p):
         tau = (s["T"] - 1 - p if s.get("reverse", 0) else p) + s.get("idx_shift", 0)
         if tau < 0:
@@ -77,7 +86,7 @@ class FakeOps:
                 h = (1 - z) * n + z * h
                 s["h_all"][p].copy_(h)
                 if s.get("gates") is not None:
-                    g = s["gates"][p]
+                    g = self._gview(s["gates"], p, B, H)
                     g[:, 0].copy_(r), g[:, 1].copy_(z), g[:, 2].copy_(n), g[:, 3].copy_(gh[:, 2 * H:])
 
     def gru_seq_bwd(self, scans):
@@ -89,7 +98,7 @@ class FakeOps:
                 carry = carry + s["dh_last"]
             for q in range(T - 1, -1, -1):
                 dh = carry + (s["dh_ext"][q] if s.get("dh_ext") is not None else 0)
-                g = s["gates"][q]
+                g = self._gview(s["gates"], q, B, H)
                 r, z, n, hn = g[:, 0], g[:, 1], g[:, 2], g[:, 3]
                 hp = (s["h0"] if s.get("h0") is not None else torch.zeros(B, H)) if q == 0 else s["h_all"][q - 1]
                 dn = dh * (1 - z)
