@@ -16,6 +16,9 @@
 //     holds r/z/n of the SAME (row, unit) in the same lane, so the gate epilogue is lane-local;
 //   * the saved gates use a private blocked layout in which every wave store / load instruction is one
 //     contiguous 256-byte run (see gate_off).
+#include <cstdio>
+#include <cstdlib>
+
 #include "common.h"
 #include "mma_core.h"
 
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
     int si = 0;
 #pragma unroll
     for (int k = 1; k < NS; ++k)
-        if (v >= args.s[k].tile0) si = k;
+        if (k < args.n && v >= args.s[k].tile0) si = k;
     const FwdStep& S = args.s[si];
     const int local = v - S.tile0;
     const int tn = local / S.ntm, tm = local % S.ntm;     // row tiles fastest: neighbours share weight rows
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(NT) void gru_bwd_step_kernel(const BwdArgs args) {
     int si = 0;
 #pragma unroll
     for (int k = 1; k < NS; ++k)
-        if (v >= args.s[k].tile0) si = k;
+        if (k < args.n && v >= args.s[k].tile0) si = k;
     const BwdStep& S = args.s[si];
     const int local = v - S.tile0;
     const int tn = local / S.ntm, tm = local % S.ntm;
@@ -334,21 +337,46 @@ __global__ __launch_bounds__(NT) void gru_bwd_step_kernel(const BwdArgs args) {
     }
 }
 
+// ---- launch configuration -------------------------------------------------------------------------------
+// (TM, TN, D) = M-tiles per workgroup, N-tiles (backward only), chunks in flight per wave.  Defaults were picked by
+// measurement on MI355X (profiles/); FN_FWD_CFG / FN_BWD_CFG = "TM,TN,D" override them for tuning runs.
+struct Cfg { int tm, tn, d; };
+
+bool env_cfg(const char* name, Cfg& c) {
+    const char* e = getenv(name);
+    Cfg t;
+    if (!e || sscanf(e, "%d,%d,%d", &t.tm, &t.tn, &t.d) != 3) return false;
+    c = t;
+    return true;
+}
+
 template <int TM, int D>
-void launch_fwd(const FwdArgs& a, int tiles, hipStream_t st) {
-    switch (a.n) {
-#define FN_CASE(N) case N: hipLaunchKernelGGL((gru_fwd_step_kernel<N, TM, D>), dim3(tiles), dim3(NT), 0, st, a); break;
-        FN_CASE(1) FN_CASE(2) FN_CASE(3) FN_CASE(4) FN_CASE(5) FN_CASE(6) FN_CASE(7) FN_CASE(8)
-#undef FN_CASE
-    }
+void launch_fwd_ns(const FwdArgs& a, int tiles, hipStream_t st) {
+    if (a.n == 1) hipLaunchKernelGGL((gru_fwd_step_kernel<1, TM, D>), dim3(tiles), dim3(NT), 0, st, a);
+    else if (a.n <= 3) hipLaunchKernelGGL((gru_fwd_step_kernel<3, TM, D>), dim3(tiles), dim3(NT), 0, st, a);
+    else if (a.n == 4) hipLaunchKernelGGL((gru_fwd_step_kernel<4, TM, D>), dim3(tiles), dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((gru_fwd_step_kernel<8, TM, D>), dim3(tiles), dim3(NT), 0, st, a);
 }
 template <int TM, int TN, int D>
-void launch_bwd(const BwdArgs& a, int tiles, hipStream_t st) {
-    switch (a.n) {
-#define FN_CASE(N) case N: hipLaunchKernelGGL((gru_bwd_step_kernel<N, TM, TN, D>), dim3(tiles), dim3(NT), 0, st, a); break;
-        FN_CASE(1) FN_CASE(2) FN_CASE(3) FN_CASE(4) FN_CASE(5) FN_CASE(6) FN_CASE(7) FN_CASE(8)
-#undef FN_CASE
-    }
+void launch_bwd_ns(const BwdArgs& a, int tiles, hipStream_t st) {
+    if (a.n == 1) hipLaunchKernelGGL((gru_bwd_step_kernel<1, TM, TN, D>), dim3(tiles), dim3(NT), 0, st, a);
+    else if (a.n <= 3) hipLaunchKernelGGL((gru_bwd_step_kernel<3, TM, TN, D>), dim3(tiles), dim3(NT), 0, st, a);
+    else if (a.n == 4) hipLaunchKernelGGL((gru_bwd_step_kernel<4, TM, TN, D>), dim3(tiles), dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((gru_bwd_step_kernel<8, TM, TN, D>), dim3(tiles), dim3(NT), 0, st, a);
+}
+
+bool launch_fwd(const Cfg& c, const FwdArgs& a, int tiles, hipStream_t st) {
+#define FN_F(TM_, D_) if (c.tm == TM_ && c.d == D_) { launch_fwd_ns<TM_, D_>(a, tiles, st); return true; }
+    FN_F(1, 2) FN_F(1, 3) FN_F(1, 4) FN_F(2, 2) FN_F(2, 3) FN_F(2, 4) FN_F(4, 1) FN_F(4, 2) FN_F(4, 3)
+#undef FN_F
+    return false;
+}
+bool launch_bwd(const Cfg& c, const BwdArgs& a, int tiles, hipStream_t st) {
+#define FN_B(TM_, TN_, D_) if (c.tm == TM_ && c.tn == TN_ && c.d == D_) { launch_bwd_ns<TM_, TN_, D_>(a, tiles, st); return true; }
+    FN_B(1, 1, 3) FN_B(1, 1, 4) FN_B(2, 1, 2) FN_B(2, 1, 3) FN_B(2, 1, 4) FN_B(2, 2, 2) FN_B(2, 2, 3) FN_B(2, 2, 4)
+    FN_B(4, 1, 2) FN_B(4, 1, 3) FN_B(4, 2, 2) FN_B(4, 2, 3) FN_B(4, 2, 4) FN_B(1, 2, 3) FN_B(1, 2, 4)
+#undef FN_B
+    return false;
 }
 
 }  // namespace
@@ -375,8 +403,9 @@ int fn_gru_seq_fwd(const FnGruFwd* scans, int n_scans, void* stream) {
         long big_tiles = 0;
         for (int s = 0; s < n_scans; ++s)
             if (p < scans[s].T) big_tiles += (long)((scans[s].B + 63) / 64) * (scans[s].H / 16);
-        const bool big = big_tiles >= 256;
-        const int bm = big ? 64 : 32;
+        Cfg cfg = big_tiles >= 256 ? Cfg{4, 0, 2} : Cfg{2, 0, 3};
+        env_cfg(big_tiles >= 256 ? "FN_FWD_CFG" : "FN_FWD_CFG1", cfg);
+        const int bm = 16 * cfg.tm;
         FwdArgs a;
         a.n = 0;
         int tiles = 0;
@@ -402,8 +431,7 @@ int fn_gru_seq_fwd(const FnGruFwd* scans, int n_scans, void* stream) {
             tiles += f.ntm * (d.H / 16);
         }
         a.total = tiles;
-        if (big) launch_fwd<4, 2>(a, tiles, st);
-        else launch_fwd<2, 3>(a, tiles, st);
+        if (!launch_fwd(cfg, a, tiles, st)) return FN_E_SHAPE;
         FN_CHECK_LAUNCH();
     }
     return FN_OK;
@@ -429,8 +457,9 @@ int fn_gru_seq_bwd(const FnGruBwd* scans, int n_scans, void* stream) {
             big_tiles += (long)((d.B + 63) / 64) * ((d.H + 31) / 32);
         }
         if (big_tiles == 0) continue;
-        const bool big = big_tiles >= 192;
-        const int bm = big ? 64 : 32, bn = big ? 32 : 16;
+        Cfg cfg = big_tiles >= 192 ? Cfg{4, 2, 2} : Cfg{2, 1, 3};
+        env_cfg(big_tiles >= 192 ? "FN_BWD_CFG" : "FN_BWD_CFG1", cfg);
+        const int bm = 16 * cfg.tm, bn = 16 * cfg.tn;
         BwdArgs a;
         a.n = 0;
         int tiles = 0;
@@ -469,8 +498,7 @@ int fn_gru_seq_bwd(const FnGruBwd* scans, int n_scans, void* stream) {
             tiles += f.ntm * ((d.H + bn - 1) / bn);
         }
         a.total = tiles;
-        if (big) launch_bwd<4, 2, 2>(a, tiles, st);
-        else launch_bwd<2, 1, 3>(a, tiles, st);
+        if (!launch_bwd(cfg, a, tiles, st)) return FN_E_SHAPE;
         FN_CHECK_LAUNCH();
     }
     return FN_OK;
