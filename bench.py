@@ -44,7 +44,7 @@ def measure_dominant_kernel(trainer, batch, eps, reps=3):
         for e in ("r", "n"):
             for key, sfx, rev in ((e, "_l0", 0), (e + "_reverse", "_l0_reverse", 1)):
                 pfx = "gru_%s." % e
-                scans.append(dict(B=B, T=T, H=H, reverse=rev, w_hh=P[pfx + "weight_hh" + sfx], b_hh=P[pfx + "bias_hh" + sfx],
+                scans.append(dict(B=B, T=T, H=H, reverse=rev, w_hh_frag=eng.whh_f[key], b_hh=P[pfx + "bias_hh" + sfx],
                                   b_ih=P[pfx + "bias_ih" + sfx], gx_table=eng.tab[key], idx=d, idx_shift=0,
                                   h_all=eng.buf("enc_h_" + key, (T, B, H)), gates=eng.buf("enc_g_" + key, (T, eng.ops.gates_floats(B, H)))))
         e0.record()

@@ -72,12 +72,14 @@ int fn_sum_f32(const float* x, int64_t n, float scale, float* out, void* stream)
  *    gx[b,:] = b_ih + gx_dense[p][b,:] + gx_table[tok][:] + gx_rowbias[b,:]     (each optional)
  *    tok = (tau < 0) ? start_token : idx[b*idx_ld + tau],  tau = (reverse ? T-1-p : p) + idx_shift
  * Storage is in PROCESSING order p = 0..T-1 (for reverse scans p=0 is the last time step).
- * H must be a multiple of 32; w_hh, h0, h_all 16-byte aligned.
+ * H must be a multiple of 32.  The recurrent weights are passed in the FRAGMENT-MAJOR image produced by
+ * fn_frag_pack (one contiguous 1 KB run per wave load instruction); frag_ws is caller-owned scratch of
+ * 2 * fn_frag_floats(B, H) floats in which the scan ping-pongs the state in the same layout.
  * ------------------------------------------------------------------------------------------ */
 typedef struct FnGruFwd {
     int32_t B, T, H;
     int32_t reverse;          /* 1: consume tokens from the end (the *_reverse direction)      */
-    const float* w_hh;        /* [3H][H]                                                       */
+    const float* w_hh_frag;   /* fn_frag_pack(W_hh [3H][H])                                     */
     const float* b_hh;        /* [3H]                                                          */
     const float* b_ih;        /* [3H] or NULL                                                  */
     const float* h0;          /* [B][H] or NULL (= zeros)                                      */
@@ -91,7 +93,13 @@ typedef struct FnGruFwd {
     float* h_all;             /* [T][B][H] state after each step                               */
     float* gates;             /* [T][fn_gru_gates_floats(B,H)] saved r,z,n,(W_hn h + b_hn) in a    */
                               /* private blocked layout (opaque to the caller); NULL = inference */
+    float* frag_ws;           /* scratch, 2 * fn_frag_floats(B, H) floats, 16-byte aligned         */
 } FnGruFwd;
+
+/* fragment-major operand image: floats needed for a [rows][K] matrix, and the packing kernel
+ * (src row-major with leading dimension ld, K % 32 == 0; rows are zero-padded to a multiple of 16) */
+size_t fn_frag_floats(int rows, int K);
+int fn_frag_pack(const float* src, int rows, int K, int ld, float* dst, void* stream);
 
 /* floats per time step of the saved-gates buffer (4*H*ceil16(B)) */
 size_t fn_gru_gates_floats(int B, int H);
@@ -105,10 +113,10 @@ int fn_gru_seq_fwd(const FnGruFwd* scans, int n_scans, void* stream);
  *            dh0 [B][H]  gradient wrt h0 (NULL = not needed)
  *            dgx_rowsum [B][3H] += sum_p dgx_all[p], dghn_rowsum [B][H] += sum_p dghn_all[p]
  *                        (NULL = not needed; caller zero-fills; their column sums are the bias gradients)
- * w_hh_t is W_hh transposed: [H][3H].  scratch: [B][H] floats per scan. */
+ * w_hh_t_frag = fn_frag_pack(W_hh^T [H][3H]).  scratch: [B][H] floats; frag_ws: 2 * fn_frag_floats(B, 3H) floats. */
 typedef struct FnGruBwd {
     int32_t B, T, H;
-    const float* w_hh_t;      /* [H][3H]                                                       */
+    const float* w_hh_t_frag; /* fn_frag_pack(W_hh^T [H][3H])                                  */
     const float* h0;          /* [B][H] or NULL                                                */
     const float* h_all;       /* [T][B][H]  from forward                                       */
     const float* gates;       /* [T][fn_gru_gates_floats(B,H)] from forward                    */
@@ -120,6 +128,7 @@ typedef struct FnGruBwd {
     float* dgx_rowsum;        /* [B][3H] or NULL                                               */
     float* dghn_rowsum;       /* [B][H] or NULL                                                */
     float* scratch;           /* [B][H]                                                        */
+    float* frag_ws;           /* 2 * fn_frag_floats(B, 3H) floats, 16-byte aligned             */
 } FnGruBwd;
 
 int fn_gru_seq_bwd(const FnGruBwd* scans, int n_scans, void* stream);

@@ -17,15 +17,15 @@ vp = C.c_void_p
 
 class FnGruFwd(C.Structure):
     _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("H", C.c_int32), ("reverse", C.c_int32),
-                ("w_hh", vp), ("b_hh", vp), ("b_ih", vp), ("h0", vp), ("gx_dense", vp), ("gx_table", vp),
+                ("w_hh_frag", vp), ("b_hh", vp), ("b_ih", vp), ("h0", vp), ("gx_dense", vp), ("gx_table", vp),
                 ("idx", vp), ("idx_ld", C.c_int32), ("idx_shift", C.c_int32), ("start_token", C.c_int32),
-                ("gx_rowbias", vp), ("h_all", vp), ("gates", vp)]
+                ("gx_rowbias", vp), ("h_all", vp), ("gates", vp), ("frag_ws", vp)]
 
 
 class FnGruBwd(C.Structure):
     _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("H", C.c_int32),
-                ("w_hh_t", vp), ("h0", vp), ("h_all", vp), ("gates", vp), ("dh_last", vp), ("dh_ext", vp),
-                ("dgx_all", vp), ("dghn_all", vp), ("dh0", vp), ("dgx_rowsum", vp), ("dghn_rowsum", vp), ("scratch", vp)]
+                ("w_hh_t_frag", vp), ("h0", vp), ("h_all", vp), ("gates", vp), ("dh_last", vp), ("dh_ext", vp),
+                ("dgx_all", vp), ("dghn_all", vp), ("dh0", vp), ("dgx_rowsum", vp), ("dghn_rowsum", vp), ("scratch", vp), ("frag_ws", vp)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/fadernets.h
@@ -41,6 +41,8 @@ SIGNATURES = {
     "fn_axpy_f32": (C.c_int, [C.c_int64, C.c_float, vp, vp, vp]),
     "fn_sum_f32": (C.c_int, [vp, C.c_int64, C.c_float, vp, vp]),
     "fn_gru_gates_floats": (C.c_size_t, [C.c_int, C.c_int]),
+    "fn_frag_floats": (C.c_size_t, [C.c_int, C.c_int]),
+    "fn_frag_pack": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "fn_gru_seq_fwd": (C.c_int, [C.POINTER(FnGruFwd), C.c_int, vp]),
     "fn_gru_seq_bwd": (C.c_int, [C.POINTER(FnGruBwd), C.c_int, vp]),
     "fn_embed_grad_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),

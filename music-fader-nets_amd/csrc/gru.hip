@@ -7,10 +7,14 @@
 // Step kernel structure (forward: h_{p-1} W_hh^T -> gates; backward: dgh W_hh -> dh -> gate backward):
 //   * workgroup tile = (16*TM batch rows) x (16 hidden units [x r,z,n] forward / 16*TN units backward);
 //   * the 4 waves of a workgroup SPLIT K: wave w owns the 32-wide K chunks w, w+4, ...  and streams its
-//     operand fragments global -> VGPR directly in MFMA layout (no LDS staging, no barrier in the K loop):
-//     lane (i = l&15, g = l>>4) reads, per tile row i, two float4 at k0 + 4g and k0 + 16 + 4g, i.e. every
-//     dwordx4 instruction covers 16 rows x 64 contiguous bytes; MFMA step j of a chunk consumes k = 4g + j
-//     (j < 4) or 16 + 4g + (j-4)  - the same K permutation for A and B, so the product is unchanged;
+//     operand fragments global -> VGPR directly in MFMA layout (no LDS staging, no barrier in the K loop).
+//     Both operands live in a FRAGMENT-MAJOR image (frag_off): [row tile 16][chunk 32][half][g][i][4 floats],
+//     so that the 64 lanes (i = l&15, g = l>>4) of one global_load_dwordx4 read 1 KB of consecutive bytes
+//     (a row-major source makes every lane quad touch 4 different cache lines and the kernel TA-bound:
+//     measured 3x slower).  The weights are packed once per optimiser step (fn_frag_pack), the recurrent
+//     activations are written in this layout by the previous step's epilogue (ping-pong scratch).
+//     MFMA step j of a chunk consumes k = 4g + j (j < 4) or 16 + 4g + (j-4) - the same K permutation for
+//     A and B, so the product is unchanged;
 //   * D chunks are kept in flight per wave (register ring) - the step is latency-bound otherwise;
 //   * one LDS exchange + barrier at the end adds the 4 partial accumulators; wave m then owns M-tile m and
 //     holds r/z/n of the SAME (row, unit) in the same lane, so the gate epilogue is lane-local;
@@ -33,6 +37,11 @@ FN_DEVINL long gate_off(int b, int q, int u, int nrt) {
     return ((((long)(u >> 4) * nrt + (b >> 4)) * 4 + q) * 4 + (b & 3)) * 64 + ((b & 15) >> 2) * 16 + (u & 15);
 }
 
+// fragment-major image of a [rows][K] matrix (K % 32 == 0, rows padded to 16), NC = K / 32 chunks
+FN_DEVINL long frag_off(int row, int k, int NC) {
+    return ((((long)(row >> 4) * NC + (k >> 5)) * 2 + ((k >> 4) & 1)) * 64 + (((k & 15) >> 2) * 16 + (row & 15))) * 4 + (k & 3);
+}
+
 FN_DEVINL float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 FN_DEVINL float f4at(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
 
@@ -40,10 +49,12 @@ FN_DEVINL float f4at(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v
 // forward step
 // ---------------------------------------------------------------------------------------------
 struct FwdStep {
-    const float* w_hh;
+    const float* w_frag;   // W_hh, fragment-major
     const float* b_hh;
     const float* b_ih;
-    const float* h_prev;   // null = zeros
+    const float* h_prev;   // [B][H] row-major state before this step (epilogue operand); null = zeros
+    const float* hf_in;    // the same state, fragment-major (MFMA operand)
+    float* hf_out;         // state after this step, fragment-major (next step's operand)
     float* h_out;
     float* gates;          // null = do not save
     const float* gx_dense;
@@ -119,19 +130,19 @@ __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
     if (S.h_prev) {
         const float* ap[TM];
         const float* bp[3];
-#pragma unroll
-        for (int m = 0; m < TM; ++m) ap[m] = S.h_prev + (long)min(m0 + 16 * m + li, B - 1) * H + 4 * lg;
-#pragma unroll
-        for (int n = 0; n < 3; ++n) bp[n] = S.w_hh + ((long)n * H + hh0 + li) * H + 4 * lg;
         const int nk = H >> 5;
+#pragma unroll
+        for (int m = 0; m < TM; ++m) ap[m] = S.hf_in + (long)min(tm * TM + m, nrt - 1) * nk * 512 + lane * 4;
+#pragma unroll
+        for (int n = 0; n < 3; ++n) bp[n] = S.w_frag + (long)(n * (H >> 4) + tn) * nk * 512 + lane * 4;
         const int nkw = wave < nk ? (nk - wave + 3) >> 2 : 0;        // chunks wave, wave+4, ...
         float4 fa[D][TM][2], fb[D][3][2];
         auto load = [&](int set, int it) {
-            const int k0 = (wave + 4 * it) << 5;
+            const int k0 = (wave + 4 * it) * 512;                    // one chunk = 2 halves x 64 lanes x 4 floats
 #pragma unroll
-            for (int m = 0; m < TM; ++m) { fa[set][m][0] = ld4(ap[m] + k0); fa[set][m][1] = ld4(ap[m] + k0 + 16); }
+            for (int m = 0; m < TM; ++m) { fa[set][m][0] = ld4(ap[m] + k0); fa[set][m][1] = ld4(ap[m] + k0 + 256); }
 #pragma unroll
-            for (int n = 0; n < 3; ++n) { fb[set][n][0] = ld4(bp[n] + k0); fb[set][n][1] = ld4(bp[n] + k0 + 16); }
+            for (int n = 0; n < 3; ++n) { fb[set][n][0] = ld4(bp[n] + k0); fb[set][n][1] = ld4(bp[n] + k0 + 256); }
         };
 #pragma unroll
         for (int s = 0; s < D; ++s)
@@ -181,6 +192,7 @@ __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
         const float n = tanhf(gx[i][2] + r * ghn);
         const float h = (1.0f - z) * n + z * hp[i];
         S.h_out[(long)b * H + jj] = h;
+        if (S.hf_out) S.hf_out[frag_off(b, jj, H >> 5)] = h;
         if (S.gates) {
             float* g = S.gates;
             g[gate_off(b, 0, jj, nrt)] = r;
@@ -195,9 +207,9 @@ __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
 // backward step:  dh_{q} = [dgh_{q+1} W_hh] + dh_in + dh_ext ; then the gate backward of step q
 // ---------------------------------------------------------------------------------------------
 struct BwdStep {
-    const float* w_hh_t;   // [H][3H]
-    const float* a_rz;     // dgx slab of step q+1 ([B][3H], columns [0,2H) used); null = no GEMM
-    const float* a_n;      // dghn slab of step q+1 ([B][H])
+    const float* wt_frag;  // W_hh^T ([H][3H]), fragment-major
+    const float* df_in;    // [dr | dz | dn*r] pre-activation gradients of step q+1 ([B][3H]), fragment-major; null = no GEMM
+    float* df_out;         // the same for step q (next iteration's operand)
     const float* dh_in;    // [B][H] carried dh*z (or dh_last on the first iteration); may alias dhz_out
     const float* dh_ext;   // [B][H] or null
     const float* gates_q;  // null = no gate backward (final iteration: write dh0_out)
@@ -239,31 +251,21 @@ __global__ __launch_bounds__(NT) void gru_bwd_step_kernel(const BwdArgs args) {
 #pragma unroll
         for (int n = 0; n < TN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    if (S.a_rz) {
-        const int K2 = 2 * H, K = 3 * H;
-        const float *arz[TM], *an[TM], *bp[TN];
+    if (S.df_in) {
+        const int nk = (3 * H) >> 5;
+        const float *ap[TM], *bp[TN];
 #pragma unroll
-        for (int m = 0; m < TM; ++m) {
-            const long row = min(m0 + 16 * m + li, B - 1);
-            arz[m] = S.a_rz + row * K + 4 * lg;
-            an[m] = S.a_n + row * H + 4 * lg - K2;          // indexed with the global k of the [rz | n] concatenation
-        }
+        for (int m = 0; m < TM; ++m) ap[m] = S.df_in + (long)min(tm * TM + m, nrt - 1) * nk * 512 + lane * 4;
 #pragma unroll
-        for (int n = 0; n < TN; ++n) bp[n] = S.w_hh_t + (long)min(n0 + 16 * n + li, H - 1) * K + 4 * lg;
-        const int nk = K >> 5;
+        for (int n = 0; n < TN; ++n) bp[n] = S.wt_frag + (long)min(tn * TN + n, (H >> 4) - 1) * nk * 512 + lane * 4;
         const int nkw = wave < nk ? (nk - wave + 3) >> 2 : 0;
         float4 fa[D][TM][2], fb[D][TN][2];
         auto load = [&](int set, int it) {
-            const int k0 = (wave + 4 * it) << 5;
-            const bool rz = k0 < K2;                             // wave-uniform: a chunk never straddles 2H (H % 32 == 0)
+            const int k0 = (wave + 4 * it) * 512;
 #pragma unroll
-            for (int m = 0; m < TM; ++m) {
-                const float* p = (rz ? arz[m] : an[m]) + k0;
-                fa[set][m][0] = ld4(p);
-                fa[set][m][1] = ld4(p + 16);
-            }
+            for (int m = 0; m < TM; ++m) { fa[set][m][0] = ld4(ap[m] + k0); fa[set][m][1] = ld4(ap[m] + k0 + 256); }
 #pragma unroll
-            for (int n = 0; n < TN; ++n) { fb[set][n][0] = ld4(bp[n] + k0); fb[set][n][1] = ld4(bp[n] + k0 + 16); }
+            for (int n = 0; n < TN; ++n) { fb[set][n][0] = ld4(bp[n] + k0); fb[set][n][1] = ld4(bp[n] + k0 + 256); }
         };
 #pragma unroll
         for (int s = 0; s < D; ++s)
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(NT) void gru_bwd_step_kernel(const BwdArgs args) {
 #pragma unroll
     for (int t2 = 0; t2 < TN; ++t2) {
         f32x4 a4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (S.a_rz) {
+        if (S.df_in) {
 #pragma unroll
             for (int w = 0; w < 4; ++w) a4 += *reinterpret_cast<const f32x4*>(red + ((w * TM + wave) * TN + t2) * 256 + lane * 4);
         }
@@ -328,6 +330,12 @@ __global__ __launch_bounds__(NT) void gru_bwd_step_kernel(const BwdArgs args) {
             dg[jj] = drp; dg[H + jj] = dzp; dg[2 * H + jj] = dnp;
             S.dghn_q[o] = dnp * r;
             S.dhz_out[o] = dh * z;
+            if (S.df_out) {
+                const int NC3 = (3 * H) >> 5;
+                S.df_out[frag_off(b, jj, NC3)] = drp;
+                S.df_out[frag_off(b, H + jj, NC3)] = dzp;
+                S.df_out[frag_off(b, 2 * H + jj, NC3)] = dnp * r;
+            }
             if (S.rowsum) {
                 float* rs = S.rowsum + (long)b * 3 * H;
                 rs[jj] += drp; rs[H + jj] += dzp; rs[2 * H + jj] += dnp;
@@ -335,6 +343,31 @@ __global__ __launch_bounds__(NT) void gru_bwd_step_kernel(const BwdArgs args) {
             if (S.rowsum_n) S.rowsum_n[o] += dnp * r;
         }
     }
+}
+
+// row-major [rows][K] (leading dimension ld) -> fragment-major image with rows padded to a multiple of 16 (zero filled)
+__global__ void frag_pack_kernel(const float* __restrict__ src, int rows, int K, long ld, float* __restrict__ dst) {
+    const int rows16 = (rows + 15) & ~15;
+    const long total = (long)rows16 * (K >> 2);
+    const bool vec = ((((uintptr_t)src) & 15) == 0) && ((ld & 3) == 0);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / (K >> 2)), k = (int)(i % (K >> 2)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < rows) {
+            const float* p = src + (long)row * ld + k;
+            if (vec) v = *reinterpret_cast<const float4*>(p);
+            else { v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = p[3]; }
+        }
+        *reinterpret_cast<float4*>(dst + frag_off(row, k, K >> 5)) = v;
+    }
+}
+
+int launch_pack(const float* src, int rows, int K, long ld, float* dst, hipStream_t st) {
+    const long total = (long)((rows + 15) & ~15) * (K >> 2);
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(frag_pack_kernel, dim3(blocks), dim3(256), 0, st, src, rows, K, ld, dst);
+    FN_CHECK_LAUNCH();
+    return FN_OK;
 }
 
 // ---- launch configuration -------------------------------------------------------------------------------
@@ -385,19 +418,33 @@ extern "C" {
 
 size_t fn_gru_gates_floats(int B, int H) { return (size_t)4 * H * (((size_t)B + 15) / 16 * 16); }
 
+size_t fn_frag_floats(int rows, int K) { return (size_t)((rows + 15) / 16 * 16) * K; }
+
+int fn_frag_pack(const float* src, int rows, int K, int ld, float* dst, void* stream) {
+    if (!src || !dst) return FN_E_NULL;
+    if (rows <= 0 || K <= 0 || (K % 32) != 0 || ld < K) return FN_E_SHAPE;
+    if (((uintptr_t)dst) & 15) return FN_E_ALIGN;
+    return launch_pack(src, rows, K, ld, dst, (hipStream_t)stream);
+}
+
 int fn_gru_seq_fwd(const FnGruFwd* scans, int n_scans, void* stream) {
     if (!scans) return FN_E_NULL;
     if (n_scans <= 0 || n_scans > FN_MAX_SCANS) return FN_E_COUNT;
     int Tmax = 0;
     for (int s = 0; s < n_scans; ++s) {
         const FnGruFwd& d = scans[s];
-        if (!d.w_hh || !d.b_hh || !d.h_all) return FN_E_NULL;
+        if (!d.w_hh_frag || !d.b_hh || !d.h_all || !d.frag_ws) return FN_E_NULL;
         if (d.B <= 0 || d.T <= 0 || d.H <= 0 || (d.H % 32) != 0) return FN_E_SHAPE;
         if (d.gx_table && !d.idx) return FN_E_NULL;
-        if ((((uintptr_t)d.w_hh) | ((uintptr_t)d.h_all) | ((uintptr_t)d.h0)) & 15) return FN_E_ALIGN;
+        if ((((uintptr_t)d.w_hh_frag) | ((uintptr_t)d.frag_ws)) & 15) return FN_E_ALIGN;
         Tmax = d.T > Tmax ? d.T : Tmax;
     }
     hipStream_t st = (hipStream_t)stream;
+    for (int s = 0; s < n_scans; ++s)          // initial states -> fragment-major (slot 0 of the ping-pong scratch)
+        if (scans[s].h0) {
+            const int rc = launch_pack(scans[s].h0, scans[s].B, scans[s].H, scans[s].H, scans[s].frag_ws, st);
+            if (rc != FN_OK) return rc;
+        }
     for (int p = 0; p < Tmax; ++p) {
         // row-tile height: 64 rows when the launch already fills the chip, 32 otherwise (more workgroups)
         long big_tiles = 0;
@@ -414,8 +461,11 @@ int fn_gru_seq_fwd(const FnGruFwd* scans, int n_scans, void* stream) {
             if (p >= d.T) continue;
             FwdStep& f = a.s[a.n++];
             const long BH = (long)d.B * d.H;
-            f.w_hh = d.w_hh; f.b_hh = d.b_hh; f.b_ih = d.b_ih;
+            const long FS = (long)fn_frag_floats(d.B, d.H);
+            f.w_frag = d.w_hh_frag; f.b_hh = d.b_hh; f.b_ih = d.b_ih;
             f.h_prev = p == 0 ? d.h0 : d.h_all + (p - 1) * BH;
+            f.hf_in = d.frag_ws + (p & 1) * FS;
+            f.hf_out = p + 1 < d.T ? d.frag_ws + ((p + 1) & 1) * FS : nullptr;
             f.h_out = d.h_all + p * BH;
             f.gates = d.gates ? d.gates + (long)p * fn_gru_gates_floats(d.B, d.H) : nullptr;
             f.gx_dense = d.gx_dense ? d.gx_dense + p * 3 * BH : nullptr;
@@ -443,9 +493,9 @@ int fn_gru_seq_bwd(const FnGruBwd* scans, int n_scans, void* stream) {
     int Tmax = 0;
     for (int s = 0; s < n_scans; ++s) {
         const FnGruBwd& d = scans[s];
-        if (!d.w_hh_t || !d.h_all || !d.gates || !d.dgx_all || !d.dghn_all || !d.scratch) return FN_E_NULL;
+        if (!d.w_hh_t_frag || !d.h_all || !d.gates || !d.dgx_all || !d.dghn_all || !d.scratch || !d.frag_ws) return FN_E_NULL;
         if (d.B <= 0 || d.T <= 0 || d.H <= 0 || (d.H % 32) != 0) return FN_E_SHAPE;
-        if ((((uintptr_t)d.w_hh_t) | ((uintptr_t)d.dgx_all) | ((uintptr_t)d.dghn_all)) & 15) return FN_E_ALIGN;
+        if ((((uintptr_t)d.w_hh_t_frag) | ((uintptr_t)d.frag_ws)) & 15) return FN_E_ALIGN;
         Tmax = d.T > Tmax ? d.T : Tmax;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -470,15 +520,16 @@ int fn_gru_seq_bwd(const FnGruBwd* scans, int n_scans, void* stream) {
             const long BH = (long)d.B * d.H;
             const long GS = (long)fn_gru_gates_floats(d.B, d.H);
             const int q = d.T - 1 - it;                    // step whose gate backward runs now (-1 on the last)
-            f.w_hh_t = d.w_hh_t;
+            const long FS3 = (long)fn_frag_floats(d.B, 3 * d.H);
+            f.wt_frag = d.w_hh_t_frag;
             if (it > 0) {
-                f.a_rz = d.dgx_all + (long)(q + 1) * 3 * BH;
-                f.a_n = d.dghn_all + (long)(q + 1) * BH;
+                f.df_in = d.frag_ws + ((it - 1) & 1) * FS3;
                 f.dh_in = d.scratch;
             } else {
-                f.a_rz = nullptr; f.a_n = nullptr;
+                f.df_in = nullptr;
                 f.dh_in = d.dh_last;
             }
+            f.df_out = q >= 0 ? d.frag_ws + (it & 1) * FS3 : nullptr;
             f.dh_ext = (d.dh_ext && q >= 0) ? d.dh_ext + (long)q * BH : nullptr;
             if (q >= 0) {
                 f.gates_q = d.gates + (long)q * GS;

@@ -193,7 +193,11 @@ FN_DEVINL float fn_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // XCD-aware block remap: consecutive virtual ids land on the same XCD (block b runs on XCD b % 8),
 // so tiles that share weight rows share one L2.  Bijective for any n.
+#ifndef FN_XCD_REMAP
+#define FN_XCD_REMAP 1
+#endif
 FN_DEVINL int fn_xcd_remap(int b, int n) {
+    if (!FN_XCD_REMAP) return b;
     const int q = n >> 3, r = n & 7, x = b & 7, s = b >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
 }

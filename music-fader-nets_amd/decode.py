@@ -31,11 +31,11 @@ def greedy_decode(model, z, steps, want_logp=True):
     logits = eng.buf("dec_logits", (Bi, LOGIT_LD))
     for i in range(steps):
         cur, prv = i & 1, (i & 1) ^ 1
-        ops.gru_seq_fwd([dict(B=Bi, T=1, H=H, w_hh=P["grucell_g.weight_hh"], b_hh=P["grucell_g.bias_hh"], b_ih=P["grucell_g.bias_ih"],
+        ops.gru_seq_fwd([dict(B=Bi, T=1, H=H, w_hh_frag=eng.whh_f["g"], b_hh=P["grucell_g.bias_hh"], b_ih=P["grucell_g.bias_ih"],
                               h0=h0g if i == 0 else hx0[prv][0], gx_table=eng.tab["g"], idx=tokens, idx_shift=i - 1,
                               start_token=E_VOCAB - 1, gx_rowbias=rbg, h_all=hx0[cur])])
         ops.gemm(hx0[cur][0], P["grucell_g_2.weight_ih"], gx2[0], bias=P["grucell_g_2.bias_ih"])
-        ops.gru_seq_fwd([dict(B=Bi, T=1, H=H, w_hh=P["grucell_g_2.weight_hh"], b_hh=P["grucell_g_2.bias_hh"],
+        ops.gru_seq_fwd([dict(B=Bi, T=1, H=H, w_hh_frag=eng.whh_f["g2"], b_hh=P["grucell_g_2.bias_hh"],
                               h0=hx0[cur][0] if i == 0 else hx1[prv][0], gx_dense=gx2, h_all=hx1[cur])])
         ops.gemm(hx1[cur][0], P["linear_out_g.weight"], logits[:, :E_VOCAB], bias=P["linear_out_g.bias"])
         ops.vocab_argmax(logits, E_VOCAB, logp[:, i, :] if want_logp else None, tokens[:, i])

@@ -30,7 +30,8 @@ class Engine:
         self.dev = torch.device(device)
         self._bufs = {}
         self.tab = {}                   # transposed one-hot columns of W_ih:  key -> [V][3H]
-        self.whh_t = {}                 # transposed W_hh: key -> [H][3H]
+        self.whh_f = {}                 # W_hh in the kernels' fragment-major operand layout (forward scans)
+        self.whh_t = {}                 # W_hh^T, fragment-major (backward scans)
         self.saved = None
         if hidden % 32 != 0:
             raise ValueError("hidden_dims must be a multiple of 32 (K chunks of the MFMA step kernels)")
@@ -69,10 +70,16 @@ class Engine:
                 tab = self.buf("tab_" + key, (V, 3 * H))
                 self.ops.transpose(w_ih[:, :V], tab)
                 self.tab[key] = tab
+            w_hh = self.p[pfx + "weight_hh" + sfx]
+            wf = self.buf("whhf_" + key, (self.ops.frag_floats(3 * H, H),))
+            self.ops.frag_pack(w_hh, wf)
+            self.whh_f[key] = wf
             if need_backward:
-                wt = self.buf("whht_" + key, (H, 3 * H))
-                self.ops.transpose(self.p[pfx + "weight_hh" + sfx], wt)
-                self.whh_t[key] = wt
+                wt = self.buf("whht_rm_" + key, (H, 3 * H))
+                self.ops.transpose(w_hh, wt)
+                wtf = self.buf("whht_" + key, (self.ops.frag_floats(H, 3 * H),))
+                self.ops.frag_pack(wt, wtf)
+                self.whh_t[key] = wtf
 
     # ------------------------------------------------------------------------------------------
     # forward
@@ -86,7 +93,7 @@ class Engine:
             for key, sfx, rev in ((e, "_l0", 0), (e + "_reverse", "_l0_reverse", 1)):
                 pfx = "gru_%s." % e
                 hall[key] = self.buf("enc_h_" + key, (T, B, H))
-                scans.append(dict(B=B, T=T, H=H, reverse=rev, w_hh=P[pfx + "weight_hh" + sfx], b_hh=P[pfx + "bias_hh" + sfx],
+                scans.append(dict(B=B, T=T, H=H, reverse=rev, w_hh_frag=self.whh_f[key], b_hh=P[pfx + "bias_hh" + sfx],
                                   b_ih=P[pfx + "bias_ih" + sfx], gx_table=self.tab[key], idx=d, idx_shift=0,
                                   h_all=hall[key], gates=self.buf("enc_g_" + key, (T, ops.gates_floats(B, H))) if save else None))
         ops.gru_seq_fwd(scans)
@@ -126,7 +133,7 @@ class Engine:
             rb = self.buf("sd_rb_" + e, (B, 3 * H))
             ops.gemm(z, w_ih[:, Ce:], rb)
             sd[e] = dict(h0=h0, rb=rb, h_all=self.buf("sd_h_" + e, (Tr, B, H)), gates=self.buf("sd_g_" + e, (Tr, ops.gates_floats(B, H))))
-            scans.append(dict(B=B, T=Tr, H=H, w_hh=P["gru_d_%s.weight_hh_l0" % e], b_hh=P["gru_d_%s.bias_hh_l0" % e],
+            scans.append(dict(B=B, T=Tr, H=H, w_hh_frag=self.whh_f["d_" + e], b_hh=P["gru_d_%s.bias_hh_l0" % e],
                               b_ih=P["gru_d_%s.bias_ih_l0" % e], h0=h0, gx_table=self.tab["d_" + e], idx=attr, gx_rowbias=rb,
                               h_all=sd[e]["h_all"], gates=sd[e]["gates"]))
         zc = self.buf("zc", (B, ZG))
@@ -139,7 +146,7 @@ class Engine:
         ops.gemm(zc, P["grucell_g.weight_ih"][:, E_VOCAB:], rbg)
         hx0 = self.buf("g_hx0", (T, B, H))
         g1 = self.buf("g_gates1", (T, ops.gates_floats(B, H)))
-        scans.append(dict(B=B, T=T, H=H, w_hh=P["grucell_g.weight_hh"], b_hh=P["grucell_g.bias_hh"], b_ih=P["grucell_g.bias_ih"],
+        scans.append(dict(B=B, T=T, H=H, w_hh_frag=self.whh_f["g"], b_hh=P["grucell_g.bias_hh"], b_ih=P["grucell_g.bias_ih"],
                           h0=h0g, gx_table=self.tab["g"], idx=d, idx_shift=-1, start_token=E_VOCAB - 1, gx_rowbias=rbg,
                           h_all=hx0, gates=g1))
         ops.gru_seq_fwd(scans)        # layer-1 scan and both sub-decoder scans run concurrently
@@ -148,7 +155,7 @@ class Engine:
         ops.gemm(hx0.view(T * B, H), P["grucell_g_2.weight_ih"], gx2.view(T * B, 3 * H), bias=P["grucell_g_2.bias_ih"])
         hx1 = self.buf("g_hx1", (T, B, H))
         g2 = self.buf("g_gates2", (T, ops.gates_floats(B, H)))
-        ops.gru_seq_fwd([dict(B=B, T=T, H=H, w_hh=P["grucell_g_2.weight_hh"], b_hh=P["grucell_g_2.bias_hh"], h0=hx0[0],
+        ops.gru_seq_fwd([dict(B=B, T=T, H=H, w_hh_frag=self.whh_f["g2"], b_hh=P["grucell_g_2.bias_hh"], h0=hx0[0],
                               gx_dense=gx2, h_all=hx1, gates=g2)])
         logits = self.buf("g_logits", (T * B, LOGIT_LD))
         ops.gemm(hx1.view(T * B, H), P["linear_out_g.weight"], logits[:, :E_VOCAB], bias=P["linear_out_g.bias"])
@@ -225,7 +232,7 @@ class Engine:
         dghn2 = self.buf("g_dghn2", (T, B, H))
         dh0_l2 = self.buf("g_dh0_l2", (B, H))
         rs2, rsn2 = self.zbuf("g_rs2", (B, 3 * H)), self.zbuf("g_rsn2", (B, H))
-        ops.gru_seq_bwd([dict(B=B, T=T, H=H, w_hh_t=self.whh_t["g2"], h0=dec["hx0"][0], h_all=dec["hx1"], gates=dec["g2"],
+        ops.gru_seq_bwd([dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t["g2"], h0=dec["hx0"][0], h_all=dec["hx1"], gates=dec["g2"],
                               dh_ext=dhx1, dgx_all=dgx2, dghn_all=dghn2, dh0=dh0_l2, dgx_rowsum=rs2, dghn_rowsum=rsn2,
                               scratch=self.buf("g_scr2", (B, H)))])
         self._gru_weight_grads("g2", "grucell_g_2.", "", T, B, dgx2, dghn2, dec["hx1"], dec["hx0"][0], G, sk_T, rs2, rsn2)
@@ -251,14 +258,14 @@ class Engine:
         dh0_g = self.buf("g_dh0", (B, H))
         drb_g = self.zbuf("g_drb", (B, 3 * H))
         rsn_g = self.zbuf("g_rsn1", (B, H))
-        scans = [dict(B=B, T=T, H=H, w_hh_t=self.whh_t["g"], h0=dec["h0g"], h_all=dec["hx0"], gates=dec["g1"], dh_ext=dhx0,
+        scans = [dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t["g"], h0=dec["h0g"], h_all=dec["hx0"], gates=dec["g1"], dh_ext=dhx0,
                       dgx_all=dgx1, dghn_all=dghn1, dh0=dh0_g, dgx_rowsum=drb_g, dghn_rowsum=rsn_g, scratch=self.buf("g_scr1", (B, H)))]
         sdb = {}
         for e in ("r", "n"):
             sdb[e] = dict(dgx=self.buf("sd_dgx_" + e, (Tr, B, 3 * H)), dghn=self.buf("sd_dghn_" + e, (Tr, B, H)),
                           dh0=self.buf("sd_dh0_" + e, (B, H)), drb=self.zbuf("sd_drb_" + e, (B, 3 * H)),
                           rsn=self.zbuf("sd_rsn_" + e, (B, H)))
-            scans.append(dict(B=B, T=Tr, H=H, w_hh_t=self.whh_t["d_" + e], h0=sd[e]["h0"], h_all=sd[e]["h_all"], gates=sd[e]["gates"],
+            scans.append(dict(B=B, T=Tr, H=H, w_hh_t_frag=self.whh_t["d_" + e], h0=sd[e]["h0"], h_all=sd[e]["h_all"], gates=sd[e]["gates"],
                               dh_ext=dh_sd[e], dgx_all=sdb[e]["dgx"], dghn_all=sdb[e]["dghn"], dh0=sdb[e]["dh0"],
                               dgx_rowsum=sdb[e]["drb"], dghn_rowsum=sdb[e]["rsn"], scratch=self.buf("sd_scr_" + e, (B, H))))
         ops.gru_seq_bwd(scans)
@@ -323,7 +330,7 @@ class Engine:
             for key, dh in ((e, dhf), (e + "_reverse", dhb)):
                 encb[key] = dict(dgx=self.buf("enc_dgx_" + key, (T, B, 3 * H)), dghn=self.buf("enc_dghn_" + key, (T, B, H)),
                                  rs=self.zbuf("enc_rs_" + key, (B, 3 * H)), rsn=self.zbuf("enc_rsn_" + key, (B, H)))
-                scans.append(dict(B=B, T=T, H=H, w_hh_t=self.whh_t[key], h0=None, h_all=self._bufs["enc_h_" + key],
+                scans.append(dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t[key], h0=None, h_all=self._bufs["enc_h_" + key],
                                   gates=self._bufs["enc_g_" + key], dh_last=dh, dgx_all=encb[key]["dgx"], dghn_all=encb[key]["dghn"],
                                   dgx_rowsum=encb[key]["rs"], dghn_rowsum=encb[key]["rsn"], scratch=self.buf("enc_scr_" + key, (B, H))))
         ops.gru_seq_bwd(scans)        # 4 concurrent reverse scans

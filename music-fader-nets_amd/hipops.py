@@ -112,14 +112,29 @@ class HipOps:
         """floats per time step of the (opaque, blocked) saved-gates buffer."""
         return int(self.lib.fn_gru_gates_floats(B, H))
 
+    def frag_floats(self, rows, K):
+        return int(self.lib.fn_frag_floats(rows, K))
+
+    def frag_pack(self, src, dst):
+        """row-major 2-D view -> fragment-major operand image (dst: 1-D buffer of frag_floats(rows, K))."""
+        ps, rows, K, ld = _mat(src, "src")
+        _dense(dst, name="dst")
+        if dst.numel() < self.frag_floats(rows, K):
+            raise RuntimeError("frag_pack: dst too small")
+        _lib.check(self.lib.fn_frag_pack(ps, rows, K, ld, _p(dst), self.stream()), "fn_frag_pack")
+
+    def _frag_ws(self, tag, i, n):
+        return self.workspace(4 * n, "%s%d" % (tag, i))[:n]
+
     def gru_seq_fwd(self, scans):
         arr = (_lib.FnGruFwd * len(scans))()
-        for d, s in zip(arr, scans):
-            for k in ("w_hh", "b_hh", "b_ih", "h0", "gx_dense", "gx_table", "gx_rowbias", "h_all", "gates"):
+        for i, (d, s) in enumerate(zip(arr, scans)):
+            for k in ("w_hh_frag", "b_hh", "b_ih", "h0", "gx_dense", "gx_table", "gx_rowbias", "h_all", "gates"):
                 _dense(s.get(k), name=k)
+            d.frag_ws = _p(self._frag_ws("fragf", i, 2 * self.frag_floats(s["B"], s["H"])))
             _dense(s.get("idx"), torch.int32, "idx")
             d.B, d.T, d.H, d.reverse = s["B"], s["T"], s["H"], int(s.get("reverse", 0))
-            d.w_hh, d.b_hh, d.b_ih, d.h0 = _p(s["w_hh"]), _p(s["b_hh"]), _p(s.get("b_ih")), _p(s.get("h0"))
+            d.w_hh_frag, d.b_hh, d.b_ih, d.h0 = _p(s["w_hh_frag"]), _p(s["b_hh"]), _p(s.get("b_ih")), _p(s.get("h0"))
             d.gx_dense, d.gx_table, d.idx = _p(s.get("gx_dense")), _p(s.get("gx_table")), _p(s.get("idx"))
             d.idx_ld = s["idx"].shape[1] if s.get("idx") is not None else 0
             d.idx_shift, d.start_token = int(s.get("idx_shift", 0)), int(s.get("start_token", 0))
@@ -128,11 +143,12 @@ class HipOps:
 
     def gru_seq_bwd(self, scans):
         arr = (_lib.FnGruBwd * len(scans))()
-        for d, s in zip(arr, scans):
-            for k in ("w_hh_t", "h0", "h_all", "gates", "dh_last", "dh_ext", "dgx_all", "dghn_all", "dh0", "dgx_rowsum", "dghn_rowsum", "scratch"):
+        for i, (d, s) in enumerate(zip(arr, scans)):
+            for k in ("w_hh_t_frag", "h0", "h_all", "gates", "dh_last", "dh_ext", "dgx_all", "dghn_all", "dh0", "dgx_rowsum", "dghn_rowsum", "scratch"):
                 _dense(s.get(k), name=k)
+            d.frag_ws = _p(self._frag_ws("fragb", i, 2 * self.frag_floats(s["B"], 3 * s["H"])))
             d.B, d.T, d.H = s["B"], s["T"], s["H"]
-            d.w_hh_t, d.h0, d.h_all, d.gates = _p(s["w_hh_t"]), _p(s.get("h0")), _p(s["h_all"]), _p(s["gates"])
+            d.w_hh_t_frag, d.h0, d.h_all, d.gates = _p(s["w_hh_t_frag"]), _p(s.get("h0")), _p(s["h_all"]), _p(s["gates"])
             d.dh_last, d.dh_ext = _p(s.get("dh_last")), _p(s.get("dh_ext"))
             d.dgx_all, d.dghn_all, d.dh0 = _p(s["dgx_all"]), _p(s["dghn_all"]), _p(s.get("dh0"))
             d.dgx_rowsum, d.dghn_rowsum, d.scratch = _p(s.get("dgx_rowsum")), _p(s.get("dghn_rowsum")), _p(s["scratch"])

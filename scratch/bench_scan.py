@@ -14,11 +14,13 @@ def mk(n):
     fw, bw = [], []
     for s in range(n):
         w = (torch.randn(3*H, H, device=dev) / 22).contiguous()
-        d = dict(B=B, T=T, H=H, reverse=s & 1, w_hh=w, b_hh=torch.zeros(3*H, device=dev), b_ih=torch.zeros(3*H, device=dev),
+        wf = torch.zeros(ops.frag_floats(3*H, H), device=dev); ops.frag_pack(w, wf)
+        wtf = torch.zeros(ops.frag_floats(H, 3*H), device=dev); ops.frag_pack(w.t().contiguous(), wtf)
+        d = dict(B=B, T=T, H=H, reverse=s & 1, w_hh_frag=wf, b_hh=torch.zeros(3*H, device=dev), b_ih=torch.zeros(3*H, device=dev),
                  h0=torch.randn(B, H, device=dev) * 0.1, gx_table=torch.randn(V, 3*H, device=dev) * 0.1, idx=torch.randint(0, V, (B, T), dtype=torch.int32, device=dev),
                  h_all=torch.zeros(T, B, H, device=dev), gates=torch.zeros(T, ops.gates_floats(B, H), device=dev))
         fw.append(d)
-        bw.append(dict(B=B, T=T, H=H, w_hh_t=w.t().contiguous(), h0=d["h0"], h_all=d["h_all"], gates=d["gates"], dh_ext=torch.randn(T, B, H, device=dev) * 0.01,
+        bw.append(dict(B=B, T=T, H=H, w_hh_t_frag=wtf, h0=d["h0"], h_all=d["h_all"], gates=d["gates"], dh_ext=torch.randn(T, B, H, device=dev) * 0.01,
                        dgx_all=torch.zeros(T, B, 3*H, device=dev), dghn_all=torch.zeros(T, B, H, device=dev), dh0=torch.zeros(B, H, device=dev),
                        dgx_rowsum=torch.zeros(B, 3*H, device=dev), dghn_rowsum=torch.zeros(B, H, device=dev), scratch=torch.zeros(B, H, device=dev)))
     return fw, bw
@@ -43,6 +45,9 @@ def run(var, cfgs, fn, nl, label):
 fcfgs = ["1,0,2", "1,0,3", "1,0,4", "2,0,2", "2,0,3", "2,0,4", "4,0,1", "4,0,2", "4,0,3"]
 bcfgs = ["1,1,3", "1,1,4", "1,2,3", "1,2,4", "2,1,2", "2,1,3", "2,1,4", "2,2,2", "2,2,3", "2,2,4", "4,1,2", "4,1,3", "4,2,2", "4,2,3", "4,2,4"]
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
+if which == "fwd4only":
+    c = os.environ.get("FN_FWD_CFG", "default")
+    print("fwd 4 scans", c, timeit(lambda: ops.gru_seq_fwd(fw4), T, reps=2))
 if which in ("all", "fwd"):
     run("FN_FWD_CFG", fcfgs, lambda: ops.gru_seq_fwd(fw4), T, "fwd 4 scans")
     run("FN_FWD_CFG1", fcfgs, lambda: ops.gru_seq_fwd(fw1), T, "fwd 1 scan")

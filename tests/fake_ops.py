@@ -49,6 +49,15 @@ class FakeOps:
 
     # -- GRU ----------------------------------------------------------------------------------------
     @staticmethod
+    def frag_floats(rows, K):
+        return (rows + 15) // 16 * 16 * K
+
+    @staticmethod
+    def frag_pack(src, dst):
+        """the operand image is opaque to callers; the fake keeps the plain row-major matrix in its head"""
+        dst[: src.numel()].copy_(src.reshape(-1))
+
+    @staticmethod
     def gates_floats(B, H):
         return 4 * H * ((B + 15) // 16 * 16)
 
@@ -79,7 +88,7 @@ class FakeOps:
                     gx = gx + s["gx_table"][self._tok(s, p)]
                 if s.get("gx_rowbias") is not None:
                     gx = gx + s["gx_rowbias"]
-                gh = h @ s["w_hh"].t() + s["b_hh"]
+                gh = h @ s["w_hh_frag"][: 3 * H * H].view(3 * H, H).t() + s["b_hh"]
                 r = torch.sigmoid(gx[:, :H] + gh[:, :H])
                 z = torch.sigmoid(gx[:, H:2 * H] + gh[:, H:2 * H])
                 n = torch.tanh(gx[:, 2 * H:] + r * gh[:, 2 * H:])
@@ -115,7 +124,7 @@ class FakeOps:
                 if s.get("dghn_rowsum") is not None:
                     s["dghn_rowsum"].add_(dnp * r)
                 dgh = torch.cat([drp, dzp, dnp * r], dim=1)
-                carry = dh * z + dgh @ s["w_hh_t"].t()
+                carry = dh * z + dgh @ s["w_hh_t_frag"][: 3 * H * H].view(H, 3 * H).t()
             if s.get("dh0") is not None:
                 s["dh0"].copy_(carry)
 

@@ -142,6 +142,13 @@ def _to_dev(s):
     return {k: (g(v) if torch.is_tensor(v) else v) for k, v in s.items()}
 
 
+def _pack(backend, mat, device):
+    """weights in the backend's (opaque) operand image"""
+    out = torch.zeros(backend.frag_floats(*mat.shape), device=device)
+    backend.frag_pack(mat.to(device).contiguous(), out)
+    return out
+
+
 def _unblock_gates(g, B, H):
     """the HIP kernels' private gate layout (gate_off in csrc/gru.hip) -> [T][B][4][H]"""
     T = g.shape[0]
@@ -161,6 +168,8 @@ def test_gru_scan_fwd_bwd_kernels(ops, B, T, H):
            _scan_inputs(B, max(1, T - 2), H, 21, 3, False)]
     cpu[2]["h0"] = None
     dev = [_to_dev(s) for s in cpu]
+    for c, d in zip(cpu, dev):
+        c["w_hh_frag"], d["w_hh_frag"] = _pack(fake, c["w_hh"], "cpu"), _pack(ops, c["w_hh"], DEV)
     fake.gru_seq_fwd(cpu)
     ops.gru_seq_fwd(dev)
     for i, (c, d) in enumerate(zip(cpu, dev)):
@@ -170,7 +179,7 @@ def test_gru_scan_fwd_bwd_kernels(ops, B, T, H):
     for i, c in enumerate(cpu):
         Ti = c["T"]
         torch.manual_seed(10 + i)
-        b = dict(B=B, T=Ti, H=H, w_hh_t=c["w_hh"].t().contiguous(), h0=c.get("h0"), h_all=c["h_all"], gates=c["gates"],
+        b = dict(B=B, T=Ti, H=H, w_hh_t_frag=_pack(fake, c["w_hh"].t().contiguous(), "cpu"), h0=c.get("h0"), h_all=c["h_all"], gates=c["gates"],
                  dh_last=torch.randn(B, H) if i != 1 else None, dh_ext=torch.randn(Ti, B, H) if i != 0 else None,
                  dgx_all=torch.zeros(Ti, B, 3 * H), dghn_all=torch.zeros(Ti, B, H), dh0=torch.zeros(B, H) if i != 2 else None,
                  dgx_rowsum=torch.zeros(B, 3 * H) if i == 1 else None, dghn_rowsum=torch.zeros(B, H) if i != 0 else None,
@@ -178,6 +187,7 @@ def test_gru_scan_fwd_bwd_kernels(ops, B, T, H):
         bc.append(b)
         bdev = _to_dev(b)
         bdev["gates"], bdev["h_all"] = dev[i]["gates"], dev[i]["h_all"]      # each backend consumes its OWN saved gates
+        bdev["w_hh_t_frag"] = _pack(ops, c["w_hh"].t().contiguous(), DEV)
         bd.append(bdev)
     fake.gru_seq_bwd(bc)
     ops.gru_seq_bwd(bd)
