@@ -139,6 +139,9 @@ size_t fn_embed_grad_ws_bytes(int64_t rows, int V, int N3);
 int fn_embed_grad_f32(const float* dgx_all, int B, int T, int N3, const int32_t* idx, int idx_ld, int idx_shift,
                       int start_token, int reverse, int V, float* out, float* ws, size_t ws_bytes, void* stream);
 
+/* out[m] = sum_t X[t*M + m]   (per-sequence sums over time of the gate gradients; M % 4 == 0, 16-byte aligned) */
+int fn_time_sum_f32(const float* X, int T, int64_t M, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Output heads
  * ------------------------------------------------------------------------------------------ */

@@ -48,6 +48,7 @@ SIGNATURES = {
     "fn_embed_grad_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     "fn_embed_grad_f32": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     vp, vp, C.c_size_t, vp]),
+    "fn_time_sum_f32": (C.c_int, [vp, C.c_int, C.c_int64, vp, vp]),
     "fn_vocab_logsoftmax": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_float, vp, vp]),
     "fn_vocab_logsoftmax_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "fn_vocab_argmax": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp, C.c_int, vp]),

@@ -450,7 +450,7 @@ int fn_gru_seq_fwd(const FnGruFwd* scans, int n_scans, void* stream) {
         long big_tiles = 0;
         for (int s = 0; s < n_scans; ++s)
             if (p < scans[s].T) big_tiles += (long)((scans[s].B + 63) / 64) * (scans[s].H / 16);
-        Cfg cfg = big_tiles >= 256 ? Cfg{4, 0, 2} : Cfg{2, 0, 3};
+        Cfg cfg = big_tiles >= 256 ? Cfg{4, 0, 1} : Cfg{2, 0, 3};
         env_cfg(big_tiles >= 256 ? "FN_FWD_CFG" : "FN_FWD_CFG1", cfg);
         const int bm = 16 * cfg.tm;
         FwdArgs a;
@@ -507,7 +507,7 @@ int fn_gru_seq_bwd(const FnGruBwd* scans, int n_scans, void* stream) {
             big_tiles += (long)((d.B + 63) / 64) * ((d.H + 31) / 32);
         }
         if (big_tiles == 0) continue;
-        Cfg cfg = big_tiles >= 192 ? Cfg{4, 2, 2} : Cfg{2, 1, 3};
+        Cfg cfg = big_tiles >= 192 ? Cfg{4, 1, 2} : Cfg{2, 1, 3};
         env_cfg(big_tiles >= 192 ? "FN_BWD_CFG" : "FN_BWD_CFG1", cfg);
         const int bm = 16 * cfg.tm, bn = 16 * cfg.tn;
         BwdArgs a;

@@ -231,10 +231,11 @@ class Engine:
         dgx2 = self.buf("g_dgx2", (T, B, 3 * H))
         dghn2 = self.buf("g_dghn2", (T, B, H))
         dh0_l2 = self.buf("g_dh0_l2", (B, H))
-        rs2, rsn2 = self.zbuf("g_rs2", (B, 3 * H)), self.zbuf("g_rsn2", (B, H))
+        rs2, rsn2 = self.buf("g_rs2", (B, 3 * H)), self.buf("g_rsn2", (B, H))
         ops.gru_seq_bwd([dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t["g2"], h0=dec["hx0"][0], h_all=dec["hx1"], gates=dec["g2"],
-                              dh_ext=dhx1, dgx_all=dgx2, dghn_all=dghn2, dh0=dh0_l2, dgx_rowsum=rs2, dghn_rowsum=rsn2,
-                              scratch=self.buf("g_scr2", (B, H)))])
+                              dh_ext=dhx1, dgx_all=dgx2, dghn_all=dghn2, dh0=dh0_l2, scratch=self.buf("g_scr2", (B, H)))])
+        ops.time_sum(dgx2, rs2)          # per-sequence sums over time: bias gradients (and dW of the z-conditioning) come from these
+        ops.time_sum(dghn2, rsn2)
         self._gru_weight_grads("g2", "grucell_g_2.", "", T, B, dgx2, dghn2, dec["hx1"], dec["hx0"][0], G, sk_T, rs2, rsn2)
         dgx2f = dgx2.view(T * B, 3 * H)
         ops.gemm(dgx2f, hx0f, G["grucell_g_2.weight_ih"], a_k=False, b_k=False, splitk=sk_T)
@@ -256,19 +257,24 @@ class Engine:
         dgx1 = self.buf("g_dgx1", (T, B, 3 * H))
         dghn1 = self.buf("g_dghn1", (T, B, H))
         dh0_g = self.buf("g_dh0", (B, H))
-        drb_g = self.zbuf("g_drb", (B, 3 * H))
-        rsn_g = self.zbuf("g_rsn1", (B, H))
+        drb_g = self.buf("g_drb", (B, 3 * H))
+        rsn_g = self.buf("g_rsn1", (B, H))
         scans = [dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t["g"], h0=dec["h0g"], h_all=dec["hx0"], gates=dec["g1"], dh_ext=dhx0,
-                      dgx_all=dgx1, dghn_all=dghn1, dh0=dh0_g, dgx_rowsum=drb_g, dghn_rowsum=rsn_g, scratch=self.buf("g_scr1", (B, H)))]
+                      dgx_all=dgx1, dghn_all=dghn1, dh0=dh0_g, scratch=self.buf("g_scr1", (B, H)))]
         sdb = {}
         for e in ("r", "n"):
             sdb[e] = dict(dgx=self.buf("sd_dgx_" + e, (Tr, B, 3 * H)), dghn=self.buf("sd_dghn_" + e, (Tr, B, H)),
-                          dh0=self.buf("sd_dh0_" + e, (B, H)), drb=self.zbuf("sd_drb_" + e, (B, 3 * H)),
-                          rsn=self.zbuf("sd_rsn_" + e, (B, H)))
+                          dh0=self.buf("sd_dh0_" + e, (B, H)), drb=self.buf("sd_drb_" + e, (B, 3 * H)),
+                          rsn=self.buf("sd_rsn_" + e, (B, H)))
             scans.append(dict(B=B, T=Tr, H=H, w_hh_t_frag=self.whh_t["d_" + e], h0=sd[e]["h0"], h_all=sd[e]["h_all"], gates=sd[e]["gates"],
                               dh_ext=dh_sd[e], dgx_all=sdb[e]["dgx"], dghn_all=sdb[e]["dghn"], dh0=sdb[e]["dh0"],
-                              dgx_rowsum=sdb[e]["drb"], dghn_rowsum=sdb[e]["rsn"], scratch=self.buf("sd_scr_" + e, (B, H))))
+                              scratch=self.buf("sd_scr_" + e, (B, H))))
         ops.gru_seq_bwd(scans)
+        ops.time_sum(dgx1, drb_g)
+        ops.time_sum(dghn1, rsn_g)
+        for e in ("r", "n"):
+            ops.time_sum(sdb[e]["dgx"], sdb[e]["drb"])
+            ops.time_sum(sdb[e]["dghn"], sdb[e]["rsn"])
         # layer-1 parameter gradients
         self._gru_weight_grads("g", "grucell_g.", "", T, B, dgx1, dghn1, dec["hx0"], dec["h0g"], G, sk_T, drb_g, rsn_g)
         dWg = G["grucell_g.weight_ih"]                          # [3H][E+ZG]
@@ -329,11 +335,14 @@ class Engine:
                 ops.colsum(dp, G[head + e + ".bias"])
             for key, dh in ((e, dhf), (e + "_reverse", dhb)):
                 encb[key] = dict(dgx=self.buf("enc_dgx_" + key, (T, B, 3 * H)), dghn=self.buf("enc_dghn_" + key, (T, B, H)),
-                                 rs=self.zbuf("enc_rs_" + key, (B, 3 * H)), rsn=self.zbuf("enc_rsn_" + key, (B, H)))
+                                 rs=self.buf("enc_rs_" + key, (B, 3 * H)), rsn=self.buf("enc_rsn_" + key, (B, H)))
                 scans.append(dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t[key], h0=None, h_all=self._bufs["enc_h_" + key],
                                   gates=self._bufs["enc_g_" + key], dh_last=dh, dgx_all=encb[key]["dgx"], dghn_all=encb[key]["dghn"],
-                                  dgx_rowsum=encb[key]["rs"], dghn_rowsum=encb[key]["rsn"], scratch=self.buf("enc_scr_" + key, (B, H))))
+                                  scratch=self.buf("enc_scr_" + key, (B, H))))
         ops.gru_seq_bwd(scans)        # 4 concurrent reverse scans
+        for key in encb:
+            ops.time_sum(encb[key]["dgx"], encb[key]["rs"])
+            ops.time_sum(encb[key]["dghn"], encb[key]["rsn"])
         for e in ("r", "n"):
             for key, sfx, rev in ((e, "_l0", 0), (e + "_reverse", "_l0_reverse", 1)):
                 pfx = "gru_%s." % e

@@ -162,6 +162,15 @@ class HipOps:
         _lib.check(self.lib.fn_embed_grad_f32(_p(dgx_all), B, T, N3, _p(idx), idx.shape[1], idx_shift, start_token, int(reverse), V,
                                               _p(out), _p(ws), wsb, self.stream()), "fn_embed_grad_f32")
 
+    def time_sum(self, X, out):
+        """out[...] = sum over the leading (time) axis of X."""
+        _dense(X, name="X"), _dense(out, name="out")
+        T = X.shape[0]
+        M = X.numel() // T
+        if out.numel() != M:
+            raise RuntimeError("time_sum: out has %d elements, expected %d" % (out.numel(), M))
+        _lib.check(self.lib.fn_time_sum_f32(_p(X), T, M, _p(out), self.stream()), "fn_time_sum_f32")
+
     # -- heads ----------------------------------------------------------------------------------
     def vocab_logsoftmax(self, logits, B, T, E, logp_bt=None, target=None, nll_rows=None, grad_scale=0.0, dlogits=None):
         pl, rows, _, ld = _mat(logits, "logits")

@@ -135,6 +135,9 @@ class FakeOps:
         for p in range(T):
             out.index_add_(0, self._tok(fake, p), dgx_all[p])
 
+    def time_sum(self, X, out):
+        out.copy_(X.sum(0).view_as(out))
+
     # -- heads --------------------------------------------------------------------------------------
     def vocab_logsoftmax(self, logits, B, T, E, logp_bt=None, target=None, nll_rows=None, grad_scale=0.0, dlogits=None):
         x = logits[:, :E].view(T, B, E)

@@ -203,6 +203,14 @@ def test_gru_scan_fwd_bwd_kernels(ops, B, T, H):
         close(out_d, out_c, 5e-5, "embed_grad[%d]" % i)
 
 
+def test_time_sum(ops):
+    torch.manual_seed(4)
+    X = torch.randn(67, 37, 96)
+    out = torch.zeros(37, 96, device=DEV)
+    ops.time_sum(g(X), out)
+    close(out, X.double().sum(0).float(), 2e-6)
+
+
 def test_embed_grad_full_vocab(ops):
     torch.manual_seed(8)
     T, B, N3, V = 33, 130, 200, 342
@@ -213,6 +221,17 @@ def test_embed_grad_full_vocab(ops):
     FakeOps().embed_grad(dgx, idx, 0, 0, 0, V, ref)
     ops.embed_grad(g(dgx), g(idx), 0, 0, 0, V, out)
     close(out, ref, 2e-5)
+    out2 = torch.zeros(V, N3, device=DEV)
+    ops.embed_grad(g(dgx), g(idx), 0, 0, 0, V, out2)
+    assert torch.equal(out, out2)                  # deterministic: sorted segments, no float atomics
+    # reverse direction and decoder shift (start token at tau < 0), tokens absent from the batch -> zero rows
+    idx2 = torch.randint(5, 40, (B, T), dtype=torch.int32)
+    for rev, shift, start in ((1, 0, 0), (0, -1, 341)):
+        ref, out = torch.zeros(V, N3), torch.zeros(V, N3, device=DEV)
+        FakeOps().embed_grad(dgx, idx2, shift, start, rev, V, ref)
+        ops.embed_grad(g(dgx), g(idx2), shift, start, rev, V, out)
+        close(out, ref, 2e-5)
+        assert float(out[100].abs().max()) == 0.0
 
 
 def test_head_kernels(ops):
@@ -493,8 +512,7 @@ def test_full_size_properties():
     dl_sd, lat_up, w, beta0, Bg = tr._forward_losses(20000, batch, eps, True)
     m.engine().backward(tr.flat.G, dl_sd, lat_up, *w)
     assert bool(torch.isfinite(g1).all())
-    # repeatability: identical up to the float32 summation order of the token-segment sums (LDS atomics)
-    assert float((g1 - tr.flat.grad).abs().max()) <= 1e-5 * float(g1.abs().max())
+    assert torch.equal(g1, tr.flat.grad)          # no floating-point atomics anywhere on the path
     # (2) batch-row independence: the loss of the first 64 rows alone equals the same rows' share
     #     (CE terms are per-row means) -> CE_X of a sub-batch computed separately matches the row-slice mean
     nll = m.engine()._bufs["nll_rows"].view(T, B)
@@ -516,9 +534,9 @@ def test_full_size_properties():
     tr.flat.param.copy_(p0)
     m.weights_changed()
     np.testing.assert_allclose((vals[0] - vals[1]) / (2 * hstep), gn, rtol=2e-2)
-    # (4) a few optimisation steps reduce the reconstruction loss
+    # (4) a few optimisation steps reduce the training loss (KL-dominated at beta0 = 0.2)
     step, first = 20000, None
     for it in range(6):
         step, tup = tr.train(step, None, None, None, b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"], eps=eps)
         first = first or tup
-    assert tup[1] < first[1] and all(math.isfinite(x) for x in tup)
+    assert tup[0] < first[0] and all(math.isfinite(x) for x in tup)
