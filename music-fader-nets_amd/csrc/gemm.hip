@@ -68,6 +68,87 @@ __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alp
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// "TN" GEMM for the weight gradients  C[M][N] = sum_k A[k][m] B[k][n]  (both operands stored [K][rows], rows contiguous:
+// dgx [T*B][3H], h [T*B][H], dlogits [T*B][344]).  No LDS and no barrier: with this storage the MFMA fragments can be
+// read straight from global memory with full-width coalesced loads - lane (i = l&15, g = l>>4) loads the float4
+// A[k0+g][m0+4i .. 4i+3], i.e. one operand value for each of FOUR interleaved 16-row MFMA tiles (tile a = rows m0+4i+a),
+// 16 lanes = 256 contiguous bytes per k.  One wave owns a 64x64 output tile (4x4 MFMA tiles), 4 waves = 128x128 block,
+// PF k-steps (4 k each) are kept in flight.  Output D[(l>>4)*4+r][l&15] of tile (a,b) is row m0+4((l>>4)*4+r)+a,
+// col n0+4(l&15)+b -> the 4 b-values of a lane are one float4 store.
+// ---------------------------------------------------------------------------------------------------------
+template <int PF>
+__global__ __launch_bounds__(NT) void gemm_tn_kernel(int M, int N, int K, float alpha, const float* __restrict__ A, long lda,
+                                                     const float* __restrict__ B, long ldb, float beta, float* __restrict__ C, long ldc,
+                                                     const float* __restrict__ bias, int ksplit_len, float* __restrict__ slabs) {
+    const int ntn = (N + 127) / 128, ntm = (M + 127) / 128;
+    const int tile = fn_xcd_remap(blockIdx.x, ntn * ntm);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = (tile / ntn) * 128 + (wave >> 1) * 64, n0 = (tile % ntn) * 128 + (wave & 1) * 64;
+    const int li = lane & 15, lg = lane >> 4;
+    const int kbeg = blockIdx.z * ksplit_len, kend = min(K, kbeg + ksplit_len);
+    // column offsets clamped inside the padded row (results of out-of-range rows/cols are never stored)
+    const long ca = min((long)m0 + 4 * li, lda - 4), cb = min((long)n0 + 4 * li, ldb - 4);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (m0 < M && n0 < N) {
+        const int nks = (kend - kbeg + 3) >> 2;
+        float4 fa[PF], fb[PF];
+        auto load = [&](int set, int ks) {
+            const int k = kbeg + 4 * ks + lg;
+            const long kk = min(k, kend - 1);
+            float4 va = *reinterpret_cast<const float4*>(A + kk * lda + ca);
+            float4 vb = *reinterpret_cast<const float4*>(B + kk * ldb + cb);
+            if (k >= kend) { va = make_float4(0.f, 0.f, 0.f, 0.f); vb = va; }
+            fa[set] = va;
+            fb[set] = vb;
+        };
+#pragma unroll
+        for (int s = 0; s < PF; ++s)
+            if (s < nks) load(s, s);
+        for (int base = 0; base < nks; base += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int ks = base + u;
+                if (ks < nks) {
+                    const float4 va = fa[u], vb = fb[u];
+                    if (ks + PF < nks) load(u, ks + PF);
+                    const float xa[4] = {va.x, va.y, va.z, va.w}, xb[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[a], xb[b], acc[a][b], 0, 0, 0);
+                }
+            }
+        }
+    }
+    const int colb = n0 + 4 * li;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + 4 * (lg * 4 + r) + a;
+            if (row >= M) continue;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int col = colb + b;
+                if (col >= N) continue;
+                const float v = acc[a][b][r];
+                if (slabs) {
+                    slabs[((long)blockIdx.z * M + row) * N + col] = v;
+                } else {
+                    float o = alpha * v;
+                    if (bias) o += bias[col];
+                    if (beta != 0.f) o += beta * C[(long)row * ldc + col];
+                    C[(long)row * ldc + col] = o;
+                }
+            }
+        }
+}
+
 // C = alpha * sum_s slabs[s] + beta*C + bias
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, int S, int M, int N, float alpha, float beta,
                                    float* __restrict__ C, long ldc, const float* __restrict__ bias) {
@@ -186,6 +267,26 @@ int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha, co
     if (M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return FN_E_SHAPE;
     if (splitk > 1 && (!ws || ws_bytes < fn_gemm_ws_bytes(M, N, splitk))) return FN_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    if (!a_kmajor && !b_kmajor && (lda % 4) == 0 && (ldb % 4) == 0 && lda >= 4 && ldb >= 4 &&
+        (((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0)) {
+        int klen = K;
+        if (splitk > 1) {
+            klen = ((K + splitk - 1) / splitk + 3) / 4 * 4;
+            splitk = (K + klen - 1) / klen;
+        }
+        const int ntm = (M + 127) / 128, ntn = (N + 127) / 128;
+        float* slabs = splitk > 1 ? ws : nullptr;
+        hipLaunchKernelGGL(gemm_tn_kernel<8>, dim3(ntm * ntn, 1, splitk > 1 ? splitk : 1), dim3(NT), 0, st, M, N, K, alpha, A, (long)lda, B,
+                           (long)ldb, beta, C, (long)ldc, bias, klen, slabs);
+        FN_CHECK_LAUNCH();
+        if (splitk > 1) {
+            const long total = (long)M * N;
+            const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, slabs, splitk, M, N, alpha, beta, C, (long)ldc, bias);
+            FN_CHECK_LAUNCH();
+        }
+        return FN_OK;
+    }
     const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (tiles128 * (splitk > 1 ? splitk : 1) >= 96)
         return launch_gemm<128, 128, 16, 2, 2>(a_kmajor, b_kmajor, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, splitk, ws, st);

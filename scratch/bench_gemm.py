@@ -1,0 +1,24 @@
+import os, sys
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+import torch
+from mfn_import import load_package
+load_package()
+from music_fader_nets_amd.hipops import HipOps
+dev = torch.device("cuda:0"); ops = HipOps(dev)
+def t(fn, reps=5):
+    fn(); torch.cuda.synchronize(); best = 1e9
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize(); best = min(best, e0.elapsed_time(e1))
+    return best
+cases = [("dW_hh rz  TN", False, False, 1024, 512, 65280, 16), ("dW_ih2    TN", False, False, 1536, 512, 65536, 16), ("dW_og     TN", False, False, 342, 512, 65536, 16),
+         ("gx2 fwd   NT", True, True, 65536, 1536, 512, 1), ("logits    NT", True, True, 65536, 342, 512, 1), ("dhx0      NN", True, False, 65536, 512, 1536, 1), ("dhx1      NN", True, False, 65536, 512, 342, 1)]
+for name, ak, bk, M, N, K, sk in cases:
+    lda = 344 if (not ak and M == 342) else (M if not ak else (344 if K == 342 else K))
+    A = torch.randn((K, lda) if not ak else (M, lda), device=dev)
+    Av = A[:, :M] if not ak else A[:, :K]
+    Bm = torch.randn((N, K) if bk else (K, N), device=dev)
+    ldc = 344 if N == 342 else N
+    C = torch.zeros(M, ldc, device=dev)
+    ms = t(lambda: ops.gemm(Av, Bm, C[:, :N], a_k=ak, b_k=bk, splitk=sk))
+    print("%-14s M=%6d N=%5d K=%6d splitk=%2d  %8.1f us  %6.1f TFLOP/s" % (name, M, N, K, sk, ms * 1e3, 2.0 * M * N * K / ms / 1e9), flush=True)
