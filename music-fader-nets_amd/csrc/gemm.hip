@@ -29,7 +29,6 @@ __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alp
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const bool vecA = fn_aligned16(A, lda), vecB = fn_aligned16(B, ldb);
     const RowsPlain ra{m0, M}, rb{n0, N};
 
     f32x4 acc[TM][TN];
@@ -39,9 +38,17 @@ __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alp
         for (int n = 0; n < TN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = (kend - kbeg + BK - 1) / BK;
-    auto loadA = [&](int k0, SA& st) { st.load(A, lda, ra, kbeg + k0, kend, vecA); };
-    auto loadB = [&](int k0, SB& st) { st.load(B, ldb, rb, kbeg + k0, kend, vecB); };
-    fn_kloop<PF_DEPTH, TM, TN, BK, SA, SB>(smem, nk, loadA, loadB, wm * TM * 16, wn * TN * 16, lane, acc);
+    // one decision for the whole loop: the fast path needs aligned operands and a K range made of whole tiles
+    const bool fast = SA::can_fast(A, lda, ra, kend - kbeg) && SB::can_fast(B, ldb, rb, kend - kbeg) && (kbeg % 4 == 0);
+    if (fast) {
+        auto loadA = [&](int k0, SA& st) { st.load_fast(A, lda, ra, kbeg + k0); };
+        auto loadB = [&](int k0, SB& st) { st.load_fast(B, ldb, rb, kbeg + k0); };
+        fn_kloop<PF_DEPTH, TM, TN, BK, SA, SB>(smem, nk, loadA, loadB, wm * TM * 16, wn * TN * 16, lane, acc);
+    } else {
+        auto loadA = [&](int k0, SA& st) { st.load_checked(A, lda, ra, kbeg + k0, kend); };
+        auto loadB = [&](int k0, SB& st) { st.load_checked(B, ldb, rb, kbeg + k0, kend); };
+        fn_kloop<PF_DEPTH, TM, TN, BK, SA, SB>(smem, nk, loadA, loadB, wm * TM * 16, wn * TN * 16, lane, acc);
+    }
 
     // epilogue: D[row = (lane>>4)*4 + reg][col = lane&15]
     const int cj = lane & 15, rq = (lane >> 4) * 4;
@@ -77,6 +84,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alp
 // PF k-steps (4 k each) are kept in flight.  Output D[(l>>4)*4+r][l&15] of tile (a,b) is row m0+4((l>>4)*4+r)+a,
 // col n0+4(l&15)+b -> the 4 b-values of a lane are one float4 store.
 // ---------------------------------------------------------------------------------------------------------
+FN_DEVINL float f4c(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
+
 template <int PF>
 __global__ __launch_bounds__(NT) void gemm_tn_kernel(int M, int N, int K, float alpha, const float* __restrict__ A, long lda,
                                                      const float* __restrict__ B, long ldb, float beta, float* __restrict__ C, long ldc,
@@ -95,34 +104,46 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(int M, int N, int K, float 
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (m0 < M && n0 < N) {
-        const int nks = (kend - kbeg + 3) >> 2;
-        float4 fa[PF], fb[PF];
-        auto load = [&](int set, int ks) {
-            const int k = kbeg + 4 * ks + lg;
-            const long kk = min(k, kend - 1);
-            float4 va = *reinterpret_cast<const float4*>(A + kk * lda + ca);
-            float4 vb = *reinterpret_cast<const float4*>(B + kk * ldb + cb);
-            if (k >= kend) { va = make_float4(0.f, 0.f, 0.f, 0.f); vb = va; }
-            fa[set] = va;
-            fb[set] = vb;
-        };
+        const int nks = (kend - kbeg + 3) >> 2;        // k-steps of 4 rows (the last one may be partial)
+        const int nfull = (kend - kbeg) >> 2;           // steps whose 4 rows all exist
+        const int nmain = nfull / PF * PF;               // software-pipelined part
+        // Steady state rules (each violation was measured to serialise the ring): no branch around load(), nothing consumes the
+        // loaded registers before their step, the MFMAs read fa[u]/fb[u] IN PLACE and load(u) refills the same registers right
+        // after them (a copy would be rotated at the back-edge behind s_waitcnt vmcnt(0)), sched_barrier pins that order.
+        if (nmain > 0) {
+            float4 fa[PF], fb[PF];
+            auto load = [&](int set, int ks) {
+                const long kk = kbeg + 4 * min(ks, nmain - 1) + lg;
+                fn_gld4_asm(fa[set], A + kk * lda + ca);
+                fn_gld4_asm(fb[set], B + kk * ldb + cb);
+            };
 #pragma unroll
-        for (int s = 0; s < PF; ++s)
-            if (s < nks) load(s, s);
-        for (int base = 0; base < nks; base += PF) {
+            for (int s = 0; s < PF; ++s) load(s, s);
+            for (int base = 0; base < nmain; base += PF) {
 #pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                const int ks = base + u;
-                if (ks < nks) {
-                    const float4 va = fa[u], vb = fb[u];
-                    if (ks + PF < nks) load(u, ks + PF);
-                    const float xa[4] = {va.x, va.y, va.z, va.w}, xb[4] = {vb.x, vb.y, vb.z, vb.w};
+                for (int u = 0; u < PF; ++u) {
+                    fn_wait_vm<2 * (PF - 1)>();          // the two loads of set u have landed; 2(PF-1) younger ones stay in flight
 #pragma unroll
                     for (int a = 0; a < 4; ++a)
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[a], xb[b], acc[a][b], 0, 0, 0);
+                        for (int b = 0; b < 4; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(fa[u], a), f4c(fb[u], b), acc[a][b], 0, 0, 0);
+                    load(u, base + u + PF);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            fn_wait_vm<0>();                             // the last PF prefetches (clamped re-loads) must land before reuse
+        }
+        for (int ks = nmain; ks < nks; ++ks) {          // < PF + 1 leftover steps, unpipelined, K tail zeroed
+            const int k = kbeg + 4 * ks + lg;
+            const long kk = min(k, kend - 1);
+            float4 va = *reinterpret_cast<const float4*>(A + kk * lda + ca);
+            const float4 vb = *reinterpret_cast<const float4*>(B + kk * ldb + cb);
+            if (k >= kend) va = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(va, a), f4c(vb, b), acc[a][b], 0, 0, 0);
         }
     }
     const int colb = n0 + 4 * li;

@@ -23,6 +23,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define FN_DEVINL __device__ __forceinline__
 
+// Loads whose completion WE count (cdna_hip_programming.md 5.7): hipcc's own s_waitcnt placement drains vmcnt(0) at every
+// loop back-edge, which serialises a register prefetch ring.  An asm load is invisible to that bookkeeping: the destination is
+// only valid after our own fn_wait_vm<N>() (+ sched_barrier so that no MFMA is hoisted above the wait), and every pipelined
+// loop must end with fn_wait_vm<0>() before the registers can be reused.
+FN_DEVINL void fn_gld4_asm(float4& dst, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory"); }
+template <int N>
+FN_DEVINL void fn_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 FN_DEVINL bool fn_aligned16(const void* p, long ld) { return ((((uintptr_t)p) & 15) == 0) && ((ld & 3) == 0); }
 
 // Row maps: local tile row r -> source row.  valid(r) says whether the row exists; clamped(r) is always a legal row
@@ -42,29 +53,39 @@ struct Stage {
     static constexpr int LDW = KC ? (BK + 4) : (ROWS + 8);
     static constexpr int WORDS = KC ? ROWS * LDW : BK * LDW;
     float4 r[NPT];
+    unsigned zero_mask = 0;      // bit q: r[q] belongs to a row outside the matrix -> store() writes zeros.  (Zeroing at LOAD
+                                 // time would consume the register right after the load and serialise the prefetch.)
 
     // KC : element (row, k) at src[rowmap(row)*ld + k]
     // RC : element (row, k) at src[k*ld + rowmap(row)]   (rows of one float4 are consecutive)
-    // Fast path (16-byte aligned source, tile fully inside K [and inside the rows for RC]): unconditional
-    // global_load_dwordx4, all issued back to back.  Anything else takes the element-wise bounds-checked path.
+    // can_fast(): 16-byte aligned source, K a multiple of BK [and all tile rows inside the matrix for RC]: then every tile
+    // of the K loop can use load_fast = unconditional global_load_dwordx4, all issued back to back, NO branch and NO
+    // consumer of the loaded registers (the loop stays software-pipelined).  Otherwise load_checked (element-wise bounds).
     template <class RowMap>
-    FN_DEVINL void load(const float* __restrict__ src, long ld, const RowMap& rowmap, int k0, int K, bool vec) {
-        const bool fast = vec && (k0 + BK <= K) && (KC || rowmap.all_valid(ROWS));
-        if (fast) {
+    static FN_DEVINL bool can_fast(const float* src, long ld, const RowMap& rowmap, int K) {
+        return fn_aligned16(src, ld) && (K % BK == 0) && (KC || rowmap.all_valid(ROWS));
+    }
+
+    template <class RowMap>
+    FN_DEVINL void load_fast(const float* __restrict__ src, long ld, const RowMap& rowmap, int k0) {
+        zero_mask = 0;
 #pragma unroll
-            for (int q = 0; q < NPT; ++q) {
-                const int i = min((int)threadIdx.x + q * NT, NV - 1);
-                if (KC) {
-                    const int row = i / (BK / 4), c = (i % (BK / 4)) * 4;
-                    const float4 v = *reinterpret_cast<const float4*>(src + rowmap.clamped(row) * ld + (k0 + c));
-                    r[q] = rowmap.valid(row) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-                } else {
-                    const int k = i / (ROWS / 4), c = (i % (ROWS / 4)) * 4;
-                    r[q] = *reinterpret_cast<const float4*>(src + (long)(k0 + k) * ld + rowmap.clamped(c));
-                }
+        for (int q = 0; q < NPT; ++q) {
+            const int i = min((int)threadIdx.x + q * NT, NV - 1);
+            if (KC) {
+                const int row = i / (BK / 4), c = (i % (BK / 4)) * 4;
+                r[q] = *reinterpret_cast<const float4*>(src + rowmap.clamped(row) * ld + (k0 + c));
+                if (!rowmap.valid(row)) zero_mask |= 1u << q;
+            } else {
+                const int k = i / (ROWS / 4), c = (i % (ROWS / 4)) * 4;
+                r[q] = *reinterpret_cast<const float4*>(src + (long)(k0 + k) * ld + rowmap.clamped(c));
             }
-            return;
         }
+    }
+
+    template <class RowMap>
+    FN_DEVINL void load_checked(const float* __restrict__ src, long ld, const RowMap& rowmap, int k0, int K) {
+        zero_mask = 0;
 #pragma unroll
         for (int q = 0; q < NPT; ++q) {
             const int i = threadIdx.x + q * NT;
@@ -101,12 +122,13 @@ struct Stage {
         for (int q = 0; q < NPT; ++q) {
             const int i = threadIdx.x + q * NT;
             if ((NV % NT == 0) || i < NV) {
+                const float4 v = ((zero_mask >> q) & 1u) ? make_float4(0.f, 0.f, 0.f, 0.f) : r[q];
                 if (KC) {
                     const int row = i / (BK / 4), c = (i % (BK / 4)) * 4;
-                    *reinterpret_cast<float4*>(lds + row * LDW + c) = r[q];
+                    *reinterpret_cast<float4*>(lds + row * LDW + c) = v;
                 } else {
                     const int k = i / (ROWS / 4), c = (i % (ROWS / 4)) * 4;
-                    *reinterpret_cast<float4*>(lds + k * LDW + c) = r[q];
+                    *reinterpret_cast<float4*>(lds + k * LDW + c) = v;
                 }
             }
         }
@@ -148,43 +170,39 @@ FN_DEVINL void mma_slab(const float* __restrict__ ldsA, const float* __restrict_
     }
 }
 
-// Software-pipelined K loop shared by every MFMA kernel: D register-staged tiles are kept in flight ahead of the tile
-// being multiplied (the loop is latency-bound otherwise: one 14 KB tile per ~2 us round trip), LDS is double buffered,
-// one barrier per K tile.  loadA / loadB(k0, stage&) issue the global loads of the tile starting at k0.
+// Software-pipelined K loop of the LDS-staged GEMM: D register-staged tiles are kept in flight ahead of the tile being
+// multiplied, LDS is double buffered, one barrier per K tile.  The steady state has NO branch around the loads (hipcc falls
+// back to s_waitcnt vmcnt(0) at control-flow merges, which would serialise the ring): tiles past the end are re-loads of
+// the last tile (clamped index, at most D redundant tiles) that are never stored.
 template <int D, int TM, int TN, int BK, class SA, class SB, class FA, class FB>
 FN_DEVINL void fn_kloop(float* __restrict__ smem, int nk, const FA& loadA, const FB& loadB, int arow0, int brow0, int lane,
                         f32x4 (&acc)[TM][TN]) {
     constexpr int BUFW = SA::WORDS + SB::WORDS;   // buffer b: A at smem + b*BUFW, B right behind it
+    if (nk <= 0) return;
     SA sa[D];
     SB sb[D];
+    const int last = nk - 1;
 #pragma unroll
-    for (int s = 0; s < D; ++s)
-        if (s < nk) {
-            loadA(s * BK, sa[s]);
-            loadB(s * BK, sb[s]);
-        }
-    if (nk > 0) {
-        sa[0].store(smem);
-        sb[0].store(smem + SA::WORDS);
+    for (int s = 0; s < D; ++s) {
+        loadA(min(s, last) * BK, sa[s]);
+        loadB(min(s, last) * BK, sb[s]);
     }
+    sa[0].store(smem);
+    sb[0].store(smem + SA::WORDS);
     __syncthreads();
-    for (int base = 0; base < nk; base += D) {
+    const int nk_pad = (nk + D - 1) / D * D;
+    for (int base = 0; base < nk_pad; base += D) {
 #pragma unroll
         for (int u = 0; u < D; ++u) {
             const int kt = base + u;
-            if (kt < nk) {
-                const int cur = kt & 1;
-                if (kt + D < nk) {                      // set u held tile kt (now in LDS): refill it with tile kt + D
-                    loadA((kt + D) * BK, sa[u]);
-                    loadB((kt + D) * BK, sb[u]);
-                }
-                mma_slab<TM, TN, BK, SA, SB>(smem + cur * BUFW, smem + cur * BUFW + SA::WORDS, arow0, brow0, lane, acc);
-                if (kt + 1 < nk) {
-                    sa[(u + 1) % D].store(smem + (cur ^ 1) * BUFW);
-                    sb[(u + 1) % D].store(smem + (cur ^ 1) * BUFW + SA::WORDS);
-                }
-                __syncthreads();
-            }
+            const int cur = kt & 1;
+            loadA(min(kt + D, last) * BK, sa[u]);           // set u held tile kt (already in LDS): refill with tile kt + D
+            loadB(min(kt + D, last) * BK, sb[u]);
+            if (kt < nk) mma_slab<TM, TN, BK, SA, SB>(smem + cur * BUFW, smem + cur * BUFW + SA::WORDS, arow0, brow0, lane, acc);
+            sa[(u + 1) % D].store(smem + (cur ^ 1) * BUFW);  // tile kt + 1 (or a harmless duplicate of the last tile)
+            sb[(u + 1) % D].store(smem + (cur ^ 1) * BUFW + SA::WORDS);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
