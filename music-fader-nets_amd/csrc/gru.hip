@@ -89,36 +89,81 @@ __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
     const int li = lane & 15, lg = lane >> 4;
     const int nrt = (B + 15) >> 4;
 
-    // ---- epilogue operands of the M-tile this wave will finish: issued first, consumed last --------------
     const int jj = hh0 + li;
-    float gx[4][3], hp[4];
-    float bh[3] = {0.f, 0.f, 0.f};
-    if (wave < TM) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) bh[q] = S.b_hh[q * H + jj];
+    const bool has_k = S.hf_in != nullptr && S.h_prev != nullptr;
+    const int nk = H >> 5;
+    const int nkw = (has_k && wave < nk) ? (nk - wave + 3) >> 2 : 0;        // this wave's chunks: wave, wave+4, ...
+
+    // (1) token ids of the rows this wave finishes (a compiler-visible load; the table rows depend on it)
+    int tok[4] = {0, 0, 0, 0};
+    if (wave < TM && S.gx_table) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int b = min(m0 + wave * 16 + lg * 4 + i, B - 1);
+            tok[i] = S.idx ? S.idx[(long)b * S.idx_ld] : S.tok_const;
+        }
+    }
+
+    // (2) epilogue operands of the M-tile this wave will finish: LOADED now (their latency hides under the K loop), only
+    //     ADDED in the epilogue (an add here would make hipcc wait for them before the loop)
+    float e_tab[4][3], e_den[4][3], e_rb[4][3], hp[4], bh[3], bi[3];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) gx[i][q] = S.b_ih ? S.b_ih[q * H + jj] : 0.f;
+    for (int q = 0; q < 3; ++q) { bh[q] = 0.f; bi[q] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hp[i] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { e_tab[i][q] = 0.f; e_den[i][q] = 0.f; e_rb[i][q] = 0.f; }
+    }
+    if (wave < TM) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            bh[q] = S.b_hh[q * H + jj];
+            if (S.b_ih) bi[q] = S.b_ih[q * H + jj];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int b = min(m0 + wave * 16 + lg * 4 + i, B - 1);
             if (S.gx_dense) {
                 const float* row = S.gx_dense + (long)b * 3 * H;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) gx[i][q] += row[q * H + jj];
+                for (int q = 0; q < 3; ++q) e_den[i][q] = row[q * H + jj];
             }
             if (S.gx_table) {
-                const int tok = S.idx ? S.idx[(long)b * S.idx_ld] : S.tok_const;
-                const float* row = S.gx_table + (long)tok * 3 * H;
+                const float* row = S.gx_table + (long)tok[i] * 3 * H;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) gx[i][q] += row[q * H + jj];
+                for (int q = 0; q < 3; ++q) e_tab[i][q] = row[q * H + jj];
             }
             if (S.gx_rowbias) {
                 const float* row = S.gx_rowbias + (long)b * 3 * H;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) gx[i][q] += row[q * H + jj];
+                for (int q = 0; q < 3; ++q) e_rb[i][q] = row[q * H + jj];
             }
-            hp[i] = S.h_prev ? S.h_prev[(long)b * H + jj] : 0.f;
+            if (S.h_prev) hp[i] = S.h_prev[(long)b * H + jj];
         }
+    }
+
+    // (3) first D operand chunks of the K loop (asm loads, counted by us - see fn_gld4_asm).  They are issued AFTER the
+    //     compiler-visible loads above: vmcnt is one in-order counter, so older outstanding loads only make our counted
+    //     waits stricter, never wrong.
+    const float* ap[TM];
+    const float* bp[3];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) ap[m] = S.hf_in + (long)min(tm * TM + m, nrt - 1) * nk * 512 + lane * 4;
+#pragma unroll
+    for (int n = 0; n < 3; ++n) bp[n] = S.w_frag + (long)(n * (H >> 4) + tn) * nk * 512 + lane * 4;
+    float4 fa[D][TM][2], fb[D][3][2];
+    constexpr int NL = 2 * (TM + 3);                                       // loads per chunk
+    auto load = [&](int set, int it) {
+        const int k0 = (wave + 4 * min(it, nkw - 1)) * 512;                // one chunk = 2 halves x 64 lanes x 4 floats
+#pragma unroll
+        for (int m = 0; m < TM; ++m) { fn_gld4_asm(fa[set][m][0], ap[m] + k0); fn_gld4_asm(fa[set][m][1], ap[m] + k0 + 256); }
+#pragma unroll
+        for (int n = 0; n < 3; ++n) { fn_gld4_asm(fb[set][n][0], bp[n] + k0); fn_gld4_asm(fb[set][n][1], bp[n] + k0 + 256); }
+    };
+    if (nkw > 0) {
+#pragma unroll
+        for (int s = 0; s < D; ++s) load(s, s);
     }
 
     f32x4 acc[TM][3];
@@ -127,43 +172,34 @@ __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
 #pragma unroll
         for (int n = 0; n < 3; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    if (S.h_prev) {
-        const float* ap[TM];
-        const float* bp[3];
-        const int nk = H >> 5;
+    // (4) K loop: branch-free steady state, MFMAs read the ring registers in place, load(u) refills them right behind
+    auto mma = [&](int set) {
 #pragma unroll
-        for (int m = 0; m < TM; ++m) ap[m] = S.hf_in + (long)min(tm * TM + m, nrt - 1) * nk * 512 + lane * 4;
+        for (int j = 0; j < 8; ++j)
 #pragma unroll
-        for (int n = 0; n < 3; ++n) bp[n] = S.w_frag + (long)(n * (H >> 4) + tn) * nk * 512 + lane * 4;
-        const int nkw = wave < nk ? (nk - wave + 3) >> 2 : 0;        // chunks wave, wave+4, ...
-        float4 fa[D][TM][2], fb[D][3][2];
-        auto load = [&](int set, int it) {
-            const int k0 = (wave + 4 * it) * 512;                    // one chunk = 2 halves x 64 lanes x 4 floats
+            for (int m = 0; m < TM; ++m)
 #pragma unroll
-            for (int m = 0; m < TM; ++m) { fa[set][m][0] = ld4(ap[m] + k0); fa[set][m][1] = ld4(ap[m] + k0 + 256); }
-#pragma unroll
-            for (int n = 0; n < 3; ++n) { fb[set][n][0] = ld4(bp[n] + k0); fb[set][n][1] = ld4(bp[n] + k0 + 256); }
-        };
-#pragma unroll
-        for (int s = 0; s < D; ++s)
-            if (s < nkw) load(s, s);
-        for (int base = 0; base < nkw; base += D) {
+                for (int n = 0; n < 3; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4at(fa[set][m][j >> 2], j & 3), f4at(fb[set][n][j >> 2], j & 3),
+                                                                     acc[m][n], 0, 0, 0);
+    };
+    if (nkw > 0) {
+        const int nmain = nkw / D * D;
+        for (int base = 0; base < nmain; base += D) {
 #pragma unroll
             for (int u = 0; u < D; ++u) {
-                const int it = base + u;
-                if (it < nkw) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-#pragma unroll
-                        for (int m = 0; m < TM; ++m)
-#pragma unroll
-                            for (int n = 0; n < 3; ++n)
-                                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4at(fa[u][m][j >> 2], j & 3), f4at(fb[u][n][j >> 2], j & 3),
-                                                                                 acc[m][n], 0, 0, 0);
-                    if (it + D < nkw) load(u, it + D);
-                }
+                fn_wait_vm<NL * (D - 1)>();
+                mma(u);
+                load(u, base + u + D);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        fn_wait_vm<0>();
+#pragma unroll
+        for (int u = 0; u < D; ++u)
+            if (nmain + u < nkw) mma(u);                 // leftover chunks are already in the ring
+    }
+    if (has_k) {
         // ---- add the 4 K-partials: wave m ends up with M-tile m --------------------------------------------
 #pragma unroll
         for (int m = 0; m < TM; ++m)
@@ -177,7 +213,7 @@ __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
         r3[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (S.h_prev) {
+        if (has_k) {
 #pragma unroll
             for (int w = 0; w < 4; ++w) r3[n] += *reinterpret_cast<const f32x4*>(red + ((w * TM + wave) * 3 + n) * 256 + lane * 4);
         }
@@ -187,9 +223,12 @@ __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
         const int b = m0 + wave * 16 + lg * 4 + i;
         if (b >= B) continue;
         const float ghr = r3[0][i] + bh[0], ghz = r3[1][i] + bh[1], ghn = r3[2][i] + bh[2];
-        const float r = fn_sigmoid(gx[i][0] + ghr);
-        const float z = fn_sigmoid(gx[i][1] + ghz);
-        const float n = tanhf(gx[i][2] + r * ghn);
+        const float gxr = ((bi[0] + e_den[i][0]) + e_tab[i][0]) + e_rb[i][0];
+        const float gxz = ((bi[1] + e_den[i][1]) + e_tab[i][1]) + e_rb[i][1];
+        const float gxn = ((bi[2] + e_den[i][2]) + e_tab[i][2]) + e_rb[i][2];
+        const float r = fn_sigmoid(gxr + ghr);
+        const float z = fn_sigmoid(gxz + ghz);
+        const float n = tanhf(gxn + r * ghn);
         const float h = (1.0f - z) * n + z * hp[i];
         S.h_out[(long)b * H + jj] = h;
         if (S.hf_out) S.hf_out[frag_off(b, jj, H >> 5)] = h;
@@ -251,41 +290,50 @@ __global__ __launch_bounds__(NT) void gru_bwd_step_kernel(const BwdArgs args) {
 #pragma unroll
         for (int n = 0; n < TN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    const int nk = (3 * H) >> 5;
+    const int nkw = (S.df_in && wave < nk) ? (nk - wave + 3) >> 2 : 0;
     if (S.df_in) {
-        const int nk = (3 * H) >> 5;
         const float *ap[TM], *bp[TN];
 #pragma unroll
         for (int m = 0; m < TM; ++m) ap[m] = S.df_in + (long)min(tm * TM + m, nrt - 1) * nk * 512 + lane * 4;
 #pragma unroll
         for (int n = 0; n < TN; ++n) bp[n] = S.wt_frag + (long)min(tn * TN + n, (H >> 4) - 1) * nk * 512 + lane * 4;
-        const int nkw = wave < nk ? (nk - wave + 3) >> 2 : 0;
         float4 fa[D][TM][2], fb[D][TN][2];
+        constexpr int NL = 2 * (TM + TN);
         auto load = [&](int set, int it) {
-            const int k0 = (wave + 4 * it) * 512;
+            const int k0 = (wave + 4 * min(it, nkw - 1)) * 512;
 #pragma unroll
-            for (int m = 0; m < TM; ++m) { fa[set][m][0] = ld4(ap[m] + k0); fa[set][m][1] = ld4(ap[m] + k0 + 256); }
+            for (int m = 0; m < TM; ++m) { fn_gld4_asm(fa[set][m][0], ap[m] + k0); fn_gld4_asm(fa[set][m][1], ap[m] + k0 + 256); }
 #pragma unroll
-            for (int n = 0; n < TN; ++n) { fb[set][n][0] = ld4(bp[n] + k0); fb[set][n][1] = ld4(bp[n] + k0 + 256); }
+            for (int n = 0; n < TN; ++n) { fn_gld4_asm(fb[set][n][0], bp[n] + k0); fn_gld4_asm(fb[set][n][1], bp[n] + k0 + 256); }
         };
+        auto mma = [&](int set) {
 #pragma unroll
-        for (int s = 0; s < D; ++s)
-            if (s < nkw) load(s, s);
-        for (int base = 0; base < nkw; base += D) {
+            for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int u = 0; u < D; ++u) {
-                const int it = base + u;
-                if (it < nkw) {
+                for (int m = 0; m < TM; ++m)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
+                    for (int n = 0; n < TN; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4at(fa[set][m][j >> 2], j & 3), f4at(fb[set][n][j >> 2], j & 3),
+                                                                         acc[m][n], 0, 0, 0);
+        };
+        if (nkw > 0) {
 #pragma unroll
-                        for (int m = 0; m < TM; ++m)
+            for (int s = 0; s < D; ++s) load(s, s);
+            const int nmain = nkw / D * D;
+            for (int base = 0; base < nmain; base += D) {
 #pragma unroll
-                            for (int n = 0; n < TN; ++n)
-                                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4at(fa[u][m][j >> 2], j & 3), f4at(fb[u][n][j >> 2], j & 3),
-                                                                                 acc[m][n], 0, 0, 0);
-                    if (it + D < nkw) load(u, it + D);
+                for (int u = 0; u < D; ++u) {
+                    fn_wait_vm<NL * (D - 1)>();
+                    mma(u);
+                    load(u, base + u + D);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            fn_wait_vm<0>();
+#pragma unroll
+            for (int u = 0; u < D; ++u)
+                if (nmain + u < nkw) mma(u);
         }
 #pragma unroll
         for (int m = 0; m < TM; ++m)
