@@ -161,10 +161,11 @@ __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
 #pragma unroll
         for (int n = 0; n < 3; ++n) { fn_gld4_asm(fb[set][n][0], bp[n] + k0); fn_gld4_asm(fb[set][n][1], bp[n] + k0 + 256); }
     };
-    if (nkw > 0) {
+    // (never issue an asm load whose destination is not consumed later: hipcc would re-use the "dead" registers while the
+    //  load is still in flight)
 #pragma unroll
-        for (int s = 0; s < D; ++s) load(s, s);
-    }
+    for (int s = 0; s < D; ++s)
+        if (s < nkw) load(s, s);
 
     f32x4 acc[TM][3];
 #pragma unroll
@@ -319,7 +320,8 @@ __global__ __launch_bounds__(NT) void gru_bwd_step_kernel(const BwdArgs args) {
         };
         if (nkw > 0) {
 #pragma unroll
-            for (int s = 0; s < D; ++s) load(s, s);
+            for (int s = 0; s < D; ++s)
+                if (s < nkw) load(s, s);
             const int nmain = nkw / D * D;
             for (int base = 0; base < nmain; base += D) {
 #pragma unroll
