@@ -133,6 +133,8 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(int M, int N, int K, float 
                 }
             }
             fn_wait_vm<0>();                             // the last PF prefetches (clamped re-loads) must land before reuse
+#pragma unroll
+            for (int s = 0; s < PF; ++s) { fn_keep(fa[s]); fn_keep(fb[s]); }
         }
         for (int ks = nmain; ks < nks; ++ks) {          // < PF + 1 leftover steps, unpipelined, K tail zeroed
             const int k = kbeg + 4 * ks + lg;

@@ -161,11 +161,10 @@ __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
 #pragma unroll
         for (int n = 0; n < 3; ++n) { fn_gld4_asm(fb[set][n][0], bp[n] + k0); fn_gld4_asm(fb[set][n][1], bp[n] + k0 + 256); }
     };
-    // (never issue an asm load whose destination is not consumed later: hipcc would re-use the "dead" registers while the
-    //  load is still in flight)
+    if (nkw > 0) {
 #pragma unroll
-    for (int s = 0; s < D; ++s)
-        if (s < nkw) load(s, s);
+        for (int s = 0; s < D; ++s) load(s, s);          // chunk index is clamped: always a legal (possibly repeated) chunk
+    }
 
     f32x4 acc[TM][3];
 #pragma unroll
@@ -199,6 +198,13 @@ __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
 #pragma unroll
         for (int u = 0; u < D; ++u)
             if (nmain + u < nkw) mma(u);                 // leftover chunks are already in the ring
+#pragma unroll
+        for (int u = 0; u < D; ++u) {                    // every ring register stays allocated until its load has landed
+#pragma unroll
+            for (int m = 0; m < TM; ++m) { fn_keep(fa[u][m][0]); fn_keep(fa[u][m][1]); }
+#pragma unroll
+            for (int n = 0; n < 3; ++n) { fn_keep(fb[u][n][0]); fn_keep(fb[u][n][1]); }
+        }
     }
     if (has_k) {
         // ---- add the 4 K-partials: wave m ends up with M-tile m --------------------------------------------
@@ -320,8 +326,7 @@ __global__ __launch_bounds__(NT) void gru_bwd_step_kernel(const BwdArgs args) {
         };
         if (nkw > 0) {
 #pragma unroll
-            for (int s = 0; s < D; ++s)
-                if (s < nkw) load(s, s);
+            for (int s = 0; s < D; ++s) load(s, s);
             const int nmain = nkw / D * D;
             for (int base = 0; base < nmain; base += D) {
 #pragma unroll
@@ -336,6 +341,13 @@ __global__ __launch_bounds__(NT) void gru_bwd_step_kernel(const BwdArgs args) {
 #pragma unroll
             for (int u = 0; u < D; ++u)
                 if (nmain + u < nkw) mma(u);
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+#pragma unroll
+                for (int m = 0; m < TM; ++m) { fn_keep(fa[u][m][0]); fn_keep(fa[u][m][1]); }
+#pragma unroll
+                for (int n = 0; n < TN; ++n) { fn_keep(fb[u][n][0]); fn_keep(fb[u][n][1]); }
+            }
         }
 #pragma unroll
         for (int m = 0; m < TM; ++m)
