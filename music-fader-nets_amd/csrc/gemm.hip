@@ -84,7 +84,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alp
 // PF k-steps (4 k each) are kept in flight.  Output D[(l>>4)*4+r][l&15] of tile (a,b) is row m0+4((l>>4)*4+r)+a,
 // col n0+4(l&15)+b -> the 4 b-values of a lane are one float4 store.
 // ---------------------------------------------------------------------------------------------------------
-FN_DEVINL float f4c(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
+FN_DEVINL float f4c(const f32x4& v, int j) { return v[j]; }
 
 template <int PF>
 __global__ __launch_bounds__(NT) void gemm_tn_kernel(int M, int N, int K, float alpha, const float* __restrict__ A, long lda,
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(int M, int N, int K, float 
         // loaded registers before their step, the MFMAs read fa[u]/fb[u] IN PLACE and load(u) refills the same registers right
         // after them (a copy would be rotated at the back-edge behind s_waitcnt vmcnt(0)), sched_barrier pins that order.
         if (nmain > 0) {
-            float4 fa[PF], fb[PF];
+            f32x4 fa[PF], fb[PF];
             auto load = [&](int set, int ks) {
                 const long kk = kbeg + 4 * min(ks, nmain - 1) + lg;
                 fn_gld4_asm(fa[set], A + kk * lda + ca);
@@ -139,9 +139,9 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(int M, int N, int K, float 
         for (int ks = nmain; ks < nks; ++ks) {          // < PF + 1 leftover steps, unpipelined, K tail zeroed
             const int k = kbeg + 4 * ks + lg;
             const long kk = min(k, kend - 1);
-            float4 va = *reinterpret_cast<const float4*>(A + kk * lda + ca);
-            const float4 vb = *reinterpret_cast<const float4*>(B + kk * ldb + cb);
-            if (k >= kend) va = make_float4(0.f, 0.f, 0.f, 0.f);
+            f32x4 va = *reinterpret_cast<const f32x4*>(A + kk * lda + ca);
+            const f32x4 vb = *reinterpret_cast<const f32x4*>(B + kk * ldb + cb);
+            if (k >= kend) va = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll

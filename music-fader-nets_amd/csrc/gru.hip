@@ -43,7 +43,7 @@ FN_DEVINL long frag_off(int row, int k, int NC) {
 }
 
 FN_DEVINL float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-FN_DEVINL float f4at(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
+FN_DEVINL float f4at(const f32x4& v, int j) { return v[j]; }
 
 // ---------------------------------------------------------------------------------------------
 // forward step
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
     for (int m = 0; m < TM; ++m) ap[m] = S.hf_in + (long)min(tm * TM + m, nrt - 1) * nk * 512 + lane * 4;
 #pragma unroll
     for (int n = 0; n < 3; ++n) bp[n] = S.w_frag + (long)(n * (H >> 4) + tn) * nk * 512 + lane * 4;
-    float4 fa[D][TM][2], fb[D][3][2];
+    f32x4 fa[D][TM][2], fb[D][3][2];
     constexpr int NL = 2 * (TM + 3);                                       // loads per chunk
     auto load = [&](int set, int it) {
         const int k0 = (wave + 4 * min(it, nkw - 1)) * 512;                // one chunk = 2 halves x 64 lanes x 4 floats
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(NT) void gru_bwd_step_kernel(const BwdArgs args) {
         for (int m = 0; m < TM; ++m) ap[m] = S.df_in + (long)min(tm * TM + m, nrt - 1) * nk * 512 + lane * 4;
 #pragma unroll
         for (int n = 0; n < TN; ++n) bp[n] = S.wt_frag + (long)min(tn * TN + n, (H >> 4) - 1) * nk * 512 + lane * 4;
-        float4 fa[D][TM][2], fb[D][TN][2];
+        f32x4 fa[D][TM][2], fb[D][TN][2];
         constexpr int NL = 2 * (TM + TN);
         auto load = [&](int set, int it) {
             const int k0 = (wave + 4 * min(it, nkw - 1)) * 512;
