@@ -29,7 +29,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3                           # MI355X_MICROARCH.md: v_
 
 
 def measure_dominant_kernel(trainer, batch, eps, reps=3):
-    """Average launch duration of the encoder forward step kernel gru_fwd_step_kernel<4> (4 scans x B rows per launch),
+    """Average launch duration of the encoder forward step kernel gru_fwd_step_kernel<4,4,1> (4 scans x B rows per launch),
     measured with HIP events on the stream it is launched on (torch's current stream)."""
     eng = trainer.model.engine()
     d = batch[0]
@@ -55,7 +55,7 @@ def measure_dominant_kernel(trainer, batch, eps, reps=3):
         best = ms if best is None else min(best, ms)
     flop = 4 * B * FLOP_PER_SAMPLE_STEP
     achieved = flop / (best * 1e-3) / 1e12
-    return dict(bound="mfma", kernel="gru_fwd_step_kernel<4>", achieved=round(achieved, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+    return dict(bound="mfma", kernel="gru_fwd_step_kernel<4,4,1>", achieved=round(achieved, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                 frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=None, avg_launch_us=round(best * 1e3, 3),
                 flop_per_launch=flop)
 
