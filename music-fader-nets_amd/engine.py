@@ -33,12 +33,55 @@ class Engine:
         self.whh_f = {}                 # W_hh in the kernels' fragment-major operand layout (forward scans)
         self.whh_t = {}                 # W_hh^T, fragment-major (backward scans)
         self.saved = None
+        self.chunk = 32                 # time steps per pipeline chunk of the two decoder layers
         if hidden % 32 != 0:
             raise ValueError("hidden_dims must be a multiple of 32 (K chunks of the MFMA step kernels)")
         if n_component > 8:
             raise ValueError("n_component > 8 not supported by fn_latent_*")
 
     # ------------------------------------------------------------------------------------------
+    # Two HIP streams: the caller's current stream ("main") and one side stream.  Independent pieces of the schedule
+    # (decoder layer 2 one time-chunk behind layer 1; decoder weight-gradient GEMMs under the encoder backward scans) are
+    # enqueued on the side stream so that two kernels are resident at once - the scan steps are latency-bound and leave
+    # most of the chip idle.  Each lane has its own scratch (ops.lane) so concurrent kernels never share a workspace.
+    def _side_stream(self):
+        if self.dev.type != "cuda":
+            return None
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        return self._side
+
+    class _Lane:
+        def __init__(self, eng, side):
+            self.eng, self.side, self.ctx = eng, side, None
+
+        def __enter__(self):
+            self.prev = getattr(self.eng.ops, "lane", "")
+            self.eng.ops.lane = "side/" if self.side else ""
+            st = self.eng._side_stream() if self.side else None
+            if st is not None:
+                self.ctx = torch.cuda.stream(st)
+                self.ctx.__enter__()
+            return self
+
+        def __exit__(self, *a):
+            if self.ctx is not None:
+                self.ctx.__exit__(*a)
+            self.eng.ops.lane = self.prev
+
+    def on_side(self):
+        return Engine._Lane(self, True)
+
+    def side_wait_main(self):
+        st = self._side_stream()
+        if st is not None:
+            st.wait_stream(torch.cuda.current_stream(self.dev))
+
+    def main_wait_side(self):
+        st = self._side_stream()
+        if st is not None:
+            torch.cuda.current_stream(self.dev).wait_stream(st)
+
     def buf(self, name, shape, dtype=torch.float32):
         shape = tuple(int(s) for s in shape)
         t = self._bufs.get(name)
@@ -146,17 +189,30 @@ class Engine:
         ops.gemm(zc, P["grucell_g.weight_ih"][:, E_VOCAB:], rbg)
         hx0 = self.buf("g_hx0", (T, B, H))
         g1 = self.buf("g_gates1", (T, ops.gates_floats(B, H)))
-        scans.append(dict(B=B, T=T, H=H, w_hh_frag=self.whh_f["g"], b_hh=P["grucell_g.bias_hh"], b_ih=P["grucell_g.bias_ih"],
-                          h0=h0g, gx_table=self.tab["g"], idx=d, idx_shift=-1, start_token=E_VOCAB - 1, gx_rowbias=rbg,
-                          h_all=hx0, gates=g1))
-        ops.gru_seq_fwd(scans)        # layer-1 scan and both sub-decoder scans run concurrently
-        # layer 2: input projections for all steps in one GEMM, then the recurrent scan (h_init = hx0[0], gmm_model.py:134-135)
+        l1 = dict(B=B, T=T, H=H, w_hh_frag=self.whh_f["g"], b_hh=P["grucell_g.bias_hh"], b_ih=P["grucell_g.bias_ih"],
+                  h0=h0g, gx_table=self.tab["g"], idx=d, idx_shift=-1, start_token=E_VOCAB - 1, gx_rowbias=rbg, h_all=hx0, gates=g1)
         gx2 = self.buf("g_gx2", (T, B, 3 * H))
-        ops.gemm(hx0.view(T * B, H), P["grucell_g_2.weight_ih"], gx2.view(T * B, 3 * H), bias=P["grucell_g_2.bias_ih"])
         hx1 = self.buf("g_hx1", (T, B, H))
         g2 = self.buf("g_gates2", (T, ops.gates_floats(B, H)))
-        ops.gru_seq_fwd([dict(B=B, T=T, H=H, w_hh_frag=self.whh_f["g2"], b_hh=P["grucell_g_2.bias_hh"], h0=hx0[0],
-                              gx_dense=gx2, h_all=hx1, gates=g2)])
+        l2 = dict(B=B, T=T, H=H, w_hh_frag=self.whh_f["g2"], b_hh=P["grucell_g_2.bias_hh"], h0=None, gx_dense=gx2, h_all=hx1, gates=g2)
+        # Time is cut into chunks: layer 1 (+ the two sub-decoders, which only live in the first Tr steps) runs on the main
+        # stream; behind it, on the side stream, chunk c of layer 2 = batched W_ih2 projection of hx0[chunk] (one GEMM)
+        # + the recurrent scan (h_init = hx0[0], gmm_model.py:134-135).  Layer 2 thus lags layer 1 by one chunk.
+        CH = self.chunk
+        for t0 in range(0, max(T, Tr), CH):
+            part = [self._fwd_chunk(sc, t0, t0 + CH) for sc in scans + [l1] if t0 < sc["T"]]
+            ops.gru_seq_fwd(part)
+            if t0 >= T:
+                continue
+            t1 = min(T, t0 + CH)
+            self.side_wait_main()
+            with self.on_side():
+                ops.gemm(hx0[t0:t1].view(-1, H), P["grucell_g_2.weight_ih"], gx2[t0:t1].view(-1, 3 * H), bias=P["grucell_g_2.bias_ih"])
+                c2 = self._fwd_chunk(l2, t0, t1)
+                if t0 == 0:
+                    c2["h0"] = hx0[0]
+                ops.gru_seq_fwd([c2])
+        self.main_wait_side()
         logits = self.buf("g_logits", (T * B, LOGIT_LD))
         ops.gemm(hx1.view(T * B, H), P["linear_out_g.weight"], logits[:, :E_VOCAB], bias=P["linear_out_g.bias"])
         for e, Ce in (("r", R_DIMS), ("n", N_DIMS)):
@@ -164,6 +220,37 @@ class Engine:
             ops.gemm(sd[e]["h_all"].view(Tr * B, H), P["linear_out_%s.weight" % e], sd[e]["logits"].view(Tr * B, Ce),
                      bias=P["linear_out_%s.bias" % e])
         return dict(sd=sd, zc=zc, h0g=h0g, rbg=rbg, hx0=hx0, g1=g1, gx2=gx2, hx1=hx1, g2=g2, logits=logits)
+
+    @staticmethod
+    def _fwd_chunk(sc, t0, t1):
+        """steps [t0, t1) of a forward (non-reverse) scan descriptor: the state carries over through h_all[t0-1]"""
+        t1 = min(t1, sc["T"])
+        c = dict(sc)
+        c["T"] = t1 - t0
+        if t0 > 0:
+            c["h0"] = sc["h_all"][t0 - 1]
+        c["h_all"] = sc["h_all"][t0:t1]
+        if sc.get("gates") is not None:
+            c["gates"] = sc["gates"][t0:t1]
+        if sc.get("gx_dense") is not None:
+            c["gx_dense"] = sc["gx_dense"][t0:t1]
+        c["idx_shift"] = sc.get("idx_shift", 0) + t0
+        return c
+
+    @staticmethod
+    def _bwd_chunk(sc, t0, t1, carry_in, carry_out):
+        """steps [t0, t1) of a backward scan descriptor; the gradient wrt the state before t0 leaves through carry_out and
+        enters the previous chunk as dh_last"""
+        c = dict(sc)
+        c["T"] = t1 - t0
+        if t0 > 0:
+            c["h0"] = sc["h_all"][t0 - 1]
+        for k in ("h_all", "gates", "dh_ext", "dgx_all", "dghn_all"):
+            if sc.get(k) is not None:
+                c[k] = sc[k][t0:t1]
+        c["dh_last"] = carry_in
+        c["dh0"] = carry_out
+        return c
 
     def forward(self, d, r, n, c, eps_r, eps_n, labels=None):
         """Full training-mode forward up to logits; everything backward needs stays in named buffers."""
@@ -223,93 +310,117 @@ class Engine:
         # ---- global decoder output layer ----------------------------------------------------------
         dlog = dec["logits"]                                   # [T*B][344], holds dlogits
         hx1f, hx0f = dec["hx1"].view(T * B, H), dec["hx0"].view(T * B, H)
-        ops.gemm(dlog[:, :E_VOCAB], hx1f, G["linear_out_g.weight"], a_k=False, b_k=False, splitk=sk_T)
-        ops.colsum(dlog[:, :E_VOCAB], G["linear_out_g.bias"])
         dhx1 = self.buf("g_dhx1", (T, B, H))
         ops.gemm(dlog[:, :E_VOCAB], P["linear_out_g.weight"], dhx1.view(T * B, H), a_k=True, b_k=False)
-        # ---- layer 2 scan -------------------------------------------------------------------------
+        # ---- decoder scans, chunk-pipelined over two streams ----------------------------------------------------
+        # side stream : layer-2 backward scan, chunks of time from the end to the start
+        # main stream : one chunk behind: dhx0[chunk] = dgx2[chunk] W_ih2 (one GEMM) -> layer-1 (+ sub-decoder) backward scan
         dgx2 = self.buf("g_dgx2", (T, B, 3 * H))
         dghn2 = self.buf("g_dghn2", (T, B, H))
-        dh0_l2 = self.buf("g_dh0_l2", (B, H))
-        rs2, rsn2 = self.buf("g_rs2", (B, 3 * H)), self.buf("g_rsn2", (B, H))
-        ops.gru_seq_bwd([dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t["g2"], h0=dec["hx0"][0], h_all=dec["hx1"], gates=dec["g2"],
-                              dh_ext=dhx1, dgx_all=dgx2, dghn_all=dghn2, dh0=dh0_l2, scratch=self.buf("g_scr2", (B, H)))])
-        ops.time_sum(dgx2, rs2)          # per-sequence sums over time: bias gradients (and dW of the z-conditioning) come from these
-        ops.time_sum(dghn2, rsn2)
-        self._gru_weight_grads("g2", "grucell_g_2.", "", T, B, dgx2, dghn2, dec["hx1"], dec["hx0"][0], G, sk_T, rs2, rsn2)
         dgx2f = dgx2.view(T * B, 3 * H)
-        ops.gemm(dgx2f, hx0f, G["grucell_g_2.weight_ih"], a_k=False, b_k=False, splitk=sk_T)
-        ops.colsum(rs2, G["grucell_g_2.bias_ih"])
         dhx0 = self.buf("g_dhx0", (T, B, H))
-        ops.gemm(dgx2f, P["grucell_g_2.weight_ih"], dhx0.view(T * B, H), a_k=True, b_k=False)
-        ops.axpy(1.0, dh0_l2, dhx0[0])                        # hx1 was initialised with hx0[0]
-        # ---- sub-decoder output layers ------------------------------------------------------------
         sd = dec["sd"]
         dh_sd = {}
         for e, Ce in (("r", R_DIMS), ("n", N_DIMS)):
             dl = dlogits_sd[e].view(Tr * B, Ce)
-            hf = sd[e]["h_all"].view(Tr * B, H)
-            ops.gemm(dl, hf, G["linear_out_%s.weight" % e], a_k=False, b_k=False, splitk=sk_Tr)
-            ops.colsum(dl, G["linear_out_%s.bias" % e])
             dh_sd[e] = self.buf("sd_dh_" + e, (Tr, B, H))
             ops.gemm(dl, P["linear_out_%s.weight" % e], dh_sd[e].view(Tr * B, H), a_k=True, b_k=False)
-        # ---- layer 1 scan + both sub-decoder scans (concurrent) -----------------------------------
         dgx1 = self.buf("g_dgx1", (T, B, 3 * H))
         dghn1 = self.buf("g_dghn1", (T, B, H))
-        dh0_g = self.buf("g_dh0", (B, H))
-        drb_g = self.buf("g_drb", (B, 3 * H))
-        rsn_g = self.buf("g_rsn1", (B, H))
-        scans = [dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t["g"], h0=dec["h0g"], h_all=dec["hx0"], gates=dec["g1"], dh_ext=dhx0,
-                      dgx_all=dgx1, dghn_all=dghn1, dh0=dh0_g, scratch=self.buf("g_scr1", (B, H)))]
-        sdb = {}
+        l2 = dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t["g2"], h0=dec["hx0"][0], h_all=dec["hx1"], gates=dec["g2"], dh_ext=dhx1,
+                  dgx_all=dgx2, dghn_all=dghn2, scratch=self.buf("g_scr2", (B, H)))
+        l1 = dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t["g"], h0=dec["h0g"], h_all=dec["hx0"], gates=dec["g1"], dh_ext=dhx0,
+                  dgx_all=dgx1, dghn_all=dghn1, scratch=self.buf("g_scr1", (B, H)))
+        sdb, sds = {}, {}
         for e in ("r", "n"):
             sdb[e] = dict(dgx=self.buf("sd_dgx_" + e, (Tr, B, 3 * H)), dghn=self.buf("sd_dghn_" + e, (Tr, B, H)),
-                          dh0=self.buf("sd_dh0_" + e, (B, H)), drb=self.buf("sd_drb_" + e, (B, 3 * H)),
-                          rsn=self.buf("sd_rsn_" + e, (B, H)))
-            scans.append(dict(B=B, T=Tr, H=H, w_hh_t_frag=self.whh_t["d_" + e], h0=sd[e]["h0"], h_all=sd[e]["h_all"], gates=sd[e]["gates"],
-                              dh_ext=dh_sd[e], dgx_all=sdb[e]["dgx"], dghn_all=sdb[e]["dghn"], dh0=sdb[e]["dh0"],
-                              scratch=self.buf("sd_scr_" + e, (B, H))))
-        ops.gru_seq_bwd(scans)
-        ops.time_sum(dgx1, drb_g)
-        ops.time_sum(dghn1, rsn_g)
+                          drb=self.buf("sd_drb_" + e, (B, 3 * H)), rsn=self.buf("sd_rsn_" + e, (B, H)))
+            sds[e] = dict(B=B, T=Tr, H=H, w_hh_t_frag=self.whh_t["d_" + e], h0=sd[e]["h0"], h_all=sd[e]["h_all"], gates=sd[e]["gates"],
+                          dh_ext=dh_sd[e], dgx_all=sdb[e]["dgx"], dghn_all=sdb[e]["dghn"], scratch=self.buf("sd_scr_" + e, (B, H)))
+        CH = self.chunk
+        starts = list(range(0, max(T, Tr), CH))
+        carry = {k: [self.buf("carry_%s_%d" % (k, i), (B, H)) for i in range(2)] for k in ("l2", "l1", "r", "n")}
+
+        def chunk_call(items, t0, last):
+            """items: (name, descriptor); builds the chunk descriptors with ping-pong carries (slot = chunk parity)"""
+            part = []
+            for name, sc in items:
+                if t0 >= sc["T"]:
+                    continue
+                t1 = min(t0 + CH, sc["T"])
+                slot = (t0 // CH) & 1
+                cin = None if t1 >= sc["T"] else carry[name][slot ^ 1]
+                part.append(self._bwd_chunk(sc, t0, t1, cin, carry[name][slot]))
+            return part
+
+        self.side_wait_main()
+        for i, t0 in enumerate(reversed(starts)):
+            if t0 < T:
+                with self.on_side():
+                    ops.gru_seq_bwd(chunk_call([("l2", l2)], t0, i == 0))
+                self.main_wait_side()      # layer 1 may start on this chunk as soon as layer 2 has produced dgx2[chunk]
+                t1 = min(T, t0 + CH)
+                ops.gemm(dgx2[t0:t1].view(-1, 3 * H), P["grucell_g_2.weight_ih"], dhx0[t0:t1].view(-1, H), a_k=True, b_k=False)
+                if t0 == 0:
+                    ops.axpy(1.0, carry["l2"][0], dhx0[0])          # hx1 was initialised with hx0[0]: dL/dh_init of layer 2
+            ops.gru_seq_bwd(chunk_call([("l1", l1), ("r", sds["r"]), ("n", sds["n"])], t0, i == 0))
+        dh0_g = carry["l1"][0]
         for e in ("r", "n"):
-            ops.time_sum(sdb[e]["dgx"], sdb[e]["drb"])
-            ops.time_sum(sdb[e]["dghn"], sdb[e]["rsn"])
-        # layer-1 parameter gradients
-        self._gru_weight_grads("g", "grucell_g.", "", T, B, dgx1, dghn1, dec["hx0"], dec["h0g"], G, sk_T, drb_g, rsn_g)
-        dWg = G["grucell_g.weight_ih"]                          # [3H][E+ZG]
-        dtab = self.buf("dtab_E", (E_VOCAB, 3 * H))
-        ops.embed_grad(dgx1, d, -1, E_VOCAB - 1, 0, E_VOCAB, dtab)
-        ops.transpose(dtab, dWg[:, :E_VOCAB])
-        ops.gemm(drb_g, dec["zc"], dWg[:, E_VOCAB:], a_k=False, b_k=False)
-        ops.colsum(drb_g, G["grucell_g.bias_ih"])
-        # d zc -> accumulated straight into the two latent gradients (the chroma columns need no gradient)
+            sdb[e]["dh0"] = carry[e][0]
+        # ---- what the encoder side needs from the decoders (main stream, critical path): dz ---------------------
+        drb_g = self.buf("g_drb", (B, 3 * H))
+        ops.time_sum(dgx1, drb_g)          # per-sequence sums over time of d(pre-activations)
         Wz_g, Wig = P["grucell_g.weight_ih"], P["linear_init_global.weight"]
         for e, c0 in (("r", 0), ("n", Z)):
             gz = lat_up[e]["g_z"]
             ops.gemm(drb_g, Wz_g[:, E_VOCAB + c0:E_VOCAB + c0 + Z], gz, a_k=True, b_k=False, beta=1.0)
             ops.gemm(dh0_g, Wig[:, c0:c0 + Z], gz, a_k=True, b_k=False, beta=1.0)
-        ops.gemm(dh0_g, dec["zc"], G["linear_init_global.weight"], a_k=False, b_k=False)
-        ops.colsum(dh0_g, G["linear_init_global.bias"])
-        # sub-decoder parameter gradients and their contribution to dz
-        for e, attr, Ce in (("r", r, R_DIMS), ("n", n, N_DIMS)):
-            pfx = "gru_d_%s." % e
-            z = lat[e]["z"]
+        for e, Ce in (("r", R_DIMS), ("n", N_DIMS)):
             gz = lat_up[e]["g_z"]
-            self._gru_weight_grads("d_" + e, pfx, "_l0", Tr, B, sdb[e]["dgx"], sdb[e]["dghn"], sd[e]["h_all"], sd[e]["h0"], G, sk_Tr,
-                                   sdb[e]["drb"], sdb[e]["rsn"])
-            dW = G[pfx + "weight_ih_l0"]                        # [3H][Ce+Z]
-            dt = self.buf("dtab_" + e, (Ce, 3 * H))
-            ops.embed_grad(sdb[e]["dgx"], attr, 0, 0, 0, Ce, dt)
-            ops.transpose(dt, dW[:, :Ce])
-            ops.gemm(sdb[e]["drb"], z, dW[:, Ce:], a_k=False, b_k=False)
-            ops.colsum(sdb[e]["drb"], G[pfx + "bias_ih_l0"])
-            ops.gemm(sdb[e]["drb"], P[pfx + "weight_ih_l0"][:, Ce:], gz, a_k=True, b_k=False, beta=1.0)
+            ops.time_sum(sdb[e]["dgx"], sdb[e]["drb"])
+            ops.gemm(sdb[e]["drb"], P["gru_d_%s.weight_ih_l0" % e][:, Ce:], gz, a_k=True, b_k=False, beta=1.0)
             ops.gemm(sdb[e]["dh0"], P["linear_init_%s.weight" % e], gz, a_k=True, b_k=False, beta=1.0)
-            ops.gemm(sdb[e]["dh0"], z, G["linear_init_%s.weight" % e], a_k=False, b_k=False)
-            ops.colsum(sdb[e]["dh0"], G["linear_init_%s.bias" % e])
-        if after_decoders is not None:
-            after_decoders()
+        # ---- decoder-side PARAMETER gradients: side stream, overlapping the latent block and the encoder scans ---
+        self.side_wait_main()
+        with self.on_side():
+            rs2, rsn2, rsn_g = self.buf("g_rs2", (B, 3 * H)), self.buf("g_rsn2", (B, H)), self.buf("g_rsn1", (B, H))
+            ops.gemm(dlog[:, :E_VOCAB], hx1f, G["linear_out_g.weight"], a_k=False, b_k=False, splitk=sk_T)
+            ops.colsum(dlog[:, :E_VOCAB], G["linear_out_g.bias"])
+            ops.time_sum(dgx2, rs2)
+            ops.time_sum(dghn2, rsn2)
+            ops.time_sum(dghn1, rsn_g)
+            self._gru_weight_grads("g2", "grucell_g_2.", "", T, B, dgx2, dghn2, dec["hx1"], dec["hx0"][0], G, sk_T, rs2, rsn2)
+            ops.gemm(dgx2f, hx0f, G["grucell_g_2.weight_ih"], a_k=False, b_k=False, splitk=sk_T)
+            ops.colsum(rs2, G["grucell_g_2.bias_ih"])
+            self._gru_weight_grads("g", "grucell_g.", "", T, B, dgx1, dghn1, dec["hx0"], dec["h0g"], G, sk_T, drb_g, rsn_g)
+            dWg = G["grucell_g.weight_ih"]                          # [3H][E+ZG]
+            dtab = self.buf("dtab_E_side", (E_VOCAB, 3 * H))
+            ops.embed_grad(dgx1, d, -1, E_VOCAB - 1, 0, E_VOCAB, dtab)
+            ops.transpose(dtab, dWg[:, :E_VOCAB])
+            ops.gemm(drb_g, dec["zc"], dWg[:, E_VOCAB:], a_k=False, b_k=False)
+            ops.colsum(drb_g, G["grucell_g.bias_ih"])
+            ops.gemm(dh0_g, dec["zc"], G["linear_init_global.weight"], a_k=False, b_k=False)
+            ops.colsum(dh0_g, G["linear_init_global.bias"])
+            for e, attr, Ce in (("r", r, R_DIMS), ("n", n, N_DIMS)):
+                pfx = "gru_d_%s." % e
+                z = lat[e]["z"]
+                dl = dlogits_sd[e].view(Tr * B, Ce)
+                ops.gemm(dl, sd[e]["h_all"].view(Tr * B, H), G["linear_out_%s.weight" % e], a_k=False, b_k=False, splitk=sk_Tr)
+                ops.colsum(dl, G["linear_out_%s.bias" % e])
+                ops.time_sum(sdb[e]["dghn"], sdb[e]["rsn"])
+                self._gru_weight_grads("d_" + e, pfx, "_l0", Tr, B, sdb[e]["dgx"], sdb[e]["dghn"], sd[e]["h_all"], sd[e]["h0"], G, sk_Tr,
+                                       sdb[e]["drb"], sdb[e]["rsn"])
+                dW = G[pfx + "weight_ih_l0"]                        # [3H][Ce+Z]
+                dt = self.buf("dtab_" + e, (Ce, 3 * H))
+                ops.embed_grad(sdb[e]["dgx"], attr, 0, 0, 0, Ce, dt)
+                ops.transpose(dt, dW[:, :Ce])
+                ops.gemm(sdb[e]["drb"], z, dW[:, Ce:], a_k=False, b_k=False)
+                ops.colsum(sdb[e]["drb"], G[pfx + "bias_ih_l0"])
+                ops.gemm(sdb[e]["dh0"], z, G["linear_init_%s.weight" % e], a_k=False, b_k=False)
+                ops.colsum(sdb[e]["dh0"], G["linear_init_%s.bias" % e])
+            if after_decoders is not None:
+                after_decoders()           # data parallel: this bucket's all-reduce is ordered behind the side stream
+
         # ---- latent block + heads -----------------------------------------------------------------
         scans = []
         encb = {}
@@ -352,3 +463,4 @@ class Engine:
                 ops.embed_grad(encb[key]["dgx"], d, 0, 0, rev, E_VOCAB, dtab)
                 ops.transpose(dtab, G[pfx + "weight_ih" + sfx])
                 ops.colsum(encb[key]["rs"], G[pfx + "bias_ih" + sfx])
+        self.main_wait_side()

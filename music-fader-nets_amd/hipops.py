@@ -52,6 +52,7 @@ class HipOps:
         if self.device.type != "cuda":
             raise RuntimeError("HipOps needs a GPU device")
         self._ws = {}
+        self.lane = ""            # scratch namespace: kernels enqueued on different streams must not share workspaces
 
     # -- plumbing -------------------------------------------------------------------------------
     def stream(self):
@@ -59,6 +60,7 @@ class HipOps:
 
     def workspace(self, nbytes, tag="ws"):
         """Grow-only scratch buffer per tag (stable pointer once warm -> graph friendly)."""
+        tag = self.lane + tag
         cur = self._ws.get(tag)
         if cur is None or cur.numel() * 4 < nbytes:
             cur = torch.empty((max(nbytes, 4) + 3) // 4, dtype=torch.float32, device=self.device)

@@ -17,6 +17,7 @@ class FakeOps:
 
     def __init__(self):
         self.calls = []
+        self.lane = ""
 
     # -- dense --------------------------------------------------------------------------------------
     def gemm(self, A, B, Cm, a_k=True, b_k=True, alpha=1.0, beta=0.0, bias=None, splitk=1):

@@ -70,11 +70,14 @@ def test_dropin_forward_and_autograd(small):
         assert relerr(p.grad.numpy(), ref) < 3e-4 or np.abs(ref).max() < 1e-6, (k, relerr(p.grad.numpy(), ref))
 
 
-@pytest.mark.parametrize("sup", [False, True])
-def test_fused_step_gradients(small, sup):
+@pytest.mark.parametrize("sup,chunk", [(False, 32), (True, 32), (False, 8), (False, 5), (False, 3)])
+def test_fused_step_gradients(small, sup, chunk):
+    """chunk = time steps per pipeline chunk of the decoder layers (T=20, Tr=8 here): the carried states / gradients
+    across chunk boundaries must not change any result."""
     pkg = load_package()
     m = make_model(64, 32, sd_from(small, "w0/"), ops=FakeOps())
     tr = pkg.GMVAETrainer(m, lr=1e-3, beta=0.2)
+    m.engine().chunk = chunk
     b = batch_of(small)
     batch = tr.prepare_batch(b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"], b["a"] if sup else None)
     eps = (torch.from_numpy(small["eps_r"]), torch.from_numpy(small["eps_n"]))
