@@ -110,6 +110,7 @@ def main():
     for _ in range(args.steps):
         trainer.step_device(step, batch, eps)
         step += 1
+    t_host = time.perf_counter() - t0                       # host enqueue time (the GPU runs behind asynchronously)
     torch.cuda.synchronize()
     if ctx is not None:
         torch.distributed.barrier()
@@ -123,7 +124,7 @@ def main():
     assert all(np.isfinite(tup)), tup
 
     tokens_per_s = world * B * T * args.steps / dt
-    log("timed region done: %.3f ms/step" % (dt / args.steps * 1e3))
+    log("timed region done: %.3f ms/step (host enqueue %.3f ms/step)" % (dt / args.steps * 1e3, t_host / args.steps * 1e3))
     roof = measure_dominant_kernel(trainer, batch, eps)
     log("dominant-kernel timing done")
     roof["step_frac"] = round(tokens_per_s / world * F_ALG_PER_TOKEN / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)

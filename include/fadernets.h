@@ -182,15 +182,16 @@ int fn_latent_fwd(const float* pre, const float* eps, const float* mu_lk, const 
                   const int32_t* labels, float* sigma, float* z, float* ll, float* qy, int32_t* y, float* terms,
                   void* stream);
 /* Backward. Upstream gradients (any may be NULL): g_z, g_mu, g_sigma [B][Z]; g_ll, g_qy [B][K].
- * Fused loss gradient (trainer_gmm.py:150-194) when w_lat/w_cls/w_clf != 0:
+ * w3 = DEVICE pointer to {w_lat, w_cls, w_clf} (NULL = all zero; written by fn_step_params so that a captured graph never
+ * bakes the step-dependent beta into a kernel argument).  Fused loss gradient (trainer_gmm.py:150-194):
  *    L += w_lat * sum_b sum_k qy KLmean_k  + w_cls * sum_b mean_k(qy log qy)          (unsupervised)
  *    L += w_lat * sum_b KLmean_label       + w_clf * sum_b CE(softmax(qy), label)     (labels != NULL)
  * outputs: dpre [B][2Z]; dmu_lk_rows [B][K][Z] per-row contributions to d mu_lookup (reduce with
  * fn_colsum_f32 over B). */
 int fn_latent_bwd(const float* pre, const float* eps, const float* mu_lk, const float* lv_lk, int B, int Z, int K,
                   const int32_t* labels, const float* z, const float* qy, const float* g_z, const float* g_mu,
-                  const float* g_sigma, const float* g_ll, const float* g_qy, float w_lat, float w_cls, float w_clf,
-                  float* dpre, float* dmu_lk_rows, void* stream);
+                  const float* g_sigma, const float* g_ll, const float* g_qy, const float* w3, float* dpre,
+                  float* dmu_lk_rows, void* stream);
 
 /* Pairwise latent regulariser (trainer_gmm.py:199-217): rows [row0,row0+nrows) of the global batch.
  *   attr_all is float64 like the reference's numpy densities (only the sign of a_i - a_j is used).
@@ -203,11 +204,19 @@ int fn_pairwise_reg(const float* z0_all, const double* attr_all, int n_all, int 
  * clip_grad_norm_(., max_norm) + Adam (trainer_gmm.py:250-251, torch.optim.Adam defaults) over a
  * flat fp32 buffer.  fn_sumsq writes sum(g^2) to out[0]; fn_clip_adam reads the (all-reduced)
  * total from sumsq[0] on device, so no host sync is needed.
+ *
+ * fn_step_params keeps the step counters ON THE DEVICE (counters[0] = training step, counters[1] = Adam t; int64) and
+ * derives every step-dependent scalar from them: out[0..2] = {w_lat, w_cls, w_clf} for fn_latent_bwd with
+ * beta0 = 0 if step < 1000 else min((step-10000)/10000*beta, beta)  (trainer_gmm.py:125-128), out[3] = lr/(1-beta1^t),
+ * out[4] = 1/sqrt(1-beta2^t), out[5] = beta0; advance != 0 increments both counters (t is advanced BEFORE use, the step
+ * AFTER).  fn_clip_adam takes hyper = &out[3].  The whole training step is therefore capturable in one hipGraph.
  * ------------------------------------------------------------------------------------------ */
+int fn_step_params(int64_t* counters, float beta, float lr, float beta1, float beta2, int supervised, float inv_global_batch,
+                   int advance, float* out, void* stream);
 int fn_sumsq_f32(const float* g, int64_t n, float* out, float* ws, size_t ws_bytes, void* stream);
 size_t fn_sumsq_ws_bytes(int64_t n);
-int fn_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, float max_norm, float lr,
-                 float beta1, float beta2, float eps, int step, void* stream);
+int fn_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, float max_norm,
+                 const float* hyper, float beta1, float beta2, float eps, void* stream);
 
 /* one-hot (B,T,V) -> int32 indices (argmax along the last axis); used at the class boundary where callers
  * hand over convert_to_one_hot tensors (trainer_gmm.py:296-303) */

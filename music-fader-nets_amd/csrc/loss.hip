@@ -234,9 +234,10 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict
                                                          int K, const int* __restrict__ labels, const float* __restrict__ zin,
                                                          const float* __restrict__ qy, const float* __restrict__ g_z,
                                                          const float* __restrict__ g_mu, const float* __restrict__ g_sigma,
-                                                         const float* __restrict__ g_ll, const float* __restrict__ g_qy, float w_lat,
-                                                         float w_cls, float w_clf, float* __restrict__ dpre,
+                                                         const float* __restrict__ g_ll, const float* __restrict__ g_qy,
+                                                         const float* __restrict__ w3, float* __restrict__ dpre,
                                                          float* __restrict__ dmu_lk_rows) {
+    const float w_lat = w3 ? w3[0] : 0.f, w_cls = w3 ? w3[1] : 0.f, w_clf = w3 ? w3[2] : 0.f;
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -440,12 +441,11 @@ int fn_latent_fwd(const float* pre, const float* eps, const float* mu_lk, const 
 
 int fn_latent_bwd(const float* pre, const float* eps, const float* mu_lk, const float* lv_lk, int B, int Z, int K,
                   const int32_t* labels, const float* z, const float* qy, const float* g_z, const float* g_mu, const float* g_sigma,
-                  const float* g_ll, const float* g_qy, float w_lat, float w_cls, float w_clf, float* dpre, float* dmu_lk_rows,
-                  void* stream) {
+                  const float* g_ll, const float* g_qy, const float* w3, float* dpre, float* dmu_lk_rows, void* stream) {
     if (!pre || !eps || !mu_lk || !lv_lk || !z || !qy || !dpre) return FN_E_NULL;
     if (B <= 0 || Z <= 0 || K <= 0 || K > KMAX) return FN_E_SHAPE;
     hipLaunchKernelGGL(latent_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, pre, eps, mu_lk, lv_lk, B, Z, K, labels, z,
-                       qy, g_z, g_mu, g_sigma, g_ll, g_qy, w_lat, w_cls, w_clf, dpre, dmu_lk_rows);
+                       qy, g_z, g_mu, g_sigma, g_ll, g_qy, w3, dpre, dmu_lk_rows);
     FN_CHECK_LAUNCH();
     return FN_OK;
 }

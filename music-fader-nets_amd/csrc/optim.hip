@@ -38,9 +38,37 @@ __global__ __launch_bounds__(1024) void sumsq_final_kernel(const float* __restri
     }
 }
 
+// One thread: advances the device-resident counters and derives everything that depends on the step number, so that a
+// captured hipGraph of the whole training step never bakes a step-dependent scalar into a kernel argument.
+//   counters[0] = training step (beta annealing, trainer_gmm.py:125-128), counters[1] = Adam's t
+//   out[0..2] = w_lat, w_cls, w_clf of fn_latent_bwd ; out[3] = lr / (1 - beta1^t) ; out[4] = 1 / sqrt(1 - beta2^t) ; out[5] = beta0
+__global__ void step_params_kernel(long long* __restrict__ counters, float beta, float lr, float beta1, float beta2, int supervised,
+                                   float inv_bg, int advance, float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const long long step = counters[0];
+    const long long t = counters[1] + (advance ? 1 : 0);
+    double beta0 = 0.0;
+    if (step >= 1000) {
+        const double a = (double)(step - 10000) / 10000.0 * (double)beta;
+        beta0 = a < (double)beta ? a : (double)beta;
+    }
+    out[0] = (float)(beta0 * inv_bg);
+    out[1] = supervised ? 0.0f : (float)(beta0 * inv_bg);
+    out[2] = supervised ? inv_bg : 0.0f;
+    const double tt = (double)(t > 0 ? t : 1);
+    out[3] = (float)((double)lr / (1.0 - pow((double)beta1, tt)));
+    out[4] = (float)(1.0 / sqrt(1.0 - pow((double)beta2, tt)));
+    out[5] = (float)beta0;
+    if (advance) {
+        counters[0] = step + 1;
+        counters[1] = t;
+    }
+}
+
 __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, long n, const float* __restrict__ sumsq, float max_norm,
-                                                        float step_size, float beta1, float beta2, float eps, float inv_sqrt_bc2) {
+                                                        const float* __restrict__ hyper, float beta1, float beta2, float eps) {
+    const float step_size = hyper[0], inv_sqrt_bc2 = hyper[1];
     const float total = sqrtf(sumsq[0]);
     const float coef = fminf(1.0f, max_norm / (total + 1e-6f));      // torch clip_grad_norm_: clamp(max_norm/(norm+1e-6), max=1)
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
@@ -72,15 +100,22 @@ int fn_sumsq_f32(const float* g, int64_t n, float* out, float* ws, size_t ws_byt
     return FN_OK;
 }
 
-int fn_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, float max_norm, float lr, float beta1,
-                 float beta2, float eps, int step, void* stream) {
-    if (!p || !g || !m || !v || !sumsq) return FN_E_NULL;
-    if (n <= 0 || step <= 0) return FN_E_SHAPE;
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    const float step_size = (float)(lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+int fn_step_params(int64_t* counters, float beta, float lr, float beta1, float beta2, int supervised, float inv_global_batch,
+                   int advance, float* out, void* stream) {
+    if (!counters || !out) return FN_E_NULL;
+    hipLaunchKernelGGL(step_params_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long*)counters, beta, lr, beta1, beta2,
+                       supervised, inv_global_batch, advance, out);
+    FN_CHECK_LAUNCH();
+    return FN_OK;
+}
+
+int fn_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, float max_norm, const float* hyper,
+                 float beta1, float beta2, float eps, void* stream) {
+    if (!p || !g || !m || !v || !sumsq || !hyper) return FN_E_NULL;
+    if (n <= 0) return FN_E_SHAPE;
     const long blocks = (n + 255) / 256;
     hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                       (long)n, sumsq, max_norm, step_size, beta1, beta2, eps, inv_sqrt_bc2);
+                       (long)n, sumsq, max_norm, hyper, beta1, beta2, eps);
     FN_CHECK_LAUNCH();
     return FN_OK;
 }

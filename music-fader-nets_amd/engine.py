@@ -287,7 +287,7 @@ class Engine:
     def _splitk(rows):
         return 16 if rows >= 32768 else (8 if rows >= 4096 else (4 if rows >= 1024 else 1))
 
-    def backward(self, G, dlogits_sd, lat_up, w_lat, w_cls, w_clf, after_decoders=None):
+    def backward(self, G, dlogits_sd, lat_up, w3=None, after_decoders=None):
         """Backward of forward().
 
         G            name -> gradient tensor to FILL (views of the flat gradient buffer)
@@ -295,7 +295,7 @@ class Engine:
         dlogits_sd   {'r','n'} -> [Tr][B][Ce] gradient wrt the sub-decoder pre-softmax logits
         lat_up       {'r','n'} -> dict(g_z, g_mu, g_sigma, g_ll, g_qy) upstream gradients (entries may be None;
                      g_z is a REQUIRED zero-or-filled [B][Z] buffer that decoder gradients are accumulated into)
-        w_*          fused loss weights for fn_latent_bwd (0 = only the upstream gradients)
+        w3           device tensor {w_lat, w_cls, w_clf}: fused loss weights of fn_latent_bwd (None = only the upstream gradients)
         after_decoders  optional callback fired once every decoder-side parameter gradient is enqueued
                      (data parallel: start reducing that bucket while the encoder scans run)
         """
@@ -430,7 +430,7 @@ class Engine:
             dmu_rows = self.buf("dmulk_rows_" + e, (B, K * Z))
             ops.latent_bwd(pre[e], S["eps"][e], P["mu_%s_lookup.weight" % e], P["logvar_%s_lookup.weight" % e], S["labels"],
                            lat[e]["z"], lat[e]["qy"], up["g_z"], up.get("g_mu"), up.get("g_sigma"), up.get("g_ll"), up.get("g_qy"),
-                           w_lat, w_cls, w_clf, dpre, dmu_rows)
+                           w3, dpre, dmu_rows)
             ops.colsum(dmu_rows, G["mu_%s_lookup.weight" % e].view(-1))
             hf = self._bufs["enc_h_" + e][T - 1]
             hb = self._bufs["enc_h_" + e + "_reverse"][T - 1]

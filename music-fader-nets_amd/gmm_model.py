@@ -271,5 +271,5 @@ class _GMVAEFunction(torch.autograd.Function):
             "n": dict(g_z=dense(g_z_n, S["lat"]["n"]["z"]).clone(), g_mu=opt(g_mu_n), g_sigma=opt(g_sg_n), g_ll=opt(g_ll_n), g_qy=opt(g_qy_n)),
         }
         G = {k: torch.empty_like(p) for k, p in model.used_parameters()}
-        eng.backward(G, dl_sd, lat_up, 0.0, 0.0, 0.0)
+        eng.backward(G, dl_sd, lat_up, None)
         return (None,) * 8 + tuple(G[k] for k in ctx.names)

@@ -222,15 +222,16 @@ class HipOps:
         _lib.check(self.lib.fn_latent_fwd(_p(pre), _p(eps), _p(mu_lk), _p(lv_lk), B, Z, K, _p(labels), _p(sigma), _p(z), _p(ll), _p(qy),
                                           _p(y), _p(terms), self.stream()), "fn_latent_fwd")
 
-    def latent_bwd(self, pre, eps, mu_lk, lv_lk, labels, z, qy, g_z, g_mu, g_sigma, g_ll, g_qy, w_lat, w_cls, w_clf, dpre, dmu_lk_rows):
+    def latent_bwd(self, pre, eps, mu_lk, lv_lk, labels, z, qy, g_z, g_mu, g_sigma, g_ll, g_qy, w3, dpre, dmu_lk_rows):
+        """w3: device float tensor {w_lat, w_cls, w_clf} (see fn_step_params) or None (= zeros)"""
         for t, n in ((pre, "pre"), (eps, "eps"), (mu_lk, "mu_lk"), (lv_lk, "lv_lk"), (z, "z"), (qy, "qy"), (g_z, "g_z"), (g_mu, "g_mu"),
-                     (g_sigma, "g_sigma"), (g_ll, "g_ll"), (g_qy, "g_qy"), (dpre, "dpre"), (dmu_lk_rows, "dmu_lk_rows")):
+                     (g_sigma, "g_sigma"), (g_ll, "g_ll"), (g_qy, "g_qy"), (dpre, "dpre"), (dmu_lk_rows, "dmu_lk_rows"), (w3, "w3")):
             _dense(t, name=n)
         _dense(labels, torch.int32, "labels")
         B, Z = eps.shape
         K = mu_lk.shape[0]
         _lib.check(self.lib.fn_latent_bwd(_p(pre), _p(eps), _p(mu_lk), _p(lv_lk), B, Z, K, _p(labels), _p(z), _p(qy), _p(g_z), _p(g_mu),
-                                          _p(g_sigma), _p(g_ll), _p(g_qy), w_lat, w_cls, w_clf, _p(dpre), _p(dmu_lk_rows),
+                                          _p(g_sigma), _p(g_ll), _p(g_qy), _p(w3), _p(dpre), _p(dmu_lk_rows),
                                           self.stream()), "fn_latent_bwd")
 
     def pairwise_reg(self, z0_all, attr_all, row0, nrows, loss_rows, grad_scale=0.0, dz0=None):
@@ -245,11 +246,19 @@ class HipOps:
         ws = self.workspace(wsb, "sumsq")
         _lib.check(self.lib.fn_sumsq_f32(_p(g), g.numel(), _p(out), _p(ws), wsb, self.stream()), "fn_sumsq_f32")
 
-    def clip_adam(self, p, g, m, v, sumsq, max_norm, lr, beta1, beta2, eps, step):
+    def step_params(self, counters, beta, lr, beta1, beta2, supervised, inv_global_batch, advance, out):
+        """device-resident step counters -> {w_lat, w_cls, w_clf, lr/(1-b1^t), 1/sqrt(1-b2^t), beta0} (see fn_step_params)"""
+        _dense(counters, torch.int64, "counters"), _dense(out, name="out")
+        if counters.numel() < 2 or out.numel() < 6:
+            raise RuntimeError("step_params: counters[2] / out[6] expected")
+        _lib.check(self.lib.fn_step_params(_p(counters), beta, lr, beta1, beta2, int(supervised), inv_global_batch, int(advance), _p(out),
+                                           self.stream()), "fn_step_params")
+
+    def clip_adam(self, p, g, m, v, sumsq, max_norm, hyper, beta1, beta2, eps):
         for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
             _dense(t, name=n)
-        _chk(sumsq, name="sumsq")
-        _lib.check(self.lib.fn_clip_adam(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(sumsq), max_norm, lr, beta1, beta2, eps, step,
+        _chk(sumsq, name="sumsq"), _chk(hyper, name="hyper")
+        _lib.check(self.lib.fn_clip_adam(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(sumsq), max_norm, _p(hyper), beta1, beta2, eps,
                                          self.stream()), "fn_clip_adam")
 
     def onehot_to_index(self, oh, idx):

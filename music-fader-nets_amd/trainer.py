@@ -79,7 +79,13 @@ class GMVAETrainer:
         dev = self.flat.param.device
         self.stats = torch.zeros(S_LEN, device=dev)  # partial sums of the loss terms (device side)
         self.sumsq = torch.zeros(1, device=dev)
-        self.last_grad_sumsq = None
+        # step counters live on the device (fn_step_params): [training step, Adam t]; sp = derived scalars
+        self.counters = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.sp = torch.zeros(8, device=dev)
+        self._dev_step = 0                          # host mirror of counters[0]
+        self.use_graph = dev.type == "cuda"          # replay the whole step as ONE hipGraph (no per-launch host cost)
+        self._graphs = {}
+        self._static = {}
         model.train()
 
     # ------------------------------------------------------------------------------------------
@@ -145,8 +151,7 @@ class GMVAETrainer:
                 gz = eng.zbuf("g_z_" + e, (B, Z))
                 gz[:, 0].copy_(dz0)
                 lat_up[e] = dict(g_z=gz)
-        w = (beta0 / Bg, beta0 / Bg, 0.0) if labels is None else (beta0 / Bg, 0.0, 1.0 / Bg)
-        return dl_sd, lat_up, w, beta0, Bg
+        return dl_sd, lat_up, self.sp[0:3], beta0, Bg
 
     def _tuple8(self, beta0, Bg, supervised):
         """device partial sums -> the reference's 8 numbers (ONE D2H copy; the reference does 8 .item() calls, :257)."""
@@ -168,24 +173,88 @@ class GMVAETrainer:
         return (loss, ce_x, ce_r, ce_n, l_r, l_n, kld_lat, kld_cls)
 
     # ------------------------------------------------------------------------------------------
-    def step_device(self, step, batch, eps):
-        """One optimisation step, fully asynchronous (no host sync): returns nothing; statistics stay on the device."""
+    def loss_and_grads(self, step, batch, eps):
+        """forward + losses + backward WITHOUT the optimiser update: fills flat.grad, returns the reference's 8 numbers
+        (used by the parity tests; the step counters are not advanced)"""
         m = self.model
         eng = m.engine()
-        dl_sd, lat_up, w, beta0, Bg = self._forward_losses(step, batch, eps, want_grads=True)
+        self._sync_step_counter(step)
+        supervised = batch[6] is not None
+        Bg = batch[0].shape[0] if self.dist is None else self.dist.global_batch(batch[0].shape[0])
+        eng.ops.step_params(self.counters, self.beta, self.lr, 0.9, 0.999, supervised, 1.0 / Bg, False, self.sp)
+        dl_sd, lat_up, w3, beta0, Bg = self._forward_losses(step, batch, eps, want_grads=True)
+        eng.backward(self.flat.G, dl_sd, lat_up, w3)
+        eng.ops.sumsq(self.flat.grad, self.sumsq)
+        return self._tuple8(beta0, Bg, supervised)
+
+    def _sync_step_counter(self, step):
+        """the caller owns `step` (trainer_gmm.py:60,252); the device counter follows it (one tiny copy only when they differ)"""
+        if step != self._dev_step:
+            self.counters[0:1].copy_(torch.tensor([step], dtype=torch.int64))
+            self._dev_step = step
+
+    def _step_body(self, step, batch, eps, advance=True):
+        """everything one optimisation step enqueues (no host sync, no step-dependent host scalar in a kernel argument)"""
+        m = self.model
+        eng = m.engine()
+        ops = eng.ops
+        supervised = batch[6] is not None
+        Bg = batch[0].shape[0] if self.dist is None else self.dist.global_batch(batch[0].shape[0])
+        ops.step_params(self.counters, self.beta, self.lr, 0.9, 0.999, supervised, 1.0 / Bg, advance, self.sp)
+        dl_sd, lat_up, w3, beta0, Bg = self._forward_losses(step, batch, eps, want_grads=True)
         hook = None
         if self.dist is not None:
             hook = lambda: self.dist.start_bucket(self.flat.grad[:self.flat.bucket_split])
-        eng.backward(self.flat.G, dl_sd, lat_up, *w, after_decoders=hook)
+        eng.backward(self.flat.G, dl_sd, lat_up, w3, after_decoders=hook)
         if self.dist is not None:
             self.dist.start_bucket(self.flat.grad[self.flat.bucket_split:])
             self.dist.finish_buckets()
-        ops = eng.ops
         ops.sumsq(self.flat.grad, self.sumsq)      # norm of the (all-reduced) gradient: identical on every rank
+        ops.clip_adam(self.flat.param, self.flat.grad, self.flat.m, self.flat.v, self.sumsq, self.max_norm, self.sp[3:5], 0.9, 0.999, 1e-8)
+        eng.refresh_weights()                      # packed / transposed weight images for the next step
+        return beta0, Bg
+
+    def step_device(self, step, batch, eps):
+        """One optimisation step, fully asynchronous (no host sync); statistics stay on the device.
+
+        On the GPU the step is captured ONCE per (shapes, supervised) into a hipGraph (two streams included) and replayed:
+        ~2400 kernel launches otherwise cost more host time than the GPU needs to run them.  Call 1 runs eagerly (buffers get
+        allocated), call 2 is captured, later calls copy the batch into the captured buffers and replay."""
+        m = self.model
+        self._sync_step_counter(step)
+        beta0 = beta_schedule(step, self.beta)
+        B = batch[0].shape[0]
+        Bg = B if self.dist is None else self.dist.global_batch(B)
+        self._dev_step = step + 1
         self.flat.t += 1
-        ops.clip_adam(self.flat.param, self.flat.grad, self.flat.m, self.flat.v, self.sumsq, self.max_norm, self.lr,
-                      0.9, 0.999, 1e-8, self.flat.t)
-        m.weights_changed()
+        if not self.use_graph:
+            m.engine()
+            self._step_body(step, batch, eps)
+            m._weights_version = m._version        # refresh_weights() already ran at the end of the step
+            return beta0, Bg
+        key = (tuple(batch[0].shape), tuple(batch[1].shape), batch[6] is not None)
+        st = self._static.get(key)
+        if st is None:                              # first call with these shapes: static input buffers + one eager run
+            st = dict(batch=[None if t is None else t.clone() for t in batch], eps=[e.clone() for e in eps], runs=0)
+            self._static[key] = st
+        for dst, src in zip(st["batch"] + st["eps"], list(batch) + list(eps)):
+            if dst is not None and dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        sbatch, seps = tuple(st["batch"]), tuple(st["eps"])
+        m.engine()                                  # (re)builds the engine / weight images outside of any capture
+        if key in self._graphs:
+            self._graphs[key].replay()
+        elif st["runs"] == 0:
+            self._step_body(step, sbatch, seps)
+        else:
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                self._step_body(step, sbatch, seps)
+            self._graphs[key] = g                   # the capture itself does not execute: run the step now
+            g.replay()
+        st["runs"] += 1
+        m._weights_version = m._version
         return beta0, Bg
 
     def train(self, step, d_oh, r_oh, n_oh, d, r, n, c, r_density, n_density, is_supervised=False, y_label=None, eps=None):
@@ -205,6 +274,7 @@ class GMVAETrainer:
                                    c, r_density, n_density, y_label if is_supervised else None)
         if eps is None:
             eps = self.draw_eps(*batch[0].shape)
+        self.model.engine()
         _, _, _, beta0, Bg = self._forward_losses(step, batch, eps, want_grads=False)
         return self._tuple8(beta0, Bg, is_supervised)
 

@@ -11,8 +11,7 @@ def run(dev, ops=None):
     b = batch_of(gold)
     batch = tr.prepare_batch(b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"], None)
     eps = (torch.from_numpy(gold["eps_r"]).to(dev), torch.from_numpy(gold["eps_n"]).to(dev))
-    dl_sd, lat_up, w, beta0, Bg = tr._forward_losses(20000, batch, eps, want_grads=True)
-    m.engine().backward(tr.flat.G, dl_sd, lat_up, *w)
+    tr.loss_and_grads(20000, batch, eps)
     return {k: tr.flat.G[k].cpu().numpy().copy() for k in tr.flat.names}, m
 gg, m = run("cuda:0")
 gf, _ = run("cpu", FakeOps())

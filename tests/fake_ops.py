@@ -209,7 +209,8 @@ class FakeOps:
             terms[:, 2] = klm.gather(1, lb).view(-1)
             terms[:, 3] = -torch.log_softmax(q, dim=1).gather(1, lb).view(-1)
 
-    def latent_bwd(self, pre, eps, mu_lk, lv_lk, labels, z, qy, g_z, g_mu, g_sigma, g_ll, g_qy, w_lat, w_cls, w_clf, dpre, dmu_lk_rows):
+    def latent_bwd(self, pre, eps, mu_lk, lv_lk, labels, z, qy, g_z, g_mu, g_sigma, g_ll, g_qy, w3, dpre, dmu_lk_rows):
+        w_lat, w_cls, w_clf = (0.0, 0.0, 0.0) if w3 is None else (float(w3[0]), float(w3[1]), float(w3[2]))
         # gradients by autograd of the documented forward + fused loss: checks the schedule AND documents the maths
         with torch.enable_grad():
             self._latent_bwd(pre, eps, mu_lk, lv_lk, labels, g_z, g_mu, g_sigma, g_ll, g_qy, w_lat, w_cls, w_clf, dpre, dmu_lk_rows)
@@ -253,13 +254,26 @@ class FakeOps:
     def sumsq(self, g, out):
         out.copy_((g.double() ** 2).sum().float().view_as(out))
 
-    def clip_adam(self, p, g, m, v, sumsq, max_norm, lr, beta1, beta2, eps, step):
+    def step_params(self, counters, beta, lr, beta1, beta2, supervised, inv_global_batch, advance, out):
+        step, t = int(counters[0]), int(counters[1]) + (1 if advance else 0)
+        beta0 = 0.0 if step < 1000 else min((step - 10000) / 10000 * beta, beta)
+        tt = max(t, 1)
+        out[0] = beta0 * inv_global_batch
+        out[1] = 0.0 if supervised else beta0 * inv_global_batch
+        out[2] = inv_global_batch if supervised else 0.0
+        out[3] = lr / (1 - beta1 ** tt)
+        out[4] = 1.0 / math.sqrt(1 - beta2 ** tt)
+        out[5] = beta0
+        if advance:
+            counters[0] = step + 1
+            counters[1] = t
+
+    def clip_adam(self, p, g, m, v, sumsq, max_norm, hyper, beta1, beta2, eps):
         coef = min(1.0, max_norm / (math.sqrt(float(sumsq[0])) + 1e-6))
         gg = g * coef
         m.mul_(beta1).add_(gg, alpha=1 - beta1)
         v.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
-        bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
-        p.sub_((lr / bc1) * m / (v.sqrt() / math.sqrt(bc2) + eps))
+        p.sub_(float(hyper[0]) * m / (v.sqrt() * float(hyper[1]) + eps))
 
     def onehot_to_index(self, oh, idx):
         idx.copy_(oh.max(-1)[1].to(torch.int32))

@@ -302,8 +302,9 @@ def test_latent_kernels(ops, sup):
     w = (0.3, 0.0, 0.7) if sup else (0.3, 0.2, 0.0)
     dc, mc = torch.zeros(B, 2 * Z), torch.zeros(B, K * Z)
     dd, md = g(dc.clone()), g(mc.clone())
-    fake.latent_bwd(pre, eps, mu_lk, lv_lk, labels, oc["z"], oc["qy"], *ups, *w, dc, mc)
-    ops.latent_bwd(g(pre), g(eps), g(mu_lk), g(lv_lk), g(labels), od["z"], od["qy"], *[g(u) for u in ups], *w, dd, md)
+    w3 = torch.tensor(w)
+    fake.latent_bwd(pre, eps, mu_lk, lv_lk, labels, oc["z"], oc["qy"], *ups, w3, dc, mc)
+    ops.latent_bwd(g(pre), g(eps), g(mu_lk), g(lv_lk), g(labels), od["z"], od["qy"], *[g(u) for u in ups], g(w3), dd, md)
     close(dd, dc, 1e-4, "dpre")
     close(md, mc, 1e-4, "dmu_lk_rows")
 
@@ -319,7 +320,7 @@ def test_latent_kernel_saturated_posterior(ops):
     ops.latent_fwd(g(pre), g(eps), g(mu_lk), g(lv_lk), None, *o)
     assert float(o[3].min()) == 0.0                                # saturated
     dd, md = torch.zeros(B, 2 * Z, device=DEV), torch.zeros(B, K * Z, device=DEV)
-    ops.latent_bwd(g(pre), g(eps), g(mu_lk), g(lv_lk), None, o[1], o[3], None, None, None, None, None, 0.1, 0.1, 0.0, dd, md)
+    ops.latent_bwd(g(pre), g(eps), g(mu_lk), g(lv_lk), None, o[1], o[3], None, None, None, None, None, g(torch.tensor([0.1, 0.1, 0.0])), dd, md)
     assert bool(torch.isfinite(dd).all()) and bool(torch.isfinite(md).all())
 
 
@@ -340,8 +341,16 @@ def test_pairwise_and_adam_kernels(ops):
     pd, md, vd = g(p.clone()), g(m.clone()), g(v.clone())
     ssc = torch.zeros(1)
     fake.sumsq(gr, ssc)
-    fake.clip_adam(pc, gr, mc, vc, ssc, 1.0, 1e-3, 0.9, 0.999, 1e-8, 7)
-    ops.clip_adam(pd, g(gr), md, vd, g(ssc), 1.0, 1e-3, 0.9, 0.999, 1e-8, 7)
+    # step-dependent scalars come from the device-resident counters (fn_step_params)
+    cnt_c, cnt_d = torch.tensor([12345, 6], dtype=torch.int64), torch.tensor([12345, 6], dtype=torch.int64, device=DEV)
+    sp_c, sp_d = torch.zeros(8), torch.zeros(8, device=DEV)
+    fake.step_params(cnt_c, 0.2, 1e-3, 0.9, 0.999, False, 1.0 / 256, True, sp_c)
+    ops.step_params(cnt_d, 0.2, 1e-3, 0.9, 0.999, False, 1.0 / 256, True, sp_d)
+    assert cnt_d.tolist() == [12346, 7] == cnt_c.tolist()
+    close(sp_d[:6], sp_c[:6], 1e-6)
+    np.testing.assert_allclose(float(sp_d[5]), min((12345 - 10000) / 10000 * 0.2, 0.2), rtol=1e-6)
+    fake.clip_adam(pc, gr, mc, vc, ssc, 1.0, sp_c[3:5], 0.9, 0.999, 1e-8)
+    ops.clip_adam(pd, g(gr), md, vd, g(ssc), 1.0, sp_d[3:5], 0.9, 0.999, 1e-8)
     close(pd, pc, 1e-6), close(md, mc, 1e-5), close(vd, vc, 1e-5)
 
 
@@ -412,10 +421,8 @@ def test_fused_gradients_vs_reference(case, sup, chunk, small, c0):
     b = batch_of(gold)
     batch = tr.prepare_batch(b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"], b["a"] if sup else None)
     eps = (torch.from_numpy(gold["eps_r"]).to(DEV), torch.from_numpy(gold["eps_n"]).to(DEV))
-    dl_sd, lat_up, w, beta0, Bg = tr._forward_losses(20000, batch, eps, want_grads=True)
-    m.engine().backward(tr.flat.G, dl_sd, lat_up, *w)
+    tup = tr.loss_and_grads(20000, batch, eps)
     tag = "sup" if sup else "unsup"
-    tup = tr._tuple8(beta0, Bg, sup)
     np.testing.assert_allclose(tup[0], gold["total_loss_%s_20000" % tag][0], rtol=2e-5)
     if case == "small":
         exact = oracle_grads_f64(gold, sd_from(gold, "w0/"), sup)
@@ -428,7 +435,6 @@ def test_fused_gradients_vs_reference(case, sup, chunk, small, c0):
         else:
             ref = gold["gradsum_%s/%s" % (tag, k)]
             np.testing.assert_allclose(float(gk.abs().sum()), ref[1], rtol=5e-4, atol=1e-5, err_msg=k)
-    m.engine().ops.sumsq(tr.flat.grad, tr.sumsq)
     np.testing.assert_allclose(tr.grad_norm(), gold["gradnorm_%s_20000" % tag][0], rtol=1e-3)
 
 
@@ -506,12 +512,10 @@ def test_full_size_properties():
     torch.manual_seed(99)
     eps = tr.draw_eps(B, T)
     # (1) determinism: the same step twice from the same state gives bit-identical gradients
-    dl_sd, lat_up, w, beta0, Bg = tr._forward_losses(20000, batch, eps, True)
-    m.engine().backward(tr.flat.G, dl_sd, lat_up, *w)
+    t1 = tr.loss_and_grads(20000, batch, eps)
     g1 = tr.flat.grad.clone()
-    t1 = tr._tuple8(beta0, Bg, False)
-    dl_sd, lat_up, w, beta0, Bg = tr._forward_losses(20000, batch, eps, True)
-    m.engine().backward(tr.flat.G, dl_sd, lat_up, *w)
+    tr.loss_and_grads(20000, batch, eps)
+    beta0, Bg = 0.2, B
     assert bool(torch.isfinite(g1).all())
     assert torch.equal(g1, tr.flat.grad)          # no floating-point atomics anywhere on the path
     # (2) batch-row independence: the loss of the first 64 rows alone equals the same rows' share
