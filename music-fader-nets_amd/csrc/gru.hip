@@ -26,6 +26,19 @@
 #include "common.h"
 #include "mma_core.h"
 
+#ifdef FN_TIMING
+__device__ unsigned long long fn_dbg[64 * 8];
+#define FN_STAMP(k)                                                                                   \
+    do {                                                                                              \
+        if (blockIdx.x < 64 && threadIdx.x == 0) fn_dbg[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); \
+    } while (0)
+extern "C" int fn_dbg_read(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fn_dbg), sizeof(unsigned long long) * 64 * 8);
+}
+#else
+#define FN_STAMP(k)
+#endif
+
 namespace {
 
 constexpr int NT = 256;
@@ -89,6 +102,7 @@ __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
     const int li = lane & 15, lg = lane >> 4;
     const int nrt = (B + 15) >> 4;
 
+    FN_STAMP(0);
     const int jj = hh0 + li;
     const bool has_k = S.hf_in != nullptr && S.h_prev != nullptr;
     const int nk = H >> 5;
@@ -172,6 +186,7 @@ __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
 #pragma unroll
         for (int n = 0; n < 3; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    FN_STAMP(1);
     // (4) K loop: branch-free steady state, MFMAs read the ring registers in place, load(u) refills them right behind
     auto mma = [&](int set) {
 #pragma unroll
@@ -206,6 +221,7 @@ __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
             for (int n = 0; n < 3; ++n) { fn_keep(fb[u][n][0]); fn_keep(fb[u][n][1]); }
         }
     }
+    FN_STAMP(2);
     if (has_k) {
         // ---- add the 4 K-partials: wave m ends up with M-tile m --------------------------------------------
 #pragma unroll
@@ -215,6 +231,7 @@ __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
                 *reinterpret_cast<f32x4*>(red + ((wave * TM + m) * 3 + n) * 256 + lane * 4) = acc[m][n];
         __syncthreads();
     }
+    FN_STAMP(3);
     if (wave >= TM) return;
     f32x4 r3[3];
 #pragma unroll
@@ -235,7 +252,7 @@ __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
         const float gxn = ((bi[2] + e_den[i][2]) + e_tab[i][2]) + e_rb[i][2];
         const float r = fn_sigmoid(gxr + ghr);
         const float z = fn_sigmoid(gxz + ghz);
-        const float n = tanhf(gxn + r * ghn);
+        const float n = fn_tanh(gxn + r * ghn);
         const float h = (1.0f - z) * n + z * hp[i];
         S.h_out[(long)b * H + jj] = h;
         if (S.hf_out) S.hf_out[frag_off(b, jj, H >> 5)] = h;
@@ -247,6 +264,7 @@ __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
             g[gate_off(b, 3, jj, nrt)] = ghn;
         }
     }
+    FN_STAMP(4);
 }
 
 // ---------------------------------------------------------------------------------------------
