@@ -54,8 +54,12 @@ def init_from_env(backend=None):
     """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher (torch.distributed.run)."""
     import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if world <= 1 and os.environ.get("FN_FORCE_DIST", "0") != "1":     # FN_FORCE_DIST=1: exercise the collectives with 1 rank
         return None, 0
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
