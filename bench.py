@@ -55,9 +55,11 @@ def measure_dominant_kernel(trainer, batch, eps, reps=3):
         best = ms if best is None else min(best, ms)
     flop = 4 * B * FLOP_PER_SAMPLE_STEP
     achieved = flop / (best * 1e-3) / 1e12
+    # traffic: HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes),
+    # see profiles/r01_pmc_gru_fwd_step_4scans.txt - bench.py itself cannot run the profiler, so this is the committed measurement.
     return dict(bound="mfma", kernel="gru_fwd_step_kernel<4,4,1>", achieved=round(achieved, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=None, avg_launch_us=round(best * 1e3, 3),
-                flop_per_launch=flop)
+                frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=35.5e6, traffic_source="profiles/r01_pmc_gru_fwd_step_4scans.txt",
+                avg_launch_us=round(best * 1e3, 3), flop_per_launch=flop)
 
 
 def main():
