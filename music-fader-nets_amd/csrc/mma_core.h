@@ -28,6 +28,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // only valid after our own fn_wait_vm<N>() (+ sched_barrier so that no MFMA is hoisted above the wait), and every pipelined
 // loop must end with fn_wait_vm<0>() before the registers can be reused.
 FN_DEVINL void fn_gld4_asm(f32x4& dst, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory"); }
+FN_DEVINL void fn_gld1_asm(float& dst, const float* p) { asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory"); }
 // A fake use: keeps an asm-loaded register allocated (not re-used for anything else) up to this point.  Every register a
 // fn_gld4_asm targets must reach a fn_keep() placed AFTER the wait that covers it, otherwise hipcc may recycle a
 // "dead" destination while the load is still in flight.
