@@ -22,7 +22,6 @@
 //     contiguous 256-byte run (see gate_off).
 #include <cstdio>
 #include <cstdlib>
-#include <type_traits>
 
 #include "common.h"
 #include "mma_core.h"
@@ -109,10 +108,9 @@ __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
     const int nk = H >> 5;
     const int nkw = (has_k && wave < nk) ? (nk - wave + 3) >> 2 : 0;        // this wave's chunks: wave, wave+4, ...
 
-    // (1) token ids of the rows this wave finishes (compiler-visible loads; the table rows depend on them)
-    const bool fin = wave < TM;                           // this wave finishes M-tile `wave` in the epilogue
+    // (1) token ids of the rows this wave finishes (a compiler-visible load; the table rows depend on it)
     int tok[4] = {0, 0, 0, 0};
-    if (fin && S.gx_table) {
+    if (wave < TM && S.gx_table) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int b = min(m0 + wave * 16 + lg * 4 + i, B - 1);
@@ -120,7 +118,48 @@ __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
         }
     }
 
-    // (2) first D operand chunks of the K loop (asm loads, counted by us - see fn_gld4_asm)
+    // (2) epilogue operands of the M-tile this wave will finish: LOADED now (their latency hides under the K loop), only
+    //     ADDED in the epilogue (an add here would make hipcc wait for them before the loop)
+    float e_tab[4][3], e_den[4][3], e_rb[4][3], hp[4], bh[3], bi[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { bh[q] = 0.f; bi[q] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hp[i] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { e_tab[i][q] = 0.f; e_den[i][q] = 0.f; e_rb[i][q] = 0.f; }
+    }
+    if (wave < TM) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            bh[q] = S.b_hh[q * H + jj];
+            if (S.b_ih) bi[q] = S.b_ih[q * H + jj];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int b = min(m0 + wave * 16 + lg * 4 + i, B - 1);
+            if (S.gx_dense) {
+                const float* row = S.gx_dense + (long)b * 3 * H;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) e_den[i][q] = row[q * H + jj];
+            }
+            if (S.gx_table) {
+                const float* row = S.gx_table + (long)tok[i] * 3 * H;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) e_tab[i][q] = row[q * H + jj];
+            }
+            if (S.gx_rowbias) {
+                const float* row = S.gx_rowbias + (long)b * 3 * H;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) e_rb[i][q] = row[q * H + jj];
+            }
+            if (S.h_prev) hp[i] = S.h_prev[(long)b * H + jj];
+        }
+    }
+
+    // (3) first D operand chunks of the K loop (asm loads, counted by us - see fn_gld4_asm).  They are issued AFTER the
+    //     compiler-visible loads above: vmcnt is one in-order counter, so older outstanding loads only make our counted
+    //     waits stricter, never wrong.
     const float* ap[TM];
     const float* bp[3];
 #pragma unroll
@@ -141,37 +180,6 @@ __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
         for (int s = 0; s < D; ++s) load(s, s);          // chunk index is clamped: always a legal (possibly repeated) chunk
     }
 
-    // (3) epilogue operands of the M-tile this wave will finish, ALSO as counted asm loads: exactly EP loads are issued
-    //     (absent sources read a dummy address and are multiplied by 0 later), so the K loop can allow them to stay in
-    //     flight (first-round wait count NL(D-1)+EP) and their latency - incl. the dependent token -> table-row chain -
-    //     hides under the MFMAs instead of in front of them.
-    constexpr int EP = 4 * 10 + 6;
-    float e_tab[4][3], e_den[4][3], e_rb[4][3], hp[4], bh[3], bi[3];
-    const float f_den = S.gx_dense ? 1.f : 0.f, f_tab = S.gx_table ? 1.f : 0.f, f_rb = S.gx_rowbias ? 1.f : 0.f,
-                f_bi = S.b_ih ? 1.f : 0.f, f_hp = S.h_prev ? 1.f : 0.f;
-    if (fin) {
-        const float* dummy = S.b_hh;                      // always 3H valid floats
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            fn_gld1_asm(bh[q], S.b_hh + q * H + jj);
-            fn_gld1_asm(bi[q], (S.b_ih ? S.b_ih : dummy) + q * H + jj);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int b = min(m0 + wave * 16 + lg * 4 + i, B - 1);
-            const float* rd = S.gx_dense ? S.gx_dense + (long)b * 3 * H : dummy;
-            const float* rt = S.gx_table ? S.gx_table + (long)tok[i] * 3 * H : dummy;
-            const float* rr = S.gx_rowbias ? S.gx_rowbias + (long)b * 3 * H : dummy;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                fn_gld1_asm(e_den[i][q], rd + q * H + jj);
-                fn_gld1_asm(e_tab[i][q], rt + q * H + jj);
-                fn_gld1_asm(e_rb[i][q], rr + q * H + jj);
-            }
-            fn_gld1_asm(hp[i], S.h_prev ? S.h_prev + (long)b * H + jj : dummy + jj);
-        }
-    }
-
     f32x4 acc[TM][3];
 #pragma unroll
     for (int m = 0; m < TM; ++m)
@@ -190,19 +198,9 @@ __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4at(fa[set][m][j >> 2], j & 3), f4at(fb[set][n][j >> 2], j & 3),
                                                                      acc[m][n], 0, 0, 0);
     };
-    auto kloop = [&](auto epc) {
-        constexpr int EPW = decltype(epc)::value;         // epilogue loads of THIS wave still allowed in flight in round 1
+    if (nkw > 0) {
         const int nmain = nkw / D * D;
-        if (nmain > 0) {
-#pragma unroll
-            for (int u = 0; u < D; ++u) {                 // round 1: younger than chunk u = (D-1) chunks + the EPW epilogue loads
-                fn_wait_vm<(NL * (D - 1) + EPW < 63 ? NL * (D - 1) + EPW : 63)>();
-                mma(u);
-                load(u, u + D);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        for (int base = D; base < nmain; base += D) {
+        for (int base = 0; base < nmain; base += D) {
 #pragma unroll
             for (int u = 0; u < D; ++u) {
                 fn_wait_vm<NL * (D - 1)>();
@@ -222,12 +220,6 @@ __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
 #pragma unroll
             for (int n = 0; n < 3; ++n) { fn_keep(fb[u][n][0]); fn_keep(fb[u][n][1]); }
         }
-    };
-    if (nkw > 0) {
-        if (fin) kloop(std::integral_constant<int, EP>{});
-        else kloop(std::integral_constant<int, 0>{});
-    } else {
-        fn_wait_vm<0>();                                 // no K loop (first step without h0): still wait for the epilogue loads
     }
     FN_STAMP(2);
     if (has_k) {
@@ -255,13 +247,13 @@ __global__ __launch_bounds__(NT) void gru_fwd_step_kernel(const FwdArgs args) {
         const int b = m0 + wave * 16 + lg * 4 + i;
         if (b >= B) continue;
         const float ghr = r3[0][i] + bh[0], ghz = r3[1][i] + bh[1], ghn = r3[2][i] + bh[2];
-        const float gxr = ((f_bi * bi[0] + f_den * e_den[i][0]) + f_tab * e_tab[i][0]) + f_rb * e_rb[i][0];
-        const float gxz = ((f_bi * bi[1] + f_den * e_den[i][1]) + f_tab * e_tab[i][1]) + f_rb * e_rb[i][1];
-        const float gxn = ((f_bi * bi[2] + f_den * e_den[i][2]) + f_tab * e_tab[i][2]) + f_rb * e_rb[i][2];
+        const float gxr = ((bi[0] + e_den[i][0]) + e_tab[i][0]) + e_rb[i][0];
+        const float gxz = ((bi[1] + e_den[i][1]) + e_tab[i][1]) + e_rb[i][1];
+        const float gxn = ((bi[2] + e_den[i][2]) + e_tab[i][2]) + e_rb[i][2];
         const float r = fn_sigmoid(gxr + ghr);
         const float z = fn_sigmoid(gxz + ghz);
         const float n = fn_tanh(gxn + r * ghn);
-        const float h = (1.0f - z) * n + z * (f_hp * hp[i]);
+        const float h = (1.0f - z) * n + z * hp[i];
         S.h_out[(long)b * H + jj] = h;
         if (S.hf_out) S.hf_out[frag_off(b, jj, H >> 5)] = h;
         if (S.gates) {
