@@ -34,6 +34,7 @@ class Engine:
         self.whh_t = {}                 # W_hh^T, fragment-major (backward scans)
         self.saved = None
         self.chunk = 32                 # time steps per pipeline chunk of the two decoder layers
+        self.split_encoders = __import__("os").environ.get("FN_SPLIT_ENC", "1") == "1"
         if hidden % 32 != 0:
             raise ValueError("hidden_dims must be a multiple of 32 (K chunks of the MFMA step kernels)")
         if n_component > 8:
@@ -139,7 +140,16 @@ class Engine:
                 scans.append(dict(B=B, T=T, H=H, reverse=rev, w_hh_frag=self.whh_f[key], b_hh=P[pfx + "bias_hh" + sfx],
                                   b_ih=P[pfx + "bias_ih" + sfx], gx_table=self.tab[key], idx=d, idx_shift=0,
                                   h_all=hall[key], gates=self.buf("enc_g_" + key, (T, ops.gates_floats(B, H))) if save else None))
-        ops.gru_seq_fwd(scans)
+        # the two encoders run on the two streams: their step kernels drift out of phase, so one's gate epilogue /
+        # operand latency overlaps the other's MFMA loop (each launch alone leaves the matrix pipes idle ~55 % of the time)
+        if self.split_encoders and self._side_stream() is not None:
+            self.side_wait_main()
+            with self.on_side():
+                ops.gru_seq_fwd(scans[2:])
+            ops.gru_seq_fwd(scans[:2])
+            self.main_wait_side()
+        else:
+            ops.gru_seq_fwd(scans)
         pre = {}
         for e in ("r", "n"):
             hf, hb = hall[e][T - 1], hall[e + "_reverse"][T - 1]
@@ -450,7 +460,14 @@ class Engine:
                 scans.append(dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t[key], h0=None, h_all=self._bufs["enc_h_" + key],
                                   gates=self._bufs["enc_g_" + key], dh_last=dh, dgx_all=encb[key]["dgx"], dghn_all=encb[key]["dghn"],
                                   scratch=self.buf("enc_scr_" + key, (B, H))))
-        ops.gru_seq_bwd(scans)        # 4 concurrent reverse scans
+        if self.split_encoders and self._side_stream() is not None:
+            self.side_wait_main()
+            with self.on_side():
+                ops.gru_seq_bwd(scans[2:])
+            ops.gru_seq_bwd(scans[:2])
+            self.main_wait_side()
+        else:
+            ops.gru_seq_bwd(scans)    # 4 concurrent reverse scans
         for key in encb:
             ops.time_sum(encb[key]["dgx"], encb[key]["rs"])
             ops.time_sum(encb[key]["dghn"], encb[key]["rsn"])
