@@ -34,7 +34,7 @@ class Engine:
         self.whh_t = {}                 # W_hh^T, fragment-major (backward scans)
         self.saved = None
         self.chunk = 32                 # time steps per pipeline chunk of the two decoder layers
-        self.split_encoders = __import__("os").environ.get("FN_SPLIT_ENC", "1") == "1"
+        self.split_encoders = __import__("os").environ.get("FN_SPLIT_ENC", "0") == "1"   # measured: no gain on MI355X (profiles/), kept as a switch
         if hidden % 32 != 0:
             raise ValueError("hidden_dims must be a multiple of 32 (K chunks of the MFMA step kernels)")
         if n_component > 8:
