@@ -12,15 +12,46 @@ from .engine import E_VOCAB, LOGIT_LD
 
 
 @torch.no_grad()
-def greedy_decode(model, z, steps, want_logp=True):
-    """z (Bi, 2Z+24) -> (log-probs (Bi, steps, 342) or None, tokens (Bi, steps) int32)."""
+def greedy_decode(model, z, steps, want_logp=True, use_graph=None):
+    """z (Bi, 2Z+24) -> (log-probs (Bi, steps, 342) or None, tokens (Bi, steps) int32).
+
+    On the GPU the whole decode (steps x {layer-1 cell, W_ih2 projection, layer-2 cell, output GEMM, log_softmax+argmax}) is
+    captured once per (Bi, steps) into a hipGraph and replayed: the loop is launch-latency bound (7 small kernels per token)."""
     eng = model.engine()
-    ops, P, H = eng.ops, eng.p, eng.H
     z = z.float().contiguous()
+    if use_graph is None:
+        use_graph = z.is_cuda
+    if not use_graph:
+        return _decode_body(eng, z, steps, want_logp, None, None)
+    cache = eng.__dict__.setdefault("_decode_graphs", {})
+    key = (z.shape[0], steps, bool(want_logp), model._version)
+    ent = cache.get(key)
+    if ent is None:
+        for k in [k for k in cache if k[3] != model._version]:     # weights changed: captured weight images are stale
+            del cache[k]
+        zs = z.clone()
+        tokens = torch.zeros(z.shape[0], steps, dtype=torch.int32, device=z.device)
+        logp = torch.empty(z.shape[0], steps, E_VOCAB, device=z.device) if want_logp else None
+        _decode_body(eng, zs, min(steps, 2), want_logp, logp, tokens)                # warm-up: allocates every buffer
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            _decode_body(eng, zs, steps, want_logp, logp, tokens)
+        ent = cache[key] = (g, zs, logp, tokens)
+    g, zs, logp, tokens = ent
+    zs.copy_(z)
+    g.replay()
+    return (None if logp is None else logp.clone()), tokens.clone()
+
+
+def _decode_body(eng, z, steps, want_logp, logp, tokens):
+    ops, P, H = eng.ops, eng.p, eng.H
     Bi = z.shape[0]
     dev = z.device
-    tokens = torch.zeros(Bi, steps, dtype=torch.int32, device=dev)
-    logp = torch.empty(Bi, steps, E_VOCAB, device=dev) if want_logp else None
+    if tokens is None:
+        tokens = torch.zeros(Bi, steps, dtype=torch.int32, device=dev)
+    if logp is None and want_logp:
+        logp = torch.empty(Bi, steps, E_VOCAB, device=dev)
     hx0 = [eng.buf("dec_hx0_a", (1, Bi, H)), eng.buf("dec_hx0_b", (1, Bi, H))]
     hx1 = [eng.buf("dec_hx1_a", (1, Bi, H)), eng.buf("dec_hx1_b", (1, Bi, H))]
     h0g = eng.buf("dec_h0g", (Bi, H))
