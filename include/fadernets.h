@@ -94,6 +94,11 @@ typedef struct FnGruFwd {
     float* gates;             /* [T][fn_gru_gates_floats(B,H)] saved r,z,n,(W_hn h + b_hn) in a    */
                               /* private blocked layout (opaque to the caller); NULL = inference */
     float* frag_ws;           /* scratch, 2 * fn_frag_floats(B, H) floats, 16-byte aligned         */
+    void* sync_ws;            /* fn_gru_sync_ws_bytes() bytes, zero-filled ONCE by the caller, shared by  */
+                              /* the scans of one call (scans[0]'s is used); NULL = per-step launches only */
+    int32_t cu_budget;        /* compute units the single launch may occupy (scans[0]'s is used; 0 = all). */
+                              /* Launches that can overlap on different streams must share the chip:       */
+                              /* the sum of their budgets must not exceed the CU count.                    */
 } FnGruFwd;
 
 /* fragment-major operand image: floats needed for a [rows][K] matrix, and the packing kernel
@@ -104,6 +109,11 @@ int fn_frag_pack(const float* src, int rows, int K, int ld, float* dst, void* st
 /* floats per time step of the saved-gates buffer (4*H*ceil16(B)) */
 size_t fn_gru_gates_floats(int B, int H);
 
+/* When sync_ws is given, all scans share H <= 512 and sum_s ceil(B_s / rows) * H/16 fits one workgroup per CU, the
+ * whole call is ONE weight-stationary launch whose workgroups exchange the state through frag_ws and meet at arrival
+ * counters in sync_ws (every spin is bounded).  The last word of sync_ws is a sticky error flag: non-zero after a
+ * launch whose workgroups gave up waiting (results of that and later calls are invalid until it is cleared). */
+size_t fn_gru_sync_ws_bytes(void);
 int fn_gru_seq_fwd(const FnGruFwd* scans, int n_scans, void* stream);
 
 /* Backward of the same scans (autograd of nn.GRU / GRUCell in loss.backward(), trainer_gmm.py:249).

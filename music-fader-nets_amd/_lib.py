@@ -19,7 +19,7 @@ class FnGruFwd(C.Structure):
     _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("H", C.c_int32), ("reverse", C.c_int32),
                 ("w_hh_frag", vp), ("b_hh", vp), ("b_ih", vp), ("h0", vp), ("gx_dense", vp), ("gx_table", vp),
                 ("idx", vp), ("idx_ld", C.c_int32), ("idx_shift", C.c_int32), ("start_token", C.c_int32),
-                ("gx_rowbias", vp), ("h_all", vp), ("gates", vp), ("frag_ws", vp)]
+                ("gx_rowbias", vp), ("h_all", vp), ("gates", vp), ("frag_ws", vp), ("sync_ws", vp), ("cu_budget", C.c_int32)]
 
 
 class FnGruBwd(C.Structure):
@@ -43,6 +43,7 @@ SIGNATURES = {
     "fn_gru_gates_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "fn_frag_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "fn_frag_pack": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "fn_gru_sync_ws_bytes": (C.c_size_t, []),
     "fn_gru_seq_fwd": (C.c_int, [C.POINTER(FnGruFwd), C.c_int, vp]),
     "fn_gru_seq_bwd": (C.c_int, [C.POINTER(FnGruBwd), C.c_int, vp]),
     "fn_embed_grad_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),

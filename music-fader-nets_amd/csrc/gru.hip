@@ -23,8 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 
-#include "common.h"
-#include "mma_core.h"
+#include "gru_layout.h"
 
 #ifdef FN_TIMING
 __device__ unsigned long long fn_dbg[64 * 8];
@@ -42,21 +41,6 @@ extern "C" int fn_dbg_read(unsigned long long* host) {
 namespace {
 
 constexpr int NT = 256;
-
-// offset of (batch row b, gate q in {r,z,n,hn}, hidden unit u) inside one step's gate slab; nrt = ceil(B/16).
-// [unit tile][row tile][gate][i = b&3][quad = (b&15)>>2][j = u&15]: for fixed (tiles, gate, i) the 64 lanes
-// (quad, j) of a wave touch 64 consecutive floats.
-FN_DEVINL long gate_off(int b, int q, int u, int nrt) {
-    return ((((long)(u >> 4) * nrt + (b >> 4)) * 4 + q) * 4 + (b & 3)) * 64 + ((b & 15) >> 2) * 16 + (u & 15);
-}
-
-// fragment-major image of a [rows][K] matrix (K % 32 == 0, rows padded to 16), NC = K / 32 chunks
-FN_DEVINL long frag_off(int row, int k, int NC) {
-    return ((((long)(row >> 4) * NC + (k >> 5)) * 2 + ((k >> 4) & 1)) * 64 + (((k & 15) >> 2) * 16 + (row & 15))) * 4 + (k & 3);
-}
-
-FN_DEVINL float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-FN_DEVINL float f4at(const f32x4& v, int j) { return v[j]; }
 
 // ---------------------------------------------------------------------------------------------
 // forward step
@@ -442,6 +426,8 @@ __global__ void frag_pack_kernel(const float* __restrict__ src, int rows, int K,
     }
 }
 
+}  // namespace
+
 int launch_pack(const float* src, int rows, int K, long ld, float* dst, hipStream_t st) {
     const long total = (long)((rows + 15) & ~15) * (K >> 2);
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
@@ -449,6 +435,8 @@ int launch_pack(const float* src, int rows, int K, long ld, float* dst, hipStrea
     FN_CHECK_LAUNCH();
     return FN_OK;
 }
+
+namespace {
 
 // ---- launch configuration -------------------------------------------------------------------------------
 // (TM, TN, D) = M-tiles per workgroup, N-tiles (backward only), chunks in flight per wave.  Defaults were picked by
@@ -520,6 +508,10 @@ int fn_gru_seq_fwd(const FnGruFwd* scans, int n_scans, void* stream) {
         Tmax = d.T > Tmax ? d.T : Tmax;
     }
     hipStream_t st = (hipStream_t)stream;
+    {   // weight-stationary single launch when the configuration fits one workgroup per CU (gru_persist.hip)
+        const int rc = fn_gru_fwd_persist(scans, n_scans, st);
+        if (rc != FN_PERSIST_NA) return rc;
+    }
     for (int s = 0; s < n_scans; ++s)          // initial states -> fragment-major (slot 0 of the ping-pong scratch)
         if (scans[s].h0) {
             const int rc = launch_pack(scans[s].h0, scans[s].B, scans[s].H, scans[s].H, scans[s].frag_ws, st);

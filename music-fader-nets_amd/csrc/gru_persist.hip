@@ -1,0 +1,406 @@
+// gru_persist.hip - weight-stationary GRU scans: ONE launch runs all T time steps of up to FN_MAX_SCANS scans
+// (encoders gmm_model.py:84,89; sub-decoders :109,114; decoder cells :131-136).
+//
+// Why: the per-step kernels of gru.hip re-stream W_hh (3 MB per scan) from HBM/MALL on every step (the per-XCD L2s are
+// invalidated at each kernel boundary) and pay a dependent-launch boundary per step; together that is 60 % of a step.
+//
+// Decomposition (H = 512: 32 unit slices x 8 row groups = 256 workgroups = one per CU):
+//   * workgroup (g, j): row group g = (scan, block of RPW batch rows), slice j = hidden units [16j, 16j+16) for all of
+//     r, z, n.  Its W_hh slice (48 rows x H, 96 KB at H = 512) is copied into LDS ONCE, in MFMA B-fragment order;
+//   * every step the recurrent operand h_{p-1}[rows of g][0..H) is read from a fragment-major exchange slab in global memory
+//     (asm dwordx4 loads kept D chunks in flight) and multiplied against the LDS-resident slice;
+//   * the gate epilogue is element-wise; the new state slice goes to h_all (row-major, for the backward pass and the heads)
+//     and, write-through (sc1), to the other exchange slab;
+//   * the 32 workgroups of a row group then meet at a monotonic arrival counter (cdna_hip_programming.md G16, recipe R1:
+//     sc1 payload stores -> every wave drains vmcnt -> barrier -> one relaxed agent-scope atomic; consumer: one lane polls,
+//     barrier, sc1 loads).  Block ids are dealt so that a row group sits on ONE XCD when there are 8 groups (speed only,
+//     correctness never depends on placement).
+//   * every spin is bounded: on timeout (or when another workgroup has timed out) the workgroup raises err and leaves.
+#include "gru_layout.h"
+
+#ifdef FN_TIMING
+__device__ unsigned long long fn_pdbg[8 * 8];
+#define FN_PSTAMP(k)                                                                                         \
+    do {                                                                                                     \
+        if (blockIdx.x < 8 && threadIdx.x == 0 && p == 10) fn_pdbg[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); \
+    } while (0)
+extern "C" int fn_pdbg_read(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fn_pdbg), sizeof(unsigned long long) * 64);
+}
+#else
+#define FN_PSTAMP(k)
+#endif
+
+namespace {
+
+constexpr int NT = 256;
+typedef unsigned int u32;
+
+struct PScan {
+    const float* w_frag;
+    const float* b_hh;
+    const float* b_ih;
+    const float* h0;
+    const float* gx_dense;
+    const float* gx_table;
+    const int* idx;
+    const float* gx_rowbias;
+    float* h_all;
+    float* gates;
+    float* xf;            // 2 exchange slabs, fragment-major
+    int idx_ld, idx_shift, start_token, reverse;
+    int B, T;
+    int group0;           // first row group of this scan
+};
+struct PArgs {
+    PScan s[FN_MAX_SCANS];
+    int n, ngroups, H;
+    u32* sync;            // [ngroups * 32] arrival counters (one per 128-byte line), then err at sync[FN_MAX_GROUPS*32]
+};
+constexpr int FN_MAX_GROUPS = 64;
+constexpr u32 SPIN_LIMIT = 1u << 21;
+
+FN_DEVINL void gld4_sc1(f32x4& dst, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory"); }
+// write-through 16-byte store (recipe R1); the trailing s_nop keeps hipcc from reusing the data registers too early
+FN_DEVINL void stv4_sc1(float* p, const f32x4& v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
+FN_DEVINL f32x4 ldv4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+FN_DEVINL void stv4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+constexpr int RT = 256 + 16;                        // floats per accumulator tile in LDS (padded)
+FN_DEVINL u32 ld_cnt(u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// waves = WM (row blocks of MT tiles) x WK (K split); rows per workgroup RPW = 16 * WM * MT
+template <int WM, int WK, int MT, int D>
+__global__ __launch_bounds__(NT) void gru_fwd_persist_kernel(const PArgs args) {
+    static_assert(WM * WK == 4 && (D % 2) == 0, "4 waves; ring depth even");
+    constexpr int EM = WM * MT;                      // row tiles per workgroup = epilogue rows per thread
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int H = args.H, nk = H >> 5;
+    float* wl = smem;                                // [3][nk][2][64][4]  W_hh slice, B-fragment order
+    float* red = smem + 3 * H * 16;                  // [WK][EM][3][RT]    accumulator exchange
+    volatile int& dead = *reinterpret_cast<volatile int*>(red + WK * EM * 3 * RT);   // all LDS is dynamic (16-byte aligned base)
+
+    const int g = blockIdx.x % args.ngroups, slice = blockIdx.x / args.ngroups;
+    int si = 0;
+#pragma unroll
+    for (int k = 1; k < FN_MAX_SCANS; ++k)
+        if (k < args.n && g >= args.s[k].group0) si = k;
+    const PScan& S = args.s[si];
+    const int B = S.B, T = S.T;
+    const int m0 = (g - S.group0) * (16 * EM), hh0 = slice * 16;
+    const int nrt = (B + 15) >> 4;
+    const int nslices = H >> 4;
+    const long FS = (long)nrt * 16 * H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wk = wave / WM;
+    u32* counter = args.sync + g * 32;
+    u32* err = args.sync + FN_MAX_GROUPS * 32;
+
+    // ---- one-time: W_hh slice -> LDS (already in fragment order in global memory) -------------------------------------
+    if (tid == 0) dead = 0;
+#pragma unroll 1
+    for (int q = 0; q < 3; ++q) {
+        const float4* src = reinterpret_cast<const float4*>(S.w_frag + (long)(q * nslices + slice) * nk * 512);
+        float4* dst = reinterpret_cast<float4*>(wl + (long)q * nk * 512);
+        for (int i = tid; i < nk * 128; i += NT) dst[i] = src[i];
+    }
+
+    // ---- one-time: per-thread epilogue constants.  Epilogue item = (row, 4 consecutive units): every global access of
+    //      the epilogue is a 16-byte vector (scalar sc1 stores cost ~6x per byte, MI355X_MICROARCH.md price list) -------
+    constexpr int NI = (EM * 64 + NT - 1) / NT;      // items per thread
+    int ib[NI], iu4[NI], icoff[NI];
+    bool iact[NI];
+    f32x4 bh[3], bi[3], e_rb[NI][3], hp[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int item = tid + NT * i;
+        const int rl = item >> 2;                    // row inside the workgroup's row block
+        iu4[i] = item & 3;
+        iact[i] = item < EM * 64 && m0 + rl < B;
+        ib[i] = min(m0 + rl, B - 1);
+        // accumulator tile (rl >> 4) in padded MFMA C layout: lane' = ((r&15)>>2)*16 + unit, reg = r & 3, +4 floats per 64
+        icoff[i] = (min(rl >> 4, EM - 1) * 3) * RT + ((rl & 15) >> 2) * 68 + iu4[i] * 16 + (rl & 3);
+    }
+    const int jj0 = hh0 + 4 * (tid & 3);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        bh[q] = ldv4(S.b_hh + q * H + jj0);
+        bi[q] = S.b_ih ? ldv4(S.b_ih + q * H + jj0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        hp[i] = S.h0 ? ldv4(S.h0 + (long)ib[i] * H + jj0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            e_rb[i][q] = S.gx_rowbias ? ldv4(S.gx_rowbias + (long)ib[i] * 3 * H + q * H + jj0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+
+    // this wave's K chunks [c0, c0 + nkw) and operand row tiles
+    const int c0 = nk * wk / WK, nkw = nk * (wk + 1) / WK - c0;
+    long aoff[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) aoff[m] = (long)min((m0 >> 4) + wm * MT + m, nrt - 1) * nk * 512 + lane * 4;
+    constexpr int NLA = 2 * MT;                      // asm loads per chunk
+
+#pragma unroll 1
+    for (int p = 0; p < T; ++p) {
+        // (a) h-independent epilogue operands of this step (their latency hides under the wait and the K loop)
+        const int tau = (S.reverse ? T - 1 - p : p) + S.idx_shift;
+        f32x4 e_x[NI][3];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) e_x[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (S.gx_table) {
+                const int tok = tau >= 0 ? S.idx[(long)ib[i] * S.idx_ld + tau] : S.start_token;
+                const float* row = S.gx_table + (long)tok * 3 * H + jj0;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) e_x[i][q] = ldv4(row + q * H);
+            }
+            if (S.gx_dense) {
+                const float* row = S.gx_dense + ((long)p * B + ib[i]) * 3 * H + jj0;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) e_x[i][q] += ldv4(row + q * H);
+            }
+        }
+
+        FN_PSTAMP(0);
+        // (b) wait until every slice of this row group has published h_{p-1}
+        const bool has_k = p > 0 || S.h0 != nullptr;
+        if (p > 0) {
+            if (tid == 0) {
+                const u32 target = (u32)nslices * (u32)p;
+                u32 spins = 0;
+                while (ld_cnt(counter) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 63u) == 0 && (spins > SPIN_LIMIT || ld_cnt(err) != 0)) {
+                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        dead = 1;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            if (dead) return;
+        }
+
+        FN_PSTAMP(1);
+        // (c) gh = h_{p-1} W_hh^T slice
+        f32x4 acc[MT][3];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < 3; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (has_k && nkw > 0) {
+            const float* xin = S.xf + (long)(p & 1) * FS;
+            f32x4 fa[D][MT][2], fb[2][3][2];
+            auto loadA = [&](int set, int it) {
+                const long k0 = (long)(c0 + min(it, nkw - 1)) * 512;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) { gld4_sc1(fa[set][m][0], xin + aoff[m] + k0); gld4_sc1(fa[set][m][1], xin + aoff[m] + k0 + 256); }
+            };
+            auto loadB = [&](int set, int it) {
+                const int c = c0 + min(it, nkw - 1);
+#pragma unroll
+                for (int n = 0; n < 3; ++n) {
+                    fb[set][n][0] = *reinterpret_cast<const f32x4*>(wl + ((long)(n * nk + c) * 2 + 0) * 256 + lane * 4);
+                    fb[set][n][1] = *reinterpret_cast<const f32x4*>(wl + ((long)(n * nk + c) * 2 + 1) * 256 + lane * 4);
+                }
+            };
+            auto mma = [&](int set, int bs) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < 3; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4at(fa[set][m][j >> 2], j & 3), f4at(fb[bs][n][j >> 2], j & 3),
+                                                                             acc[m][n], 0, 0, 0);
+            };
+#pragma unroll
+            for (int s = 0; s < D; ++s) loadA(s, s);
+            loadB(0, 0);
+            const int nmain = nkw / D * D;
+            for (int base = 0; base < nmain; base += D) {
+#pragma unroll
+                for (int uu = 0; uu < D; ++uu) {
+                    loadB((uu + 1) & 1, base + uu + 1);
+                    fn_wait_vm<NLA * (D - 1)>();
+                    mma(uu, uu & 1);
+                    loadA(uu, base + uu + D);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            fn_wait_vm<0>();
+#pragma unroll
+            for (int uu = 0; uu < D; ++uu)
+                if (nmain + uu < nkw) {
+                    loadB((uu + 1) & 1, nmain + uu + 1);
+                    mma(uu, uu & 1);
+                }
+#pragma unroll
+            for (int s = 0; s < D; ++s)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) { fn_keep(fa[s][m][0]); fn_keep(fa[s][m][1]); }
+        }
+
+        FN_PSTAMP(2);
+        // (d) accumulators -> LDS in MFMA C layout (row = 4*(lane>>4) + reg, col = lane & 15), 4 floats of padding per
+        //     16 lanes so that the epilogue's reads (4 row quads x 4 unit quads per wave) hit 64 different banks
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < 3; ++n)
+                *reinterpret_cast<f32x4*>(red + ((long)((wk * EM + wm * MT + m) * 3 + n)) * RT + lane * 4 + (lane >> 4) * 4) = acc[m][n];
+        __syncthreads();
+
+        FN_PSTAMP(3);
+        // (e) gates and the new state: thread -> items (row, units 4u4 .. 4u4+3)
+        float* h_out = S.h_all + (long)p * B * H;
+        float* gt = S.gates ? S.gates + (long)p * 4 * H * nrt * 16 : nullptr;
+        float* xout = (p + 1 < T) ? S.xf + (long)((p + 1) & 1) * FS : nullptr;
+        f32x4 o_r[NI], o_z[NI], o_n[NI], o_g[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            f32x4 gh[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WK; ++w) a += red[(long)(w * EM * 3 + q) * RT + icoff[i] + c * 4];
+                    gh[q][c] = a + bh[q][c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float r = fn_sigmoid(((bi[0][c] + e_x[i][0][c]) + e_rb[i][0][c]) + gh[0][c]);
+                const float z = fn_sigmoid(((bi[1][c] + e_x[i][1][c]) + e_rb[i][1][c]) + gh[1][c]);
+                const float n = fn_tanh(((bi[2][c] + e_x[i][2][c]) + e_rb[i][2][c]) + r * gh[2][c]);
+                hp[i][c] = (1.0f - z) * n + z * hp[i][c];
+                o_r[i][c] = r; o_z[i][c] = z; o_n[i][c] = n; o_g[i][c] = gh[2][c];
+            }
+            // the exchange slab first: it is all the other workgroups wait for
+            if (xout && iact[i]) stv4_sc1(xout + frag_off(ib[i], jj0, nk), hp[i]);
+        }
+
+        FN_PSTAMP(4);
+        // (f) publish: every wave drains its stores, then ONE lane arrives at the group counter
+        if (p + 1 < T) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FN_PSTAMP(5);
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        FN_PSTAMP(6);
+        // (g) outputs nobody in this launch waits for
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (!iact[i]) continue;
+            stv4(h_out + (long)ib[i] * H + jj0, hp[i]);
+            if (gt) {
+                stv4(gt + gate_off(ib[i], 0, jj0, nrt), o_r[i]);
+                stv4(gt + gate_off(ib[i], 1, jj0, nrt), o_z[i]);
+                stv4(gt + gate_off(ib[i], 2, jj0, nrt), o_n[i]);
+                stv4(gt + gate_off(ib[i], 3, jj0, nrt), o_g[i]);
+            }
+        }
+    }
+}
+
+int cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        n = prop.multiProcessorCount;
+    }
+    return n;
+}
+
+template <int WM, int WK, int MT, int D>
+int launch_cfg(const PArgs& a, int grid, size_t lds, hipStream_t st) {
+    auto k = gru_fwd_persist_kernel<WM, WK, MT, D>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, a);
+    FN_CHECK_LAUNCH();
+    return FN_OK;
+}
+
+}  // namespace
+
+extern "C" size_t fn_gru_sync_ws_bytes() { return ((size_t)FN_MAX_GROUPS * 32 + 32) * 4; }
+
+int fn_gru_fwd_persist(const FnGruFwd* scans, int n_scans, hipStream_t st) {
+    const char* e = getenv("FN_PERSIST");
+    if (e && atoi(e) == 0) return FN_PERSIST_NA;
+    const int H = scans[0].H;
+    if (H > 512 || !scans[0].sync_ws) return FN_PERSIST_NA;
+    int Tmax = 0;
+    for (int s = 0; s < n_scans; ++s) {
+        const FnGruFwd& d = scans[s];
+        if (d.H != H) return FN_PERSIST_NA;
+        // the epilogue moves 16-byte vectors
+        const uintptr_t al = (uintptr_t)d.b_hh | (uintptr_t)d.b_ih | (uintptr_t)d.h0 | (uintptr_t)d.gx_dense | (uintptr_t)d.gx_table |
+                             (uintptr_t)d.gx_rowbias | (uintptr_t)d.h_all | (uintptr_t)d.gates;
+        if (al & 15) return FN_PERSIST_NA;
+        Tmax = d.T > Tmax ? d.T : Tmax;
+    }
+    if (Tmax < 2) return FN_PERSIST_NA;                 // nothing to keep stationary
+    int cus = cu_count();
+    if (scans[0].cu_budget > 0 && scans[0].cu_budget < cus) cus = scans[0].cu_budget;
+    const int nslices = H / 16;
+    if (cus <= 0 || nslices > cus) return FN_PERSIST_NA;
+    const int maxgroups = cus / nslices < FN_MAX_GROUPS ? cus / nslices : FN_MAX_GROUPS;
+    // smallest row block whose group count fits on the chip with one workgroup per CU
+    int rpw = 0;
+    const int cand[4] = {16, 32, 64, 128};
+    const char* er = getenv("FN_PERSIST_ROWS");
+    for (int c = 0; c < 4 && !rpw; ++c) {
+        if (er && atoi(er) != cand[c]) continue;
+        long groups = 0;
+        for (int s = 0; s < n_scans; ++s) groups += (scans[s].B + cand[c] - 1) / cand[c];
+        if (groups <= maxgroups) rpw = cand[c];
+    }
+    if (!rpw) return FN_PERSIST_NA;
+
+    PArgs a;
+    a.n = n_scans;
+    a.H = H;
+    a.sync = reinterpret_cast<u32*>(scans[0].sync_ws);
+    int groups = 0;
+    for (int s = 0; s < n_scans; ++s) {
+        const FnGruFwd& d = scans[s];
+        PScan& f = a.s[s];
+        f.w_frag = d.w_hh_frag; f.b_hh = d.b_hh; f.b_ih = d.b_ih; f.h0 = d.h0;
+        f.gx_dense = d.gx_dense; f.gx_table = d.gx_table; f.idx = d.idx; f.gx_rowbias = d.gx_rowbias;
+        f.h_all = d.h_all; f.gates = d.gates; f.xf = d.frag_ws;
+        f.idx_ld = d.idx_ld; f.idx_shift = d.idx_shift; f.start_token = d.start_token; f.reverse = d.reverse;
+        f.B = d.B; f.T = d.T;
+        f.group0 = groups;
+        groups += (d.B + rpw - 1) / rpw;
+        if (d.h0) {
+            const int rc = launch_pack(d.h0, d.B, d.H, d.H, d.frag_ws, st);
+            if (rc != FN_OK) return rc;
+        }
+    }
+    a.ngroups = groups;
+    hipError_t me = hipMemsetAsync(a.sync, 0, (size_t)FN_MAX_GROUPS * 32 * 4, st);      // counters only: err is sticky
+    if (me != hipSuccess) return (int)me;
+    const int grid = groups * nslices;
+    const int wk = rpw == 16 ? 4 : rpw == 32 ? 2 : 1;
+    const size_t lds = ((size_t)3 * H * 16 + (size_t)wk * (rpw / 16) * 3 * RT) * 4 + 16;
+    switch (rpw) {
+        case 128: return launch_cfg<4, 1, 2, 4>(a, grid, lds, st);
+        case 64: return launch_cfg<4, 1, 1, 4>(a, grid, lds, st);
+        case 32: return launch_cfg<2, 2, 1, 4>(a, grid, lds, st);
+        default: return launch_cfg<1, 4, 1, 4>(a, grid, lds, st);
+    }
+}

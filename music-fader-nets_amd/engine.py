@@ -211,7 +211,7 @@ class Engine:
         CH = self.chunk
         for t0 in range(0, max(T, Tr), CH):
             part = [self._fwd_chunk(sc, t0, t0 + CH) for sc in scans + [l1] if t0 < sc["T"]]
-            ops.gru_seq_fwd(part)
+            ops.gru_seq_fwd(part, persistent=False)
             if t0 >= T:
                 continue
             t1 = min(T, t0 + CH)
@@ -221,7 +221,7 @@ class Engine:
                 c2 = self._fwd_chunk(l2, t0, t1)
                 if t0 == 0:
                     c2["h0"] = hx0[0]
-                ops.gru_seq_fwd([c2])
+                ops.gru_seq_fwd([c2], persistent=False)
         self.main_wait_side()
         logits = self.buf("g_logits", (T * B, LOGIT_LD))
         ops.gemm(hx1.view(T * B, H), P["linear_out_g.weight"], logits[:, :E_VOCAB], bias=P["linear_out_g.bias"])

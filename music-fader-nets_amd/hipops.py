@@ -128,12 +128,24 @@ class HipOps:
     def _frag_ws(self, tag, i, n):
         return self.workspace(4 * n, "%s%d" % (tag, i))[:n]
 
-    def gru_seq_fwd(self, scans):
+    def _sync_ws(self):
+        """arrival counters + sticky error flag of the weight-stationary scan launches (zero-filled once)."""
+        if getattr(self, "_sync", None) is None:
+            self._sync = torch.zeros(int(self.lib.fn_gru_sync_ws_bytes()) // 4, dtype=torch.int32, device=self.device)
+        return self._sync
+
+    def gru_sync_error(self):
+        """True when a weight-stationary launch gave up waiting (host sync)."""
+        return getattr(self, "_sync", None) is not None and int(self._sync[-32].item()) != 0
+
+    def gru_seq_fwd(self, scans, persistent=True, cu_budget=0):
         arr = (_lib.FnGruFwd * len(scans))()
         for i, (d, s) in enumerate(zip(arr, scans)):
             for k in ("w_hh_frag", "b_hh", "b_ih", "h0", "gx_dense", "gx_table", "gx_rowbias", "h_all", "gates"):
                 _dense(s.get(k), name=k)
             d.frag_ws = _p(self._frag_ws("fragf", i, 2 * self.frag_floats(s["B"], s["H"])))
+            d.sync_ws = _p(self._sync_ws()) if persistent else None
+            d.cu_budget = int(cu_budget)
             _dense(s.get("idx"), torch.int32, "idx")
             d.B, d.T, d.H, d.reverse = s["B"], s["T"], s["H"], int(s.get("reverse", 0))
             d.w_hh_frag, d.b_hh, d.b_ih, d.h0 = _p(s["w_hh_frag"]), _p(s["b_hh"]), _p(s.get("b_ih")), _p(s.get("h0"))

@@ -74,7 +74,7 @@ class FakeOps:
             return torch.full((s["B"],), s.get("start_token", 0), dtype=torch.long)
         return s["idx"][:, tau].long()
 
-    def gru_seq_fwd(self, scans):
+    def gru_seq_fwd(self, scans, persistent=True, cu_budget=0):
         self.calls.append("gru_seq_fwd")
         for s in scans:
             B, T, H = s["B"], s["T"], s["H"]
