@@ -139,6 +139,8 @@ typedef struct FnGruBwd {
     float* dghn_rowsum;       /* [B][H] or NULL                                                */
     float* scratch;           /* [B][H]                                                        */
     float* frag_ws;           /* 2 * fn_frag_floats(B, 3H) floats, 16-byte aligned             */
+    void* sync_ws;            /* as in FnGruFwd (NULL = per-step launches; then scratch is required) */
+    int32_t cu_budget;        /* as in FnGruFwd                                                */
 } FnGruBwd;
 
 int fn_gru_seq_bwd(const FnGruBwd* scans, int n_scans, void* stream);

@@ -25,7 +25,8 @@ class FnGruFwd(C.Structure):
 class FnGruBwd(C.Structure):
     _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("H", C.c_int32),
                 ("w_hh_t_frag", vp), ("h0", vp), ("h_all", vp), ("gates", vp), ("dh_last", vp), ("dh_ext", vp),
-                ("dgx_all", vp), ("dghn_all", vp), ("dh0", vp), ("dgx_rowsum", vp), ("dghn_rowsum", vp), ("scratch", vp), ("frag_ws", vp)]
+                ("dgx_all", vp), ("dghn_all", vp), ("dh0", vp), ("dgx_rowsum", vp), ("dghn_rowsum", vp), ("scratch", vp), ("frag_ws", vp),
+                ("sync_ws", vp), ("cu_budget", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/fadernets.h

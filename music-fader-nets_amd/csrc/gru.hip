@@ -571,6 +571,10 @@ int fn_gru_seq_bwd(const FnGruBwd* scans, int n_scans, void* stream) {
         Tmax = d.T > Tmax ? d.T : Tmax;
     }
     hipStream_t st = (hipStream_t)stream;
+    {
+        const int rc = fn_gru_bwd_persist(scans, n_scans, st);
+        if (rc != FN_PERSIST_NA) return rc;
+    }
     for (int it = 0; it <= Tmax; ++it) {
         long big_tiles = 0;
         for (int s = 0; s < n_scans; ++s) {

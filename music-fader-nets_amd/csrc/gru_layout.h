@@ -21,4 +21,5 @@ FN_DEVINL float f4at(const f32x4& v, int j) { return v[j]; }
 // FN_PERSIST_NA when the configuration is not eligible (the caller then uses the per-step kernels).
 #define FN_PERSIST_NA 1000000
 int fn_gru_fwd_persist(const FnGruFwd* scans, int n_scans, hipStream_t st);
+int fn_gru_bwd_persist(const FnGruBwd* scans, int n_scans, hipStream_t st);
 int launch_pack(const float* src, int rows, int K, long ld, float* dst, hipStream_t st);

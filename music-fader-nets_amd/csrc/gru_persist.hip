@@ -309,6 +309,264 @@ __global__ __launch_bounds__(NT) void gru_fwd_persist_kernel(const PArgs args) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// backward: dh_q = [dr' | dz' | dn' r]_{q+1} W_hh + dh_q z_{q+1} (carried in registers) + dh_ext[q]; gate backward of step q.
+// Workgroup (g, j) owns dh columns [16j, 16j+16): its W_hh^T slice (16 rows x 3H, 96 KB at H = 512) stays in LDS; the
+// operand exchanged between the slices is the [rows][3H] pre-activation gradient (3x the forward's volume).
+// ---------------------------------------------------------------------------------------------------------------
+struct QScan {
+    const float* wt_frag;
+    const float* h0;
+    const float* h_all;
+    const float* gates;
+    const float* dh_last;
+    const float* dh_ext;
+    float* dgx_all;
+    float* dghn_all;
+    float* dh0;
+    float* rowsum;
+    float* rowsum_n;
+    float* xf;            // 2 exchange slabs [rows][3H], fragment-major
+    int B, T;
+    int group0;
+};
+struct QArgs {
+    QScan s[FN_MAX_SCANS];
+    int n, ngroups, H;
+    u32* sync;
+};
+
+template <int WM, int WK, int MT, int D>
+__global__ __launch_bounds__(NT) void gru_bwd_persist_kernel(const QArgs args) {
+    static_assert(WM * WK == 4 && (D % 2) == 0, "4 waves; ring depth even");
+    constexpr int EM = WM * MT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int H = args.H, nk3 = (3 * H) >> 5;
+    float* wl = smem;                                // [nk3][2][64][4]  W_hh^T slice, B-fragment order
+    float* red = smem + 3 * H * 16;                  // [WK][EM][RT]
+    volatile int& dead = *reinterpret_cast<volatile int*>(red + WK * EM * RT);
+
+    const int g = blockIdx.x % args.ngroups, slice = blockIdx.x / args.ngroups;
+    int si = 0;
+#pragma unroll
+    for (int k = 1; k < FN_MAX_SCANS; ++k)
+        if (k < args.n && g >= args.s[k].group0) si = k;
+    const QScan& S = args.s[si];
+    const int B = S.B, T = S.T;
+    const int m0 = (g - S.group0) * (16 * EM), hh0 = slice * 16;
+    const int nrt = (B + 15) >> 4;
+    const int nslices = H >> 4;
+    const long FS3 = (long)nrt * 16 * 3 * H;
+    const long BH = (long)B * H;
+    const long GS = (long)4 * H * nrt * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wk = wave / WM;
+    u32* counter = args.sync + g * 32;
+    u32* err = args.sync + FN_MAX_GROUPS * 32;
+
+    if (tid == 0) dead = 0;
+    {
+        const float4* src = reinterpret_cast<const float4*>(S.wt_frag + (long)slice * nk3 * 512);
+        float4* dst = reinterpret_cast<float4*>(wl);
+        for (int i = tid; i < nk3 * 128; i += NT) dst[i] = src[i];
+    }
+
+    constexpr int NI = (EM * 64 + NT - 1) / NT;
+    int ib[NI], icoff[NI];
+    bool iact[NI];
+    f32x4 carry[NI], rs[NI][3], rsn[NI];
+    const int jj0 = hh0 + 4 * (tid & 3);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int item = tid + NT * i;
+        const int rl = item >> 2;
+        iact[i] = item < EM * 64 && m0 + rl < B;
+        ib[i] = min(m0 + rl, B - 1);
+        icoff[i] = min(rl >> 4, EM - 1) * RT + ((rl & 15) >> 2) * 68 + (item & 3) * 16 + (rl & 3);
+        carry[i] = S.dh_last ? ldv4(S.dh_last + (long)ib[i] * H + jj0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        rsn[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) rs[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+
+    const int c0 = nk3 * wk / WK, nkw = nk3 * (wk + 1) / WK - c0;
+    long aoff[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) aoff[m] = (long)min((m0 >> 4) + wm * MT + m, nrt - 1) * nk3 * 512 + lane * 4;
+    constexpr int NLA = 2 * MT;
+    const int iters = T + (S.dh0 ? 1 : 0);
+
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+        const int q = T - 1 - it;                     // step whose gate backward runs now (-1: only dh0 is left)
+        // (a) operands that do not depend on the exchange
+        f32x4 g_r[NI], g_z[NI], g_n[NI], g_hn[NI], hpv[NI], ext[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            g_r[i] = g_z[i] = g_n[i] = g_hn[i] = hpv[i] = ext[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (q >= 0) {
+                const float* gq = S.gates + (long)q * GS;
+                g_r[i] = ldv4(gq + gate_off(ib[i], 0, jj0, nrt));
+                g_z[i] = ldv4(gq + gate_off(ib[i], 1, jj0, nrt));
+                g_n[i] = ldv4(gq + gate_off(ib[i], 2, jj0, nrt));
+                g_hn[i] = ldv4(gq + gate_off(ib[i], 3, jj0, nrt));
+                if (q > 0) hpv[i] = ldv4(S.h_all + (long)(q - 1) * BH + (long)ib[i] * H + jj0);
+                else if (S.h0) hpv[i] = ldv4(S.h0 + (long)ib[i] * H + jj0);
+                if (S.dh_ext) ext[i] = ldv4(S.dh_ext + (long)q * BH + (long)ib[i] * H + jj0);
+            }
+        }
+
+        // (b) wait for every slice's gradient slab of the previous iteration
+        if (it > 0) {
+            if (tid == 0) {
+                const u32 target = (u32)nslices * (u32)it;
+                u32 spins = 0;
+                while (ld_cnt(counter) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 63u) == 0 && (spins > SPIN_LIMIT || ld_cnt(err) != 0)) {
+                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        dead = 1;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            if (dead) return;
+        }
+
+        // (c) dh partial = df_{q+1} W_hh (columns of this slice)
+        f32x4 acc[MT][2];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][0] = acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (it > 0 && nkw > 0) {
+            const float* xin = S.xf + (long)((it - 1) & 1) * FS3;
+            f32x4 fa[D][MT][2], fb[2][2];
+            auto loadA = [&](int set, int k) {
+                const long k0 = (long)(c0 + min(k, nkw - 1)) * 512;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) { gld4_sc1(fa[set][m][0], xin + aoff[m] + k0); gld4_sc1(fa[set][m][1], xin + aoff[m] + k0 + 256); }
+            };
+            auto loadB = [&](int set, int k) {
+                const int c = c0 + min(k, nkw - 1);
+                fb[set][0] = *reinterpret_cast<const f32x4*>(wl + ((long)c * 2 + 0) * 256 + lane * 4);
+                fb[set][1] = *reinterpret_cast<const f32x4*>(wl + ((long)c * 2 + 1) * 256 + lane * 4);
+            };
+            auto mma = [&](int set, int bs) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        acc[m][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4at(fa[set][m][j >> 2], j & 3), f4at(fb[bs][j >> 2], j & 3),
+                                                                             acc[m][j & 1], 0, 0, 0);
+            };
+#pragma unroll
+            for (int s = 0; s < D; ++s) loadA(s, s);
+            loadB(0, 0);
+            const int nmain = nkw / D * D;
+            for (int base = 0; base < nmain; base += D) {
+#pragma unroll
+                for (int uu = 0; uu < D; ++uu) {
+                    loadB((uu + 1) & 1, base + uu + 1);
+                    fn_wait_vm<NLA * (D - 1)>();
+                    mma(uu, uu & 1);
+                    loadA(uu, base + uu + D);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            fn_wait_vm<0>();
+#pragma unroll
+            for (int uu = 0; uu < D; ++uu)
+                if (nmain + uu < nkw) {
+                    loadB((uu + 1) & 1, nmain + uu + 1);
+                    mma(uu, uu & 1);
+                }
+#pragma unroll
+            for (int s = 0; s < D; ++s)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) { fn_keep(fa[s][m][0]); fn_keep(fa[s][m][1]); }
+        }
+
+        // (d) accumulators -> LDS (padded MFMA C layout)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            *reinterpret_cast<f32x4*>(red + (long)(wk * EM + wm * MT + m) * RT + lane * 4 + (lane >> 4) * 4) = acc[m][0] + acc[m][1];
+        __syncthreads();
+
+        // (e) gate backward, element-wise
+        const bool publish = q > 0 || (q == 0 && S.dh0 != nullptr);
+        float* xout = S.xf + (long)(it & 1) * FS3;
+        const int nkc = nk3;
+        f32x4 o_r[NI], o_z[NI], o_n[NI], o_g[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            f32x4 dh;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < WK; ++w) a += red[(long)(w * EM) * RT + icoff[i] + c * 4];
+                dh[c] = (a + carry[i][c]) + ext[i][c];
+            }
+            if (q < 0) {
+                if (iact[i]) stv4(S.dh0 + (long)ib[i] * H + jj0, dh);
+                continue;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float r = g_r[i][c], z = g_z[i][c], n = g_n[i][c], hn = g_hn[i][c];
+                const float dn = dh[c] * (1.0f - z);
+                const float dz = dh[c] * (hpv[i][c] - n);
+                const float dnp = dn * (1.0f - n * n);
+                const float dr = dnp * hn;
+                o_z[i][c] = dz * z * (1.0f - z);
+                o_r[i][c] = dr * r * (1.0f - r);
+                o_n[i][c] = dnp;
+                o_g[i][c] = dnp * r;
+                carry[i][c] = dh[c] * z;
+            }
+            if (publish && iact[i]) {
+                stv4_sc1(xout + frag_off(ib[i], jj0, nkc), o_r[i]);
+                stv4_sc1(xout + frag_off(ib[i], H + jj0, nkc), o_z[i]);
+                stv4_sc1(xout + frag_off(ib[i], 2 * H + jj0, nkc), o_g[i]);
+            }
+        }
+
+        // (f) publish
+        if (publish) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // (g) outputs nobody in this launch waits for
+        if (q >= 0) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                rs[i][0] += o_r[i]; rs[i][1] += o_z[i]; rs[i][2] += o_n[i]; rsn[i] += o_g[i];
+                if (!iact[i]) continue;
+                float* dg = S.dgx_all + (long)q * 3 * BH + (long)ib[i] * 3 * H + jj0;
+                stv4(dg, o_r[i]);
+                stv4(dg + H, o_z[i]);
+                stv4(dg + 2 * H, o_n[i]);
+                stv4(S.dghn_all + (long)q * BH + (long)ib[i] * H + jj0, o_g[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        if (!iact[i]) continue;
+        if (S.rowsum) {
+            float* p = S.rowsum + (long)ib[i] * 3 * H + jj0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) stv4(p + q * H, ldv4(p + q * H) + rs[i][q]);
+        }
+        if (S.rowsum_n) {
+            float* p = S.rowsum_n + (long)ib[i] * H + jj0;
+            stv4(p, ldv4(p) + rsn[i]);
+        }
+    }
+}
+
 int cu_count() {
     static int n = 0;
     if (n == 0) {
@@ -320,9 +578,9 @@ int cu_count() {
     return n;
 }
 
-template <int WM, int WK, int MT, int D>
-int launch_cfg(const PArgs& a, int grid, size_t lds, hipStream_t st) {
-    auto k = gru_fwd_persist_kernel<WM, WK, MT, D>;
+template <class Args, void (*K)(const Args)>
+int launch_k(const Args& a, int grid, size_t lds, hipStream_t st) {
+    auto k = K;
     static bool attr_done = false;
     if (!attr_done) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
@@ -398,9 +656,70 @@ int fn_gru_fwd_persist(const FnGruFwd* scans, int n_scans, hipStream_t st) {
     const int wk = rpw == 16 ? 4 : rpw == 32 ? 2 : 1;
     const size_t lds = ((size_t)3 * H * 16 + (size_t)wk * (rpw / 16) * 3 * RT) * 4 + 16;
     switch (rpw) {
-        case 128: return launch_cfg<4, 1, 2, 4>(a, grid, lds, st);
-        case 64: return launch_cfg<4, 1, 1, 4>(a, grid, lds, st);
-        case 32: return launch_cfg<2, 2, 1, 4>(a, grid, lds, st);
-        default: return launch_cfg<1, 4, 1, 4>(a, grid, lds, st);
+        case 128: return launch_k<PArgs, gru_fwd_persist_kernel<4, 1, 2, 4>>(a, grid, lds, st);
+        case 64: return launch_k<PArgs, gru_fwd_persist_kernel<4, 1, 1, 4>>(a, grid, lds, st);
+        case 32: return launch_k<PArgs, gru_fwd_persist_kernel<2, 2, 1, 4>>(a, grid, lds, st);
+        default: return launch_k<PArgs, gru_fwd_persist_kernel<1, 4, 1, 4>>(a, grid, lds, st);
+    }
+}
+
+int fn_gru_bwd_persist(const FnGruBwd* scans, int n_scans, hipStream_t st) {
+    const char* e = getenv("FN_PERSIST_BWD");
+    if (e && atoi(e) == 0) return FN_PERSIST_NA;
+    const int H = scans[0].H;
+    if (H > 512 || !scans[0].sync_ws) return FN_PERSIST_NA;
+    int Tmax = 0;
+    for (int s = 0; s < n_scans; ++s) {
+        const FnGruBwd& d = scans[s];
+        if (d.H != H) return FN_PERSIST_NA;
+        const uintptr_t al = (uintptr_t)d.h0 | (uintptr_t)d.h_all | (uintptr_t)d.gates | (uintptr_t)d.dh_last | (uintptr_t)d.dh_ext |
+                             (uintptr_t)d.dgx_all | (uintptr_t)d.dghn_all | (uintptr_t)d.dh0 | (uintptr_t)d.dgx_rowsum | (uintptr_t)d.dghn_rowsum;
+        if (al & 15) return FN_PERSIST_NA;
+        Tmax = d.T > Tmax ? d.T : Tmax;
+    }
+    if (Tmax < 2) return FN_PERSIST_NA;
+    int cus = cu_count();
+    if (scans[0].cu_budget > 0 && scans[0].cu_budget < cus) cus = scans[0].cu_budget;
+    const int nslices = H / 16;
+    if (cus <= 0 || nslices > cus) return FN_PERSIST_NA;
+    const int maxgroups = cus / nslices < FN_MAX_GROUPS ? cus / nslices : FN_MAX_GROUPS;
+    int rpw = 0;
+    const int cand[4] = {16, 32, 64, 128};
+    const char* er = getenv("FN_PERSIST_ROWS");
+    for (int c = 0; c < 4 && !rpw; ++c) {
+        if (er && atoi(er) != cand[c]) continue;
+        long groups = 0;
+        for (int s = 0; s < n_scans; ++s) groups += (scans[s].B + cand[c] - 1) / cand[c];
+        if (groups <= maxgroups) rpw = cand[c];
+    }
+    if (!rpw) return FN_PERSIST_NA;
+
+    QArgs a;
+    a.n = n_scans;
+    a.H = H;
+    a.sync = reinterpret_cast<u32*>(scans[0].sync_ws);
+    int groups = 0;
+    for (int s = 0; s < n_scans; ++s) {
+        const FnGruBwd& d = scans[s];
+        QScan& f = a.s[s];
+        f.wt_frag = d.w_hh_t_frag; f.h0 = d.h0; f.h_all = d.h_all; f.gates = d.gates;
+        f.dh_last = d.dh_last; f.dh_ext = d.dh_ext;
+        f.dgx_all = d.dgx_all; f.dghn_all = d.dghn_all; f.dh0 = d.dh0;
+        f.rowsum = d.dgx_rowsum; f.rowsum_n = d.dghn_rowsum; f.xf = d.frag_ws;
+        f.B = d.B; f.T = d.T;
+        f.group0 = groups;
+        groups += (d.B + rpw - 1) / rpw;
+    }
+    a.ngroups = groups;
+    hipError_t me = hipMemsetAsync(a.sync, 0, (size_t)FN_MAX_GROUPS * 32 * 4, st);
+    if (me != hipSuccess) return (int)me;
+    const int grid = groups * nslices;
+    const int wk = rpw == 16 ? 4 : rpw == 32 ? 2 : 1;
+    const size_t lds = ((size_t)3 * H * 16 + (size_t)wk * (rpw / 16) * RT) * 4 + 16;
+    switch (rpw) {
+        case 128: return launch_k<QArgs, gru_bwd_persist_kernel<4, 1, 2, 8>>(a, grid, lds, st);
+        case 64: return launch_k<QArgs, gru_bwd_persist_kernel<4, 1, 1, 8>>(a, grid, lds, st);
+        case 32: return launch_k<QArgs, gru_bwd_persist_kernel<2, 2, 1, 8>>(a, grid, lds, st);
+        default: return launch_k<QArgs, gru_bwd_persist_kernel<1, 4, 1, 8>>(a, grid, lds, st);
     }
 }

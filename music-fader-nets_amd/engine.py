@@ -367,13 +367,13 @@ class Engine:
         for i, t0 in enumerate(reversed(starts)):
             if t0 < T:
                 with self.on_side():
-                    ops.gru_seq_bwd(chunk_call([("l2", l2)], t0, i == 0))
+                    ops.gru_seq_bwd(chunk_call([("l2", l2)], t0, i == 0), persistent=False)
                 self.main_wait_side()      # layer 1 may start on this chunk as soon as layer 2 has produced dgx2[chunk]
                 t1 = min(T, t0 + CH)
                 ops.gemm(dgx2[t0:t1].view(-1, 3 * H), P["grucell_g_2.weight_ih"], dhx0[t0:t1].view(-1, H), a_k=True, b_k=False)
                 if t0 == 0:
                     ops.axpy(1.0, carry["l2"][0], dhx0[0])          # hx1 was initialised with hx0[0]: dL/dh_init of layer 2
-            ops.gru_seq_bwd(chunk_call([("l1", l1), ("r", sds["r"]), ("n", sds["n"])], t0, i == 0))
+            ops.gru_seq_bwd(chunk_call([("l1", l1), ("r", sds["r"]), ("n", sds["n"])], t0, i == 0), persistent=False)
         dh0_g = carry["l1"][0]
         for e in ("r", "n"):
             sdb[e]["dh0"] = carry[e][0]

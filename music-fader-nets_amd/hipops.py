@@ -155,12 +155,14 @@ class HipOps:
             d.gx_rowbias, d.h_all, d.gates = _p(s.get("gx_rowbias")), _p(s["h_all"]), _p(s.get("gates"))
         _lib.check(self.lib.fn_gru_seq_fwd(arr, len(scans), self.stream()), "fn_gru_seq_fwd")
 
-    def gru_seq_bwd(self, scans):
+    def gru_seq_bwd(self, scans, persistent=True, cu_budget=0):
         arr = (_lib.FnGruBwd * len(scans))()
         for i, (d, s) in enumerate(zip(arr, scans)):
             for k in ("w_hh_t_frag", "h0", "h_all", "gates", "dh_last", "dh_ext", "dgx_all", "dghn_all", "dh0", "dgx_rowsum", "dghn_rowsum", "scratch"):
                 _dense(s.get(k), name=k)
             d.frag_ws = _p(self._frag_ws("fragb", i, 2 * self.frag_floats(s["B"], 3 * s["H"])))
+            d.sync_ws = _p(self._sync_ws()) if persistent else None
+            d.cu_budget = int(cu_budget)
             d.B, d.T, d.H = s["B"], s["T"], s["H"]
             d.w_hh_t_frag, d.h0, d.h_all, d.gates = _p(s["w_hh_t_frag"]), _p(s.get("h0")), _p(s["h_all"]), _p(s["gates"])
             d.dh_last, d.dh_ext = _p(s.get("dh_last")), _p(s.get("dh_ext"))

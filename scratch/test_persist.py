@@ -61,3 +61,45 @@ for name, kw in cases:
     t0 = timeit(lambda: ops.gru_seq_fwd(fw, persistent=False), Tm)
     t1 = timeit(lambda: ops.gru_seq_fwd(fw, persistent=True), Tm)
     print("%-24s per-step %.2f us/step   persistent %.2f us/step" % (name, t0, t1), flush=True)
+
+print("---- backward ----", flush=True)
+def mkb(fw, dh0=True, rows=True, ext=True, last=True):
+    bw = []
+    for d in fw:
+        B, T, H = d["B"], d["T"], d["H"]
+        w = torch.randn(3*H, H, device=dev) / (H ** 0.5)
+        wtf = torch.zeros(ops.frag_floats(H, 3*H), device=dev); ops.frag_pack(w.t().contiguous(), wtf)
+        b = dict(B=B, T=T, H=H, w_hh_t_frag=wtf, h0=d.get("h0"), h_all=d["h_all"], gates=d["gates"],
+                 dgx_all=torch.zeros(T, B, 3*H, device=dev), dghn_all=torch.zeros(T, B, H, device=dev), scratch=torch.zeros(B, H, device=dev))
+        if ext: b["dh_ext"] = torch.randn(T, B, H, device=dev) * 0.1
+        if last: b["dh_last"] = torch.randn(B, H, device=dev) * 0.1
+        if dh0: b["dh0"] = torch.zeros(B, H, device=dev)
+        if rows: b["dgx_rowsum"] = torch.zeros(B, 3*H, device=dev); b["dghn_rowsum"] = torch.zeros(B, H, device=dev)
+        bw.append(b)
+    return bw
+OUT = ("dgx_all", "dghn_all", "dh0", "dgx_rowsum", "dghn_rowsum")
+def runb(bw, persistent):
+    for b in bw:
+        for k in OUT:
+            if b.get(k) is not None: b[k].fill_(0.25 if "rowsum" in k else float("nan"))
+        b["scratch"].zero_()
+    ops.gru_seq_bwd(bw, persistent=persistent)
+    torch.cuda.synchronize()
+    return [{k: b[k].clone() for k in OUT if b.get(k) is not None} for b in bw]
+for name, kw in cases:
+    fw = mk(**kw); run(fw, False)
+    for opts in (dict(), dict(dh0=False, rows=False, ext=False)):
+        bw = mkb(fw, **opts)
+        ref = runb(bw, False)
+        for rep in range(2):
+            got = runb(bw, True)
+            worst = 0.0; nan = False
+            for a, b in zip(ref, got):
+                for k in a:
+                    sc = float(a[k].abs().max()) + 1e-30
+                    worst = max(worst, float((a[k] - b[k]).abs().max()) / sc); nan |= bool(torch.isnan(b[k]).any())
+            print("%-24s %-10s rep %d: max rel-to-max err %.3e nan=%s sync_err=%s" % (name, "full" if not opts else "minimal", rep, worst, nan, ops.gru_sync_error()), flush=True)
+    Tm = max(d["T"] for d in fw)
+    t0 = timeit(lambda: ops.gru_seq_bwd(bw, persistent=False), Tm)
+    t1 = timeit(lambda: ops.gru_seq_bwd(bw, persistent=True), Tm)
+    print("%-24s bwd per-step %.2f us/step   persistent %.2f us/step" % (name, t0, t1), flush=True)

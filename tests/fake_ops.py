@@ -99,7 +99,7 @@ class FakeOps:
                     g = self._gview(s["gates"], p, B, H)
                     g[:, 0].copy_(r), g[:, 1].copy_(z), g[:, 2].copy_(n), g[:, 3].copy_(gh[:, 2 * H:])
 
-    def gru_seq_bwd(self, scans):
+    def gru_seq_bwd(self, scans, persistent=True, cu_budget=0):
         self.calls.append("gru_seq_bwd")
         for s in scans:
             B, T, H = s["B"], s["T"], s["H"]
