@@ -34,6 +34,9 @@ class Engine:
         self.whh_t = {}                 # W_hh^T, fragment-major (backward scans)
         self.saved = None
         self.chunk = 32                 # time steps per pipeline chunk of the two decoder layers
+        # decoder scans as weight-stationary launches: the two sub-decoders on the whole chip, then layer 1 || layer 2 on half
+        # of the CUs each (two single-launch scans that overlap must fit on the chip TOGETHER, see FnGruFwd.cu_budget)
+        self.persist_dec = __import__("os").environ.get("FN_PERSIST_DEC", "1") == "1"
         self.split_encoders = __import__("os").environ.get("FN_SPLIT_ENC", "0") == "1"   # measured: no gain on MI355X (profiles/), kept as a switch
         if hidden % 32 != 0:
             raise ValueError("hidden_dims must be a multiple of 32 (K chunks of the MFMA step kernels)")
@@ -69,6 +72,9 @@ class Engine:
             if self.ctx is not None:
                 self.ctx.__exit__(*a)
             self.eng.ops.lane = self.prev
+
+    def _cu_count(self):
+        return torch.cuda.get_device_properties(self.dev).multi_processor_count if self.dev.type == "cuda" else 256
 
     def on_side(self):
         return Engine._Lane(self, True)
@@ -209,9 +215,15 @@ class Engine:
         # stream; behind it, on the side stream, chunk c of layer 2 = batched W_ih2 projection of hx0[chunk] (one GEMM)
         # + the recurrent scan (h_init = hx0[0], gmm_model.py:134-135).  Layer 2 thus lags layer 1 by one chunk.
         CH = self.chunk
-        for t0 in range(0, max(T, Tr), CH):
-            part = [self._fwd_chunk(sc, t0, t0 + CH) for sc in scans + [l1] if t0 < sc["T"]]
-            ops.gru_seq_fwd(part, persistent=False)
+        half = self._cu_count() // 2
+        if self.persist_dec:
+            ops.gru_seq_fwd(scans)                           # both sub-decoders, all Tr steps, whole chip
+        for t0 in range(0, T if self.persist_dec else max(T, Tr), CH):
+            if self.persist_dec:
+                ops.gru_seq_fwd([self._fwd_chunk(l1, t0, t0 + CH)], cu_budget=half)
+            else:
+                part = [self._fwd_chunk(sc, t0, t0 + CH) for sc in scans + [l1] if t0 < sc["T"]]
+                ops.gru_seq_fwd(part, persistent=False)
             if t0 >= T:
                 continue
             t1 = min(T, t0 + CH)
@@ -221,7 +233,7 @@ class Engine:
                 c2 = self._fwd_chunk(l2, t0, t1)
                 if t0 == 0:
                     c2["h0"] = hx0[0]
-                ops.gru_seq_fwd([c2], persistent=False)
+                ops.gru_seq_fwd([c2], persistent=self.persist_dec, cu_budget=half)
         self.main_wait_side()
         logits = self.buf("g_logits", (T * B, LOGIT_LD))
         ops.gemm(hx1.view(T * B, H), P["linear_out_g.weight"], logits[:, :E_VOCAB], bias=P["linear_out_g.bias"])
@@ -363,17 +375,25 @@ class Engine:
                 part.append(self._bwd_chunk(sc, t0, t1, cin, carry[name][slot]))
             return part
 
+        half = self._cu_count() // 2
+        pd = self.persist_dec
         self.side_wait_main()
         for i, t0 in enumerate(reversed(starts)):
             if t0 < T:
                 with self.on_side():
-                    ops.gru_seq_bwd(chunk_call([("l2", l2)], t0, i == 0), persistent=False)
+                    ops.gru_seq_bwd(chunk_call([("l2", l2)], t0, i == 0), persistent=pd, cu_budget=half)
                 self.main_wait_side()      # layer 1 may start on this chunk as soon as layer 2 has produced dgx2[chunk]
                 t1 = min(T, t0 + CH)
                 ops.gemm(dgx2[t0:t1].view(-1, 3 * H), P["grucell_g_2.weight_ih"], dhx0[t0:t1].view(-1, H), a_k=True, b_k=False)
                 if t0 == 0:
                     ops.axpy(1.0, carry["l2"][0], dhx0[0])          # hx1 was initialised with hx0[0]: dL/dh_init of layer 2
-            ops.gru_seq_bwd(chunk_call([("l1", l1), ("r", sds["r"]), ("n", sds["n"])], t0, i == 0), persistent=False)
+            if pd:
+                if t0 < T:
+                    ops.gru_seq_bwd(chunk_call([("l1", l1)], t0, i == 0), cu_budget=half)
+            else:
+                ops.gru_seq_bwd(chunk_call([("l1", l1), ("r", sds["r"]), ("n", sds["n"])], t0, i == 0), persistent=False)
+        if pd:                                   # both sub-decoders, all Tr steps, whole chip (layer 2 has finished on the side stream)
+            ops.gru_seq_bwd([self._bwd_chunk(sds[e], 0, Tr, None, carry[e][0]) for e in ("r", "n")])
         dh0_g = carry["l1"][0]
         for e in ("r", "n"):
             sdb[e]["dh0"] = carry[e][0]

@@ -130,13 +130,14 @@ class HipOps:
 
     def _sync_ws(self):
         """arrival counters + sticky error flag of the weight-stationary scan launches (zero-filled once)."""
-        if getattr(self, "_sync", None) is None:
-            self._sync = torch.zeros(int(self.lib.fn_gru_sync_ws_bytes()) // 4, dtype=torch.int32, device=self.device)
-        return self._sync
+        syncs = self.__dict__.setdefault("_syncs", {})      # one per lane: launches on different streams may overlap
+        if self.lane not in syncs:
+            syncs[self.lane] = torch.zeros(int(self.lib.fn_gru_sync_ws_bytes()) // 4, dtype=torch.int32, device=self.device)
+        return syncs[self.lane]
 
     def gru_sync_error(self):
         """True when a weight-stationary launch gave up waiting (host sync)."""
-        return getattr(self, "_sync", None) is not None and int(self._sync[-32].item()) != 0
+        return any(int(t[-32].item()) != 0 for t in self.__dict__.get("_syncs", {}).values())
 
     def gru_seq_fwd(self, scans, persistent=True, cu_budget=0):
         arr = (_lib.FnGruFwd * len(scans))()
