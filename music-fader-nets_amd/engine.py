@@ -33,10 +33,12 @@ class Engine:
         self.whh_f = {}                 # W_hh in the kernels' fragment-major operand layout (forward scans)
         self.whh_t = {}                 # W_hh^T, fragment-major (backward scans)
         self.saved = None
-        self.chunk = 32                 # time steps per pipeline chunk of the two decoder layers
+        self.chunk = int(__import__("os").environ.get("FN_CHUNK", "32"))                 # time steps per pipeline chunk of the two decoder layers
         # decoder scans as weight-stationary launches: the two sub-decoders on the whole chip, then layer 1 || layer 2 on half
         # of the CUs each (two single-launch scans that overlap must fit on the chip TOGETHER, see FnGruFwd.cu_budget)
         self.persist_dec = __import__("os").environ.get("FN_PERSIST_DEC", "1") == "1"
+        self._lane_alias = {}           # lane -> lane it is folded into (debug / tuning: FN_AUX=0 runs the aux lane on the side stream)
+        self._aux_mode = __import__("os").environ.get("FN_AUX", "1")      # 1 | 0 | fwd | bwd
         self.split_encoders = __import__("os").environ.get("FN_SPLIT_ENC", "0") == "1"   # measured: no gain on MI355X (profiles/), kept as a switch
         if hidden % 32 != 0:
             raise ValueError("hidden_dims must be a multiple of 32 (K chunks of the MFMA step kernels)")
@@ -48,21 +50,27 @@ class Engine:
     # (decoder layer 2 one time-chunk behind layer 1; decoder weight-gradient GEMMs under the encoder backward scans) are
     # enqueued on the side stream so that two kernels are resident at once - the scan steps are latency-bound and leave
     # most of the chip idle.  Each lane has its own scratch (ops.lane) so concurrent kernels never share a workspace.
-    def _side_stream(self):
+    def _lane_stream(self, lane):
+        """lane: "side" or "aux" -> its HIP stream (None on CPU test backends)."""
         if self.dev.type != "cuda":
             return None
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.dev)
-        return self._side
+        lane = self._lane_alias.get(lane, lane)
+        streams = self.__dict__.setdefault("_streams", {})
+        if lane not in streams:
+            streams[lane] = torch.cuda.Stream(device=self.dev)
+        return streams[lane]
+
+    def _side_stream(self):
+        return self._lane_stream("side")
 
     class _Lane:
-        def __init__(self, eng, side):
-            self.eng, self.side, self.ctx = eng, side, None
+        def __init__(self, eng, side, lane="side"):
+            self.eng, self.side, self.ctx, self.lane = eng, side, None, lane
 
         def __enter__(self):
             self.prev = getattr(self.eng.ops, "lane", "")
-            self.eng.ops.lane = "side/" if self.side else ""
-            st = self.eng._side_stream() if self.side else None
+            self.eng.ops.lane = self.eng._lane_alias.get(self.lane, self.lane) + "/" if self.side else ""
+            st = self.eng._lane_stream(self.lane) if self.side else None
             if st is not None:
                 self.ctx = torch.cuda.stream(st)
                 self.ctx.__enter__()
@@ -78,6 +86,18 @@ class Engine:
 
     def on_side(self):
         return Engine._Lane(self, True)
+
+    def on_aux(self):
+        return Engine._Lane(self, True, "aux")
+
+    def lane_wait(self, waiter, waited):
+        """stream of lane `waiter` waits for everything enqueued so far on lane `waited` ("main" = the current stream)."""
+        if self.dev.type != "cuda":
+            return
+        get = lambda l: torch.cuda.current_stream(self.dev) if l == "main" else self._lane_stream(l)
+        a, b = get(waiter), get(waited)
+        if a != b:
+            a.wait_stream(b)
 
     def side_wait_main(self):
         st = self._side_stream()
@@ -216,6 +236,7 @@ class Engine:
         # + the recurrent scan (h_init = hx0[0], gmm_model.py:134-135).  Layer 2 thus lags layer 1 by one chunk.
         CH = self.chunk
         half = self._cu_count() // 2
+        self._lane_alias = {} if self._aux_mode in ("1", "fwd") else {"aux": "side"}
         if self.persist_dec:
             ops.gru_seq_fwd(scans)                           # both sub-decoders, all Tr steps, whole chip
         for t0 in range(0, T if self.persist_dec else max(T, Tr), CH):
@@ -227,9 +248,13 @@ class Engine:
             if t0 >= T:
                 continue
             t1 = min(T, t0 + CH)
-            self.side_wait_main()
-            with self.on_side():
+            # three lanes: layer 1 (main) -> input projection of layer 2 (aux) -> layer 2 (side); chunk c+1 of a lane runs
+            # beside chunk c of the next one
+            self.lane_wait("aux", "main")
+            with self.on_aux():
                 ops.gemm(hx0[t0:t1].view(-1, H), P["grucell_g_2.weight_ih"], gx2[t0:t1].view(-1, 3 * H), bias=P["grucell_g_2.bias_ih"])
+            self.lane_wait("side", "aux")
+            with self.on_side():
                 c2 = self._fwd_chunk(l2, t0, t1)
                 if t0 == 0:
                     c2["h0"] = hx0[0]
@@ -377,16 +402,20 @@ class Engine:
 
         half = self._cu_count() // 2
         pd = self.persist_dec
+        self._lane_alias = {} if self._aux_mode in ("1", "bwd") else {"aux2": "side"}
         self.side_wait_main()
         for i, t0 in enumerate(reversed(starts)):
             if t0 < T:
                 with self.on_side():
                     ops.gru_seq_bwd(chunk_call([("l2", l2)], t0, i == 0), persistent=pd, cu_budget=half)
-                self.main_wait_side()      # layer 1 may start on this chunk as soon as layer 2 has produced dgx2[chunk]
+                # layer 2 (side) -> dhx0[chunk] = dgx2[chunk] W_ih2 (aux) -> layer 1 (main)
+                self.lane_wait("aux2", "side")
                 t1 = min(T, t0 + CH)
-                ops.gemm(dgx2[t0:t1].view(-1, 3 * H), P["grucell_g_2.weight_ih"], dhx0[t0:t1].view(-1, H), a_k=True, b_k=False)
-                if t0 == 0:
-                    ops.axpy(1.0, carry["l2"][0], dhx0[0])          # hx1 was initialised with hx0[0]: dL/dh_init of layer 2
+                with Engine._Lane(self, True, "aux2"):
+                    ops.gemm(dgx2[t0:t1].view(-1, 3 * H), P["grucell_g_2.weight_ih"], dhx0[t0:t1].view(-1, H), a_k=True, b_k=False)
+                    if t0 == 0:
+                        ops.axpy(1.0, carry["l2"][0], dhx0[0])          # hx1 was initialised with hx0[0]: dL/dh_init of layer 2
+                self.lane_wait("main", "aux2")
             if pd:
                 if t0 < T:
                     ops.gru_seq_bwd(chunk_call([("l1", l1)], t0, i == 0), cu_budget=half)

@@ -98,8 +98,8 @@ class GMVAETrainer:
         r = m._indices(torch.as_tensor(r).to(dev), 3)
         n = m._indices(torch.as_tensor(n).to(dev), 16)
         c = torch.as_tensor(c).to(dev).float().contiguous()
-        rd = torch.as_tensor(np.asarray(r_density, dtype=np.float64)).to(dev).contiguous()
-        nd = torch.as_tensor(np.asarray(n_density, dtype=np.float64)).to(dev).contiguous()
+        f64 = lambda x: (x.to(dev).double() if torch.is_tensor(x) else torch.as_tensor(np.asarray(x, dtype=np.float64)).to(dev)).contiguous()
+        rd, nd = f64(r_density), f64(n_density)
         lab = None if y_label is None else torch.as_tensor(y_label).to(dev).to(torch.int32).contiguous()
         return d, r, n, c, rd, nd, lab
 
