@@ -33,7 +33,7 @@ class Engine:
         self.whh_f = {}                 # W_hh in the kernels' fragment-major operand layout (forward scans)
         self.whh_t = {}                 # W_hh^T, fragment-major (backward scans)
         self.saved = None
-        self.chunk = int(__import__("os").environ.get("FN_CHUNK", "32"))                 # time steps per pipeline chunk of the two decoder layers
+        self.chunk = int(__import__("os").environ.get("FN_CHUNK", "64"))                 # time steps per pipeline chunk of the two decoder layers
         # decoder scans as weight-stationary launches: the two sub-decoders on the whole chip, then layer 1 || layer 2 on half
         # of the CUs each (two single-launch scans that overlap must fit on the chip TOGETHER, see FnGruFwd.cu_budget)
         self.persist_dec = __import__("os").environ.get("FN_PERSIST_DEC", "1") == "1"
@@ -374,16 +374,20 @@ class Engine:
             ops.gemm(dl, P["linear_out_%s.weight" % e], dh_sd[e].view(Tr * B, H), a_k=True, b_k=False)
         dgx1 = self.buf("g_dgx1", (T, B, 3 * H))
         dghn1 = self.buf("g_dghn1", (T, B, H))
+        # per-sequence sums over time of the gate gradients (bias / z-projection gradients) are accumulated by the scans
+        rs2, rsn2 = self.zbuf("g_rs2", (B, 3 * H)), self.zbuf("g_rsn2", (B, H))
+        drb_g, rsn_g = self.zbuf("g_drb", (B, 3 * H)), self.zbuf("g_rsn1", (B, H))
         l2 = dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t["g2"], h0=dec["hx0"][0], h_all=dec["hx1"], gates=dec["g2"], dh_ext=dhx1,
-                  dgx_all=dgx2, dghn_all=dghn2, scratch=self.buf("g_scr2", (B, H)))
+                  dgx_all=dgx2, dghn_all=dghn2, scratch=self.buf("g_scr2", (B, H)), dgx_rowsum=rs2, dghn_rowsum=rsn2)
         l1 = dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t["g"], h0=dec["h0g"], h_all=dec["hx0"], gates=dec["g1"], dh_ext=dhx0,
-                  dgx_all=dgx1, dghn_all=dghn1, scratch=self.buf("g_scr1", (B, H)))
+                  dgx_all=dgx1, dghn_all=dghn1, scratch=self.buf("g_scr1", (B, H)), dgx_rowsum=drb_g, dghn_rowsum=rsn_g)
         sdb, sds = {}, {}
         for e in ("r", "n"):
             sdb[e] = dict(dgx=self.buf("sd_dgx_" + e, (Tr, B, 3 * H)), dghn=self.buf("sd_dghn_" + e, (Tr, B, H)),
-                          drb=self.buf("sd_drb_" + e, (B, 3 * H)), rsn=self.buf("sd_rsn_" + e, (B, H)))
+                          drb=self.zbuf("sd_drb_" + e, (B, 3 * H)), rsn=self.zbuf("sd_rsn_" + e, (B, H)))
             sds[e] = dict(B=B, T=Tr, H=H, w_hh_t_frag=self.whh_t["d_" + e], h0=sd[e]["h0"], h_all=sd[e]["h_all"], gates=sd[e]["gates"],
-                          dh_ext=dh_sd[e], dgx_all=sdb[e]["dgx"], dghn_all=sdb[e]["dghn"], scratch=self.buf("sd_scr_" + e, (B, H)))
+                          dh_ext=dh_sd[e], dgx_all=sdb[e]["dgx"], dghn_all=sdb[e]["dghn"], scratch=self.buf("sd_scr_" + e, (B, H)),
+                          dgx_rowsum=sdb[e]["drb"], dghn_rowsum=sdb[e]["rsn"])
         CH = self.chunk
         starts = list(range(0, max(T, Tr), CH))
         carry = {k: [self.buf("carry_%s_%d" % (k, i), (B, H)) for i in range(2)] for k in ("l2", "l1", "r", "n")}
@@ -427,8 +431,6 @@ class Engine:
         for e in ("r", "n"):
             sdb[e]["dh0"] = carry[e][0]
         # ---- what the encoder side needs from the decoders (main stream, critical path): dz ---------------------
-        drb_g = self.buf("g_drb", (B, 3 * H))
-        ops.time_sum(dgx1, drb_g)          # per-sequence sums over time of d(pre-activations)
         Wz_g, Wig = P["grucell_g.weight_ih"], P["linear_init_global.weight"]
         for e, c0 in (("r", 0), ("n", Z)):
             gz = lat_up[e]["g_z"]
@@ -436,18 +438,13 @@ class Engine:
             ops.gemm(dh0_g, Wig[:, c0:c0 + Z], gz, a_k=True, b_k=False, beta=1.0)
         for e, Ce in (("r", R_DIMS), ("n", N_DIMS)):
             gz = lat_up[e]["g_z"]
-            ops.time_sum(sdb[e]["dgx"], sdb[e]["drb"])
             ops.gemm(sdb[e]["drb"], P["gru_d_%s.weight_ih_l0" % e][:, Ce:], gz, a_k=True, b_k=False, beta=1.0)
             ops.gemm(sdb[e]["dh0"], P["linear_init_%s.weight" % e], gz, a_k=True, b_k=False, beta=1.0)
         # ---- decoder-side PARAMETER gradients: side stream, overlapping the latent block and the encoder scans ---
         self.side_wait_main()
         with self.on_side():
-            rs2, rsn2, rsn_g = self.buf("g_rs2", (B, 3 * H)), self.buf("g_rsn2", (B, H)), self.buf("g_rsn1", (B, H))
             ops.gemm(dlog[:, :E_VOCAB], hx1f, G["linear_out_g.weight"], a_k=False, b_k=False, splitk=sk_T)
             ops.colsum(dlog[:, :E_VOCAB], G["linear_out_g.bias"])
-            ops.time_sum(dgx2, rs2)
-            ops.time_sum(dghn2, rsn2)
-            ops.time_sum(dghn1, rsn_g)
             self._gru_weight_grads("g2", "grucell_g_2.", "", T, B, dgx2, dghn2, dec["hx1"], dec["hx0"][0], G, sk_T, rs2, rsn2)
             ops.gemm(dgx2f, hx0f, G["grucell_g_2.weight_ih"], a_k=False, b_k=False, splitk=sk_T)
             ops.colsum(rs2, G["grucell_g_2.bias_ih"])
@@ -466,7 +463,6 @@ class Engine:
                 dl = dlogits_sd[e].view(Tr * B, Ce)
                 ops.gemm(dl, sd[e]["h_all"].view(Tr * B, H), G["linear_out_%s.weight" % e], a_k=False, b_k=False, splitk=sk_Tr)
                 ops.colsum(dl, G["linear_out_%s.bias" % e])
-                ops.time_sum(sdb[e]["dghn"], sdb[e]["rsn"])
                 self._gru_weight_grads("d_" + e, pfx, "_l0", Tr, B, sdb[e]["dgx"], sdb[e]["dghn"], sd[e]["h_all"], sd[e]["h0"], G, sk_Tr,
                                        sdb[e]["drb"], sdb[e]["rsn"])
                 dW = G[pfx + "weight_ih_l0"]                        # [3H][Ce+Z]
@@ -505,10 +501,10 @@ class Engine:
                 ops.colsum(dp, G[head + e + ".bias"])
             for key, dh in ((e, dhf), (e + "_reverse", dhb)):
                 encb[key] = dict(dgx=self.buf("enc_dgx_" + key, (T, B, 3 * H)), dghn=self.buf("enc_dghn_" + key, (T, B, H)),
-                                 rs=self.buf("enc_rs_" + key, (B, 3 * H)), rsn=self.buf("enc_rsn_" + key, (B, H)))
+                                 rs=self.zbuf("enc_rs_" + key, (B, 3 * H)), rsn=self.zbuf("enc_rsn_" + key, (B, H)))
                 scans.append(dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t[key], h0=None, h_all=self._bufs["enc_h_" + key],
                                   gates=self._bufs["enc_g_" + key], dh_last=dh, dgx_all=encb[key]["dgx"], dghn_all=encb[key]["dghn"],
-                                  scratch=self.buf("enc_scr_" + key, (B, H))))
+                                  scratch=self.buf("enc_scr_" + key, (B, H)), dgx_rowsum=encb[key]["rs"], dghn_rowsum=encb[key]["rsn"]))
         if self.split_encoders and self._side_stream() is not None:
             self.side_wait_main()
             with self.on_side():
@@ -517,9 +513,6 @@ class Engine:
             self.main_wait_side()
         else:
             ops.gru_seq_bwd(scans)    # 4 concurrent reverse scans
-        for key in encb:
-            ops.time_sum(encb[key]["dgx"], encb[key]["rs"])
-            ops.time_sum(encb[key]["dghn"], encb[key]["rsn"])
         for e in ("r", "n"):
             for key, sfx, rev in ((e, "_l0", 0), (e + "_reverse", "_l0_reverse", 1)):
                 pfx = "gru_%s." % e
