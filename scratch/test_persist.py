@@ -48,6 +48,7 @@ cases = [("small H64 x4 scans", dict(n=4, B=6, T=20, H=64, kind="table")),
          ("H512 B256 x4", dict(n=4, B=256, T=64, H=512, kind="table")),
          ("H512 B256 x3 ragged", dict(n=3, B=256, T=32, H=512, kind="table", Ts=[32, 8, 8]))]
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
+if which == "x4only": cases = [c for c in cases if c[0] == "H512 B256 x4"]
 for name, kw in cases:
     fw = mk(**kw)
     ref = run(fw, False)
