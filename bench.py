@@ -29,37 +29,39 @@ PEAK_F32_MFMA_TFLOPS = 157.3                           # MI355X_MICROARCH.md: v_
 
 
 def measure_dominant_kernel(trainer, batch, eps, reps=3):
-    """Average launch duration of the encoder forward step kernel gru_fwd_step_kernel<4,4,1> (4 scans x B rows per launch),
-    measured with HIP events on the stream it is launched on (torch's current stream)."""
+    """Launch duration of the dominant kernel, the weight-stationary encoder forward scan gru_fwd_persist_kernel<4,1,2,4>
+    (ONE launch = T time steps x 4 scans x B rows), measured with HIP events on the stream it is launched on (torch's current
+    stream).  The event pair also brackets the counter memset node that precedes the launch (a few microseconds of 4+ ms)."""
     eng = trainer.model.engine()
     d = batch[0]
     eng.encode(d)
     torch.cuda.synchronize()
+    P = eng.p
+    scans = []
+    for e in ("r", "n"):
+        for key, sfx, rev in ((e, "_l0", 0), (e + "_reverse", "_l0_reverse", 1)):
+            pfx = "gru_%s." % e
+            scans.append(dict(B=B, T=T, H=H, reverse=rev, w_hh_frag=eng.whh_f[key], b_hh=P[pfx + "bias_hh" + sfx],
+                              b_ih=P[pfx + "bias_ih" + sfx], gx_table=eng.tab[key], idx=d, idx_shift=0,
+                              h_all=eng.buf("enc_h_" + key, (T, B, H)), gates=eng.buf("enc_g_" + key, (T, eng.ops.gates_floats(B, H)))))
     best = None
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        # only the scan launches: build the descriptors once, time fn_gru_seq_fwd alone
-        scans = []
-        P = eng.p
-        for e in ("r", "n"):
-            for key, sfx, rev in ((e, "_l0", 0), (e + "_reverse", "_l0_reverse", 1)):
-                pfx = "gru_%s." % e
-                scans.append(dict(B=B, T=T, H=H, reverse=rev, w_hh_frag=eng.whh_f[key], b_hh=P[pfx + "bias_hh" + sfx],
-                                  b_ih=P[pfx + "bias_ih" + sfx], gx_table=eng.tab[key], idx=d, idx_shift=0,
-                                  h_all=eng.buf("enc_h_" + key, (T, B, H)), gates=eng.buf("enc_g_" + key, (T, eng.ops.gates_floats(B, H)))))
         e0.record()
         eng.ops.gru_seq_fwd(scans)
         e1.record()
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / T
+        ms = e0.elapsed_time(e1)
         best = ms if best is None else min(best, ms)
-    flop = 4 * B * FLOP_PER_SAMPLE_STEP
+    if eng.ops.gru_sync_error():
+        raise RuntimeError("weight-stationary scan: a workgroup gave up waiting (sync error flag set)")
+    flop = T * 4 * B * FLOP_PER_SAMPLE_STEP
     achieved = flop / (best * 1e-3) / 1e12
     # traffic: HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes),
-    # see profiles/r01_pmc_gru_fwd_step_4scans.txt - bench.py itself cannot run the profiler, so this is the committed measurement.
-    return dict(bound="mfma", kernel="gru_fwd_step_kernel<4,4,1>", achieved=round(achieved, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=35.5e6, traffic_source="profiles/r01_pmc_gru_fwd_step_4scans.txt",
-                avg_launch_us=round(best * 1e3, 3), flop_per_launch=flop)
+    # see profiles/r01_pmc_gru_fwd_persist_4scans.txt - bench.py itself cannot run the profiler, so this is the committed measurement.
+    return dict(bound="mfma", kernel="gru_fwd_persist_kernel<4,1,2,4>", achieved=round(achieved, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=4.45e9, traffic_source="profiles/r01_pmc_gru_fwd_persist_4scans.txt",
+                avg_launch_us=round(best * 1e3, 1), flop_per_launch=flop, steps_per_launch=T)
 
 
 def main():

@@ -29,3 +29,6 @@ def test_argument_errors_without_gpu():
     assert lib.fn_gemm_ws_bytes(128, 64, 4) == 4 * 128 * 64 * 4
     arr = (_lib.FnGruFwd * 9)()
     assert lib.fn_gru_seq_fwd(arr, 9, None) == -5
+    # counters + sticky error word of the weight-stationary launches: whole 128-byte lines, error word in the last one
+    nbytes = lib.fn_gru_sync_ws_bytes()
+    assert nbytes % 128 == 0 and nbytes >= 64 * 128 + 128

@@ -160,10 +160,13 @@ def _unblock_gates(g, B, H):
     return g[:, off.reshape(-1)].view(T, B, 4, H)
 
 
-@pytest.mark.parametrize("B,T,H", [(6, 5, 64), (70, 9, 96), (256, 4, 512)])
-def test_gru_scan_fwd_bwd_kernels(ops, B, T, H):
-    """fn_gru_seq_fwd / fn_gru_seq_bwd: three concurrent scans (table+reverse, table+shift, dense; different T)."""
+@pytest.mark.parametrize("mode", ["per_step", "stationary", "stationary_half_chip"])
+@pytest.mark.parametrize("B,T,H", [(6, 5, 64), (70, 9, 96), (256, 4, 512), (40, 37, 512)])
+def test_gru_scan_fwd_bwd_kernels(ops, B, T, H, mode):
+    """fn_gru_seq_fwd / fn_gru_seq_bwd: three concurrent scans (table+reverse, table+shift, dense; different T), through
+    the per-step launches, the weight-stationary single launch, and the latter restricted to half of the CUs."""
     fake = FakeOps()
+    kw = dict(persistent=mode != "per_step", cu_budget=128 if mode.endswith("half_chip") else 0)
     cpu = [_scan_inputs(B, T, H, 21, 1, True, reverse=1), _scan_inputs(B, T + 2, H, 21, 2, True, shift=-1),
            _scan_inputs(B, max(1, T - 2), H, 21, 3, False)]
     cpu[2]["h0"] = None
@@ -171,7 +174,7 @@ def test_gru_scan_fwd_bwd_kernels(ops, B, T, H):
     for c, d in zip(cpu, dev):
         c["w_hh_frag"], d["w_hh_frag"] = _pack(fake, c["w_hh"], "cpu"), _pack(ops, c["w_hh"], DEV)
     fake.gru_seq_fwd(cpu)
-    ops.gru_seq_fwd(dev)
+    ops.gru_seq_fwd(dev, **kw)
     for i, (c, d) in enumerate(zip(cpu, dev)):
         close(d["h_all"], c["h_all"], 2e-5, "h_all[%d]" % i)
         close(_unblock_gates(d["gates"].cpu(), B, H), c["gates"][:, : B * 4 * H].reshape(c["T"], B, 4, H), 2e-5, "gates[%d]" % i)
@@ -190,7 +193,8 @@ def test_gru_scan_fwd_bwd_kernels(ops, B, T, H):
         bdev["w_hh_t_frag"] = _pack(ops, c["w_hh"].t().contiguous(), DEV)
         bd.append(bdev)
     fake.gru_seq_bwd(bc)
-    ops.gru_seq_bwd(bd)
+    ops.gru_seq_bwd(bd, **kw)
+    assert not ops.gru_sync_error()
     for i, (c, d) in enumerate(zip(bc, bd)):
         for k in ("dgx_all", "dghn_all", "dh0", "dgx_rowsum", "dghn_rowsum"):
             if c[k] is not None:
