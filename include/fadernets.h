@@ -145,6 +145,13 @@ typedef struct FnGruBwd {
 
 int fn_gru_seq_bwd(const FnGruBwd* scans, int n_scans, void* stream);
 
+/* Recurrent weight gradient of one scan from its saved gate gradients (autograd of W_hh in nn.GRU / GRUCell,
+ * trainer_gmm.py:249):  dW_hh[3H][H] = beta * dW_hh + [dgx[:, 0:2H] | dghn]^T hprev  over `rows` (time x batch) rows;
+ * dgx [rows][3H], dghn [rows][H], hprev [rows][H] (the state BEFORE each step).  One split-K launch when 2H % 128 == 0. */
+size_t fn_gru_dwhh_ws_bytes(int H, int splitk);
+int fn_gru_dwhh_f32(const float* dgx, const float* dghn, const float* hprev, int64_t rows, int H, float beta, float* dW,
+                    int splitk, float* ws, size_t ws_bytes, void* stream);
+
 /* dTable[v][:] = sum over (p,b) with tok(p,b)==v of dgx_all[p][b][:]   (W_ih one-hot columns' grad;
  * tok defined as in FnGruFwd).  out is [V][N3]; ws >= fn_embed_grad_ws_bytes(T*B, V, N3). */
 size_t fn_embed_grad_ws_bytes(int64_t rows, int V, int N3);

@@ -47,6 +47,8 @@ SIGNATURES = {
     "fn_gru_sync_ws_bytes": (C.c_size_t, []),
     "fn_gru_seq_fwd": (C.c_int, [C.POINTER(FnGruFwd), C.c_int, vp]),
     "fn_gru_seq_bwd": (C.c_int, [C.POINTER(FnGruBwd), C.c_int, vp]),
+    "fn_gru_dwhh_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "fn_gru_dwhh_f32": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, C.c_float, vp, C.c_int, vp, C.c_size_t, vp]),
     "fn_embed_grad_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     "fn_embed_grad_f32": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     vp, vp, C.c_size_t, vp]),

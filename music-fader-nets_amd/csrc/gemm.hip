@@ -89,7 +89,8 @@ FN_DEVINL float f4c(const f32x4& v, int j) { return v[j]; }
 template <int PF>
 __global__ __launch_bounds__(NT) void gemm_tn_kernel(int M, int N, int K, float alpha, const float* __restrict__ A, long lda,
                                                      const float* __restrict__ B, long ldb, float beta, float* __restrict__ C, long ldc,
-                                                     const float* __restrict__ bias, int ksplit_len, float* __restrict__ slabs) {
+                                                     const float* __restrict__ bias, int ksplit_len, float* __restrict__ slabs,
+                                                     const float* __restrict__ A2, long lda2, int msplit) {
     const int ntn = (N + 127) / 128, ntm = (M + 127) / 128;
     const int tile = fn_xcd_remap(blockIdx.x, ntn * ntm);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -97,7 +98,10 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(int M, int N, int K, float 
     const int li = lane & 15, lg = lane >> 4;
     const int kbeg = blockIdx.z * ksplit_len, kend = min(K, kbeg + ksplit_len);
     // column offsets clamped inside the padded row (results of out-of-range rows/cols are never stored)
-    const long ca = min((long)m0 + 4 * li, lda - 4), cb = min((long)n0 + 4 * li, ldb - 4);
+    // optional second source for the output rows >= msplit (a multiple of the 128-row tile): A = [A | A2] along M
+    if (A2 != nullptr && m0 >= msplit) { A = A2 - msplit; lda = lda2; }
+    const long ca = A2 != nullptr && m0 >= msplit ? msplit + min((long)(m0 - msplit) + 4 * li, lda - 4) : min((long)m0 + 4 * li, lda - 4);
+    const long cb = min((long)n0 + 4 * li, ldb - 4);
     f32x4 acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -300,7 +304,7 @@ int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha, co
         const int ntm = (M + 127) / 128, ntn = (N + 127) / 128;
         float* slabs = splitk > 1 ? ws : nullptr;
         hipLaunchKernelGGL(gemm_tn_kernel<8>, dim3(ntm * ntn, 1, splitk > 1 ? splitk : 1), dim3(NT), 0, st, M, N, K, alpha, A, (long)lda, B,
-                           (long)ldb, beta, C, (long)ldc, bias, klen, slabs);
+                           (long)ldb, beta, C, (long)ldc, bias, klen, slabs, (const float*)nullptr, 0L, 0);
         FN_CHECK_LAUNCH();
         if (splitk > 1) {
             const long total = (long)M * N;
@@ -314,6 +318,40 @@ int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha, co
     if (tiles128 * (splitk > 1 ? splitk : 1) >= 96)
         return launch_gemm<128, 128, 16, 2, 2>(a_kmajor, b_kmajor, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, splitk, ws, st);
     return launch_gemm<64, 64, 16, 2, 2>(a_kmajor, b_kmajor, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, splitk, ws, st);
+}
+
+size_t fn_gru_dwhh_ws_bytes(int H, int splitk) { return fn_gemm_ws_bytes(3 * H, H, splitk); }
+
+int fn_gru_dwhh_f32(const float* dgx, const float* dghn, const float* hprev, int64_t rows, int H, float beta, float* dW, int splitk,
+                    float* ws, size_t ws_bytes, void* stream) {
+    if (!dgx || !dghn || !hprev || !dW) return FN_E_NULL;
+    if (rows <= 0 || rows > 0x7fffffff || H <= 0) return FN_E_SHAPE;
+    if (splitk > 1 && (!ws || ws_bytes < fn_gru_dwhh_ws_bytes(H, splitk))) return FN_E_WORKSPACE;
+    const int M = 3 * H, N = H, K = (int)rows;
+    const bool one_launch = (2 * H) % 128 == 0 && (H % 4) == 0 && (((((uintptr_t)dgx) | ((uintptr_t)dghn) | ((uintptr_t)hprev)) & 15) == 0);
+    if (!one_launch) {          // two products: rows [0, 2H) from dgx, rows [2H, 3H) from dghn
+        int rc = fn_gemm_f32(0, 0, 2 * H, N, K, 1.0f, dgx, 3 * H, hprev, H, beta, dW, H, nullptr, splitk, ws, ws_bytes, stream);
+        if (rc != FN_OK) return rc;
+        return fn_gemm_f32(0, 0, H, N, K, 1.0f, dghn, H, hprev, H, beta, dW + (size_t)2 * H * H, H, nullptr, splitk, ws, ws_bytes, stream);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int klen = K;
+    if (splitk > 1) {
+        klen = ((K + splitk - 1) / splitk + 3) / 4 * 4;
+        splitk = (K + klen - 1) / klen;
+    }
+    const int ntm = (M + 127) / 128, ntn = (N + 127) / 128;
+    float* slabs = splitk > 1 ? ws : nullptr;
+    hipLaunchKernelGGL(gemm_tn_kernel<8>, dim3(ntm * ntn, 1, splitk > 1 ? splitk : 1), dim3(NT), 0, st, M, N, K, 1.0f, dgx, (long)3 * H, hprev,
+                       (long)H, beta, dW, (long)H, (const float*)nullptr, klen, slabs, dghn, (long)H, 2 * H);
+    FN_CHECK_LAUNCH();
+    if (splitk > 1) {
+        const long total = (long)M * N;
+        const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, slabs, splitk, M, N, 1.0f, beta, dW, (long)H, (const float*)nullptr);
+        FN_CHECK_LAUNCH();
+    }
+    return FN_OK;
 }
 
 int fn_transpose_f32(const float* src, int R, int C, int src_ld, float* dst, int dst_ld, void* stream) {

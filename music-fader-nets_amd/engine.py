@@ -318,14 +318,11 @@ class Engine:
         dgx2 = dgx.view(T * B, 3 * H)
         dgn2 = dghn.view(T * B, H)
         if T > 1:
-            hprev = h_all.view(T * B, H)[: (T - 1) * B]
-            ops.gemm(dgx2[B:, : 2 * H], hprev, dW[: 2 * H], a_k=False, b_k=False, splitk=splitk)
-            ops.gemm(dgn2[B:], hprev, dW[2 * H:], a_k=False, b_k=False, splitk=splitk)
+            ops.gru_dwhh(dgx2[B:], dgn2[B:], h_all.view(T * B, H)[: (T - 1) * B], dW, splitk=splitk)
         else:
             dW.zero_()
         if h0 is not None:
-            ops.gemm(dgx2[:B, : 2 * H], h0, dW[: 2 * H], a_k=False, b_k=False, beta=1.0)
-            ops.gemm(dgn2[:B], h0, dW[2 * H:], a_k=False, b_k=False, beta=1.0)
+            ops.gru_dwhh(dgx2[:B], dgn2[:B], h0, dW, beta=1.0)
         db = G[pfx + "bias_hh" + sfx]
         ops.colsum(rs[:, : 2 * H], db[: 2 * H])
         ops.colsum(rsn, db[2 * H:])

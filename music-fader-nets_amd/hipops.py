@@ -171,6 +171,17 @@ class HipOps:
             d.dgx_rowsum, d.dghn_rowsum, d.scratch = _p(s.get("dgx_rowsum")), _p(s.get("dghn_rowsum")), _p(s["scratch"])
         _lib.check(self.lib.fn_gru_seq_bwd(arr, len(scans), self.stream()), "fn_gru_seq_bwd")
 
+    def gru_dwhh(self, dgx, dghn, hprev, dW, beta=0.0, splitk=1):
+        """dW [3H][H] = beta*dW + [dgx[:, :2H] | dghn]^T hprev  (dgx [rows][3H], dghn / hprev [rows][H])."""
+        for t, nm in ((dgx, "dgx"), (dghn, "dghn"), (hprev, "hprev"), (dW, "dW")):
+            _dense(t, name=nm)
+        rows, H = hprev.shape
+        if tuple(dgx.shape) != (rows, 3 * H) or tuple(dghn.shape) != (rows, H) or tuple(dW.shape) != (3 * H, H):
+            raise RuntimeError("gru_dwhh shape mismatch")
+        wsb = int(self.lib.fn_gru_dwhh_ws_bytes(H, splitk))
+        ws = self.workspace(wsb, "gemm") if wsb else None
+        _lib.check(self.lib.fn_gru_dwhh_f32(_p(dgx), _p(dghn), _p(hprev), rows, H, beta, _p(dW), splitk, _p(ws), wsb, self.stream()), "fn_gru_dwhh_f32")
+
     def embed_grad(self, dgx_all, idx, idx_shift, start_token, reverse, V, out):
         _dense(dgx_all, name="dgx_all"), _dense(idx, torch.int32, "idx"), _dense(out, name="out")
         T, B, N3 = dgx_all.shape

@@ -129,6 +129,11 @@ class FakeOps:
             if s.get("dh0") is not None:
                 s["dh0"].copy_(carry)
 
+    def gru_dwhh(self, dgx, dghn, hprev, dW, beta=0.0, splitk=1):
+        H = hprev.shape[1]
+        g = torch.cat([dgx[:, : 2 * H], dghn], dim=1)
+        dW.copy_(beta * dW + g.t() @ hprev)
+
     def embed_grad(self, dgx_all, idx, idx_shift, start_token, reverse, V, out):
         T, B, N3 = dgx_all.shape
         out.zero_()

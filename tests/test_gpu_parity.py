@@ -207,6 +207,18 @@ def test_gru_scan_fwd_bwd_kernels(ops, B, T, H, mode):
         close(out_d, out_c, 5e-5, "embed_grad[%d]" % i)
 
 
+@pytest.mark.parametrize("rows,H,splitk,beta", [(37, 64, 1, 0.0), (1030, 64, 4, 1.0), (300, 96, 4, 0.0), (5000, 512, 8, 1.0)])
+def test_gru_weight_gradient(ops, rows, H, splitk, beta):
+    """fn_gru_dwhh_f32: dW_hh = beta dW_hh + [dgx[:, :2H] | dghn]^T hprev (one split-A launch when 2H % 128 == 0, else two products)."""
+    torch.manual_seed(rows + H)
+    dgx, dghn, hp = torch.randn(rows, 3 * H), torch.randn(rows, H), torch.randn(rows, H)
+    dW0 = torch.randn(3 * H, H)
+    ref = beta * dW0.double() + torch.cat([dgx[:, : 2 * H], dghn], 1).double().t() @ hp.double()
+    dW = g(dW0)
+    ops.gru_dwhh(g(dgx), g(dghn), g(hp), dW, beta=beta, splitk=splitk)
+    close(dW, ref.float(), 2e-5 * max(1.0, (rows ** 0.5)))
+
+
 def test_time_sum(ops):
     torch.manual_seed(4)
     X = torch.randn(67, 37, 96)
