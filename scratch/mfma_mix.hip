@@ -12,6 +12,14 @@ __global__ __launch_bounds__(256) void k(float* out, const float* in, int iters,
     f32x4 A[4], B[4];
     for (int i = 0; i < 4; ++i) { A[i] = *(const f32x4*)(in + threadIdx.x * 4 + i * 1024); B[i] = *(const f32x4*)(in + 4096 + threadIdx.x * 4 + i * 1024); }
     const float* gp = in + (blockIdx.x & 63) * 4096 + threadIdx.x * 4;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const unsigned long long base = (unsigned long long)(in + (blockIdx.x & 63) * 4096);
+    i32x4 rsrc;
+    rsrc[0] = __builtin_amdgcn_readfirstlane((int)(base & 0xffffffffu));
+    rsrc[1] = __builtin_amdgcn_readfirstlane((int)((base >> 32) & 0xffff));
+    rsrc[2] = 1 << 20;
+    rsrc[3] = 0x00020000;
+    const int voff = threadIdx.x * 16;
     long long t0 = clock64();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -24,10 +32,12 @@ __global__ __launch_bounds__(256) void k(float* out, const float* in, int iters,
                           asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(A[q]) : "v"(gp + ((it * 4 + q) & 15) * 256) : "memory"); }
             if (V == 5) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(A[(q + 2) & 3]) : "v"(gp + ((it * 4 + q) & 15) * 256) : "memory"); }
             if (V == 6) { B[(q + 2) & 3] = *(const f32x4*)(lds + ((threadIdx.x * 4 + it * 64 + q * 1024) & 4092)); }
+            if (V == 8) { asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(A[(q + 2) & 3]) : "v"(voff + ((it * 4 + q) & 15) * 1024), "s"(rsrc) : "memory"); }
+            if (V == 9) { asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen sc1" : "=v"(A[(q + 2) & 3]) : "v"(voff + ((it * 4 + q) & 15) * 1024), "s"(rsrc) : "memory"); }
             if (V == 7) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(A[(q + 2) & 3]) : "v"(gp + ((it * 4 + q) & 15) * 256) : "memory"); }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if ((V == 3 || V == 4 || V == 5 || V == 7) && (it & 63) == 63) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if ((V == 3 || V == 4 || V == 5 || V >= 7) && (it & 63) == 63) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     long long t1 = clock64();
     f32x4 s = acc[0] + acc[1] + acc[2] + acc[3] + A[0] + A[1] + A[2] + A[3];
@@ -52,5 +62,7 @@ int main() {
     run<5>("global_load into the registers used 2 groups ago", d, in, c);
     run<6>("ds_read_b128 into the registers used 2 groups ago", d, in, c);
     run<7>("global_load (no sc1) into the registers used 2 groups ago", d, in, c);
+    run<8>("buffer_load offen into the registers used 2 groups ago", d, in, c);
+    run<9>("buffer_load offen sc1 into the registers used 2 groups ago", d, in, c);
     return 0;
 }

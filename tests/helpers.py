@@ -67,3 +67,42 @@ def grad_tolerances(gold, tag, exact):
         ref = gold["grad_%s/%s" % (tag, k)]
         tol[k] = max(5e-4, 4.0 * relerr(ref, ex))
     return tol
+
+
+def epoch_loaders(g):
+    """the four loaders of tests/golden/epoch.npz, batches laid out as the reference's DataLoaders yield them"""
+    def dl(name, n, width):
+        out = []
+        for i in range(n):
+            x = [g["%s%d_%d" % (name, i, j)] for j in range(width)]
+            out.append(tuple(torch.from_numpy(np.asarray(t)) if j < width - 2 else np.asarray(t) for j, t in enumerate(x)))
+        return out
+    return dl("vt", 2, 8), dl("vv", 1, 8), dl("yt", 2, 6), dl("yv", 1, 6)
+
+
+def check_epoch_run(pkg, m, g, tmp_path, rtol):
+    """run pkg.training_phase on the golden loaders and compare every printed number and the saved checkpoint with what the
+    reference's own training_phase (trainer_gmm.py:306-467) printed / saved (tests/golden/make_golden_epoch.py)"""
+    import re
+    tr = pkg.GMVAETrainer(m, lr=1e-3, beta=0.2)
+    vt, vv, yt, yv = epoch_loaders(g)
+    lines = []
+    save_path = os.path.join(str(tmp_path), "golden.pt")
+    torch.manual_seed(4242)
+    step = pkg.training_phase(tr, int(g["start_step"]), 2, vt, vv, yt, yv, save_path, name="golden", log=lines.append)
+    assert step == int(g["start_step"]) + 8
+    ref = [str(l) for l in g["lines"]]
+    assert len(lines) == len(ref), (lines, ref)
+    num = re.compile(r"-?\d+\.\d+")
+    for got, want in zip(lines[:-1], ref[:-1]):
+        assert num.sub("#", got) == num.sub("#", want), (got, want)              # same text, same number of fields
+        a, b = [float(x) for x in num.findall(got)], [float(x) for x in num.findall(want)]
+        np.testing.assert_allclose(a, b, rtol=rtol, atol=2e-4, err_msg=want)     # printed with 4-5 decimals
+    assert lines[-1].startswith("Model saved as ") and ref[-1].startswith("Model saved as ")
+    saved = torch.load(save_path)
+    want_keys = [k[len("wend/"):] for k in g.keys() if k.startswith("wend/")]
+    assert sorted(saved.keys()) == sorted(want_keys)
+    assert all(v.device.type == "cpu" for v in saved.values())
+    stamped = [f for f in os.listdir(str(tmp_path)) if f.startswith("golden_") and f.endswith(".pt")]
+    assert len(stamped) == 1
+    return saved

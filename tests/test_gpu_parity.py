@@ -487,6 +487,19 @@ def test_three_train_steps_vs_reference_train(case, small, c0):
     np.testing.assert_allclose(ev, gold["eval_tuple"], rtol=5e-4)
 
 
+def test_epoch_driver_vs_reference_training_phase(tmp_path):
+    """the reference's training_phase (two epochs, supervised + unsupervised halves) on the HIP path: same log lines, same checkpoint"""
+    from helpers import check_epoch_run
+    g = load_golden("epoch")
+    pkg = load_package()
+    m = make_model(64, 32, device=DEV)
+    saved = check_epoch_run(pkg, m, g, tmp_path, rtol=5e-4)
+    for k, v in saved.items():
+        if k not in NOISE_PARAMS:
+            np.testing.assert_allclose(v.numpy(), g["wend/" + k], rtol=0, atol=1e-3, err_msg=k)
+    assert not m.engine().ops.gru_sync_error()
+
+
 @pytest.mark.parametrize("case", ["small", "c0"])
 def test_greedy_decode_tokens(case, small, c0):
     gold = small if case == "small" else c0

@@ -147,3 +147,21 @@ def test_encode_and_fader_sweep_shapes(small):
                                         pkg.convert_to_one_hot(n, 16), torch.from_numpy(small["fw_z_n"]))
     np.testing.assert_allclose(r_out.numpy(), small["fw_r_out"], rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(n_out.numpy(), small["fw_n_out"], rtol=2e-5, atol=2e-5)
+
+
+def test_epoch_driver_vs_reference_training_phase(tmp_path):
+    """two epochs (supervised + unsupervised halves, evaluation at step-1, checkpoint every epoch) print the same
+    numbers as the reference's training_phase and save a reference-format checkpoint that loads back (CPU semantics backend)."""
+    from helpers import check_epoch_run
+    g = load_golden("epoch")
+    pkg = load_package()
+    m = make_model(64, 32, ops=FakeOps())
+    saved = check_epoch_run(pkg, m, g, tmp_path, rtol=2e-4)
+    for k, v in saved.items():
+        if k not in NOISE_PARAMS:
+            np.testing.assert_allclose(v.numpy(), g["wend/" + k], rtol=0, atol=5e-4, err_msg=k)   # 8 Adam steps of 1e-3
+    # checkpoint interop (trainer_gmm.py:46-48): the file loads into a fresh model, strictly
+    m2 = make_model(64, 32, ops=FakeOps(), seed=5)
+    m2.load_state_dict(saved, strict=True)
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v, saved[k]), k
