@@ -1,6 +1,7 @@
 import os, sys, shutil
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-if os.environ.get("HALF") == "1":
-    shutil.copy(os.path.join(R, "scratch/lib_halfA.so"), os.path.join(R, "music-fader-nets_amd/libfadernets_hip.so"))
+v = os.environ.get("KNOCK", "")
+if v:
+    shutil.copy(os.path.join(R, "scratch/lib_knock_%s.so" % v), os.path.join(R, "music-fader-nets_amd/libfadernets_hip.so"))
 sys.argv = [sys.argv[0], "x4only"]
 exec(open(os.path.join(R, "scratch/test_persist.py")).read())
