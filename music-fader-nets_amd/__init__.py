@@ -4,9 +4,10 @@ The directory name contains '-' (it follows the upstream repo name), so import i
 ``mfn_import.load_package()`` at the repo root, which registers it as ``music_fader_nets_amd``.
 """
 from .gmm_model import MusicAttrRegGMVAE  # noqa: F401
-from .trainer import GMVAETrainer, beta_schedule, convert_to_one_hot  # noqa: F401
+from .trainer import GMVAETrainer, VAETrainer, beta_schedule, convert_to_one_hot  # noqa: F401
+from .vae_model import MusicAttrRegVAE  # noqa: F401
 from .decode import clean_output, fader_sweep, greedy_decode  # noqa: F401
 from .epochs import cpu_state_dict, training_phase  # noqa: F401
 
-__all__ = ["MusicAttrRegGMVAE", "GMVAETrainer", "beta_schedule", "convert_to_one_hot", "clean_output", "fader_sweep",
+__all__ = ["MusicAttrRegGMVAE", "MusicAttrRegVAE", "GMVAETrainer", "VAETrainer", "beta_schedule", "convert_to_one_hot", "clean_output", "fader_sweep",
            "greedy_decode", "training_phase", "cpu_state_dict"]

@@ -483,7 +483,8 @@ class Engine:
             ops.latent_bwd(pre[e], S["eps"][e], P["mu_%s_lookup.weight" % e], P["logvar_%s_lookup.weight" % e], S["labels"],
                            lat[e]["z"], lat[e]["qy"], up["g_z"], up.get("g_mu"), up.get("g_sigma"), up.get("g_ll"), up.get("g_qy"),
                            w3, dpre, dmu_rows)
-            ops.colsum(dmu_rows, G["mu_%s_lookup.weight" % e].view(-1))
+            if "mu_%s_lookup.weight" % e in G:           # the plain-VAE sibling has no component means to train
+                ops.colsum(dmu_rows, G["mu_%s_lookup.weight" % e].view(-1))
             hf = self._bufs["enc_h_" + e][T - 1]
             hb = self._bufs["enc_h_" + e + "_reverse"][T - 1]
             dhf, dhb = self.buf("enc_dhf_" + e, (B, H)), self.buf("enc_dhb_" + e, (B, H))

@@ -84,14 +84,17 @@ class MusicAttrRegGMVAE(nn.Module):
         if self._engine is None or self._engine_key != key:
             from .hipops import HipOps
             ops = self._ops_override if getattr(self, "_ops_override", None) is not None else HipOps(dev)
-            params = {k: p.data for k, p in self.named_parameters()}
-            self._engine = Engine(ops, params, self.hidden_dims, self.latent_dim, self.n_component, dev)
+            self._engine = Engine(ops, self._engine_params(), self.hidden_dims, self.latent_dim, self.n_component, dev)
             self._engine_key = key
             self._weights_version = -1
         if self._weights_version != self._version:
             self._engine.refresh_weights()
             self._weights_version = self._version
         return self._engine
+
+    def _engine_params(self):
+        """name -> tensor table the engine works on (subclasses may add tensors that are not parameters)"""
+        return {k: p.data for k, p in self.named_parameters()}
 
     def weights_changed(self):
         """Tell the engine that parameter values changed (optimizer.step(), load_state_dict): the transposed

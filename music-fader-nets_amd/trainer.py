@@ -288,6 +288,27 @@ class GMVAETrainer:
         return math.sqrt(float(self.sumsq.item()))
 
 
+class VAETrainer(GMVAETrainer):
+    """Step of the vanilla-VAE sibling (reference ``trainer.py:87-187``): CE + KL-to-N(0,1) + the pairwise regulariser.
+
+    Quirk reproduced on purpose: the reference's ``loss_function`` reads the MODULE-LEVEL ``step`` (trainer.py:57,93), which its
+    ``train(step, ...)`` never updates (it increments its own argument, :135,159), so ``beta0`` is 0 for the whole run and the KL term
+    never contributes to the loss or the gradient.  ``train`` returns ``(step + 1, (loss, CE_X, CE_R, CE_N, l_r, l_n))`` (:161-162) and
+    ``evaluate`` takes no step (:165)."""
+
+    def __init__(self, model, lr=1e-3, beta=0.1, max_norm=1.0, dist_ctx=None):
+        super().__init__(model, lr=lr, beta=0.0, max_norm=max_norm, dist_ctx=dist_ctx)
+        self.beta_arg = beta                         # accepted like args['beta'] (trainer.py:150); without effect, see above
+
+    def train(self, step, d_oh, r_oh, n_oh, d, r, n, c, r_density, n_density, eps=None):
+        step, t8 = super().train(step, d_oh, r_oh, n_oh, d, r, n, c, r_density, n_density, eps=eps)
+        return step, t8[:6]
+
+    @torch.no_grad()
+    def evaluate(self, d_oh, r_oh, n_oh, d, r, n, c, r_density, n_density, eps=None):
+        return super().evaluate(0, d_oh, r_oh, n_oh, d, r, n, c, r_density, n_density, eps=eps)[:6]
+
+
 def convert_to_one_hot(input, dims):
     """trainer_gmm.py:296-303 (kept for callers that still build one-hot tensors; the kernels read indices)."""
     input = input.long()

@@ -106,3 +106,53 @@ def check_epoch_run(pkg, m, g, tmp_path, rtol):
     stamped = [f for f in os.listdir(str(tmp_path)) if f.startswith("golden_") and f.endswith(".pt")]
     assert len(stamped) == 1
     return saved
+
+
+def make_vae_model(hidden, zdim, device="cpu", ops=None, seed=1234):
+    """seeded MusicAttrRegVAE (model_v2.py:9) from the package, on the test backend `ops` (CPU) or the HIP kernels (device)"""
+    pkg = load_package()
+    torch.manual_seed(seed)
+    m = pkg.MusicAttrRegVAE(roll_dims=342, rhythm_dims=3, note_dims=16, chroma_dims=24, hidden_dims=hidden, z_dims=zdim, n_step=20)
+    if ops is not None:
+        m._ops_override = ops
+    return m.to(device)
+
+
+def check_vae_against_reference(pkg, m, g, dev, rtol_fw, tol_grad, rtol_tuple, atol_w):
+    """drop-in forward, fused gradients, three train() steps and evaluate() of the vanilla-VAE sibling vs tests/golden/vae.npz"""
+    t = lambda k, dt=None: torch.from_numpy(g[k]).to(dev) if dt is None else torch.from_numpy(g[k]).to(dev).to(dt)
+    d, r, n, c = t("d"), t("r"), t("n"), t("c")
+    eps = (t("eps_r"), t("eps_n"))
+    sd = m.state_dict()
+    for k, v in sd.items():
+        np.testing.assert_allclose([float(v.double().sum()), float(v.double().abs().sum())], g["w0sum/" + k], rtol=1e-6, atol=1e-6, err_msg=k)
+    assert set(sd) == {k[len("w0sum/"):] for k in g if k.startswith("w0sum/")}
+    # drop-in forward: the reference's nested tuple (model_v2.py:165-171)
+    (out, r_out, n_out), (dis_r, dis_n), (z_r, z_n) = m(pkg.convert_to_one_hot(d, 342), pkg.convert_to_one_hot(r, 3), pkg.convert_to_one_hot(n, 16), c, eps=eps)
+    got = dict(out=out, r_out=r_out, n_out=n_out, mu_r=dis_r.mean, sigma_r=dis_r.stddev, mu_n=dis_n.mean, sigma_n=dis_n.stddev, z_r=z_r, z_n=z_n)
+    for k, v in got.items():
+        np.testing.assert_allclose(v.detach().cpu().numpy(), g["fw_" + k], rtol=rtol_fw, atol=rtol_fw, err_msg=k)
+    # fused step
+    tr = pkg.VAETrainer(m, lr=1e-3, beta=0.1)
+    batch = tr.prepare_batch(g["d"], g["r"], g["n"], g["c"], g["r_density"], g["n_density"])
+    tup = tr.loss_and_grads(5000, batch, eps)
+    np.testing.assert_allclose(tup[:6], g["loss_terms"], rtol=rtol_tuple)
+    for k in tr.flat.names:
+        ref = g["grad/" + k]
+        e = relerr(tr.flat.G[k].cpu().numpy(), ref)
+        assert e < tol_grad or np.abs(ref).max() < 1e-6, (k, e)
+    assert set(tr.flat.names) == {k[len("grad/"):] for k in g if k.startswith("grad/")}
+    np.testing.assert_allclose(tr.grad_norm(), g["gradnorm"][0], rtol=1e-3)
+    step = 5000
+    for it in range(3):
+        torch.manual_seed(99 + it)
+        step, tup = tr.train(step, None, None, None, g["d"], g["r"], g["n"], g["c"], g["r_density"], g["n_density"])
+        assert len(tup) == 6
+        np.testing.assert_allclose(tup, g["train_tuples"][it], rtol=rtol_tuple, err_msg="step %d" % it)
+    assert step == 5003
+    torch.manual_seed(123)
+    ev = tr.evaluate(None, None, None, g["d"], g["r"], g["n"], g["c"], g["r_density"], g["n_density"])
+    np.testing.assert_allclose(ev, g["eval_tuple"], rtol=rtol_tuple)
+    for k, v in m.state_dict().items():
+        if k not in NOISE_PARAMS:
+            np.testing.assert_allclose(v.cpu().numpy(), g["w3/" + k], rtol=0, atol=atol_w, err_msg=k)

@@ -500,6 +500,14 @@ def test_epoch_driver_vs_reference_training_phase(tmp_path):
     assert not m.engine().ops.gru_sync_error()
 
 
+def test_vae_sibling_vs_reference():
+    """model_v2.MusicAttrRegVAE + trainer.py's step on the HIP path vs the reference run (tests/golden/vae.npz)"""
+    from helpers import check_vae_against_reference, make_vae_model
+    pkg = load_package()
+    check_vae_against_reference(pkg, make_vae_model(64, 32, device=DEV), load_golden("vae"), DEV, rtol_fw=5e-5, tol_grad=5e-4,
+                                rtol_tuple=5e-4, atol_w=1e-3)
+
+
 @pytest.mark.parametrize("case", ["small", "c0"])
 def test_greedy_decode_tokens(case, small, c0):
     gold = small if case == "small" else c0

@@ -165,3 +165,11 @@ def test_epoch_driver_vs_reference_training_phase(tmp_path):
     m2.load_state_dict(saved, strict=True)
     for k, v in m2.state_dict().items():
         assert torch.equal(v, saved[k]), k
+
+
+def test_vae_sibling_vs_reference():
+    """model_v2.MusicAttrRegVAE + trainer.py (incl. its frozen-global-step quirk) on the same engine (CPU semantics backend)."""
+    from helpers import check_vae_against_reference, make_vae_model
+    pkg = load_package()
+    check_vae_against_reference(pkg, make_vae_model(64, 32, ops=FakeOps()), load_golden("vae"), "cpu", rtol_fw=2e-5, tol_grad=3e-4,
+                                rtol_tuple=3e-4, atol_w=1e-4)

@@ -184,3 +184,26 @@ def test_cpu_baseline_model_matches_reference_train(c0):
         eps_r, eps_n = torch.randn(B, Z), torch.randn(B, Z)
         tup = cpu_baseline.train_step(model, opt, _batch(c0), eps_r, eps_n, 19999 + it, beta=0.2)
         np.testing.assert_allclose(tup, c0["train_tuples"][it], rtol=3e-4)
+
+
+# ---- vanilla-VAE sibling (model_v2.MusicAttrRegVAE + trainer.py), pinned by tests/golden/vae.npz -------------------------------
+def test_vae_oracle_vs_reference(golden_dir):
+    from oracle import vae_oracle as vo
+    from helpers import relerr
+    g = _load(golden_dir, "vae")
+    H, Z = int(g["meta_dims"][0]), int(g["meta_dims"][1])
+    sd = vo.init_state_dict(H, Z)
+    for k, v in sd.items():                                   # seeded construction == the reference's (order of model_v2.py:26-60)
+        ref = g["w0sum/" + k]
+        np.testing.assert_allclose([float(v.double().sum()), float(v.double().abs().sum())], ref, rtol=1e-6, atol=1e-6, err_msg=k)
+    assert set(sd) == {k[len("w0sum/"):] for k in g if k.startswith("w0sum/")}
+    batch = {k: g[k] for k in ("d", "r", "n", "c", "r_density", "n_density")}
+    grads, tup, fw = vo.gradients(sd, batch, torch.from_numpy(g["eps_r"]), torch.from_numpy(g["eps_n"]))
+    for k in ("out", "r_out", "n_out", "mu_r", "sigma_r", "mu_n", "sigma_n", "z_r", "z_n"):
+        np.testing.assert_allclose(fw[k].detach().numpy(), g["fw_" + k], rtol=2e-5, atol=2e-5, err_msg=k)
+    np.testing.assert_allclose([float(t.detach()) for t in tup], g["loss_terms"], rtol=1e-5)
+    for k, gr in grads.items():
+        ref = g.get("grad/" + k)
+        assert ref is not None, k
+        assert relerr(gr.numpy(), ref) < 2e-4 or np.abs(ref).max() < 1e-6, (k, relerr(gr.numpy(), ref))
+    assert {k[len("grad/"):] for k in g if k.startswith("grad/")} == set(vo.trainable_used_keys(sd))
