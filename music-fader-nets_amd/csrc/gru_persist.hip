@@ -1,8 +1,9 @@
 // gru_persist.hip - weight-stationary GRU scans: ONE launch runs all T time steps of up to FN_MAX_SCANS scans
 // (encoders gmm_model.py:84,89; sub-decoders :109,114; decoder cells :131-136).
 //
-// Why: the per-step kernels of gru.hip re-stream W_hh (3 MB per scan) from HBM/MALL on every step (the per-XCD L2s are
-// invalidated at each kernel boundary) and pay a dependent-launch boundary per step; together that is 60 % of a step.
+// Why: the per-step kernels of gru.hip fetch W_hh (3 MB per scan) again on every step - 23 MB of HBM/MALL reads per 4-scan step
+// launch in the PMC counters, the per-XCD L2s do not keep it across kernel boundaries - and pay a dependent-launch boundary
+// (~2.7 us) per step: 24.5 us per encoder step against 10.2 us of MFMA time.  One launch per scan: 17.3 us (profiles/).
 //
 // Decomposition (H = 512: 32 unit slices x 8 row groups = 256 workgroups = one per CU):
 //   * workgroup (g, j): row group g = (scan, block of RPW batch rows), slice j = hidden units [16j, 16j+16) for all of
