@@ -99,6 +99,9 @@ typedef struct FnGruFwd {
     int32_t cu_budget;        /* compute units the single launch may occupy (scans[0]'s is used; 0 = all). */
                               /* Launches that can overlap on different streams must share the chip:       */
                               /* the sum of their budgets must not exceed the CU count.                    */
+    const float* h0_frag;     /* optional: h0 already in the fragment-major operand layout (fn_frag_floats(B,H)  */
+                              /* floats) - saves the packing launch of step-by-step decoding; h0 is still needed */
+    float* h_last_frag;       /* optional: the final state, fragment-major (the next call's h0_frag)       */
 } FnGruFwd;
 
 /* fragment-major operand image: floats needed for a [rows][K] matrix, and the packing kernel

@@ -19,7 +19,7 @@ class FnGruFwd(C.Structure):
     _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("H", C.c_int32), ("reverse", C.c_int32),
                 ("w_hh_frag", vp), ("b_hh", vp), ("b_ih", vp), ("h0", vp), ("gx_dense", vp), ("gx_table", vp),
                 ("idx", vp), ("idx_ld", C.c_int32), ("idx_shift", C.c_int32), ("start_token", C.c_int32),
-                ("gx_rowbias", vp), ("h_all", vp), ("gates", vp), ("frag_ws", vp), ("sync_ws", vp), ("cu_budget", C.c_int32)]
+                ("gx_rowbias", vp), ("h_all", vp), ("gates", vp), ("frag_ws", vp), ("sync_ws", vp), ("cu_budget", C.c_int32), ("h0_frag", vp), ("h_last_frag", vp)]
 
 
 class FnGruBwd(C.Structure):

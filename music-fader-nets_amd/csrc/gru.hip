@@ -504,7 +504,8 @@ int fn_gru_seq_fwd(const FnGruFwd* scans, int n_scans, void* stream) {
         if (!d.w_hh_frag || !d.b_hh || !d.h_all || !d.frag_ws) return FN_E_NULL;
         if (d.B <= 0 || d.T <= 0 || d.H <= 0 || (d.H % 32) != 0) return FN_E_SHAPE;
         if (d.gx_table && !d.idx) return FN_E_NULL;
-        if ((((uintptr_t)d.w_hh_frag) | ((uintptr_t)d.frag_ws)) & 15) return FN_E_ALIGN;
+        if ((((uintptr_t)d.w_hh_frag) | ((uintptr_t)d.frag_ws) | ((uintptr_t)d.h0_frag) | ((uintptr_t)d.h_last_frag)) & 15) return FN_E_ALIGN;
+        if (d.h0_frag && !d.h0) return FN_E_NULL;            // the gate epilogue reads the row-major state
         Tmax = d.T > Tmax ? d.T : Tmax;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -513,7 +514,7 @@ int fn_gru_seq_fwd(const FnGruFwd* scans, int n_scans, void* stream) {
         if (rc != FN_PERSIST_NA) return rc;
     }
     for (int s = 0; s < n_scans; ++s)          // initial states -> fragment-major (slot 0 of the ping-pong scratch)
-        if (scans[s].h0) {
+        if (scans[s].h0 && !scans[s].h0_frag) {
             const int rc = launch_pack(scans[s].h0, scans[s].B, scans[s].H, scans[s].H, scans[s].frag_ws, st);
             if (rc != FN_OK) return rc;
         }
@@ -536,8 +537,8 @@ int fn_gru_seq_fwd(const FnGruFwd* scans, int n_scans, void* stream) {
             const long FS = (long)fn_frag_floats(d.B, d.H);
             f.w_frag = d.w_hh_frag; f.b_hh = d.b_hh; f.b_ih = d.b_ih;
             f.h_prev = p == 0 ? d.h0 : d.h_all + (p - 1) * BH;
-            f.hf_in = d.frag_ws + (p & 1) * FS;
-            f.hf_out = p + 1 < d.T ? d.frag_ws + ((p + 1) & 1) * FS : nullptr;
+            f.hf_in = (p == 0 && d.h0_frag) ? d.h0_frag : d.frag_ws + (p & 1) * FS;
+            f.hf_out = p + 1 < d.T ? d.frag_ws + ((p + 1) & 1) * FS : d.h_last_frag;
             f.h_out = d.h_all + p * BH;
             f.gates = d.gates ? d.gates + (long)p * fn_gru_gates_floats(d.B, d.H) : nullptr;
             f.gx_dense = d.gx_dense ? d.gx_dense + p * 3 * BH : nullptr;

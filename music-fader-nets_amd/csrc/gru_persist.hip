@@ -605,7 +605,7 @@ int fn_gru_fwd_persist(const FnGruFwd* scans, int n_scans, hipStream_t st) {
     int Tmax = 0;
     for (int s = 0; s < n_scans; ++s) {
         const FnGruFwd& d = scans[s];
-        if (d.H != H) return FN_PERSIST_NA;
+        if (d.H != H || d.h_last_frag) return FN_PERSIST_NA;   // fragment-major hand-over of the last state: per-step path only
         // the epilogue moves 16-byte vectors
         const uintptr_t al = (uintptr_t)d.b_hh | (uintptr_t)d.b_ih | (uintptr_t)d.h0 | (uintptr_t)d.gx_dense | (uintptr_t)d.gx_table |
                              (uintptr_t)d.gx_rowbias | (uintptr_t)d.h_all | (uintptr_t)d.gates;

@@ -60,14 +60,20 @@ def _decode_body(eng, z, steps, want_logp, logp, tokens):
     ops.gemm(z, P["grucell_g.weight_ih"][:, E_VOCAB:], rbg)
     gx2 = eng.buf("dec_gx2", (1, Bi, 3 * H))
     logits = eng.buf("dec_logits", (Bi, LOGIT_LD))
+    # every cell also leaves its new state in the MFMA operand layout, which the next cell call takes as h0_frag: no packing launches
+    nf = ops.frag_floats(Bi, H)
+    hf0 = [eng.buf("dec_hf0_a", (nf,)), eng.buf("dec_hf0_b", (nf,))]
+    hf1 = [eng.buf("dec_hf1_a", (nf,)), eng.buf("dec_hf1_b", (nf,))]
     for i in range(steps):
         cur, prv = i & 1, (i & 1) ^ 1
         ops.gru_seq_fwd([dict(B=Bi, T=1, H=H, w_hh_frag=eng.whh_f["g"], b_hh=P["grucell_g.bias_hh"], b_ih=P["grucell_g.bias_ih"],
-                              h0=h0g if i == 0 else hx0[prv][0], gx_table=eng.tab["g"], idx=tokens, idx_shift=i - 1,
+                              h0=h0g if i == 0 else hx0[prv][0], h0_frag=None if i == 0 else hf0[prv], h_last_frag=hf0[cur],
+                              gx_table=eng.tab["g"], idx=tokens, idx_shift=i - 1,
                               start_token=E_VOCAB - 1, gx_rowbias=rbg, h_all=hx0[cur])])
         ops.gemm(hx0[cur][0], P["grucell_g_2.weight_ih"], gx2[0], bias=P["grucell_g_2.bias_ih"])
         ops.gru_seq_fwd([dict(B=Bi, T=1, H=H, w_hh_frag=eng.whh_f["g2"], b_hh=P["grucell_g_2.bias_hh"],
-                              h0=hx0[cur][0] if i == 0 else hx1[prv][0], gx_dense=gx2, h_all=hx1[cur])])
+                              h0=hx0[cur][0] if i == 0 else hx1[prv][0], h0_frag=hf0[cur] if i == 0 else hf1[prv], h_last_frag=hf1[cur],
+                              gx_dense=gx2, h_all=hx1[cur])])
         ops.gemm(hx1[cur][0], P["linear_out_g.weight"], logits[:, :E_VOCAB], bias=P["linear_out_g.bias"])
         ops.vocab_argmax(logits, E_VOCAB, logp[:, i, :] if want_logp else None, tokens[:, i])
     return logp, tokens

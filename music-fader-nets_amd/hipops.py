@@ -142,8 +142,11 @@ class HipOps:
     def gru_seq_fwd(self, scans, persistent=True, cu_budget=0):
         arr = (_lib.FnGruFwd * len(scans))()
         for i, (d, s) in enumerate(zip(arr, scans)):
-            for k in ("w_hh_frag", "b_hh", "b_ih", "h0", "gx_dense", "gx_table", "gx_rowbias", "h_all", "gates"):
+            for k in ("w_hh_frag", "b_hh", "b_ih", "h0", "gx_dense", "gx_table", "gx_rowbias", "h_all", "gates", "h0_frag", "h_last_frag"):
                 _dense(s.get(k), name=k)
+            for k in ("h0_frag", "h_last_frag"):
+                if s.get(k) is not None and s[k].numel() < self.frag_floats(s["B"], s["H"]):
+                    raise RuntimeError("%s needs frag_floats(B, H) floats" % k)
             d.frag_ws = _p(self._frag_ws("fragf", i, 2 * self.frag_floats(s["B"], s["H"])))
             d.sync_ws = _p(self._sync_ws()) if persistent else None
             d.cu_budget = int(cu_budget)
@@ -154,6 +157,7 @@ class HipOps:
             d.idx_ld = s["idx"].shape[1] if s.get("idx") is not None else 0
             d.idx_shift, d.start_token = int(s.get("idx_shift", 0)), int(s.get("start_token", 0))
             d.gx_rowbias, d.h_all, d.gates = _p(s.get("gx_rowbias")), _p(s["h_all"]), _p(s.get("gates"))
+            d.h0_frag, d.h_last_frag = _p(s.get("h0_frag")), _p(s.get("h_last_frag"))
         _lib.check(self.lib.fn_gru_seq_fwd(arr, len(scans), self.stream()), "fn_gru_seq_fwd")
 
     def gru_seq_bwd(self, scans, persistent=True, cu_budget=0):

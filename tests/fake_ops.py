@@ -79,6 +79,8 @@ class FakeOps:
         for s in scans:
             B, T, H = s["B"], s["T"], s["H"]
             h = s["h0"] if s.get("h0") is not None else torch.zeros(B, H)
+            if s.get("h0_frag") is not None:          # the operand image and the row-major state must describe the same h0
+                assert torch.equal(s["h0_frag"][: B * H].view(B, H), h)
             for p in range(T):
                 gx = torch.zeros(B, 3 * H)
                 if s.get("b_ih") is not None:
@@ -98,6 +100,8 @@ class FakeOps:
                 if s.get("gates") is not None:
                     g = self._gview(s["gates"], p, B, H)
                     g[:, 0].copy_(r), g[:, 1].copy_(z), g[:, 2].copy_(n), g[:, 3].copy_(gh[:, 2 * H:])
+            if s.get("h_last_frag") is not None:
+                self.frag_pack(h, s["h_last_frag"])
 
     def gru_seq_bwd(self, scans, persistent=True, cu_budget=0):
         self.calls.append("gru_seq_bwd")
