@@ -315,7 +315,9 @@ int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha, co
         return FN_OK;
     }
     const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    if (tiles128 * (splitk > 1 ? splitk : 1) >= 96)
+    // 128 x 128 tiles only when they fill the chip (one workgroup per CU); below that the 64 x 64 kernel's 4x more workgroups win
+    // (decode at 2048 rows: 192 big tiles -> 55 us, 768 small ones -> 40 us per W_ih2 projection)
+    if (tiles128 * (splitk > 1 ? splitk : 1) >= 256)
         return launch_gemm<128, 128, 16, 2, 2>(a_kmajor, b_kmajor, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, splitk, ws, st);
     return launch_gemm<64, 64, 16, 2, 2>(a_kmajor, b_kmajor, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, splitk, ws, st);
 }
