@@ -254,10 +254,20 @@ class GMVAETrainer:
         else:
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
-            with torch.cuda.graph(g):
+            try:
+                with torch.cuda.graph(g):
+                    self._step_body(step, sbatch, seps)
+            except Exception as e:                  # e.g. a collective library that cannot be captured: keep training, eagerly
+                import warnings
+                warnings.warn("hipGraph capture of the training step failed (%s: %s); continuing with eager launches" % (type(e).__name__, e))
+                self.use_graph = False
+                if self.dist is not None:
+                    self.dist._pending = []           # work handles of the aborted capture
+                torch.cuda.synchronize()
                 self._step_body(step, sbatch, seps)
-            self._graphs[key] = g                   # the capture itself does not execute: run the step now
-            g.replay()
+            else:
+                self._graphs[key] = g               # the capture itself does not execute: run the step now
+                g.replay()
         st["runs"] += 1
         m._weights_version = m._version
         return beta0, Bg
