@@ -207,6 +207,46 @@ def test_gru_scan_fwd_bwd_kernels(ops, B, T, H, mode):
         close(out_d, out_c, 5e-5, "embed_grad[%d]" % i)
 
 
+def test_weight_stationary_scans_random_configurations(ops):
+    """60 random (scans, rows, lengths, H, input kinds, CU budgets) drawn with a fixed seed: the single-launch scans, run three times
+    in a row on the same buffers (cache-warm exchange slabs), must reproduce the per-step kernels (forward state + saved gates)."""
+    rng = np.random.RandomState(5)
+    V = 57
+    for case in range(60):
+        H = int(rng.choice([64, 96, 128, 512]))
+        B = int(rng.choice([1, 5, 16, 33, 64, 100, 200, 256]))
+        budget = int(rng.choice([0, 0, 128]))
+        scans = []
+        for s in range(int(rng.randint(1, 5))):
+            T = int(rng.randint(2, 24))
+            wf = torch.zeros(ops.frag_floats(3 * H, H), device=DEV)
+            ops.frag_pack((torch.randn(3 * H, H, device=DEV) / H ** 0.5).contiguous(), wf)
+            d = dict(B=B, T=T, H=H, reverse=int(rng.randint(2)), w_hh_frag=wf, b_hh=torch.randn(3 * H, device=DEV) * 0.1,
+                     h_all=torch.zeros(T, B, H, device=DEV), gates=torch.zeros(T, ops.gates_floats(B, H), device=DEV))
+            if rng.rand() < 0.6:
+                d["h0"] = torch.randn(B, H, device=DEV) * 0.3
+            if rng.rand() < 0.5:
+                d["gx_table"] = torch.randn(V, 3 * H, device=DEV) * 0.3
+                d["idx"] = torch.randint(0, V, (B, T + 1), dtype=torch.int32, device=DEV)
+                if rng.rand() < 0.3:
+                    d["idx_shift"], d["start_token"] = -1, V - 1
+            else:
+                d["gx_dense"] = torch.randn(T, B, 3 * H, device=DEV) * 0.3
+            if rng.rand() < 0.5:
+                d["gx_rowbias"] = torch.randn(B, 3 * H, device=DEV) * 0.2
+            scans.append(d)
+        ops.gru_seq_fwd(scans, persistent=False)
+        ref = [(d["h_all"].clone(), d["gates"].clone()) for d in scans]
+        for rep in range(3):
+            for d in scans:
+                d["h_all"].fill_(float("nan"))
+            ops.gru_seq_fwd(scans, persistent=True, cu_budget=budget)
+            for (h, gt), d in zip(ref, scans):
+                close(d["h_all"], h, 2e-5, "case %d rep %d h_all" % (case, rep))
+                close(d["gates"], gt, 2e-5, "case %d rep %d gates" % (case, rep))
+    assert not ops.gru_sync_error()
+
+
 @pytest.mark.parametrize("rows,H,splitk,beta", [(37, 64, 1, 0.0), (1030, 64, 4, 1.0), (300, 96, 4, 0.0), (5000, 512, 8, 1.0)])
 def test_gru_weight_gradient(ops, rows, H, splitk, beta):
     """fn_gru_dwhh_f32: dW_hh = beta dW_hh + [dgx[:, :2H] | dghn]^T hprev (one split-A launch when 2H % 128 == 0, else two products)."""
