@@ -39,7 +39,6 @@ class Engine:
         self.persist_dec = __import__("os").environ.get("FN_PERSIST_DEC", "1") == "1"
         self._lane_alias = {}           # lane -> lane it is folded into (debug / tuning: FN_AUX=0 runs the aux lane on the side stream)
         self._aux_mode = __import__("os").environ.get("FN_AUX", "1")      # 1 | 0 | fwd | bwd
-        self.split_encoders = __import__("os").environ.get("FN_SPLIT_ENC", "0") == "1"   # measured: no gain on MI355X (profiles/), kept as a switch
         if hidden % 32 != 0:
             raise ValueError("hidden_dims must be a multiple of 32 (K chunks of the MFMA step kernels)")
         if n_component > 8:
@@ -166,16 +165,7 @@ class Engine:
                 scans.append(dict(B=B, T=T, H=H, reverse=rev, w_hh_frag=self.whh_f[key], b_hh=P[pfx + "bias_hh" + sfx],
                                   b_ih=P[pfx + "bias_ih" + sfx], gx_table=self.tab[key], idx=d, idx_shift=0,
                                   h_all=hall[key], gates=self.buf("enc_g_" + key, (T, ops.gates_floats(B, H))) if save else None))
-        # the two encoders run on the two streams: their step kernels drift out of phase, so one's gate epilogue /
-        # operand latency overlaps the other's MFMA loop (each launch alone leaves the matrix pipes idle ~55 % of the time)
-        if self.split_encoders and self._side_stream() is not None:
-            self.side_wait_main()
-            with self.on_side():
-                ops.gru_seq_fwd(scans[2:])
-            ops.gru_seq_fwd(scans[:2])
-            self.main_wait_side()
-        else:
-            ops.gru_seq_fwd(scans)
+        ops.gru_seq_fwd(scans)
         pre = {}
         for e in ("r", "n"):
             hf, hb = hall[e][T - 1], hall[e + "_reverse"][T - 1]
@@ -503,14 +493,7 @@ class Engine:
                 scans.append(dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t[key], h0=None, h_all=self._bufs["enc_h_" + key],
                                   gates=self._bufs["enc_g_" + key], dh_last=dh, dgx_all=encb[key]["dgx"], dghn_all=encb[key]["dghn"],
                                   scratch=self.buf("enc_scr_" + key, (B, H)), dgx_rowsum=encb[key]["rs"], dghn_rowsum=encb[key]["rsn"]))
-        if self.split_encoders and self._side_stream() is not None:
-            self.side_wait_main()
-            with self.on_side():
-                ops.gru_seq_bwd(scans[2:])
-            ops.gru_seq_bwd(scans[:2])
-            self.main_wait_side()
-        else:
-            ops.gru_seq_bwd(scans)    # 4 concurrent reverse scans
+        ops.gru_seq_bwd(scans)        # 4 concurrent reverse scans, one weight-stationary launch
         for e in ("r", "n"):
             for key, sfx, rev in ((e, "_l0", 0), (e + "_reverse", "_l0_reverse", 1)):
                 pfx = "gru_%s." % e
