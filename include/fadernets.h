@@ -164,6 +164,35 @@ int fn_embed_grad_f32(const float* dgx_all, int B, int T, int N3, const int32_t*
 /* out[m] = sum_t X[t*M + m]   (per-sequence sums over time of the gate gradients; M % 4 == 0, 16-byte aligned) */
 int fn_time_sum_f32(const float* X, int T, int64_t M, float* out, void* stream);
 
+/* Greedy autoregressive decode of the global decoder for SMALL batches (B <= 64, H <= 512) as ONE launch
+ * (gmm_model.py:119-149 with model.eval(): layer-1 cell, layer-2 cell (state initialised with the first layer-1 state, :134-135),
+ * 512 -> V output layer, log_softmax, feedback = first-index argmax, :73-80,147-148).  Workgroup sets keep the four weight
+ * matrices in LDS and hand activations over through L2 (bounded spins, sticky error word as in fn_gru_seq_fwd). */
+typedef struct FnDecode {
+    int32_t B, steps, H, V;
+    int32_t start_token;      /* input token of step 0 (V - 1)                                       */
+    const float* w_hh1_frag;  /* fn_frag_pack(grucell_g.weight_hh [3H][H])                            */
+    const float* b_hh1;       /* [3H]                                                                */
+    const float* b_ih1;       /* [3H] or NULL                                                        */
+    const float* table1;      /* [V][3H] = grucell_g.weight_ih[:, :V]^T (token rows)                  */
+    const float* rowbias1;    /* [B][3H] = z @ grucell_g.weight_ih[:, V:]^T, or NULL                  */
+    const float* h0;          /* [B][H] = linear_init_global(z)                                       */
+    const float* w_ih2_frag;  /* fn_frag_pack(grucell_g_2.weight_ih [3H][H])                          */
+    const float* b_ih2;       /* [3H] or NULL                                                        */
+    const float* w_hh2_frag;  /* fn_frag_pack(grucell_g_2.weight_hh [3H][H])                          */
+    const float* b_hh2;       /* [3H]                                                                */
+    const float* w_out_frag;  /* fn_frag_pack(linear_out_g.weight [V][H])                             */
+    const float* b_out;       /* [V]                                                                 */
+    int32_t* tokens;          /* out [B][tok_ld]: token of every step                                */
+    int32_t tok_ld;
+    float* logp;              /* out [B][steps][V] log-probabilities, or NULL                        */
+    float* ws;                /* fn_decode_ws_bytes(B, H, V) bytes, 16-byte aligned                   */
+    void* sync_ws;            /* fn_decode_sync_ws_bytes() bytes, zero-filled once by the caller       */
+} FnDecode;
+size_t fn_decode_ws_bytes(int B, int H, int V);
+size_t fn_decode_sync_ws_bytes(void);
+int fn_decode_greedy(const FnDecode* d, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Output heads
  * ------------------------------------------------------------------------------------------ */

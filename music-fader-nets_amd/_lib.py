@@ -29,6 +29,13 @@ class FnGruBwd(C.Structure):
                 ("sync_ws", vp), ("cu_budget", C.c_int32)]
 
 
+class FnDecode(C.Structure):
+    _fields_ = [("B", C.c_int32), ("steps", C.c_int32), ("H", C.c_int32), ("V", C.c_int32), ("start_token", C.c_int32),
+                ("w_hh1_frag", vp), ("b_hh1", vp), ("b_ih1", vp), ("table1", vp), ("rowbias1", vp), ("h0", vp),
+                ("w_ih2_frag", vp), ("b_ih2", vp), ("w_hh2_frag", vp), ("b_hh2", vp), ("w_out_frag", vp), ("b_out", vp),
+                ("tokens", vp), ("tok_ld", C.c_int32), ("logp", vp), ("ws", vp), ("sync_ws", vp)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/fadernets.h
 SIGNATURES = {
     "fn_version": (C.c_int, []),
@@ -47,6 +54,9 @@ SIGNATURES = {
     "fn_gru_sync_ws_bytes": (C.c_size_t, []),
     "fn_gru_seq_fwd": (C.c_int, [C.POINTER(FnGruFwd), C.c_int, vp]),
     "fn_gru_seq_bwd": (C.c_int, [C.POINTER(FnGruBwd), C.c_int, vp]),
+    "fn_decode_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "fn_decode_sync_ws_bytes": (C.c_size_t, []),
+    "fn_decode_greedy": (C.c_int, [C.POINTER(FnDecode), vp]),
     "fn_gru_dwhh_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "fn_gru_dwhh_f32": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, C.c_float, vp, C.c_int, vp, C.c_size_t, vp]),
     "fn_embed_grad_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),

@@ -1,0 +1,383 @@
+// decode_persist.hip - greedy autoregressive decode of the global decoder (gmm_model.py:119-149 with model.eval()) for SMALL batches
+// (<= 64 sequences) as ONE launch: the per-token chain  layer-1 cell -> W_ih2 projection -> layer-2 cell -> 512->V output layer ->
+// log-softmax + argmax -> next token  is latency-bound (five dependent kernels per token otherwise), so each link gets its own set
+// of workgroups that keep their weight slice in LDS for the whole decode and hand the activations to the next set through L2:
+//
+//   L1  (H/16 workgroups)  W_hh1 slice [48 x H]    waits C1(t-1), then token t-1 -> h1_t slice -> X1[t&1]  arrive C1
+//   P2  (H/16)             W_ih2 slice [48 x H]    waits C1                   -> gx2 slice    -> G2        arrive C2
+//   L2  (H/16)             W_hh2 slice [48 x H]    waits C3(t-1) [C1 at t=0], then C2 -> h2_t -> X2[t&1]   arrive C3
+//   OUT (ceil(V/16))       W_out slice [16 x H]    waits C3                   -> logits slice -> LOGITS    arrive C4
+//   ARG (1)                -                       waits C4                   -> log-softmax, first-index argmax -> token t, arrive C5
+//
+// Every hand-over is recipe R1 of the guide (write-through sc1 payload, every wave drains vmcnt, barrier, one relaxed agent-scope
+// atomic on a monotonic counter; consumer: one lane polls, barrier, sc1 loads); every spin is bounded (timeout -> sticky error word,
+// all workgroups leave).  The ping-pong slabs cannot be overwritten early: a writer of step t+2 only starts after token t+1 exists,
+// which is after every reader of step t has arrived.  The 4 waves of a workgroup split K and add their partial tiles through LDS.
+#include "gru_layout.h"
+
+namespace {
+
+constexpr int NT = 256;
+typedef unsigned int u32;
+constexpr int RT = 256 + 16;                        // floats per accumulator tile in LDS (padded, see gru_persist.hip)
+constexpr u32 SPIN_LIMIT = 1u << 21;
+constexpr int C1 = 0, C2 = 32, C3 = 64, C4 = 96, C5 = 128, ERRW = 160;   // word offsets in sync (one 128-byte line each)
+
+struct DArgs {
+    int B, steps, H, V, nvt;                         // nvt = ceil(V / 16) output slices
+    int start_token, tok_ld;
+    const float *w1, *bhh1, *bih1, *table1, *rowbias1, *h0;
+    const float *wi2, *bih2, *w2, *bhh2;
+    const float *wo, *bo;
+    float *x1, *x2, *g2, *logits;
+    int* tokens;
+    float* logp;                                     // [B][steps][V] or null
+    u32* sync;
+};
+
+FN_DEVINL void gld4_sc1(f32x4& dst, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory"); }
+FN_DEVINL void stv4_sc1(float* p, const f32x4& v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
+FN_DEVINL f32x4 ldv4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+FN_DEVINL f32x4 ldv4_sc1(const float* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    return v;
+}
+FN_DEVINL u32 ld_cnt(u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct Sync {
+    u32* base;
+    volatile int* dead;
+    // one lane waits until *counter >= target, then the whole workgroup continues; false = give up (bounded spin / error elsewhere)
+    FN_DEVINL bool wait(int counter, u32 target) const {
+        if (threadIdx.x == 0) {
+            u32 spins = 0;
+            while (ld_cnt(base + counter) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 63u) == 0 && (spins > SPIN_LIMIT || ld_cnt(base + ERRW) != 0)) {
+                    __hip_atomic_store(base + ERRW, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *dead = 1;
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        return *dead == 0;
+    }
+    // publish: every wave has drained its stores, then one lane arrives
+    FN_DEVINL void arrive(int counter) const {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(base + counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+
+// acc[m][n] (this wave's K quarter) = X[rows of tile m][k] * Wslice[n][k]; X fragment-major in global memory, W in LDS
+template <int MT, int NTN>
+FN_DEVINL void kquarter(const float* xin, const float* wl, int nk, int lane, int wave, f32x4 (&acc)[MT][NTN]) {
+    const int c0 = nk * wave / 4, nkw = nk * (wave + 1) / 4 - c0;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NTN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // at most 4 chunks per wave (H <= 512): all operand loads go out first, ONE wait, then the MFMAs
+    f32x4 fa[4][MT][2];
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+        if (it < nkw) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                gld4_sc1(fa[it][m][0], xin + ((long)m * nk + c0 + it) * 512 + lane * 4);
+                gld4_sc1(fa[it][m][1], xin + ((long)m * nk + c0 + it) * 512 + 256 + lane * 4);
+            }
+        }
+    fn_wait_vm<0>();
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+        if (it < nkw) {
+            const int c = c0 + it;
+            f32x4 fb[NTN][2];
+#pragma unroll
+            for (int n = 0; n < NTN; ++n) {
+                fb[n][0] = *reinterpret_cast<const f32x4*>(wl + ((long)(n * nk + c) * 2 + 0) * 256 + lane * 4);
+                fb[n][1] = *reinterpret_cast<const f32x4*>(wl + ((long)(n * nk + c) * 2 + 1) * 256 + lane * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NTN; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4at(fa[it][m][j >> 2], j & 3), f4at(fb[n][j >> 2], j & 3), acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) { fn_keep(fa[it][m][0]); fn_keep(fa[it][m][1]); }
+        }
+}
+
+template <int MT, int NTN>
+FN_DEVINL void spill_partials(float* red, int lane, int wave, const f32x4 (&acc)[MT][NTN]) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NTN; ++n)
+            *reinterpret_cast<f32x4*>(red + (long)((wave * MT + m) * NTN + n) * RT + lane * 4 + (lane >> 4) * 4) = acc[m][n];
+    __syncthreads();
+}
+
+// sum over the 4 K quarters of accumulator (tile, n) at item (row rl, units 4 u4 ..)
+template <int MT, int NTN>
+FN_DEVINL f32x4 gather_sum(const float* red, int tile, int n, int coff) {
+    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[c] += red[(long)((w * MT + tile) * NTN + n) * RT + coff + c * 4];
+    return s;
+}
+
+template <int MT>
+__global__ __launch_bounds__(NT) void decode_greedy_kernel(const DArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int H = a.H, nk = H >> 5, nsl = H >> 4, B = a.B;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* wl = smem;                                 // weight slice, B-fragment order
+    float* red = smem + 3 * H * 16;                   // [4][MT][3][RT]
+    volatile int* dead = reinterpret_cast<volatile int*>(red + 4 * MT * 3 * RT);
+    const Sync sy = {a.sync, dead};
+    if (tid == 0) *dead = 0;
+    const long FS = (long)MT * 16 * H;
+
+    int role, slice;
+    {
+        const int b = blockIdx.x;
+        if (b < nsl) { role = 0; slice = b; }
+        else if (b < 2 * nsl) { role = 1; slice = b - nsl; }
+        else if (b < 3 * nsl) { role = 2; slice = b - 2 * nsl; }
+        else if (b < 3 * nsl + a.nvt) { role = 3; slice = b - 3 * nsl; }
+        else { role = 4; slice = 0; }
+    }
+    // one-time: weight slice -> LDS
+    if (role < 3) {
+        const float* w = role == 0 ? a.w1 : (role == 1 ? a.wi2 : a.w2);
+#pragma unroll 1
+        for (int q = 0; q < 3; ++q) {
+            const float4* src = reinterpret_cast<const float4*>(w + (long)(q * nsl + slice) * nk * 512);
+            float4* dst = reinterpret_cast<float4*>(wl + (long)q * nk * 512);
+            for (int i = tid; i < nk * 128; i += NT) dst[i] = src[i];
+        }
+    } else if (role == 3) {
+        const float4* src = reinterpret_cast<const float4*>(a.wo + (long)slice * nk * 512);
+        float4* dst = reinterpret_cast<float4*>(wl);
+        for (int i = tid; i < nk * 128; i += NT) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    // epilogue item of this thread: row rl of the batch, units / columns 4 u4 .. of the slice
+    const int item = tid, rl = item >> 2, u4 = item & 3;
+    const bool act = item < MT * 64 && rl < B;
+    const int b = min(rl, B - 1);
+    const int tile = min(rl >> 4, MT - 1);
+    const int coff = ((rl & 15) >> 2) * 68 + u4 * 16 + (rl & 3);
+    const int jj0 = slice * 16 + 4 * u4;              // hidden unit (roles 0-2) or vocabulary column (role 3)
+    const u32 unsl = (u32)nsl;
+
+    if (role == 0) {                                  // ---------------- layer-1 cell ----------------
+        f32x4 bh[3], bi[3], rb[3], hp;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            bh[q] = ldv4(a.bhh1 + q * H + jj0);
+            bi[q] = a.bih1 ? ldv4(a.bih1 + q * H + jj0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            rb[q] = a.rowbias1 ? ldv4(a.rowbias1 + (long)b * 3 * H + q * H + jj0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        hp = ldv4(a.h0 + (long)b * H + jj0);
+        for (int t = 0; t < a.steps; ++t) {
+            // the recurrent product needs h1_{t-1} only, not the token: it runs while the previous token is still being produced
+            if (t > 0 && !sy.wait(C1, unsl * (u32)t)) return;
+            f32x4 acc[MT][3];
+            kquarter<MT, 3>(a.x1 + (long)((t + 1) & 1) * FS, wl, nk, lane, wave, acc);     // slot 1 holds h0 at t = 0
+            spill_partials<MT, 3>(red, lane, wave, acc);
+            f32x4 gh[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) gh[q] = gather_sum<MT, 3>(red, tile, q, coff) + bh[q];
+            if (t > 0 && !sy.wait(C5, (u32)t)) return;
+            int tok = a.start_token;
+            if (t > 0) tok = __hip_atomic_load(a.tokens + (long)b * a.tok_ld + (t - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            f32x4 ex[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) ex[q] = ldv4(a.table1 + (long)tok * 3 * H + q * H + jj0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float r = fn_sigmoid(((bi[0][c] + ex[0][c]) + rb[0][c]) + gh[0][c]);
+                const float z = fn_sigmoid(((bi[1][c] + ex[1][c]) + rb[1][c]) + gh[1][c]);
+                const float n = fn_tanh(((bi[2][c] + ex[2][c]) + rb[2][c]) + r * gh[2][c]);
+                hp[c] = (1.0f - z) * n + z * hp[c];
+            }
+            if (act) stv4_sc1(a.x1 + (long)(t & 1) * FS + frag_off(b, jj0, nk), hp);
+            sy.arrive(C1);
+        }
+    } else if (role == 1) {                           // ---------------- W_ih2 projection ----------------
+        f32x4 bi[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) bi[q] = a.bih2 ? ldv4(a.bih2 + q * H + jj0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < a.steps; ++t) {
+            if (!sy.wait(C1, unsl * (u32)(t + 1))) return;
+            f32x4 acc[MT][3];
+            kquarter<MT, 3>(a.x1 + (long)(t & 1) * FS, wl, nk, lane, wave, acc);
+            spill_partials<MT, 3>(red, lane, wave, acc);
+            if (act) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) stv4_sc1(a.g2 + (long)b * 3 * H + q * H + jj0, gather_sum<MT, 3>(red, tile, q, coff) + bi[q]);
+            }
+            sy.arrive(C2);
+        }
+    } else if (role == 2) {                           // ---------------- layer-2 cell ----------------
+        f32x4 bh[3], hp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) bh[q] = ldv4(a.bhh2 + q * H + jj0);
+        for (int t = 0; t < a.steps; ++t) {
+            // recurrent input: h2_{t-1}, or h1_0 at the first step (gmm_model.py:134-135: hx[1] = hx[0] at i == 0)
+            if (!(t == 0 ? sy.wait(C1, unsl) : sy.wait(C3, unsl * (u32)t))) return;
+            const float* xin = t == 0 ? a.x1 : a.x2 + (long)((t + 1) & 1) * FS;
+            if (t == 0) hp = ldv4_sc1(xin + frag_off(b, jj0, nk));
+            f32x4 acc[MT][3];
+            kquarter<MT, 3>(xin, wl, nk, lane, wave, acc);
+            spill_partials<MT, 3>(red, lane, wave, acc);
+            f32x4 gh[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) gh[q] = gather_sum<MT, 3>(red, tile, q, coff) + bh[q];
+            if (!sy.wait(C2, unsl * (u32)(t + 1))) return;
+            f32x4 gx[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) gx[q] = ldv4_sc1(a.g2 + (long)b * 3 * H + q * H + jj0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float r = fn_sigmoid(gx[0][c] + gh[0][c]);
+                const float z = fn_sigmoid(gx[1][c] + gh[1][c]);
+                const float n = fn_tanh(gx[2][c] + r * gh[2][c]);
+                hp[c] = (1.0f - z) * n + z * hp[c];
+            }
+            if (act) stv4_sc1(a.x2 + (long)(t & 1) * FS + frag_off(b, jj0, nk), hp);
+            sy.arrive(C3);
+        }
+    } else if (role == 3) {                           // ---------------- output layer slice ----------------
+        const int vpad = a.nvt * 16;
+        f32x4 bo = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (jj0 + c < a.V) bo[c] = a.bo[jj0 + c];
+        for (int t = 0; t < a.steps; ++t) {
+            if (!sy.wait(C3, unsl * (u32)(t + 1))) return;
+            f32x4 acc[MT][1];
+            kquarter<MT, 1>(a.x2 + (long)(t & 1) * FS, wl, nk, lane, wave, acc);
+            spill_partials<MT, 1>(red, lane, wave, acc);
+            if (act) stv4_sc1(a.logits + (long)b * vpad + jj0, gather_sum<MT, 1>(red, tile, 0, coff) + bo);
+            sy.arrive(C4);
+        }
+    } else {                                          // ---------------- log-softmax + first-index argmax ----------------
+        const int vpad = a.nvt * 16;
+        for (int t = 0; t < a.steps; ++t) {
+            if (!sy.wait(C4, (u32)a.nvt * (u32)(t + 1))) return;
+            for (int row = wave; row < B; row += 4) {
+                float x[6];
+                float mx = -3.0e38f;
+                int am = 0x7fffffff;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const int v = lane + 64 * k;
+                    x[k] = v < a.V ? __hip_atomic_load(a.logits + (long)row * vpad + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -3.0e38f;
+                    if (x[k] > mx) { mx = x[k]; am = v; }                 // ascending v: the first index wins inside a lane
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float om = __shfl_xor(mx, o, 64);
+                    const int oa = __shfl_xor(am, o, 64);
+                    if (om > mx || (om == mx && oa < am)) { mx = om; am = oa; }
+                }
+                if (a.logp) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k)
+                        if (lane + 64 * k < a.V) s += expf(x[k] - mx);
+                    s = fn_wave_sum(s);
+                    const float lse = mx + logf(s);
+                    float* out = a.logp + ((long)row * a.steps + t) * a.V;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k)
+                        if (lane + 64 * k < a.V) out[lane + 64 * k] = x[k] - lse;
+                }
+                if (lane == 0) __hip_atomic_store(a.tokens + (long)row * a.tok_ld + t, am, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            sy.arrive(C5);
+        }
+    }
+}
+
+template <int MT>
+int launch_decode(const DArgs& a, int grid, hipStream_t st) {
+    auto k = decode_greedy_kernel<MT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const size_t lds = ((size_t)3 * a.H * 16 + (size_t)4 * MT * 3 * RT) * 4 + 16;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, a);
+    FN_CHECK_LAUNCH();
+    return FN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t fn_decode_ws_bytes(int B, int H, int V) {
+    const size_t bp = B <= 16 ? 16 : (B <= 32 ? 32 : 64), vp = (size_t)(V + 15) / 16 * 16;    // rows as the kernel tiles them
+    return (4 * bp * H + bp * 3 * H + bp * vp) * sizeof(float);
+}
+
+size_t fn_decode_sync_ws_bytes(void) { return (size_t)(ERRW + 32) * 4; }
+
+int fn_decode_greedy(const FnDecode* d, void* stream) {
+    if (!d) return FN_E_NULL;
+    if (!d->w_hh1_frag || !d->b_hh1 || !d->table1 || !d->h0 || !d->w_ih2_frag || !d->w_hh2_frag || !d->b_hh2 || !d->w_out_frag || !d->b_out ||
+        !d->tokens || !d->ws || !d->sync_ws)
+        return FN_E_NULL;
+    if (d->B <= 0 || d->B > 64 || d->steps <= 0 || d->H <= 0 || (d->H % 32) != 0 || d->H > 512 || d->V <= 0 || d->V > 384 || d->tok_ld < d->steps)
+        return FN_E_SHAPE;
+    const uintptr_t al = (uintptr_t)d->w_hh1_frag | (uintptr_t)d->w_ih2_frag | (uintptr_t)d->w_hh2_frag | (uintptr_t)d->w_out_frag |
+                         (uintptr_t)d->b_hh1 | (uintptr_t)d->b_ih1 | (uintptr_t)d->table1 | (uintptr_t)d->rowbias1 | (uintptr_t)d->h0 |
+                         (uintptr_t)d->b_ih2 | (uintptr_t)d->b_hh2 | (uintptr_t)d->ws;
+    if (al & 15) return FN_E_ALIGN;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FN_E_SHAPE;
+    const int nsl = d->H / 16, nvt = (d->V + 15) / 16;
+    const int grid = 3 * nsl + nvt + 1;
+    if (grid > prop.multiProcessorCount) return FN_E_SHAPE;       // every workgroup must be resident: one per CU
+    hipStream_t st = (hipStream_t)stream;
+    const int mt = d->B <= 16 ? 1 : (d->B <= 32 ? 2 : 4);
+    const size_t bp = (size_t)mt * 16, vp = (size_t)nvt * 16;
+    DArgs a;
+    a.B = d->B; a.steps = d->steps; a.H = d->H; a.V = d->V; a.nvt = nvt;
+    a.start_token = d->start_token; a.tok_ld = d->tok_ld;
+    a.w1 = d->w_hh1_frag; a.bhh1 = d->b_hh1; a.bih1 = d->b_ih1; a.table1 = d->table1; a.rowbias1 = d->rowbias1; a.h0 = d->h0;
+    a.wi2 = d->w_ih2_frag; a.bih2 = d->b_ih2; a.w2 = d->w_hh2_frag; a.bhh2 = d->b_hh2;
+    a.wo = d->w_out_frag; a.bo = d->b_out;
+    a.x1 = d->ws; a.x2 = a.x1 + 2 * bp * d->H; a.g2 = a.x2 + 2 * bp * d->H; a.logits = a.g2 + bp * 3 * d->H;
+    (void)vp;
+    a.tokens = d->tokens; a.logp = d->logp;
+    a.sync = reinterpret_cast<u32*>(d->sync_ws);
+    // h0 -> slot 1 of the layer-1 exchange (the operand of step 0), rows padded with zeros
+    int rc = launch_pack(d->h0, d->B, d->H, d->H, a.x1 + bp * d->H, st);
+    if (rc != FN_OK) return rc;
+    hipError_t me = hipMemsetAsync(a.sync, 0, (size_t)ERRW * 4, st);             // counters only: the error word is sticky
+    if (me != hipSuccess) return (int)me;
+    switch (mt) {
+        case 1: return launch_decode<1>(a, grid, st);
+        case 2: return launch_decode<2>(a, grid, st);
+        default: return launch_decode<4>(a, grid, st);
+    }
+}
+
+}  // extern "C"

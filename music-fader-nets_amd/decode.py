@@ -19,6 +19,8 @@ def greedy_decode(model, z, steps, want_logp=True, use_graph=None):
     captured once per (Bi, steps) into a hipGraph and replayed: the loop is launch-latency bound (7 small kernels per token)."""
     eng = model.engine()
     z = z.float().contiguous()
+    if _single_launch_ok(eng, z):
+        return _decode_single_launch(model, eng, z, steps, want_logp)
     if use_graph is None:
         use_graph = z.is_cuda
     if not use_graph:
@@ -42,6 +44,36 @@ def greedy_decode(model, z, steps, want_logp=True, use_graph=None):
     zs.copy_(z)
     g.replay()
     return (None if logp is None else logp.clone()), tokens.clone()
+
+
+def _single_launch_ok(eng, z):
+    """small batches decode as ONE launch (fn_decode_greedy: weight slices resident in LDS, activations handed over through L2)"""
+    import os
+    return (hasattr(eng.ops, "decode_greedy") and z.is_cuda and z.shape[0] <= 32 and eng.H <= 512 and
+            os.environ.get("FN_DECODE_PERSIST", "1") == "1")
+
+
+def _decode_single_launch(model, eng, z, steps, want_logp):
+    ops, P, H = eng.ops, eng.p, eng.H
+    Bi = z.shape[0]
+    packs = eng.__dict__.setdefault("_decode_packs", {})
+    if packs.get("version") != model._version:             # operand images of the two matrices the training step never packs
+        packs.clear()
+        for key, name in (("ih2", "grucell_g_2.weight_ih"), ("out", "linear_out_g.weight")):
+            w = P[name]
+            packs[key] = torch.zeros(ops.frag_floats(w.shape[0], w.shape[1]), device=z.device)
+            ops.frag_pack(w, packs[key])
+        packs["version"] = model._version
+    h0g = eng.buf("dec_h0g", (Bi, H))
+    ops.gemm(z, P["linear_init_global.weight"], h0g, bias=P["linear_init_global.bias"])
+    rbg = eng.buf("dec_rbg", (Bi, 3 * H))
+    ops.gemm(z, P["grucell_g.weight_ih"][:, E_VOCAB:], rbg)
+    tokens = torch.zeros(Bi, steps, dtype=torch.int32, device=z.device)
+    logp = torch.empty(Bi, steps, E_VOCAB, device=z.device) if want_logp else None
+    ops.decode_greedy(Bi, steps, H, E_VOCAB, E_VOCAB - 1, eng.whh_f["g"], P["grucell_g.bias_hh"], P["grucell_g.bias_ih"], eng.tab["g"], rbg, h0g,
+                      packs["ih2"], P["grucell_g_2.bias_ih"], eng.whh_f["g2"], P["grucell_g_2.bias_hh"], packs["out"], P["linear_out_g.bias"],
+                      tokens, logp)
+    return logp, tokens
 
 
 def _decode_body(eng, z, steps, want_logp, logp, tokens):

@@ -186,6 +186,27 @@ class HipOps:
         ws = self.workspace(wsb, "gemm") if wsb else None
         _lib.check(self.lib.fn_gru_dwhh_f32(_p(dgx), _p(dghn), _p(hprev), rows, H, beta, _p(dW), splitk, _p(ws), wsb, self.stream()), "fn_gru_dwhh_f32")
 
+    def decode_greedy(self, B, steps, H, V, start_token, w_hh1_frag, b_hh1, b_ih1, table1, rowbias1, h0, w_ih2_frag, b_ih2, w_hh2_frag, b_hh2,
+                      w_out_frag, b_out, tokens, logp=None):
+        """single-launch greedy decode of <= 64 sequences (fn_decode_greedy); tokens int32 [B][>=steps], logp [B][steps][V] or None"""
+        d = _lib.FnDecode()
+        for t, nm in ((w_hh1_frag, "w_hh1_frag"), (b_hh1, "b_hh1"), (b_ih1, "b_ih1"), (table1, "table1"), (rowbias1, "rowbias1"), (h0, "h0"),
+                      (w_ih2_frag, "w_ih2_frag"), (b_ih2, "b_ih2"), (w_hh2_frag, "w_hh2_frag"), (b_hh2, "b_hh2"), (w_out_frag, "w_out_frag"),
+                      (b_out, "b_out"), (logp, "logp")):
+            _dense(t, name=nm)
+            setattr(d, nm, _p(t))
+        _dense(tokens, torch.int32, "tokens")
+        d.B, d.steps, d.H, d.V, d.start_token = B, steps, H, V, start_token
+        d.tokens, d.tok_ld = _p(tokens), tokens.shape[1]
+        wsb = int(self.lib.fn_decode_ws_bytes(B, H, V))
+        d.ws = _p(self.workspace(wsb, "decode"))
+        syncs = self.__dict__.setdefault("_syncs", {})
+        key = self.lane + "decode"
+        if key not in syncs:
+            syncs[key] = torch.zeros(int(self.lib.fn_decode_sync_ws_bytes()) // 4, dtype=torch.int32, device=self.device)
+        d.sync_ws = _p(syncs[key])
+        _lib.check(self.lib.fn_decode_greedy(C.byref(d), self.stream()), "fn_decode_greedy")
+
     def embed_grad(self, dgx_all, idx, idx_shift, start_token, reverse, V, out):
         _dense(dgx_all, name="dgx_all"), _dense(idx, torch.int32, "idx"), _dense(out, name="out")
         T, B, N3 = dgx_all.shape

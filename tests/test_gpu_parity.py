@@ -578,6 +578,30 @@ def test_greedy_decode_tokens(case, small, c0):
 # ----------------------------------------------------------------------------------------------
 # BASELINE size (B=256, T=256, Tr=64, H=512): size-independent properties
 # ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("H,Bi,steps", [(64, 1, 12), (64, 17, 30), (512, 3, 40), (512, 32, 25)])
+def test_single_launch_decode_matches_per_token_kernels(H, Bi, steps, monkeypatch):
+    """fn_decode_greedy (one launch, weight slices in LDS, five workgroup roles) vs the five-kernels-per-token path: same tokens,
+    same log-probabilities; 1, 2 and 4 row tiles, H = 64 (4 slices per role) and 512 (32)."""
+    pkg = load_package()
+    m = make_model(H, 32 if H == 64 else 128, device=DEV, seed=7)
+    m.eval()
+    torch.manual_seed(3)
+    z = torch.randn(Bi, 2 * m.latent_dim + 24, device=DEV)
+    monkeypatch.setenv("FN_DECODE_PERSIST", "0")
+    lp0, tk0 = pkg.greedy_decode(m, z, steps)
+    monkeypatch.setenv("FN_DECODE_PERSIST", "1")
+    lp1, tk1 = pkg.greedy_decode(m, z, steps)
+    lp2, tk2 = pkg.greedy_decode(m, z, steps)                       # again on the warm buffers
+    assert not m.engine().ops.gru_sync_error()
+    assert torch.equal(tk1, tk2) and torch.equal(lp1, lp2)
+    gap = lp0.topk(2, dim=-1).values
+    clear = (gap[..., 0] - gap[..., 1]) > 1e-4                     # positions where the per-token path itself is not at a near-tie
+    first_unclear = torch.where((~clear).any(0))[0]
+    upto = int(first_unclear[0]) if len(first_unclear) else steps
+    assert torch.equal(tk0[:, :upto], tk1[:, :upto])
+    close(lp1[:, :upto], lp0[:, :upto], 2e-5)
+
+
 def test_full_size_properties():
     pkg = load_package()
     from music_fader_nets_amd.synth import synth_batch
