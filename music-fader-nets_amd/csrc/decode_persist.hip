@@ -18,9 +18,6 @@
 namespace {
 
 constexpr int NT = 256;
-typedef unsigned int u32;
-constexpr int RT = 256 + 16;                        // floats per accumulator tile in LDS (padded, see gru_persist.hip)
-constexpr u32 SPIN_LIMIT = 1u << 21;
 constexpr int C1 = 0, C2 = 32, C3 = 64, C4 = 96, C5 = 128, ERRW = 160;   // word offsets in sync (one 128-byte line each)
 
 struct DArgs {
@@ -35,15 +32,11 @@ struct DArgs {
     u32* sync;
 };
 
-FN_DEVINL void gld4_sc1(f32x4& dst, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory"); }
-FN_DEVINL void stv4_sc1(float* p, const f32x4& v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
-FN_DEVINL f32x4 ldv4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 FN_DEVINL f32x4 ldv4_sc1(const float* p) {
     f32x4 v;
     asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
     return v;
 }
-FN_DEVINL u32 ld_cnt(u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 struct Sync {
     u32* base;

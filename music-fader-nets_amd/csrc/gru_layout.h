@@ -17,6 +17,19 @@ FN_DEVINL long frag_off(int row, int k, int NC) {
 
 FN_DEVINL float f4at(const f32x4& v, int j) { return v[j]; }
 
+// ---- in-launch hand-over helpers of the weight-stationary kernels (gru_persist.hip, decode_persist.hip) ----------------------
+// recipe R1 of cdna_hip_programming.md G16: 16-byte write-through (sc1) payload stores and L1-bypassing (sc1) loads; counters are
+// relaxed agent-scope atomics.  The asm loads are not counted by hipcc: pair them with fn_wait_vm<N>() / fn_keep() (mma_core.h).
+typedef unsigned int u32;
+constexpr int RT = 256 + 16;                        // floats of one 16x16 accumulator tile in LDS: MFMA C layout + 4 floats per 16 lanes
+constexpr u32 SPIN_LIMIT = 1u << 21;                // polls before a waiting workgroup gives up (~2 s)
+FN_DEVINL void gld4_sc1(f32x4& dst, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory"); }
+// the trailing s_nop keeps hipcc from reusing the data registers before the store has read them
+FN_DEVINL void stv4_sc1(float* p, const f32x4& v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
+FN_DEVINL f32x4 ldv4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+FN_DEVINL void stv4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+FN_DEVINL u32 ld_cnt(u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // host-side entry points of gru_persist.hip: return FN_OK when the persistent kernel was launched,
 // FN_PERSIST_NA when the configuration is not eligible (the caller then uses the per-step kernels).
 #define FN_PERSIST_NA 1000000

@@ -35,7 +35,6 @@ extern "C" int fn_pdbg_read(unsigned long long* host) {
 namespace {
 
 constexpr int NT = 256;
-typedef unsigned int u32;
 
 struct PScan {
     const float* w_frag;
@@ -59,15 +58,7 @@ struct PArgs {
     u32* sync;            // [ngroups * 32] arrival counters (one per 128-byte line), then err at sync[FN_MAX_GROUPS*32]
 };
 constexpr int FN_MAX_GROUPS = 64;
-constexpr u32 SPIN_LIMIT = 1u << 21;
 
-FN_DEVINL void gld4_sc1(f32x4& dst, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory"); }
-// write-through 16-byte store (recipe R1); the trailing s_nop keeps hipcc from reusing the data registers too early
-FN_DEVINL void stv4_sc1(float* p, const f32x4& v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
-FN_DEVINL f32x4 ldv4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-FN_DEVINL void stv4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
-constexpr int RT = 256 + 16;                        // floats per accumulator tile in LDS (padded)
-FN_DEVINL u32 ld_cnt(u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // waves = WM (row blocks of MT tiles) x WK (K split); rows per workgroup RPW = 16 * WM * MT
 template <int WM, int WK, int MT, int D>
