@@ -3,11 +3,12 @@
 // log-softmax + argmax -> next token  is latency-bound (five dependent kernels per token otherwise), so each link gets its own set
 // of workgroups that keep their weight slice in LDS for the whole decode and hand the activations to the next set through L2:
 //
-//   L1  (H/16 workgroups)  W_hh1 slice [48 x H]    waits C1(t-1), then token t-1 -> h1_t slice -> X1[t&1]  arrive C1
+//   L1  (H/16 workgroups)  W_hh1 slice [48 x H]    waits C1(t-1), then C4(t-1): own argmax -> h1_t slice -> X1[t&1]  arrive C1
 //   P2  (H/16)             W_ih2 slice [48 x H]    waits C1                   -> gx2 slice    -> G2        arrive C2
 //   L2  (H/16)             W_hh2 slice [48 x H]    waits C3(t-1) [C1 at t=0], then C2 -> h2_t -> X2[t&1]   arrive C3
 //   OUT (ceil(V/16))       W_out slice [16 x H]    waits C3                   -> logits slice -> LOGITS    arrive C4
-//   ARG (1)                -                       waits C4                   -> log-softmax, first-index argmax -> token t, arrive C5
+//   ARG (1)                -                       waits C4                   -> log-softmax, argmax -> tokens / logp out, arrive C5
+//                                                   (OUT waits C5(t-1) before it overwrites the logits)
 //
 // Every hand-over is recipe R1 of the guide (write-through sc1 payload, every wave drains vmcnt, barrier, one relaxed agent-scope
 // atomic on a monotonic counter; consumer: one lane polls, barrier, sc1 loads); every spin is bounded (timeout -> sticky error word,
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(NT) void decode_greedy_kernel(const DArgs a) {
     float* wl = smem;                                 // weight slice, B-fragment order
     float* red = smem + 3 * H * 16;                   // [4][MT][3][RT]
     volatile int* dead = reinterpret_cast<volatile int*>(red + 4 * MT * 3 * RT);
+    volatile int* tokl = dead + 4;                    // [64] tokens of the current step (layer-1 role)
     const Sync sy = {a.sync, dead};
     if (tid == 0) *dead = 0;
     const long FS = (long)MT * 16 * H;
@@ -192,9 +194,32 @@ __global__ __launch_bounds__(NT) void decode_greedy_kernel(const DArgs a) {
             f32x4 gh[3];
 #pragma unroll
             for (int q = 0; q < 3; ++q) gh[q] = gather_sum<MT, 3>(red, tile, q, coff) + bh[q];
-            if (t > 0 && !sy.wait(C5, (u32)t)) return;
+            // the token of step t-1: every layer-1 workgroup takes the argmax of the logits itself as soon as the output slices
+            // have arrived (the ARG workgroup, which writes tokens and log-probabilities out, is off the critical chain)
             int tok = a.start_token;
-            if (t > 0) tok = __hip_atomic_load(a.tokens + (long)b * a.tok_ld + (t - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t > 0) {
+                if (!sy.wait(C4, (u32)a.nvt * (u32)t)) return;
+                const int vpad = a.nvt * 16;
+                for (int row = wave; row < B; row += 4) {
+                    float mx = -3.0e38f;
+                    int am = 0x7fffffff;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const int v = lane + 64 * k;
+                        const float x = v < a.V ? __hip_atomic_load(a.logits + (long)row * vpad + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -3.0e38f;
+                        if (x > mx) { mx = x; am = v; }
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const float om = __shfl_xor(mx, o, 64);
+                        const int oa = __shfl_xor(am, o, 64);
+                        if (om > mx || (om == mx && oa < am)) { mx = om; am = oa; }
+                    }
+                    if (lane == 0) tokl[row] = am;
+                }
+                __syncthreads();
+                tok = tokl[b];
+            }
             f32x4 ex[3];
 #pragma unroll
             for (int q = 0; q < 3; ++q) ex[q] = ldv4(a.table1 + (long)tok * 3 * H + q * H + jj0);
@@ -259,6 +284,9 @@ __global__ __launch_bounds__(NT) void decode_greedy_kernel(const DArgs a) {
         for (int c = 0; c < 4; ++c)
             if (jj0 + c < a.V) bo[c] = a.bo[jj0 + c];
         for (int t = 0; t < a.steps; ++t) {
+            // the logits of step t-1 may only be overwritten once the ARG workgroup has read them (this wait is off the critical
+            // chain: the output slices are idle until layer 2 arrives anyway)
+            if (t > 0 && !sy.wait(C5, (u32)t)) return;
             if (!sy.wait(C3, unsl * (u32)(t + 1))) return;
             f32x4 acc[MT][1];
             kquarter<MT, 1>(a.x2 + (long)(t & 1) * FS, wl, nk, lane, wave, acc);
@@ -314,7 +342,7 @@ int launch_decode(const DArgs& a, int grid, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    const size_t lds = ((size_t)3 * a.H * 16 + (size_t)4 * MT * 3 * RT) * 4 + 16;
+    const size_t lds = ((size_t)3 * a.H * 16 + (size_t)4 * MT * 3 * RT) * 4 + 16 + 64 * 4;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, a);
     FN_CHECK_LAUNCH();
     return FN_OK;
