@@ -1,16 +1,24 @@
 #!/usr/bin/env python3
 """Headline benchmark: event-tokens/sec of one full MusicAttrRegGMVAE training step (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode train|decode]
 
-A "step" = forward + every loss term + backward + gradient all-reduce (N>1) + clip + Adam on one synthetic
-minibatch (trainer_gmm.py:220-258 semantics), inputs resident in HBM.  Workload: BASELINE config 1 - hidden 512,
-z 128, K=2, B=256 sequences per GPU (weak scaling), T=256 event tokens, Tr=64 rhythm/note steps, fp32.
-Prints ONE JSON line on rank 0 with the contract fields plus `roofline` and (N=1) `cpu_baseline`.
+--gpus N > 1 without a launcher environment re-executes itself under ``torch.distributed.run`` (one rank per GPU, RCCL); when the
+driver launches it under ``torch.distributed.run`` already, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* are taken from the environment.
+
+mode train (default; BASELINE configs[1], configs[2-3] with N>1): a "step" = forward + every loss term + backward + gradient
+  all-reduce (N>1) + clip + Adam on one synthetic minibatch (trainer_gmm.py:220-258 semantics), inputs resident in HBM.  Workload:
+  hidden 512, z 128, K=2, B=256 sequences per GPU (weak scaling), T=256 event tokens, Tr=64 rhythm/note steps, fp32.
+mode decode (BASELINE configs[4]): a "step" = encode 256 sequences (T=256), 8 fader values each on z_r[:, 0], greedy decode of the
+  2048 rows for 300 steps (test_class.py:233-254 batched; replicas only, no collective).
+
+Prints ONE JSON line on rank 0 with the contract fields plus `roofline`, `roofline_all` and (N=1) `cpu_baseline`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,89 +30,160 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 H, Z, K, B, T, TR = 512, 128, 2, 256, 256, 64
-# algorithmic work (SURVEY.md 8d / DESIGN.md): the recurrent part of one GRU step of one scan for one sample
-FLOP_PER_SAMPLE_STEP = 2.0 * H * 3 * H                 # 1.573 MFLOP
+DEC_SEQS, DEC_VALUES, DEC_STEPS = 256, 8, 300
+# algorithmic work (SURVEY.md 8d / DESIGN.md)
+FLOP_PER_SAMPLE_STEP = 2.0 * H * 3 * H                 # recurrent part of one GRU step of one scan for one sample: 1.573 MFLOP
 F_ALG_PER_TOKEN = 37.12e6                              # whole training step, per event token
+F_ALG_DECODE_PER_TOKEN = 5.07e6                        # one greedy decode step of one sequence (token projection = row gather)
+DECODE_WEIGHT_BYTES = 10.14e6                          # weights one decode step touches (W_hh_g, W_ih_g2, W_hh_g2, W_out)
 PEAK_F32_MFMA_TFLOPS = 157.3                           # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+PEAK_HBM_GBS = 8000.0
 
 
-def measure_dominant_kernel(trainer, batch, eps, reps=3):
-    """Launch duration of the dominant kernel, the weight-stationary encoder forward scan gru_fwd_persist_kernel<4,1,2,4>
-    (ONE launch = T time steps x 4 scans x B rows), measured with HIP events on the stream it is launched on (torch's current
-    stream).  The event pair also brackets the counter memset node that precedes the launch (a few microseconds of 4+ ms)."""
-    eng = trainer.model.engine()
-    d = batch[0]
-    eng.encode(d)
-    torch.cuda.synchronize()
-    P = eng.p
-    scans = []
-    for e in ("r", "n"):
-        for key, sfx, rev in ((e, "_l0", 0), (e + "_reverse", "_l0_reverse", 1)):
-            pfx = "gru_%s." % e
-            scans.append(dict(B=B, T=T, H=H, reverse=rev, w_hh_frag=eng.whh_f[key], b_hh=P[pfx + "bias_hh" + sfx],
-                              b_ih=P[pfx + "bias_ih" + sfx], gx_table=eng.tab[key], idx=d, idx_shift=0,
-                              h_all=eng.buf("enc_h_" + key, (T, B, H)), gates=eng.buf("enc_g_" + key, (T, eng.ops.gates_floats(B, H)))))
-    best = None
-    for _ in range(reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        eng.ops.gru_seq_fwd(scans)
-        e1.record()
-        torch.cuda.synchronize()
+class TimedOps:
+    """Proxy around HipOps that brackets every op call with HIP events ON THE STREAM THE OP IS LAUNCHED ON (the engine enters the
+    lane's stream before calling the op, so torch's current stream is that stream).  Used for the per-kernel roofline numbers only,
+    in eager passes outside the timed region."""
+
+    def __init__(self, ops):
+        object.__setattr__(self, "_ops", ops)
+        object.__setattr__(self, "records", [])
+
+    def __getattr__(self, name):
+        attr = getattr(self._ops, name)
+        if not callable(attr) or name in ("stream", "workspace", "gates_floats", "frag_floats", "gru_sync_error", "_frag_ws", "_sync_ws"):
+            return attr
+
+        def call(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            res = attr(*a, **k)
+            e1.record()
+            self.records.append((name, a, k, e0, e1))
+            return res
+        return call
+
+    def __setattr__(self, name, value):
+        setattr(self._ops, name, value)
+
+
+def _classify(name, a, k):
+    """op call -> (roofline row, work of that launch) or None"""
+    if name in ("gru_seq_fwd", "gru_seq_bwd"):
+        scans = a[0]
+        work = sum(s["B"] * s["T"] for s in scans) * FLOP_PER_SAMPLE_STEP
+        kind = "fwd" if name == "gru_seq_fwd" else "bwd"
+        if len(scans) == 4:
+            return "enc_%s_scan" % kind, work
+        if len(scans) == 1 and scans[0]["T"] > 1:
+            return "dec_%s_scan_chunk" % kind, work
+        if len(scans) == 2:
+            return "subdec_%s_scan" % kind, work
+        return None
+    if name == "gru_dwhh":
+        rows, Hh = a[2].shape
+        return ("dwhh_gemm_tn", 2.0 * rows * 3 * Hh * Hh) if rows >= 4096 else None
+    if name in ("embed_grad", "embed_grad_sorted"):
+        dgx = a[0]
+        return ("embed_grad", float(dgx.numel() * 4)) if dgx.shape[0] * dgx.shape[1] >= 4096 else None
+    if name == "gemm":
+        A, Bm, Cm = a[0], a[1], a[2]
+        M, N = Cm.shape
+        Kk = A.shape[1] if k.get("a_k", True) else A.shape[0]
+        if 2.0 * M * N * Kk >= 2e10:
+            return ("gemm_nt" if k.get("b_k", True) else ("gemm_nn" if k.get("a_k", True) else "gemm_tn")), 2.0 * M * N * Kk
+        return None
+    if name in ("vocab_logsoftmax", "out_head_loss"):
+        return "out_head_softmax", None
+    return None
+
+
+ROW_INFO = {   # row -> (bound, unit of work, kernel, peak share of the chip)
+    "enc_fwd_scan": ("mfma", "flop", "gru_fwd_persist_kernel (4 encoder scans x 256 steps, one launch)", 1.0),
+    "enc_bwd_scan": ("mfma", "flop", "gru_bwd_persist_kernel (4 encoder scans x 256 steps, one launch)", 1.0),
+    "dec_fwd_scan_chunk": ("mfma", "flop", "gru_fwd_persist_kernel (one decoder layer, one time chunk, HALF of the CUs)", 0.5),
+    "dec_bwd_scan_chunk": ("mfma", "flop", "gru_bwd_persist_kernel (one decoder layer, one time chunk, HALF of the CUs)", 0.5),
+    "subdec_fwd_scan": ("mfma", "flop", "gru_fwd_persist_kernel (both sub-decoders, 64 steps)", 1.0),
+    "subdec_bwd_scan": ("mfma", "flop", "gru_bwd_persist_kernel (both sub-decoders, 64 steps)", 1.0),
+    "dwhh_gemm_tn": ("mfma", "flop", "gemm_tn_kernel via fn_gru_dwhh_f32 (dW_hh, K = T*B rows)", 1.0),
+    "gemm_tn": ("mfma", "flop", "gemm_tn_kernel (dW of dense layers)", 1.0),
+    "gemm_nt": ("mfma", "flop", "gemm_kernel (X W^T: W_ih2 projection, output layer)", 1.0),
+    "gemm_nn": ("mfma", "flop", "gemm_kernel (dY W: input gradients)", 1.0),
+    "embed_grad": ("hbm", "bytes", "token-segment sum of the gate-gradient rows (embed.hip)", 1.0),
+}
+
+
+def roofline_rows(records):
+    agg = {}
+    for name, a, k, e0, e1 in records:
+        c = _classify(name, a, k)
+        if c is None or c[1] is None or c[0] not in ROW_INFO:
+            continue
         ms = e0.elapsed_time(e1)
-        best = ms if best is None else min(best, ms)
-    if eng.ops.gru_sync_error():
+        ent = agg.setdefault(c[0], [0, 0.0, 0.0])
+        ent[0] += 1
+        ent[1] += ms
+        ent[2] += c[1]
+    rows = {}
+    for row, (cnt, ms, work) in agg.items():
+        bound, unit, kernel, share = ROW_INFO[row]
+        if bound == "mfma":
+            ach, peak, u = work / (ms * 1e-3) / 1e12, PEAK_F32_MFMA_TFLOPS * share, "TFLOP/s"
+        else:
+            ach, peak, u = work / (ms * 1e-3) / 1e9, PEAK_HBM_GBS * share, "GB/s"
+        rows[row] = dict(bound=bound, kernel=kernel, launches=cnt, avg_launch_us=round(ms / cnt * 1e3, 1), achieved=round(ach, 2),
+                         peak=peak, unit=u, frac=round(ach / peak, 4), work_per_launch=work / cnt)
+    return rows
+
+
+def per_kernel_rooflines(trainer, batch, eps, reps=5):
+    """`reps` eager fwd+bwd passes (no optimiser update) under the TimedOps proxy -> per-kernel average launch durations (mean of all
+    launches, not the best) and their roofline fractions."""
+    eng = trainer.model.engine()
+    real = eng.ops
+    proxy = TimedOps(real)
+    eng.ops = proxy
+    try:
+        for _ in range(reps):
+            trainer.loss_and_grads(20000, batch, eps)
+        torch.cuda.synchronize()
+    finally:
+        eng.ops = real
+    if real.gru_sync_error():
         raise RuntimeError("weight-stationary scan: a workgroup gave up waiting (sync error flag set)")
-    flop = T * 4 * B * FLOP_PER_SAMPLE_STEP
-    achieved = flop / (best * 1e-3) / 1e12
-    # traffic: HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes),
-    # see profiles/r01_pmc_gru_fwd_persist_4scans.txt - bench.py itself cannot run the profiler, so this is the committed measurement.
-    return dict(bound="mfma", kernel="gru_fwd_persist_kernel<4,1,2,4>", achieved=round(achieved, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=4.45e9, traffic_source="profiles/r01_pmc_gru_fwd_persist_4scans.txt",
-                avg_launch_us=round(best * 1e3, 1), flop_per_launch=flop, steps_per_launch=T)
+    return roofline_rows(proxy.records)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=32)
-    args = ap.parse_args()
+def respawn_under_launcher(n):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: re-run this command as N ranks on this node."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
-    t_start = time.perf_counter()
-    from mfn_import import load_package
-    pkg = load_package()
-    from music_fader_nets_amd import parallel
+
+def bench_train(args, pkg, ctx, local, rank, world, log):
     from music_fader_nets_amd.synth import synth_batch
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    ctx, local = parallel.init_from_env("nccl")
-    world = 1 if ctx is None else ctx.world
-    rank = 0 if ctx is None else ctx.rank
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
-
     torch.manual_seed(1234)                                 # identical weights on every rank
     model = pkg.MusicAttrRegGMVAE(342, 3, 16, 24, H, Z, 32, n_component=K).to(dev)
     trainer = pkg.GMVAETrainer(model, lr=1e-3, beta=0.2, dist_ctx=ctx)
-    b = synth_batch(np.random.RandomState(rank), B, T, TR)  # each rank its own shard of the global batch
+    b = synth_batch(np.random.RandomState(rank), B, T, TR)  # each rank its own shard of the global batch (rank 0: the c1 fixture's batch)
     batch = trainer.prepare_batch(b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"])
     torch.manual_seed(99 + rank)
-    eps = (torch.randn(B, Z).to(dev), torch.randn(B, Z).to(dev))
-
-    def log(msg):
-        if rank == 0:
-            print("[bench %.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
-
+    eps = trainer.draw_eps(B, T)                            # the reference's draw order; the same eps every step
     log("model + batch ready on %s" % dev)
     step = 20000
-    for _ in range(args.warmup):
-        trainer.step_device(step, batch, eps)
+    first = None
+    for i in range(args.warmup):
+        beta0, Bg = trainer.step_device(step, batch, eps)
+        if i == 0:
+            first = trainer._tuple8(beta0, Bg, False)       # the very first optimisation step from the seeded init (one sync)
         step += 1
     torch.cuda.synchronize()
     if ctx is not None:
@@ -126,12 +205,10 @@ def main():
         dt = float(tmax.item())
     tup = trainer._tuple8(0.2, B * world, False)            # one sync: the loss numbers of the last step (finite check)
     assert all(np.isfinite(tup)), tup
-
     tokens_per_s = world * B * T * args.steps / dt
     log("timed region done: %.3f ms/step (host enqueue %.3f ms/step)" % (dt / args.steps * 1e3, t_host / args.steps * 1e3))
-    roof = measure_dominant_kernel(trainer, batch, eps)
-    log("dominant-kernel timing done")
-    roof["step_frac"] = round(tokens_per_s / world * F_ALG_PER_TOKEN / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+    rows = per_kernel_rooflines(trainer, batch, eps)       # every rank: the pass contains the regulariser's all-gather
+    log("per-kernel timing done")
     out = {
         "metric": "event-tokens/sec GM-VAE train, seq256 b256", "value": round(tokens_per_s, 1), "unit": "event-tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -139,12 +216,129 @@ def main():
         "config": {"workload": "MusicAttrRegGMVAE train step (fwd+losses+bwd+clip+Adam), hidden 512, z 128, K=2, "
                                "B=256/GPU, T=256, Tr=64 (BASELINE configs[1]; N>1: DP, RCCL grad all-reduce)",
                    "global_batch": B * world, "seq_len": T, "parallelism": "dp%d" % world},
-        "roofline": roof,
         "last_loss": round(tup[0], 4),
+    }
+    if rank == 0:
+        dom = dict(rows["enc_fwd_scan"])
+        # traffic: HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE with the gfx950 correction + WRITE_SIZE, separate
+        # passes) - bench.py itself cannot run the profiler, so this is the committed measurement of the same launch.
+        dom.update(traffic=4.45e9, traffic_source="profiles/r01_pmc_gru_fwd_persist_4scans.txt", flop_per_launch=dom.pop("work_per_launch"),
+                   steps_per_launch=T, step_frac=round(tokens_per_s / world * F_ALG_PER_TOKEN / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
+        out["roofline"] = dom
+        out["roofline_all"] = rows
+        out["roofline_worst"] = min(rows, key=lambda r: rows[r]["frac"])
+        if first is not None and world == 1:                # same seeds as tests/golden/c1.npz (the reference's own train() at this size)
+            out["first_step_loss"] = round(first[0], 4)
+            gpath = os.path.join(ROOT, "tests", "golden", "c1.npz")
+            if os.path.exists(gpath):
+                ref = float(np.load(gpath)["train_tuples"][0][0])
+                out["first_step_loss_reference"] = round(ref, 4)
+                assert abs(first[0] - ref) <= 5e-4 * abs(ref), "first optimisation step deviates from the reference: %r vs %r" % (first[0], ref)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import cpu_baseline
+        out["cpu_baseline"] = cpu_baseline.time_baseline(H, Z, B, T, TR)
+    return out
+
+
+def bench_decode(args, pkg, ctx, local, rank, world, log):
+    """BASELINE configs[4]: encode + fader sweep + greedy decode; every rank runs an independent replica (no collective)."""
+    from music_fader_nets_amd.synth import synth_batch
+    from music_fader_nets_amd.decode import fader_sweep, greedy_decode
+    dev = torch.device("cuda", local)
+    torch.manual_seed(1234)
+    model = pkg.MusicAttrRegGMVAE(342, 3, 16, 24, H, Z, 32, n_component=K).to(dev)
+    model.eval()
+    b = synth_batch(np.random.RandomState(rank), DEC_SEQS, T, TR)
+    d = torch.from_numpy(b["d"]).to(dev).to(torch.int32)
+    c = torch.from_numpy(b["c"]).to(dev)
+    torch.manual_seed(99 + rank)
+    eps = (torch.randn(DEC_SEQS, Z).to(dev), torch.randn(DEC_SEQS, Z).to(dev))
+    values = [-2.0 + 0.5 * k for k in range(DEC_VALUES)]
+    rows = DEC_SEQS * DEC_VALUES
+    for _ in range(max(1, args.warmup)):
+        tok, _ = fader_sweep(model, d, c, values, steps=DEC_STEPS, which="r", eps=eps)
+    torch.cuda.synchronize()
+    if ctx is not None:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tok, _ = fader_sweep(model, d, c, values, steps=DEC_STEPS, which="r", eps=eps)
+    torch.cuda.synchronize()
+    if ctx is not None:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if ctx is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert int(tok.min()) >= 0 and int(tok.max()) < 342
+    tokens_per_s = world * rows * DEC_STEPS * args.steps / dt
+    log("timed region done: %.3f ms per pass" % (dt / args.steps * 1e3))
+    # the decode kernels alone (graph replay of 300 x 5 kernels), HIP events on the launch stream, mean of 5
+    z = torch.randn(rows, 2 * Z + 24, device=dev)
+    greedy_decode(model, z, DEC_STEPS, want_logp=False)
+    ms = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        greedy_decode(model, z, DEC_STEPS, want_logp=False)
+        e1.record()
+        torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    ms = float(np.mean(ms))
+    ach = rows * DEC_STEPS * F_ALG_DECODE_PER_TOKEN / (ms * 1e-3) / 1e12
+    out = {
+        "metric": "event-tokens/sec GM-VAE fader-sweep inference (encode + 8 fader values + 300-step greedy decode)",
+        "value": round(tokens_per_s, 1), "unit": "event-tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "arousal-transfer / fader-sweep inference (BASELINE configs[4]): 256 sequences x T=256 encoded, 8 values "
+                               "of z_r[:,0] each, 2048 rows x 300 greedy steps, hipGraph replay; replicas only for N>1",
+                   "global_batch": rows * world, "seq_len": DEC_STEPS, "parallelism": "replicas%d" % world},
+        "roofline": dict(bound="mfma", kernel="greedy decode of 2048 rows x 300 steps (graph of gru_fwd_step_kernel x2, gemm_kernel x2, "
+                                              "vocab_argmax_kernel per token)", achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS,
+                         unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), avg_launch_us=round(ms * 1e3, 1), traffic=None,
+                         flop_per_launch=rows * DEC_STEPS * F_ALG_DECODE_PER_TOKEN,
+                         weight_stream_GBs=round(DEC_STEPS * DECODE_WEIGHT_BYTES / (ms * 1e-3) / 1e9, 1)),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cpu_baseline
-        out["cpu_baseline"] = cpu_baseline.time_baseline(H, Z, args.cpu_sample_batch, T, TR, steps=1)
+        out["cpu_baseline"] = cpu_baseline.time_decode_baseline(H, Z, 256, 30)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", choices=("train", "decode"), default="train")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_launcher(args.gpus)
+
+    t_start = time.perf_counter()
+    from mfn_import import load_package
+    pkg = load_package()
+    from music_fader_nets_amd import parallel
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    ctx, local = parallel.init_from_env("nccl")
+    world = 1 if ctx is None else ctx.world
+    rank = 0 if ctx is None else ctx.rank
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(torch.device("cuda", local))
+
+    def log(msg):
+        if rank == 0:
+            print("[bench %.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
+
+    out = (bench_train if args.mode == "train" else bench_decode)(args, pkg, ctx, local, rank, world, log)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if ctx is not None:

@@ -32,6 +32,8 @@ extern "C" {
 #define FN_E_ALIGN (-3)     /* pointer or leading dimension not aligned     */
 #define FN_E_WORKSPACE (-4) /* workspace too small                          */
 #define FN_E_COUNT (-5)     /* too many scans in one call                   */
+#define FN_E_UNSUPPORTED (-6) /* valid arguments, but this single-launch path is not eligible on this device / shape: */
+                            /* nothing was enqueued, the caller takes the general path                             */
 
 #define FN_MAX_SCANS 8
 

@@ -8,6 +8,7 @@ from .trainer import GMVAETrainer, VAETrainer, beta_schedule, convert_to_one_hot
 from .vae_model import MusicAttrRegVAE  # noqa: F401
 from .decode import clean_output, fader_sweep, greedy_decode  # noqa: F401
 from .epochs import cpu_state_dict, training_phase  # noqa: F401
+from .evaluators import GMMNoteEvaluator, GMMRhythmEvaluator, arousal_transfer, run_through_gmm  # noqa: F401
 
 __all__ = ["MusicAttrRegGMVAE", "MusicAttrRegVAE", "GMVAETrainer", "VAETrainer", "beta_schedule", "convert_to_one_hot", "clean_output", "fader_sweep",
-           "greedy_decode", "training_phase", "cpu_state_dict"]
+           "greedy_decode", "training_phase", "cpu_state_dict", "GMMRhythmEvaluator", "GMMNoteEvaluator", "arousal_transfer", "run_through_gmm"]

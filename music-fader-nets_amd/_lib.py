@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfadernets_hip.so")
 
 FN_MAX_SCANS = 8
+FN_E_UNSUPPORTED = -6
 _f = C.POINTER(C.c_float)
 _i = C.POINTER(C.c_int32)
 vp = C.c_void_p

@@ -13,6 +13,7 @@ const char* fn_strerror(int code) {
         case FN_E_ALIGN: return "pointer or leading dimension not 16-byte aligned";
         case FN_E_WORKSPACE: return "workspace too small";
         case FN_E_COUNT: return "too many scans in one call";
+        case FN_E_UNSUPPORTED: return "single-launch path not eligible for this device / shape (nothing enqueued)";
         default: break;
     }
     if (code > 0) return hipGetErrorString((hipError_t)code);

@@ -375,7 +375,7 @@ int fn_decode_greedy(const FnDecode* d, void* stream) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FN_E_SHAPE;
     const int nsl = d->H / 16, nvt = (d->V + 15) / 16;
     const int grid = 3 * nsl + nvt + 1;
-    if (grid > prop.multiProcessorCount) return FN_E_SHAPE;       // every workgroup must be resident: one per CU
+    if (grid > prop.multiProcessorCount) return FN_E_UNSUPPORTED;  // every workgroup must be resident: one per CU
     hipStream_t st = (hipStream_t)stream;
     const int mt = d->B <= 16 ? 1 : (d->B <= 32 ? 2 : 4);
     const size_t bp = (size_t)mt * 16, vp = (size_t)nvt * 16;

@@ -15,22 +15,24 @@ from .engine import E_VOCAB, LOGIT_LD
 def greedy_decode(model, z, steps, want_logp=True, use_graph=None):
     """z (Bi, 2Z+24) -> (log-probs (Bi, steps, 342) or None, tokens (Bi, steps) int32).
 
-    On the GPU the whole decode (steps x {layer-1 cell, W_ih2 projection, layer-2 cell, output GEMM, log_softmax+argmax}) is
-    captured once per (Bi, steps) into a hipGraph and replayed: the loop is launch-latency bound (7 small kernels per token)."""
+    Bi <= 32: ONE launch for the whole decode (fn_decode_greedy).  Larger batches: steps x {layer-1 cell, W_ih2 projection,
+    layer-2 cell, output GEMM, log_softmax+argmax} captured once per (Bi, steps) into a hipGraph and replayed.  The captured
+    kernels read the parameters and the engine's weight images IN PLACE (stable addresses, refreshed by Engine.refresh_weights
+    after every optimiser step / load_state_dict), so a graph stays valid when the weights change."""
     eng = model.engine()
     z = z.float().contiguous()
     if _single_launch_ok(eng, z):
-        return _decode_single_launch(model, eng, z, steps, want_logp)
+        res = _decode_single_launch(eng, z, steps, want_logp)
+        if res is not None:
+            return res
     if use_graph is None:
         use_graph = z.is_cuda
     if not use_graph:
         return _decode_body(eng, z, steps, want_logp, None, None)
     cache = eng.__dict__.setdefault("_decode_graphs", {})
-    key = (z.shape[0], steps, bool(want_logp), model._version)
+    key = (z.shape[0], steps, bool(want_logp))
     ent = cache.get(key)
     if ent is None:
-        for k in [k for k in cache if k[3] != model._version]:     # weights changed: captured weight images are stale
-            del cache[k]
         zs = z.clone()
         tokens = torch.zeros(z.shape[0], steps, dtype=torch.int32, device=z.device)
         logp = torch.empty(z.shape[0], steps, E_VOCAB, device=z.device) if want_logp else None
@@ -48,31 +50,29 @@ def greedy_decode(model, z, steps, want_logp=True, use_graph=None):
 
 def _single_launch_ok(eng, z):
     """small batches decode as ONE launch (fn_decode_greedy: weight slices resident in LDS, activations handed over through L2)"""
-    import os
-    return (hasattr(eng.ops, "decode_greedy") and z.is_cuda and z.shape[0] <= 32 and eng.H <= 512 and
-            os.environ.get("FN_DECODE_PERSIST", "1") == "1")
+    return hasattr(eng.ops, "decode_greedy") and z.is_cuda and z.shape[0] <= 32 and eng.H <= 512 and eng.single_launch_decode
 
 
-def _decode_single_launch(model, eng, z, steps, want_logp):
+def _decode_single_launch(eng, z, steps, want_logp):
+    """None when the library reports the configuration as not eligible (e.g. fewer CUs than role workgroups) or the launch
+    timed out waiting for a hand-over: the caller then takes the per-token path."""
     ops, P, H = eng.ops, eng.p, eng.H
     Bi = z.shape[0]
-    packs = eng.__dict__.setdefault("_decode_packs", {})
-    if packs.get("version") != model._version:             # operand images of the two matrices the training step never packs
-        packs.clear()
-        for key, name in (("ih2", "grucell_g_2.weight_ih"), ("out", "linear_out_g.weight")):
-            w = P[name]
-            packs[key] = torch.zeros(ops.frag_floats(w.shape[0], w.shape[1]), device=z.device)
-            ops.frag_pack(w, packs[key])
-        packs["version"] = model._version
     h0g = eng.buf("dec_h0g", (Bi, H))
     ops.gemm(z, P["linear_init_global.weight"], h0g, bias=P["linear_init_global.bias"])
     rbg = eng.buf("dec_rbg", (Bi, 3 * H))
     ops.gemm(z, P["grucell_g.weight_ih"][:, E_VOCAB:], rbg)
     tokens = torch.zeros(Bi, steps, dtype=torch.int32, device=z.device)
     logp = torch.empty(Bi, steps, E_VOCAB, device=z.device) if want_logp else None
-    ops.decode_greedy(Bi, steps, H, E_VOCAB, E_VOCAB - 1, eng.whh_f["g"], P["grucell_g.bias_hh"], P["grucell_g.bias_ih"], eng.tab["g"], rbg, h0g,
-                      packs["ih2"], P["grucell_g_2.bias_ih"], eng.whh_f["g2"], P["grucell_g_2.bias_hh"], packs["out"], P["linear_out_g.bias"],
-                      tokens, logp)
+    ok = ops.decode_greedy(Bi, steps, H, E_VOCAB, E_VOCAB - 1, eng.whh_f["g"], P["grucell_g.bias_hh"], P["grucell_g.bias_ih"], eng.tab["g"], rbg, h0g,
+                           eng.packs["ih2"], P["grucell_g_2.bias_ih"], eng.whh_f["g2"], P["grucell_g_2.bias_hh"], eng.packs["out"],
+                           P["linear_out_g.bias"], tokens, logp)
+    if not ok:
+        return None
+    if ops.gru_sync_error(clear=True):           # bounded spin gave up (another kernel held the CUs): results are garbage
+        import warnings
+        warnings.warn("single-launch greedy decode timed out waiting for a hand-over; repeating on the per-token kernels")
+        return None
     return logp, tokens
 
 
@@ -129,36 +129,43 @@ def clean_output(out):
 @torch.no_grad()
 def fader_sweep(model, x, chroma, values, steps=100, which="r", eps=None, mode="set"):
     """Batched RhythmEvaluator.shift / NoteEvaluator.shift (test_class.py:233-254, :282-303) and the notebook's
-    lambda*shift-vector transfer (cell 15).
+    lambda*shift-vector transfer (cells 11 + 15): every (sample, fader value) pair is one row of ONE decode batch.
 
-    x (n, T) token ids or (n, T, 342) one-hot; chroma (n, 24); values: fader values.
-      mode="set":   z_which[:, 0] = value                      (test_class.py:249)
-      mode="shift": z_which += value * (mu_lookup[1] - mu_lookup[0])   (notebook cells 11, 15)
-    Returns (tokens (n, len(values), steps) int32, z0 (n,)) - all n*len(values) sequences decode as ONE batch.
-    """
+    x (n, T) token ids or (n, T, 342) one-hot; chroma (n, 24); values: V fader values.
+      mode="set":   z_which[:, 0] = value                                   (test_class.py:249, :298)
+      mode="shift": z_which += value * (mu_lookup[1] - mu_lookup[0]);  which="both" moves z_r and z_n together, as the notebook does
+    eps: (eps_r, eps_n), each (n, Z) - one draw per sample, shared by its V values - or (n, V, Z) - one draw per (sample, value),
+    which is what V separate reference calls consume; None = drawn here (r first, then n).
+    Returns (tokens (n, V, steps) int32, z0 (n,) or (n, V): the value of z_which[:, 0] before the change; which="both": z_r's)."""
+    if which not in ("r", "n", "both") or mode not in ("set", "shift") or (which == "both" and mode == "set"):
+        raise ValueError("which in {r, n, both}, mode in {set, shift}; 'both' only with mode='shift'")
     was_training = model.training
     model.eval()
     try:
         dis_r, dis_n = model.encode(x)
         n, Z = dis_r.mean.shape
+        V = len(values)
+        dev = dis_r.mean.device
         if eps is None:
             eps = (torch.randn(n, Z), torch.randn(n, Z))      # repar() of test_class.py:53-56 draws r first, then n
-        z_r = dis_r.mean + dis_r.stddev * eps[0].to(dis_r.mean.device)
-        z_n = dis_n.mean + dis_n.stddev * eps[1].to(dis_r.mean.device)
-        z0 = (z_r if which == "r" else z_n)[:, 0].clone()
-        V = len(values)
-        vals = torch.as_tensor(values, dtype=torch.float32, device=z_r.device)
-        zr = z_r.unsqueeze(1).repeat(1, V, 1)
-        zn = z_n.unsqueeze(1).repeat(1, V, 1)
-        tgt = zr if which == "r" else zn
+        er, en = (e.to(dev).float() for e in eps)
+        per_value = er.dim() == 3
+        if not per_value:
+            er, en = er.unsqueeze(1).expand(n, V, Z), en.unsqueeze(1).expand(n, V, Z)
+        zr = dis_r.mean.unsqueeze(1) + dis_r.stddev.unsqueeze(1) * er          # (n, V, Z), fresh tensors
+        zn = dis_n.mean.unsqueeze(1) + dis_n.stddev.unsqueeze(1) * en
+        z0 = (zn if which == "n" else zr)[:, :, 0].clone()
+        if not per_value:
+            z0 = z0[:, 0]
+        vals = torch.as_tensor(values, dtype=torch.float32, device=dev)
         if mode == "set":
-            tgt[:, :, 0] = vals
+            (zr if which == "r" else zn)[:, :, 0] = vals
         else:
-            lk = model.mu_r_lookup if which == "r" else model.mu_n_lookup
-            shift = lk.weight.data[1] - lk.weight.data[0]
-            tgt += vals.view(1, V, 1) * shift.view(1, 1, Z)
-        c = chroma.float().to(z_r.device).unsqueeze(1).repeat(1, V, 1)
-        z = torch.cat([zr, zn, c], dim=2).view(n * V, -1)
+            for tgt, lk, on in ((zr, model.mu_r_lookup, which in ("r", "both")), (zn, model.mu_n_lookup, which in ("n", "both"))):
+                if on:
+                    tgt += vals.view(1, V, 1) * (lk.weight.data[1] - lk.weight.data[0]).view(1, 1, Z)
+        c = chroma.float().to(dev).unsqueeze(1).expand(n, V, chroma.shape[-1])
+        z = torch.cat([zr, zn, c], dim=2).reshape(n * V, -1)
         _, tok = greedy_decode(model, z, steps, want_logp=False)
         return tok.view(n, V, steps), z0
     finally:

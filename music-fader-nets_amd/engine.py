@@ -32,11 +32,13 @@ class Engine:
         self.tab = {}                   # transposed one-hot columns of W_ih:  key -> [V][3H]
         self.whh_f = {}                 # W_hh in the kernels' fragment-major operand layout (forward scans)
         self.whh_t = {}                 # W_hh^T, fragment-major (backward scans)
+        self.packs = {}                 # fragment-major W_ih2 / W_out (single-launch greedy decode)
         self.saved = None
         self.chunk = int(__import__("os").environ.get("FN_CHUNK", "64"))                 # time steps per pipeline chunk of the two decoder layers
         # decoder scans as weight-stationary launches: the two sub-decoders on the whole chip, then layer 1 || layer 2 on half
         # of the CUs each (two single-launch scans that overlap must fit on the chip TOGETHER, see FnGruFwd.cu_budget)
         self.persist_dec = __import__("os").environ.get("FN_PERSIST_DEC", "1") == "1"
+        self.single_launch_decode = __import__("os").environ.get("FN_DECODE_PERSIST", "1") == "1"    # decode.py: <= 32 sequences as one launch
         self._lane_alias = {}           # lane -> lane it is folded into (debug / tuning: FN_AUX=0 runs the aux lane on the side stream)
         self._aux_mode = __import__("os").environ.get("FN_AUX", "1")      # 1 | 0 | fwd | bwd
         if hidden % 32 != 0:
@@ -109,11 +111,15 @@ class Engine:
             torch.cuda.current_stream(self.dev).wait_stream(st)
 
     def buf(self, name, shape, dtype=torch.float32):
+        """Named scratch tensor.  The key includes the shape: a captured hipGraph holds raw pointers into these buffers, so a
+        buffer is NEVER dropped or reallocated once handed out - another batch shape gets its own set (the epoch driver alternates
+        train / validation / ragged-tail shapes, trainer_gmm.py:320-440, and replays the graph of each)."""
         shape = tuple(int(s) for s in shape)
-        t = self._bufs.get(name)
-        if t is None or tuple(t.shape) != shape or t.dtype != dtype:
+        key = (name, shape, dtype)
+        t = self._bufs.get(key)
+        if t is None:
             t = torch.empty(shape, dtype=dtype, device=self.dev)
-            self._bufs[name] = t
+            self._bufs[key] = t
         return t
 
     def zbuf(self, name, shape):
@@ -149,6 +155,14 @@ class Engine:
                 wtf = self.buf("whht_" + key, (self.ops.frag_floats(H, 3 * H),))
                 self.ops.frag_pack(wt, wtf)
                 self.whh_t[key] = wtf
+        # operand images of the two dense matrices of the single-launch greedy decode (decode.py): refreshed here so that the
+        # captured training step keeps them current - a decode after training must not see the weights of an earlier step
+        for key, name in (("ih2", "grucell_g_2.weight_ih"), ("out", "linear_out_g.weight")):
+            w = self.p[name]
+            img = self.packs.get(key)
+            if img is None:
+                img = self.packs[key] = torch.zeros(self.ops.frag_floats(w.shape[0], w.shape[1]), device=self.dev)
+            self.ops.frag_pack(w, img)
 
     # ------------------------------------------------------------------------------------------
     # forward
@@ -166,7 +180,7 @@ class Engine:
                                   b_ih=P[pfx + "bias_ih" + sfx], gx_table=self.tab[key], idx=d, idx_shift=0,
                                   h_all=hall[key], gates=self.buf("enc_g_" + key, (T, ops.gates_floats(B, H))) if save else None))
         ops.gru_seq_fwd(scans)
-        pre = {}
+        pre = {"h_all": hall, "gates": {sc_key: sc["gates"] for sc_key, sc in zip(hall, scans)}}
         for e in ("r", "n"):
             hf, hb = hall[e][T - 1], hall[e + "_reverse"][T - 1]
             pre[e] = self.buf("pre_" + e, (B, 2 * Z))
@@ -188,55 +202,64 @@ class Engine:
             out[e] = o
         return out
 
-    def decoders(self, d, r, n, c, z_r, z_n):
-        """sub-decoders + teacher-forced global decoder up to the (pre-softmax) logits."""
-        ops, P, H, Z, ZG = self.ops, self.p, self.H, self.Z, self.ZG
-        B, T = d.shape
-        Tr = r.shape[1]
-        scans = []
-        sd = {}
+    def sub_decoders_fwd(self, r, n, z_r, z_n, save=True):
+        """gmm_model.py:100-117 up to the pre-softmax logits: both attribute decoders as ONE weight-stationary launch (whole chip)."""
+        ops, P, H = self.ops, self.p, self.H
+        B, Tr = r.shape
+        scans, sd = [], {}
         for e, attr, Ce, z in (("r", r, R_DIMS, z_r), ("n", n, N_DIMS, z_n)):
             h0 = self.buf("sd_h0_" + e, (B, H))
             ops.gemm(z, P["linear_init_%s.weight" % e], h0, bias=P["linear_init_%s.bias" % e])
             w_ih = P["gru_d_%s.weight_ih_l0" % e]
             rb = self.buf("sd_rb_" + e, (B, 3 * H))
             ops.gemm(z, w_ih[:, Ce:], rb)
-            sd[e] = dict(h0=h0, rb=rb, h_all=self.buf("sd_h_" + e, (Tr, B, H)), gates=self.buf("sd_g_" + e, (Tr, ops.gates_floats(B, H))))
+            sd[e] = dict(h0=h0, rb=rb, h_all=self.buf("sd_h_" + e, (Tr, B, H)),
+                         gates=self.buf("sd_g_" + e, (Tr, ops.gates_floats(B, H))) if save else None)
             scans.append(dict(B=B, T=Tr, H=H, w_hh_frag=self.whh_f["d_" + e], b_hh=P["gru_d_%s.bias_hh_l0" % e],
                               b_ih=P["gru_d_%s.bias_ih_l0" % e], h0=h0, gx_table=self.tab["d_" + e], idx=attr, gx_rowbias=rb,
                               h_all=sd[e]["h_all"], gates=sd[e]["gates"]))
-        zc = self.buf("zc", (B, ZG))
+        ops.gru_seq_fwd(scans)
+        for e, Ce in (("r", R_DIMS), ("n", N_DIMS)):
+            sd[e]["logits"] = self.buf("sd_logits_" + e, (Tr, B, Ce))
+            ops.gemm(sd[e]["h_all"].view(Tr * B, H), P["linear_out_%s.weight" % e], sd[e]["logits"].view(Tr * B, Ce),
+                     bias=P["linear_out_%s.bias" % e])
+        return sd
+
+    def pack_zc(self, z_r, z_n, c):
+        """z = cat([z_r, z_n, chroma], 1) (gmm_model.py:249)"""
+        Z = self.Z
+        zc = self.buf("zc", (z_r.shape[0], self.ZG))
         zc[:, :Z].copy_(z_r)
         zc[:, Z:2 * Z].copy_(z_n)
         zc[:, 2 * Z:].copy_(c)
+        return zc
+
+    def global_decoder_tf(self, d, zc, save=True):
+        """gmm_model.py:119-149 in train mode (teacher forced with d, start token 341, input shifted by one step) up to the
+        pre-softmax logits [T*B][LOGIT_LD]."""
+        ops, P, H = self.ops, self.p, self.H
+        B, T = d.shape
         h0g = self.buf("g_h0", (B, H))
         ops.gemm(zc, P["linear_init_global.weight"], h0g, bias=P["linear_init_global.bias"])
         rbg = self.buf("g_rb", (B, 3 * H))
         ops.gemm(zc, P["grucell_g.weight_ih"][:, E_VOCAB:], rbg)
         hx0 = self.buf("g_hx0", (T, B, H))
-        g1 = self.buf("g_gates1", (T, ops.gates_floats(B, H)))
+        g1 = self.buf("g_gates1", (T, ops.gates_floats(B, H))) if save else None
         l1 = dict(B=B, T=T, H=H, w_hh_frag=self.whh_f["g"], b_hh=P["grucell_g.bias_hh"], b_ih=P["grucell_g.bias_ih"],
                   h0=h0g, gx_table=self.tab["g"], idx=d, idx_shift=-1, start_token=E_VOCAB - 1, gx_rowbias=rbg, h_all=hx0, gates=g1)
         gx2 = self.buf("g_gx2", (T, B, 3 * H))
         hx1 = self.buf("g_hx1", (T, B, H))
-        g2 = self.buf("g_gates2", (T, ops.gates_floats(B, H)))
+        g2 = self.buf("g_gates2", (T, ops.gates_floats(B, H))) if save else None
         l2 = dict(B=B, T=T, H=H, w_hh_frag=self.whh_f["g2"], b_hh=P["grucell_g_2.bias_hh"], h0=None, gx_dense=gx2, h_all=hx1, gates=g2)
-        # Time is cut into chunks: layer 1 (+ the two sub-decoders, which only live in the first Tr steps) runs on the main
-        # stream; behind it, on the side stream, chunk c of layer 2 = batched W_ih2 projection of hx0[chunk] (one GEMM)
-        # + the recurrent scan (h_init = hx0[0], gmm_model.py:134-135).  Layer 2 thus lags layer 1 by one chunk.
+        # Time is cut into chunks: layer 1 runs on the main stream; behind it, on the side stream, chunk c of layer 2 = batched
+        # W_ih2 projection of hx0[chunk] (one GEMM) + the recurrent scan (h_init = hx0[0], gmm_model.py:134-135).  Layer 2 thus
+        # lags layer 1 by one chunk; each layer is a weight-stationary launch on half of the CUs.
         CH = self.chunk
         half = self._cu_count() // 2
+        pd = self.persist_dec
         self._lane_alias = {} if self._aux_mode in ("1", "fwd") else {"aux": "side"}
-        if self.persist_dec:
-            ops.gru_seq_fwd(scans)                           # both sub-decoders, all Tr steps, whole chip
-        for t0 in range(0, T if self.persist_dec else max(T, Tr), CH):
-            if self.persist_dec:
-                ops.gru_seq_fwd([self._fwd_chunk(l1, t0, t0 + CH)], cu_budget=half)
-            else:
-                part = [self._fwd_chunk(sc, t0, t0 + CH) for sc in scans + [l1] if t0 < sc["T"]]
-                ops.gru_seq_fwd(part, persistent=False)
-            if t0 >= T:
-                continue
+        for t0 in range(0, T, CH):
+            ops.gru_seq_fwd([self._fwd_chunk(l1, t0, t0 + CH)], persistent=pd, cu_budget=half)
             t1 = min(T, t0 + CH)
             # three lanes: layer 1 (main) -> input projection of layer 2 (aux) -> layer 2 (side); chunk c+1 of a lane runs
             # beside chunk c of the next one
@@ -248,15 +271,18 @@ class Engine:
                 c2 = self._fwd_chunk(l2, t0, t1)
                 if t0 == 0:
                     c2["h0"] = hx0[0]
-                ops.gru_seq_fwd([c2], persistent=self.persist_dec, cu_budget=half)
+                ops.gru_seq_fwd([c2], persistent=pd, cu_budget=half)
         self.main_wait_side()
         logits = self.buf("g_logits", (T * B, LOGIT_LD))
         ops.gemm(hx1.view(T * B, H), P["linear_out_g.weight"], logits[:, :E_VOCAB], bias=P["linear_out_g.bias"])
-        for e, Ce in (("r", R_DIMS), ("n", N_DIMS)):
-            sd[e]["logits"] = self.buf("sd_logits_" + e, (Tr, B, Ce))
-            ops.gemm(sd[e]["h_all"].view(Tr * B, H), P["linear_out_%s.weight" % e], sd[e]["logits"].view(Tr * B, Ce),
-                     bias=P["linear_out_%s.bias" % e])
-        return dict(sd=sd, zc=zc, h0g=h0g, rbg=rbg, hx0=hx0, g1=g1, gx2=gx2, hx1=hx1, g2=g2, logits=logits)
+        return dict(zc=zc, h0g=h0g, rbg=rbg, hx0=hx0, g1=g1, gx2=gx2, hx1=hx1, g2=g2, logits=logits)
+
+    def decoders(self, d, r, n, c, z_r, z_n, save=True):
+        """sub-decoders + teacher-forced global decoder up to the (pre-softmax) logits."""
+        sd = self.sub_decoders_fwd(r, n, z_r, z_n, save)
+        dec = self.global_decoder_tf(d, self.pack_zc(z_r, z_n, c), save)
+        dec["sd"] = sd
+        return dec
 
     @staticmethod
     def _fwd_chunk(sc, t0, t1):
@@ -289,13 +315,15 @@ class Engine:
         c["dh0"] = carry_out
         return c
 
-    def forward(self, d, r, n, c, eps_r, eps_n, labels=None):
-        """Full training-mode forward up to logits; everything backward needs stays in named buffers."""
-        pre = self.encode(d)
+    def forward(self, d, r, n, c, eps_r, eps_n, labels=None, save=True):
+        """Full training-mode forward up to logits; everything backward needs stays in named buffers (save=False: forward only,
+        the gate tensors are not written)."""
+        pre = self.encode(d, save)
         lat = self.latent(pre, {"r": eps_r, "n": eps_n}, labels)
-        dec = self.decoders(d, r, n, c, lat["r"]["z"], lat["n"]["z"])
-        self.saved = dict(d=d, r=r, n=n, c=c, eps={"r": eps_r, "n": eps_n}, labels=labels, pre=pre, lat=lat, dec=dec)
-        return self.saved
+        dec = self.decoders(d, r, n, c, lat["r"]["z"], lat["n"]["z"], save)
+        S = dict(d=d, r=r, n=n, c=c, eps={"r": eps_r, "n": eps_n}, labels=labels, pre=pre, lat=lat, dec=dec)
+        self.saved = S if save else None
+        return S
 
     # ------------------------------------------------------------------------------------------
     # backward
@@ -376,7 +404,7 @@ class Engine:
                           dh_ext=dh_sd[e], dgx_all=sdb[e]["dgx"], dghn_all=sdb[e]["dghn"], scratch=self.buf("sd_scr_" + e, (B, H)),
                           dgx_rowsum=sdb[e]["drb"], dghn_rowsum=sdb[e]["rsn"])
         CH = self.chunk
-        starts = list(range(0, max(T, Tr), CH))
+        starts = list(range(0, T, CH))
         carry = {k: [self.buf("carry_%s_%d" % (k, i), (B, H)) for i in range(2)] for k in ("l2", "l1", "r", "n")}
 
         def chunk_call(items, t0, last):
@@ -396,24 +424,19 @@ class Engine:
         self._lane_alias = {} if self._aux_mode in ("1", "bwd") else {"aux2": "side"}
         self.side_wait_main()
         for i, t0 in enumerate(reversed(starts)):
-            if t0 < T:
-                with self.on_side():
-                    ops.gru_seq_bwd(chunk_call([("l2", l2)], t0, i == 0), persistent=pd, cu_budget=half)
-                # layer 2 (side) -> dhx0[chunk] = dgx2[chunk] W_ih2 (aux) -> layer 1 (main)
-                self.lane_wait("aux2", "side")
-                t1 = min(T, t0 + CH)
-                with Engine._Lane(self, True, "aux2"):
-                    ops.gemm(dgx2[t0:t1].view(-1, 3 * H), P["grucell_g_2.weight_ih"], dhx0[t0:t1].view(-1, H), a_k=True, b_k=False)
-                    if t0 == 0:
-                        ops.axpy(1.0, carry["l2"][0], dhx0[0])          # hx1 was initialised with hx0[0]: dL/dh_init of layer 2
-                self.lane_wait("main", "aux2")
-            if pd:
-                if t0 < T:
-                    ops.gru_seq_bwd(chunk_call([("l1", l1)], t0, i == 0), cu_budget=half)
-            else:
-                ops.gru_seq_bwd(chunk_call([("l1", l1), ("r", sds["r"]), ("n", sds["n"])], t0, i == 0), persistent=False)
-        if pd:                                   # both sub-decoders, all Tr steps, whole chip (layer 2 has finished on the side stream)
-            ops.gru_seq_bwd([self._bwd_chunk(sds[e], 0, Tr, None, carry[e][0]) for e in ("r", "n")])
+            with self.on_side():
+                ops.gru_seq_bwd(chunk_call([("l2", l2)], t0, i == 0), persistent=pd, cu_budget=half)
+            # layer 2 (side) -> dhx0[chunk] = dgx2[chunk] W_ih2 (aux) -> layer 1 (main)
+            self.lane_wait("aux2", "side")
+            t1 = min(T, t0 + CH)
+            with Engine._Lane(self, True, "aux2"):
+                ops.gemm(dgx2[t0:t1].view(-1, 3 * H), P["grucell_g_2.weight_ih"], dhx0[t0:t1].view(-1, H), a_k=True, b_k=False)
+                if t0 == 0:
+                    ops.axpy(1.0, carry["l2"][0], dhx0[0])          # hx1 was initialised with hx0[0]: dL/dh_init of layer 2
+            self.lane_wait("main", "aux2")
+            ops.gru_seq_bwd(chunk_call([("l1", l1)], t0, i == 0), persistent=pd, cu_budget=half)
+        # both sub-decoders, all Tr steps, whole chip (layer 2 has finished on the side stream)
+        ops.gru_seq_bwd([self._bwd_chunk(sds[e], 0, Tr, None, carry[e][0]) for e in ("r", "n")], persistent=pd)
         dh0_g = carry["l1"][0]
         for e in ("r", "n"):
             sdb[e]["dh0"] = carry[e][0]
@@ -475,8 +498,8 @@ class Engine:
                            w3, dpre, dmu_rows)
             if "mu_%s_lookup.weight" % e in G:           # the plain-VAE sibling has no component means to train
                 ops.colsum(dmu_rows, G["mu_%s_lookup.weight" % e].view(-1))
-            hf = self._bufs["enc_h_" + e][T - 1]
-            hb = self._bufs["enc_h_" + e + "_reverse"][T - 1]
+            hf = pre["h_all"][e][T - 1]
+            hb = pre["h_all"][e + "_reverse"][T - 1]
             dhf, dhb = self.buf("enc_dhf_" + e, (B, H)), self.buf("enc_dhb_" + e, (B, H))
             for i, (head, c0) in enumerate((("mu_", 0), ("var_", Z))):
                 W = P[head + e + ".weight"]                     # [Z][2H]
@@ -490,14 +513,14 @@ class Engine:
             for key, dh in ((e, dhf), (e + "_reverse", dhb)):
                 encb[key] = dict(dgx=self.buf("enc_dgx_" + key, (T, B, 3 * H)), dghn=self.buf("enc_dghn_" + key, (T, B, H)),
                                  rs=self.zbuf("enc_rs_" + key, (B, 3 * H)), rsn=self.zbuf("enc_rsn_" + key, (B, H)))
-                scans.append(dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t[key], h0=None, h_all=self._bufs["enc_h_" + key],
-                                  gates=self._bufs["enc_g_" + key], dh_last=dh, dgx_all=encb[key]["dgx"], dghn_all=encb[key]["dghn"],
+                scans.append(dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t[key], h0=None, h_all=pre["h_all"][key],
+                                  gates=pre["gates"][key], dh_last=dh, dgx_all=encb[key]["dgx"], dghn_all=encb[key]["dghn"],
                                   scratch=self.buf("enc_scr_" + key, (B, H)), dgx_rowsum=encb[key]["rs"], dghn_rowsum=encb[key]["rsn"]))
         ops.gru_seq_bwd(scans)        # 4 concurrent reverse scans, one weight-stationary launch
         for e in ("r", "n"):
             for key, sfx, rev in ((e, "_l0", 0), (e + "_reverse", "_l0_reverse", 1)):
                 pfx = "gru_%s." % e
-                self._gru_weight_grads(key, pfx, sfx, T, B, encb[key]["dgx"], encb[key]["dghn"], self._bufs["enc_h_" + key], None, G, sk_T,
+                self._gru_weight_grads(key, pfx, sfx, T, B, encb[key]["dgx"], encb[key]["dghn"], pre["h_all"][key], None, G, sk_T,
                                        encb[key]["rs"], encb[key]["rsn"])
                 dtab = self.buf("dtab_E", (E_VOCAB, 3 * H))
                 ops.embed_grad(encb[key]["dgx"], d, 0, 0, rev, E_VOCAB, dtab)

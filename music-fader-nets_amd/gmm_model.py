@@ -106,10 +106,16 @@ class MusicAttrRegGMVAE(nn.Module):
         self.weights_changed()
         return res
 
-    def _indices(self, x, V):
-        """Accept the reference's one-hot tensors (trainer_gmm.py:296-303) or integer ids -> int32 [B][T]."""
-        if x.dtype in (torch.int32, torch.int64, torch.int16, torch.uint8):
+    def _indices(self, x, V, ids_ndim=None):
+        """Accept the reference's one-hot tensors (trainer_gmm.py:296-303) or integer ids -> int32 ids.
+
+        Integer dtypes are ids.  A floating tensor is a one-hot tensor (last dim V) - unless the caller states the rank of an id
+        tensor (`ids_ndim`): the data loaders yield token ids as float32 [B][T] (ptb_v2.py:459-470 pads into float arrays) which the
+        reference casts with ``.cuda().long()`` (trainer_gmm.py:323,397); a float tensor of that rank is cast the same way."""
+        if x.dtype in (torch.int32, torch.int64, torch.int16, torch.int8, torch.uint8):
             return x.to(torch.int32).contiguous()
+        if ids_ndim is not None and x.dim() == ids_ndim:
+            return x.long().to(torch.int32).contiguous()
         if x.shape[-1] != V:
             raise ValueError("expected a one-hot tensor with last dim %d, got %s" % (V, tuple(x.shape)))
         eng = self.engine()
@@ -165,13 +171,28 @@ class MusicAttrRegGMVAE(nn.Module):
 
     @torch.no_grad()
     def global_decoder(self, z, steps):
-        """gmm_model.py:119-149 in eval mode: greedy argmax feedback -> (B, steps, 342) log-probabilities."""
-        if self.training:
-            raise NotImplementedError("global_decoder() is teacher-forced inside forward() in train mode; call it directly "
-                                      "only after model.eval() (as test_class.py:250-253 and the notebook do)")
-        from .decode import greedy_decode
-        logp, _ = greedy_decode(self, z, steps)
-        return logp
+        """gmm_model.py:119-149 -> (B, steps, 342) log-probabilities.
+
+        eval mode: greedy argmax feedback (:147-148), the call of test_class.py:253 / notebook cell 15.
+        train mode: teacher forced with ``self.sample`` (the x of the last train-mode forward, :141-142), one ``torch.rand(1)`` draw
+        per step as the reference makes (:140).  No autograd through a direct call (training goes through forward())."""
+        if not self.training:
+            from .decode import greedy_decode
+            logp, _ = greedy_decode(self, z, steps)
+            return logp
+        if self.sample is None:
+            raise RuntimeError("global_decoder() in train mode reads self.sample (gmm_model.py:142): run forward() first or call model.eval()")
+        eng = self.engine()
+        d = self._indices(self.sample, self.roll_dims, ids_ndim=2)
+        if d.shape[1] < steps or d.shape[0] != z.shape[0]:
+            raise IndexError("teacher forcing needs self.sample of shape (%d, >=%d, ...), got %s" % (z.shape[0], steps, tuple(self.sample.shape)))
+        for _ in range(steps):
+            torch.rand(1)
+        d = d[:, :steps].contiguous()
+        dec = eng.global_decoder_tf(d, z.float().contiguous(), save=False)
+        out = torch.empty(z.shape[0], steps, E_VOCAB, device=z.device)
+        eng.ops.vocab_logsoftmax(dec["logits"], z.shape[0], steps, E_VOCAB, logp_bt=out)
+        return out
 
     @torch.no_grad()
     def sub_decoders(self, rhythm, z_r, note, z_n):
@@ -191,8 +212,12 @@ class MusicAttrRegGMVAE(nn.Module):
         return outs[0], outs[1], 0, 0
 
     def forward(self, x, rhythm, note, chroma, eps=None):
-        """gmm_model.py:220-259.  Returns the reference's nested tuple; outputs are autograd-connected to the
-        parameters through one fused autograd node whose backward runs the HIP backward kernels."""
+        """gmm_model.py:220-259.  Returns the reference's nested tuple.
+
+        train mode, autograd on: outputs are connected to the parameters through one fused autograd node whose backward runs the
+        HIP backward kernels.  eval mode (``model.eval()``: what the evaluators are in after their first ``shift``,
+        test_class.py:238,250): ``out`` is the GREEDY decode - the decoder feeds back ``_sampling(out)`` (:146-148) - and no
+        ``torch.rand(1)`` is drawn; forward only.  Under ``torch.no_grad()`` nothing is saved for a backward either."""
         if self.training:
             self.sample = x
         self.engine()
@@ -204,12 +229,44 @@ class MusicAttrRegGMVAE(nn.Module):
         if eps is None:
             eps = self._draw_eps(B, T, d.device)
         eps_r, eps_n = (e.float().contiguous() for e in eps)
-        names = [k for k, _ in self.used_parameters()]
-        plist = [p for _, p in self.used_parameters()]
-        res = _GMVAEFunction.apply(self, names, d, r, n, c, eps_r, eps_n, *plist)
+        if not self.training or not torch.is_grad_enabled():
+            res = self._forward_only(d, r, n, c, eps_r, eps_n)
+        else:
+            names = [k for k, _ in self.used_parameters()]
+            plist = [p for _, p in self.used_parameters()]
+            res = _GMVAEFunction.apply(self, names, d, r, n, c, eps_r, eps_n, *plist)
         out, r_out, n_out, mu_r, sg_r, mu_n, sg_n, z_r, z_n, ll_r, ll_n, qy_r, qy_n, y_r, y_n = res
         dis_r, dis_n = Normal(mu_r, sg_r), Normal(mu_n, sg_n)
         return ((out, r_out, n_out, 0, 0), (dis_r, dis_n), (z_r, z_n), (ll_r, ll_n), (qy_r, qy_n), (y_r, y_n))
+
+    @torch.no_grad()
+    def _forward_only(self, d, r, n, c, eps_r, eps_n):
+        """forward without a backward: eval mode (greedy global decoder) or train mode under no_grad (teacher forced)."""
+        eng = self._engine
+        ops = eng.ops
+        B, T = d.shape
+        Tr = r.shape[1]
+        Z = eng.Z
+        pre = eng.encode(d, save=False)
+        lat = eng.latent(pre, {"r": eps_r, "n": eps_n})
+        z_r, z_n = lat["r"]["z"], lat["n"]["z"]
+        sd = eng.sub_decoders_fwd(r, n, z_r, z_n, save=False)
+        r_out = torch.empty(B, Tr, 3, device=d.device)
+        n_out = torch.empty(B, Tr, 16, device=d.device)
+        ops.time_logsoftmax(sd["r"]["logits"], logp_bt=r_out)
+        ops.time_logsoftmax(sd["n"]["logits"], logp_bt=n_out)
+        zc = eng.pack_zc(z_r, z_n, c)
+        if self.training:
+            dec = eng.global_decoder_tf(d, zc, save=False)
+            out = torch.empty(B, T, E_VOCAB, device=d.device)
+            ops.vocab_logsoftmax(dec["logits"], B, T, E_VOCAB, logp_bt=out)
+        else:
+            from .decode import greedy_decode
+            out, _ = greedy_decode(self, zc.clone(), T)
+        return (out, r_out, n_out,
+                pre["r"][:, :Z].clone(), lat["r"]["sigma"].clone(), pre["n"][:, :Z].clone(), lat["n"]["sigma"].clone(),
+                z_r.clone(), z_n.clone(), lat["r"]["ll"].clone(), lat["n"]["ll"].clone(),
+                lat["r"]["qy"].clone(), lat["n"]["qy"].clone(), lat["r"]["y"].long(), lat["n"]["y"].long())
 
 
 class _GMVAEFunction(torch.autograd.Function):

@@ -52,6 +52,7 @@ class HipOps:
         if self.device.type != "cuda":
             raise RuntimeError("HipOps needs a GPU device")
         self._ws = {}
+        self._retired = []
         self.lane = ""            # scratch namespace: kernels enqueued on different streams must not share workspaces
 
     # -- plumbing -------------------------------------------------------------------------------
@@ -59,10 +60,14 @@ class HipOps:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def workspace(self, nbytes, tag="ws"):
-        """Grow-only scratch buffer per tag (stable pointer once warm -> graph friendly)."""
+        """Grow-only scratch buffer per tag.  A captured hipGraph holds the raw pointer it was captured with, so a buffer that is
+        outgrown is RETIRED (kept alive for the lifetime of this object), never freed: graphs of smaller batch shapes keep replaying
+        on their own scratch."""
         tag = self.lane + tag
         cur = self._ws.get(tag)
         if cur is None or cur.numel() * 4 < nbytes:
+            if cur is not None:
+                self._retired.append(cur)
             cur = torch.empty((max(nbytes, 4) + 3) // 4, dtype=torch.float32, device=self.device)
             self._ws[tag] = cur
         return cur
@@ -135,9 +140,18 @@ class HipOps:
             syncs[self.lane] = torch.zeros(int(self.lib.fn_gru_sync_ws_bytes()) // 4, dtype=torch.int32, device=self.device)
         return syncs[self.lane]
 
-    def gru_sync_error(self):
-        """True when a weight-stationary launch gave up waiting (host sync)."""
-        return any(int(t[-32].item()) != 0 for t in self.__dict__.get("_syncs", {}).values())
+    def gru_sync_error(self, clear=False):
+        """True when a weight-stationary launch (scan or single-launch decode) gave up waiting: ONE D2H copy of all the sticky
+        error words (host sync).  clear=True also resets them so that the caller can retry on the per-step kernels."""
+        syncs = list(self.__dict__.get("_syncs", {}).values())
+        if not syncs:
+            return False
+        words = torch.stack([t[-32] for t in syncs]).tolist()
+        bad = any(int(w) != 0 for w in words)
+        if bad and clear:
+            for t in syncs:
+                t[-32:].zero_()
+        return bad
 
     def gru_seq_fwd(self, scans, persistent=True, cu_budget=0):
         arr = (_lib.FnGruFwd * len(scans))()
@@ -205,7 +219,11 @@ class HipOps:
         if key not in syncs:
             syncs[key] = torch.zeros(int(self.lib.fn_decode_sync_ws_bytes()) // 4, dtype=torch.int32, device=self.device)
         d.sync_ws = _p(syncs[key])
-        _lib.check(self.lib.fn_decode_greedy(C.byref(d), self.stream()), "fn_decode_greedy")
+        rc = self.lib.fn_decode_greedy(C.byref(d), self.stream())
+        if rc == _lib.FN_E_UNSUPPORTED:            # not eligible on this device (needs one CU per role workgroup)
+            return False
+        _lib.check(rc, "fn_decode_greedy")
+        return True
 
     def embed_grad(self, dgx_all, idx, idx_shift, start_token, reverse, V, out):
         _dense(dgx_all, name="dgx_all"), _dense(idx, torch.int32, "idx"), _dense(out, name="out")

@@ -94,9 +94,11 @@ class GMVAETrainer:
         pairwise float64 differences is used, trainer_gmm.py:208-210)."""
         m = self.model
         dev = self.flat.param.device
-        d = m._indices(torch.as_tensor(d).to(dev), 342)
-        r = m._indices(torch.as_tensor(r).to(dev), 3)
-        n = m._indices(torch.as_tensor(n).to(dev), 16)
+        # [B][T] tensors are token ids whatever their dtype (the loaders yield float32 ids, cast by `.long()` at
+        # trainer_gmm.py:323,397); [B][T][V] tensors are the convert_to_one_hot images
+        d = m._indices(torch.as_tensor(d).to(dev), 342, ids_ndim=2)
+        r = m._indices(torch.as_tensor(r).to(dev), 3, ids_ndim=2)
+        n = m._indices(torch.as_tensor(n).to(dev), 16, ids_ndim=2)
         c = torch.as_tensor(c).to(dev).float().contiguous()
         f64 = lambda x: (x.to(dev).double() if torch.is_tensor(x) else torch.as_tensor(np.asarray(x, dtype=np.float64)).to(dev)).contiguous()
         rd, nd = f64(r_density), f64(n_density)

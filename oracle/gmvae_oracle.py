@@ -196,9 +196,9 @@ def global_decoder(sd, z, steps, teacher=None):
     return torch.stack(outs, dim=1)
 
 
-def forward(sd, d, r, n, c, eps_r, eps_n):
-    """gmm_model.py:220-259 in train mode.  d/r/n are int token tensors (the one-hot tensors the
-    reference receives are exactly convert_to_one_hot of these)."""
+def forward(sd, d, r, n, c, eps_r, eps_n, training=True):
+    """gmm_model.py:220-259.  d/r/n are int token tensors (the one-hot tensors the reference receives are exactly
+    convert_to_one_hot of these).  training=False = after model.eval(): the global decoder feeds back its own argmax (:146-148)."""
     x = convert_to_one_hot(d, E)
     mu_r, sg_r, mu_n, sg_n = encode(sd, x)
     z_r = mu_r + sg_r * eps_r
@@ -208,7 +208,7 @@ def forward(sd, d, r, n, c, eps_r, eps_n):
     r_out = sub_decoder(sd, "r", convert_to_one_hot(r, R), z_r)
     n_out = sub_decoder(sd, "n", convert_to_one_hot(n, N), z_n)
     zc = torch.cat([z_r, z_n, c], dim=1)
-    out = global_decoder(sd, zc, d.shape[1], teacher=d)
+    out = global_decoder(sd, zc, d.shape[1], teacher=d if training else None)
     return dict(out=out, r_out=r_out, n_out=n_out, mu_r=mu_r, sigma_r=sg_r, mu_n=mu_n, sigma_n=sg_n,
                 z_r=z_r, z_n=z_n, ll_r=ll_r, ll_n=ll_n, qy_r=qy_r, qy_n=qy_n,
                 y_r=qy_r.max(1)[1], y_n=qy_n.max(1)[1])
@@ -336,3 +336,73 @@ def greedy_decode(sd, z, steps):
     with torch.no_grad():
         lp = global_decoder(sd, z, steps, teacher=None)
     return lp, lp.argmax(-1)
+
+
+# ----------------------------------------------------------------------------------------------
+# eval-side callers.  RNG contract: the reference draws from torch's global CPU generator; these
+# restatements make the SAME draws in the same order, so seeding the generator reproduces the reference call.
+# ----------------------------------------------------------------------------------------------
+def draw_forward_eps(B, Z, T, training):
+    """what one model(...) call consumes: randn(B,Z) for z_r, randn(B,Z) for z_n (gmm_model.py:230,234-235) and, in train mode
+    only, T draws of torch.rand(1) in the decoder loop (:140)."""
+    eps_r, eps_n = torch.randn(B, Z), torch.randn(B, Z)
+    if training:
+        for _ in range(T):
+            torch.rand(1)
+    return eps_r, eps_n
+
+
+def evaluator_shift(sd, d, r, n, c, target_z_value, which, training, steps=100):
+    """GMMRhythmEvaluator.shift (which="r", test_class.py:233-254) / GMMNoteEvaluator.shift ("n", :282-303) for ONE sample:
+    model(...) (only `dis` is used, but its random draws are consumed), repar() for z_r then z_n (test_class.py:53-56,243-244),
+    z_which[:, 0] = target, model.eval(), global_decoder(cat[z_r, z_n, c], steps).  `training` = the mode the model is in when
+    the call starts (the reference leaves it in eval mode afterwards).  Returns (log-probs (1,steps,342), z_which[0,0] before)."""
+    d = torch.as_tensor(d).long().view(1, -1)
+    with torch.no_grad():
+        Z = sd["mu_r.weight"].shape[0]
+        draw_forward_eps(1, Z, d.shape[1], training)
+        mu_r, sg_r, mu_n, sg_n = encode(sd, convert_to_one_hot(d, E))
+        z_r = mu_r + sg_r * torch.randn(1, Z)
+        z_n = mu_n + sg_n * torch.randn(1, Z)
+        tgt = z_r if which == "r" else z_n
+        z0 = tgt[0, 0].item()
+        tgt[:, 0] = target_z_value
+        zc = torch.cat([z_r, z_n, torch.as_tensor(c).float().view(1, -1)], dim=1)
+        return global_decoder(sd, zc, steps), z0
+
+
+def arousal_transfer(sd, d, c, lmbda=1.0, low_to_high=True, steps=300):
+    """arousal_transfer.ipynb cells 11 + 15 (low_to_high) / 17: encode in eval mode, z = dis.rsample() (randn, r then n),
+    shift BOTH latents by lmbda * (mu_lookup[1] - mu_lookup[0]) (or the opposite sign), greedy decode `steps` tokens.
+    Returns (log-probs (1,steps,342), z (1, 2Z+24))."""
+    d = torch.as_tensor(d).long().view(1, -1)
+    with torch.no_grad():
+        Z = sd["mu_r.weight"].shape[0]
+        mu_r, sg_r, mu_n, sg_n = encode(sd, convert_to_one_hot(d, E))
+        z_r = mu_r + sg_r * torch.randn(1, Z)
+        z_n = mu_n + sg_n * torch.randn(1, Z)
+        sgn = 1.0 if low_to_high else -1.0
+        z_r = z_r + lmbda * sgn * (sd["mu_r_lookup.weight"][1] - sd["mu_r_lookup.weight"][0])
+        z_n = z_n + lmbda * sgn * (sd["mu_n_lookup.weight"][1] - sd["mu_n_lookup.weight"][0])
+        zc = torch.cat([z_r, z_n, torch.as_tensor(c).float().view(1, -1)], dim=1)
+        return global_decoder(sd, zc, steps), zc
+
+
+def run_through_gmm(sd, dl, training=True):
+    """test_gmm_v2.py:53-113: forward over a loader of (d, r, n, c, r_density, n_density) batches, collecting z and the means;
+    returns the reference's 15-tuple (a_lst stays empty as in the reference)."""
+    Z = sd["mu_r.weight"].shape[0]
+    acc = {k: [] for k in ("r", "n", "rd", "nd", "zr", "zn", "mr", "mn")}
+    with torch.no_grad():
+        for d, r, n, c, r_density, n_density in dl:
+            d, r, n = (torch.as_tensor(x).long() for x in (d, r, n))
+            eps_r, eps_n = draw_forward_eps(d.shape[0], Z, d.shape[1], training)
+            mu_r, sg_r, mu_n, sg_n = encode(sd, convert_to_one_hot(d, E))
+            acc["r"].append(r), acc["n"].append(n)
+            acc["rd"].append(torch.as_tensor(r_density).float()), acc["nd"].append(torch.as_tensor(n_density).float())
+            acc["zr"].append(mu_r + sg_r * eps_r), acc["zn"].append(mu_n + sg_n * eps_n)
+            acc["mr"].append(mu_r), acc["mn"].append(mu_n)
+    cat = {k: torch.cat(v, dim=0).numpy() for k, v in acc.items()}
+    zr, zn = cat["zr"], cat["zn"]
+    return (cat["rd"], cat["nd"], cat["r"], cat["n"], [], cat["mr"], cat["mn"], zr[:, 0], zr[:, 1:], zn[:, 0], zn[:, 1:],
+            np.amin(zr[:, 0]), np.amax(zr[:, 0]), np.amin(zn[:, 0]), np.amax(zn[:, 0]))

@@ -156,3 +156,111 @@ def check_vae_against_reference(pkg, m, g, dev, rtol_fw, tol_grad, rtol_tuple, a
     for k, v in m.state_dict().items():
         if k not in NOISE_PARAMS:
             np.testing.assert_allclose(v.cpu().numpy(), g["w3/" + k], rtol=0, atol=atol_w, err_msg=k)
+
+
+def tokens_match_upto_near_tie(tok, ref_tok, ref_gap, thr=1e-4):
+    """greedy tokens are compared per row up to the first position where the reference's own top-2 log-prob gap is below thr
+    (a flipped float32 near-tie changes every later token); returns the number of positions compared"""
+    tok, ref_tok = np.asarray(tok), np.asarray(ref_tok)
+    L = tok.shape[-1]
+    n = 0
+    for row, rrow, grow in zip(tok.reshape(-1, L), ref_tok.reshape(-1, L), np.asarray(ref_gap).reshape(-1, L)):
+        unclear = np.where(grow < thr)[0]
+        upto = int(unclear[0]) if len(unclear) else L
+        assert np.array_equal(row[:upto], rrow[:upto]), (row[:upto].tolist(), rrow[:upto].tolist())
+        n += upto
+    return n
+
+
+def eval_golden(tag):
+    return {k[len(tag) + 1:]: v for k, v in load_golden("eval").items() if k.startswith(tag + "/")}
+
+
+def check_eval_side(pkg, m, g, dev, rtol=2e-5):
+    """the product's eval-side callers (evaluators.py, eval-mode forward, fader_sweep) against tests/golden/eval.npz = the reference's
+    own evaluator / notebook code run on the same seeds (make_golden_eval.py).  `m` is a freshly seeded model on `dev`."""
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    d, r, n, c = t("d"), t("r"), t("n"), t("c")
+    B, T = d.shape
+    Z = m.latent_dim
+    for k, v in m.state_dict().items():
+        np.testing.assert_allclose([float(v.double().sum())], g["w0sum/" + k][:1], rtol=1e-9, atol=1e-9, err_msg=k)
+    # D: run_through_gmm (train mode as constructed)
+    m.train()
+    dl = [(d[i:i + 3], r[i:i + 3], n[i:i + 3], c[i:i + 3], g["r_density"][i:i + 3], g["n_density"][i:i + 3]) for i in range(0, B, 3)]
+    torch.manual_seed(5)
+    res = pkg.run_through_gmm(m, dl)
+    names = ["r_density_lst", "n_density_lst", "r_lst", "n_lst", "a_lst", "r_mean", "n_mean", "z_r_0_lst", "z_r_rest_lst",
+             "z_n_0_lst", "z_n_rest_lst", "r_min", "r_max", "n_min", "n_max"]
+    for k, v in zip(names, res):
+        if k != "a_lst":
+            np.testing.assert_allclose(np.asarray(v), g["rt_" + k], rtol=rtol, atol=rtol, err_msg=k)
+    # B: evaluator shifts, the reference's call sequence: the first call finds the model in train mode, later ones in eval mode
+    m.train()
+    ev = {0: pkg.GMMRhythmEvaluator(None), 1: pkg.GMMNoteEvaluator(None)}
+    compared = 0
+    for k, (which, i, val) in enumerate(g["shift_calls"]):
+        i = int(i)
+        assert m.training == bool(g["shift%d_training_before" % k][0])
+        torch.manual_seed(100 + k)
+        out, z0 = ev[int(which)].shift(m, d[i], r[i], n[i], c[i], float(val))
+        assert tuple(out.shape) == (1, 100, 342) and not m.training
+        np.testing.assert_allclose(z0, g["shift%d_z0" % k][0], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(out[0, 0].cpu().numpy(), g["shift%d_logp0" % k], rtol=1e-4, atol=1e-4)
+        compared += tokens_match_upto_near_tie(out.argmax(-1).cpu().numpy(), g["shift%d_tokens" % k], g["shift%d_gap" % k])
+        if (g["shift%d_gap" % k] >= 1e-4).all():
+            assert np.array_equal(np.asarray(pkg.clean_output(out)), g["shift%d_clean" % k])
+    assert compared >= 100
+    # the batched form of the same shifts: (sample, value) rows of one decode batch, eps per (sample, value)
+    for which in (0, 1):
+        calls = [(k, int(i), float(v)) for k, (w, i, v) in enumerate(g["shift_calls"]) if int(w) == which]
+        # the reference call k draws [forward eps r, n (+T rand)] then repar r, n: reproduce the repar draws
+        eps_r, eps_n = torch.zeros(B, len(calls), Z), torch.zeros(B, len(calls), Z)
+        for j, (k, i, v) in enumerate(calls):
+            torch.manual_seed(100 + k)
+            torch.randn(1, Z), torch.randn(1, Z)
+            if bool(g["shift%d_training_before" % k][0]):
+                for _ in range(T):
+                    torch.rand(1)
+            eps_r[i, j], eps_n[i, j] = torch.randn(1, Z)[0], torch.randn(1, Z)[0]
+        tk, z0 = pkg.fader_sweep(m, d, c, [v for _, _, v in calls], steps=100, which="rn"[which], eps=(eps_r, eps_n))
+        assert tuple(tk.shape) == (B, len(calls), 100) and tuple(z0.shape) == (B, len(calls))
+        for j, (k, i, v) in enumerate(calls):
+            np.testing.assert_allclose(float(z0[i, j]), g["shift%d_z0" % k][0], rtol=1e-4, atol=1e-5)
+            tokens_match_upto_near_tie(tk[i, j].cpu().numpy()[None], g["shift%d_tokens" % k], g["shift%d_gap" % k])
+    # A: eval-mode forward: the decoder feeds back its own argmax, no rand(1) draws
+    m.eval()
+    torch.manual_seed(7)
+    (o, r_out, n_out, _, _), dis, z_out, ll_out, qy_out, y_out = m(pkg.convert_to_one_hot(d, 342), pkg.convert_to_one_hot(r, 3),
+                                                                   pkg.convert_to_one_hot(n, 16), c)
+    after = torch.rand(1).item()
+    torch.manual_seed(7)
+    torch.randn(B, Z), torch.randn(B, Z)
+    assert after == torch.rand(1).item()
+    got = dict(r_out=r_out, n_out=n_out, mu_r=dis[0].mean, sigma_r=dis[0].stddev, z_r=z_out[0], z_n=z_out[1], ll_r=ll_out[0], qy_n=qy_out[1])
+    for k, v in got.items():
+        np.testing.assert_allclose(v.cpu().numpy(), g["evalfw_" + k], rtol=rtol, atol=rtol, err_msg=k)
+    np.testing.assert_allclose(o[:, 0].cpu().numpy(), g["evalfw_logp0"], rtol=1e-4, atol=1e-4)
+    assert tuple(o.shape) == (B, T, 342)
+    assert tokens_match_upto_near_tie(o.argmax(-1).cpu().numpy(), g["evalfw_tokens"], g["evalfw_gap"]) >= B * T // 2
+    assert np.array_equal(y_out[0].cpu().numpy(), g["evalfw_y_r"]) and np.array_equal(y_out[1].cpu().numpy(), g["evalfw_y_n"])
+    # C: notebook transfer (cells 11 + 15 / 17), 300 greedy steps, both latents shifted
+    for j in range(2):
+        i, seed, lmbda, steps = (int(x) for x in g["nb%d_meta" % j])
+        torch.manual_seed(seed)
+        out, z = pkg.arousal_transfer(m, d[i], c[i], lmbda=lmbda, low_to_high=(j == 0), steps=steps)
+        assert tuple(out.shape) == (1, 300, 342)
+        np.testing.assert_allclose(z.cpu().numpy(), g["nb%d_z" % j], rtol=1e-4, atol=1e-5)
+        assert tokens_match_upto_near_tie(out.argmax(-1).cpu().numpy(), g["nb%d_tokens" % j], g["nb%d_gap" % j]) >= 100
+        # and its batched form: mode="shift", which="both", lambda = +-1
+        torch.manual_seed(seed)
+        eps = (torch.randn(1, Z), torch.randn(1, Z))
+        tk, _ = pkg.fader_sweep(m, d[i:i + 1], c[i:i + 1], [lmbda if j == 0 else -lmbda], steps=steps, which="both", mode="shift", eps=eps)
+        tokens_match_upto_near_tie(tk[0].cpu().numpy(), g["nb%d_tokens" % j], g["nb%d_gap" % j])
+    # train-mode global_decoder(z, steps): teacher forced with self.sample (gmm_model.py:139-142)
+    m.train()
+    torch.manual_seed(11)
+    (o_tf, _, _, _, _), _, z_out, _, _, _ = m(d, r, n, c)
+    zc = torch.cat([z_out[0], z_out[1], c], dim=1).detach()
+    o2 = m.global_decoder(zc, steps=T)
+    np.testing.assert_allclose(o2.cpu().numpy(), o_tf.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)

@@ -72,5 +72,6 @@ def test_loader_batches_feed_the_trainer():
     rl, nl = _ragged(g["v_in_rhythm"], g["v_in_rlens"]), _ragged(g["v_in_note"], g["v_in_rlens"])
     ds = D.VGMIDIDataset(toks, rl, nl, g["v_in_chroma"], g["v_in_arousal"].copy(), g["v_in_valence"])
     d, r, n, c, a, v, rd, nd = next(iter(DataLoader(ds, batch_size=4)))
-    step, tup = tr.train(step, None, None, None, d.long(), r.long(), n.long(), c.float(), rd, nd, is_supervised=True, y_label=a)
+    assert d.is_floating_point()          # float32 ids, as the reference's dataset yields them: no manual cast (trainer_gmm.py:323 does .long())
+    step, tup = tr.train(step, None, None, None, d, r, n, c.float(), rd, nd, is_supervised=True, y_label=a)
     assert step == 2 and np.isfinite(tup).all()

@@ -572,7 +572,8 @@ def test_greedy_decode_tokens(case, small, c0):
     c = torch.from_numpy(gold["c"]).to(DEV)
     eps = (torch.from_numpy(gold["eps_r"]), torch.from_numpy(gold["eps_n"]))
     tk, _ = pkg.fader_sweep(m, d, c, [0.75, -0.5], steps=steps, which="r", eps=eps)
-    assert np.array_equal(tk[:, 0].cpu().numpy()[:, :8], ref[:, :8])
+    from helpers import tokens_match_upto_near_tie
+    assert tokens_match_upto_near_tie(tk[:, 0].cpu().numpy(), ref, gap) >= 0.9 * ref.size      # full length, not a prefix
 
 
 # ----------------------------------------------------------------------------------------------
@@ -587,9 +588,9 @@ def test_single_launch_decode_matches_per_token_kernels(H, Bi, steps, monkeypatc
     m.eval()
     torch.manual_seed(3)
     z = torch.randn(Bi, 2 * m.latent_dim + 24, device=DEV)
-    monkeypatch.setenv("FN_DECODE_PERSIST", "0")
+    m.engine().single_launch_decode = False
     lp0, tk0 = pkg.greedy_decode(m, z, steps)
-    monkeypatch.setenv("FN_DECODE_PERSIST", "1")
+    m.engine().single_launch_decode = True
     lp1, tk1 = pkg.greedy_decode(m, z, steps)
     lp2, tk2 = pkg.greedy_decode(m, z, steps)                       # again on the warm buffers
     assert not m.engine().ops.gru_sync_error()
@@ -621,7 +622,7 @@ def test_full_size_properties():
     assert torch.equal(g1, tr.flat.grad)          # no floating-point atomics anywhere on the path
     # (2) batch-row independence: the loss of the first 64 rows alone equals the same rows' share
     #     (CE terms are per-row means) -> CE_X of a sub-batch computed separately matches the row-slice mean
-    nll = m.engine()._bufs["nll_rows"].view(T, B)
+    nll = m.engine().buf("nll_rows", (T * B,)).view(T, B)
     sub = tr.prepare_batch(b["d"][:64], b["r"][:64], b["n"][:64], b["c"][:64], b["r_density"][:64], b["n_density"][:64])
     full_rows = float(nll[:, :64].double().sum()) / (64 * T)        # before: computed inside the full batch
     tr._forward_losses(20000, sub, (eps[0][:64].contiguous(), eps[1][:64].contiguous()), False)
@@ -646,3 +647,181 @@ def test_full_size_properties():
         step, tup = tr.train(step, None, None, None, b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"], eps=eps)
         first = first or tup
     assert tup[0] < first[0] and all(math.isfinite(x) for x in tup)
+
+
+# ----------------------------------------------------------------------------------------------
+# eval-side callers: eval-mode forward, evaluator shifts, notebook transfer (300 steps), run_through_gmm
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag,H,Z", [("s", 64, 32), ("c", 512, 128)])
+def test_eval_side_callers_vs_reference(tag, H, Z):
+    from helpers import check_eval_side, eval_golden
+    pkg = load_package()
+    m = make_model(H, Z, device=DEV)
+    check_eval_side(pkg, m, eval_golden(tag), DEV, rtol=1e-4)
+    assert not m.engine().ops.gru_sync_error()
+
+
+# ----------------------------------------------------------------------------------------------
+# the BENCHMARK configuration against the reference itself (tests/golden/c1.npz: B=256, T=256, Tr=64, hidden 512)
+# ----------------------------------------------------------------------------------------------
+def test_benchmark_config_vs_reference_train():
+    """The kernels bench.py times (128-row weight-stationary scans at T=256, K=65536 weight-gradient GEMMs, 65536-row token-segment
+    sums) compared with the reference's own forward / backward / train() at that size, on the seeds bench.py uses."""
+    pkg = load_package()
+    from music_fader_nets_amd.synth import synth_batch
+    g = load_golden("c1")
+    H, Z, K, B, T, Tr = (int(x) for x in g["meta_dims"])
+    m = make_model(H, Z, device=DEV)
+    tr = pkg.GMVAETrainer(m, lr=1e-3, beta=0.2)
+    b = synth_batch(np.random.RandomState(0), B, T, Tr)
+    batch = tr.prepare_batch(b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"])
+    torch.manual_seed(99)
+    eps = tr.draw_eps(B, T)
+    # forward checksums through the drop-in call (no_grad: forward only)
+    with torch.no_grad():
+        (o, r_out, n_out, _, _), dis, z_out, ll_out, qy_out, y_out = m(batch[0], batch[1], batch[2], batch[3], eps=eps)
+    got = dict(out=o, r_out=r_out, n_out=n_out, mu_r=dis[0].mean, sigma_r=dis[0].stddev, mu_n=dis[1].mean, sigma_n=dis[1].stddev,
+               z_r=z_out[0], z_n=z_out[1], ll_r=ll_out[0], ll_n=ll_out[1], qy_r=qy_out[0], qy_n=qy_out[1])
+    for k, v in got.items():
+        vd = v.double()
+        np.testing.assert_allclose([vd.sum().item(), vd.abs().sum().item(), (vd * vd).sum().item()], g["fwsum_" + k], rtol=2e-5,
+                                   atol=1e-6, err_msg=k)
+    np.testing.assert_allclose(o[0, :4].cpu().numpy(), g["fw_out_row0"], rtol=1e-4, atol=1e-4)
+    assert np.array_equal(y_out[0].cpu().numpy(), g["fw_y_r"]) and np.array_equal(y_out[1].cpu().numpy(), g["fw_y_n"])
+    del o, got
+    # raw gradients of the fused step
+    tup = tr.loss_and_grads(20000, batch, eps)
+    np.testing.assert_allclose(tup[0], g["total_loss_20000"][0], rtol=2e-5)
+    np.testing.assert_allclose(tr.grad_norm(), g["gradnorm_20000"][0], rtol=1e-3)
+    for k in tr.flat.names:
+        gk = tr.flat.G[k].double()
+        ref = g["gradsum/" + k]
+        np.testing.assert_allclose(float(gk.abs().sum()), ref[1], rtol=1e-3, atol=1e-5, err_msg=k)
+        np.testing.assert_allclose(float((gk * gk).sum()), ref[2], rtol=2e-3, atol=1e-9, err_msg=k)
+    assert set(tr.flat.names) == {k[len("gradsum/"):] for k in g if k.startswith("gradsum/")}
+    # the reference's own train(), twice (same eps every step, as bench.py runs it); step 1 eager, step 2 = graph capture + replay
+    step = 20000
+    for it in range(2):
+        step, tup = tr.train(step, None, None, None, b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"], eps=eps)
+        np.testing.assert_allclose(tup, g["train_tuples"][it], rtol=5e-4, err_msg="step %d" % it)
+        if it == 0:
+            for k, v in m.state_dict().items():
+                if k not in NOISE_PARAMS:
+                    vd = v.double()
+                    np.testing.assert_allclose([vd.abs().sum().item(), (vd * vd).sum().item()], g["w1sum/" + k][1:], rtol=2e-5, err_msg=k)
+    assert not m.engine().ops.gru_sync_error()
+
+
+# ----------------------------------------------------------------------------------------------
+# captured graphs vs changing batch shapes / changing weights (ADVICE r1)
+# ----------------------------------------------------------------------------------------------
+def test_graph_replay_survives_other_batch_shapes():
+    """The epoch driver alternates shapes (train / validation / ragged last batch); every shape keeps its own captured graph and its
+    own buffers.  Interleaving shapes must give the same numbers as running each shape alone."""
+    pkg = load_package()
+    from music_fader_nets_amd.synth import synth_batch
+    shapes = [(12, 40, 16), (5, 24, 8), (12, 24, 8)]
+    data = [synth_batch(np.random.RandomState(10 + i), *s) for i, s in enumerate(shapes)]
+    seq = [0, 1, 0, 2, 1, 0, 2, 0, 1, 2, 0]                   # every shape is replayed after the others ran
+
+    def run(order_filter):
+        m = make_model(64, 32, device=DEV)
+        tr = pkg.GMVAETrainer(m, lr=1e-3, beta=0.2)
+        outs, step = [], 20000
+        for j, si in enumerate(seq):
+            if order_filter is not None and si != order_filter:
+                continue
+            b = data[si]
+            torch.manual_seed(500 + j)
+            step, tup = tr.train(step, None, None, None, b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"])
+            outs.append((j, tup))
+            if si == 1:                                       # an eager evaluate at yet another shape in between
+                bb = {k: v[:3] for k, v in data[0].items()}
+                torch.manual_seed(900 + j)
+                outs.append((j, tr.evaluate(step - 1, None, None, None, bb["d"], bb["r"], bb["n"], bb["c"], bb["r_density"], bb["n_density"])))
+        assert len(tr._graphs) == (3 if order_filter is None else 1)
+        return outs, {k: v.clone() for k, v in m.state_dict().items()}
+
+    mixed, w_mixed = run(None)
+    assert all(np.isfinite(t).all() for _, t in mixed)
+    # reference: the same sequence on a fresh trainer with graphs disabled (eager launches, nothing captured)
+    m2 = make_model(64, 32, device=DEV)
+    tr2 = pkg.GMVAETrainer(m2, lr=1e-3, beta=0.2)
+    tr2.use_graph = False
+    step, k = 20000, 0
+    for j, si in enumerate(seq):
+        b = data[si]
+        torch.manual_seed(500 + j)
+        step, tup = tr2.train(step, None, None, None, b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"])
+        np.testing.assert_allclose(mixed[k][1], tup, rtol=1e-6, err_msg="train %d" % j)
+        k += 1
+        if si == 1:
+            bb = {kk: v[:3] for kk, v in data[0].items()}
+            torch.manual_seed(900 + j)
+            ev = tr2.evaluate(step - 1, None, None, None, bb["d"], bb["r"], bb["n"], bb["c"], bb["r_density"], bb["n_density"])
+            np.testing.assert_allclose(mixed[k][1], ev, rtol=1e-6, err_msg="eval %d" % j)
+            k += 1
+    for kk, v in m2.state_dict().items():
+        assert torch.equal(v, w_mixed[kk]), kk                # bit-identical weights: no replay touched a stale buffer
+
+
+@pytest.mark.parametrize("Bi", [4, 40])
+def test_decode_sees_the_trained_weights(Bi):
+    """decode -> train -> decode: the second decode must use the updated weights (single-launch path: the fragment images of W_ih2 /
+    W_out; graph path: the captured kernels read the live buffers) - compared with a fresh model loaded with the trained state_dict."""
+    pkg = load_package()
+    from music_fader_nets_amd.synth import synth_batch
+    m = make_model(64, 32, device=DEV)
+    tr = pkg.GMVAETrainer(m, lr=1e-2, beta=0.2)
+    torch.manual_seed(1)
+    z = torch.randn(Bi, 2 * 32 + 24, device=DEV)
+    m.eval()
+    lp0, tk0 = pkg.greedy_decode(m, z, 20)
+    m.train()
+    b = synth_batch(np.random.RandomState(0), 8, 24, 8)
+    step = 20000
+    for it in range(4):                                        # eager, capture, replay, replay
+        torch.manual_seed(it)
+        step, _ = tr.train(step, None, None, None, b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"])
+    m.eval()
+    lp1, tk1 = pkg.greedy_decode(m, z, 20)
+    assert not torch.equal(lp0, lp1)
+    fresh = make_model(64, 32, {k: v.cpu() for k, v in m.state_dict().items()}, device=DEV)
+    fresh.eval()
+    lp2, tk2 = pkg.greedy_decode(fresh, z, 20)
+    np.testing.assert_allclose(lp1.cpu().numpy(), lp2.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    assert torch.equal(tk1, tk2)
+
+
+def test_dataloader_batches_feed_the_hip_trainer():
+    """DataLoader batches of YamahaDataset / VGMIDIDataset (float32 token ids, float64 densities, arousal labels)
+    go straight into GMVAETrainer.train / evaluate on the HIP path - no manual casts - and match the oracle on the same batch."""
+    from torch.utils.data import DataLoader
+    pkg = load_package()
+    from music_fader_nets_amd import datasets as D
+    g = load_golden("data")
+    san = D.sanitize_chroma(g["y_in_data"], g["y_in_rhythm"], g["y_in_note"], g["y_in_chroma"])
+    m = make_model(64, 32, device=DEV)
+    sd0 = {k: v.cpu().clone() for k, v in m.state_dict().items()}
+    tr = pkg.GMVAETrainer(m, lr=1e-3, beta=0.2)
+    d, r, n, c, rd, nd = next(iter(DataLoader(D.YamahaDataset(*san), batch_size=4)))
+    torch.manual_seed(42)
+    eps = (torch.randn(d.shape[0], 32), torch.randn(d.shape[0], 32))
+    step, tup = tr.train(20000, None, None, None, d, r, n, c.float(), rd, nd, eps=tuple(e.to(DEV) for e in eps))
+    opt = orc.AdamState(orc.trainable_used_keys(sd0))
+    ob = dict(d=d.long().numpy(), r=r.long().numpy(), n=n.long().numpy(), c=c.float().numpy(), r_density=rd.numpy(), n_density=nd.numpy())
+    _, ref, _ = orc.train_step(sd0, opt, ob, eps[0], eps[1], 20000, beta=0.2, lr=1e-3)
+    np.testing.assert_allclose(tup, ref, rtol=5e-4)
+    from test_datasets import _ragged as rag
+    ds = D.VGMIDIDataset(rag(g["v_in_tokens"], g["v_in_lens"]), rag(g["v_in_rhythm"], g["v_in_rlens"]), rag(g["v_in_note"], g["v_in_rlens"]),
+                         g["v_in_chroma"], g["v_in_arousal"].copy(), g["v_in_valence"])
+    d, r, n, c, a, v, rd, nd = next(iter(DataLoader(ds, batch_size=4)))
+    assert d.is_floating_point()                                # as the reference's dataset yields them
+    torch.manual_seed(43)
+    eps = (torch.randn(d.shape[0], 32), torch.randn(d.shape[0], 32))
+    sd1 = {k: v.cpu().clone() for k, v in m.state_dict().items()}
+    step, tup = tr.train(step, None, None, None, d, r, n, c.float(), rd, nd, is_supervised=True, y_label=a, eps=tuple(e.to(DEV) for e in eps))
+    ob = dict(d=d.long().numpy(), r=r.long().numpy(), n=n.long().numpy(), c=c.float().numpy(), r_density=rd.numpy(), n_density=nd.numpy(),
+              a=a.long().numpy())
+    loss, ref, _ = orc.total_loss(sd1, ob, eps[0], eps[1], 20001, 0.2, is_supervised=True)
+    np.testing.assert_allclose(tup, [float(x) for x in ref], rtol=5e-4)
