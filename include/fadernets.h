@@ -157,8 +157,29 @@ size_t fn_gru_dwhh_ws_bytes(int H, int splitk);
 int fn_gru_dwhh_f32(const float* dgx, const float* dghn, const float* hprev, int64_t rows, int H, float beta, float* dW,
                     int splitk, float* ws, size_t ws_bytes, void* stream);
 
-/* dTable[v][:] = sum over (p,b) with tok(p,b)==v of dgx_all[p][b][:]   (W_ih one-hot columns' grad;
- * tok defined as in FnGruFwd).  out is [V][N3]; ws >= fn_embed_grad_ws_bytes(T*B, V, N3). */
+/* Gradient of the one-hot columns of W_ih (autograd of  onehot(x) @ W_ih[:, :V]^T, gmm_model.py:84,89,109,114,132-133):
+ *   dTable[v][:] = sum over (p,b) with tok(p,b)==v of dgx_all[p][b][:]      (tok defined as in FnGruFwd)
+ * Two steps, so that ONE sort of a token matrix serves every scan that consumes it (4 encoder directions + decoder layer 1):
+ *   fn_token_sort: idx [B][idx_ld] int32 -> img (fn_token_sort_ints(B*T, V) int32: segment starts, piece starts, positions
+ *                  sorted by token, stable); ws >= fn_token_sort_ws_bytes(B*T, V), 16-byte aligned.  Tokens are clamped to [0, V).
+ *   fn_embed_grad_sorted: up to 8 jobs (scans) that read the SAME token matrix in one launch pair; per job idx_shift in {0, -1}
+ *                  (-1 only with reverse = 0: step p reads token p-1, step 0 the start token).  out is [V][out_ld] (out_ld >= N3),
+ *                  or with transposed != 0 the transposed table [N3][out_ld] (out_ld >= V), e.g. dW_ih[:, :V] in place.
+ *                  ws >= fn_embed_grad_sorted_ws_bytes(B*T, B, V, N3, n_jobs).  Deterministic (fixed summation order).
+ * fn_embed_grad_f32 = both steps for one scan (ws >= fn_embed_grad_ws_bytes(T*B, V, N3)). */
+typedef struct FnEmbedGrad {
+    const float* dgx_all;     /* [T][B][N3] gate gradients in processing order                    */
+    float* out;               /* table, see above                                                  */
+    int32_t out_ld;
+    int32_t transposed;
+    int32_t reverse, idx_shift, start_token;
+} FnEmbedGrad;
+size_t fn_token_sort_ints(int64_t rows, int V);
+size_t fn_token_sort_ws_bytes(int64_t rows, int V);
+int fn_token_sort(const int32_t* idx, int B, int T, int idx_ld, int V, int32_t* img, void* ws, size_t ws_bytes, void* stream);
+size_t fn_embed_grad_sorted_ws_bytes(int64_t rows, int B, int V, int N3, int n_jobs);
+int fn_embed_grad_sorted(const FnEmbedGrad* jobs, int n_jobs, int B, int T, int N3, int V, const int32_t* img, float* ws,
+                         size_t ws_bytes, void* stream);
 size_t fn_embed_grad_ws_bytes(int64_t rows, int V, int N3);
 int fn_embed_grad_f32(const float* dgx_all, int B, int T, int N3, const int32_t* idx, int idx_ld, int idx_shift,
                       int start_token, int reverse, int V, float* out, float* ws, size_t ws_bytes, void* stream);

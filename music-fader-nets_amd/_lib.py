@@ -30,6 +30,11 @@ class FnGruBwd(C.Structure):
                 ("sync_ws", vp), ("cu_budget", C.c_int32)]
 
 
+class FnEmbedGrad(C.Structure):
+    _fields_ = [("dgx_all", vp), ("out", vp), ("out_ld", C.c_int32), ("transposed", C.c_int32), ("reverse", C.c_int32),
+                ("idx_shift", C.c_int32), ("start_token", C.c_int32)]
+
+
 class FnDecode(C.Structure):
     _fields_ = [("B", C.c_int32), ("steps", C.c_int32), ("H", C.c_int32), ("V", C.c_int32), ("start_token", C.c_int32),
                 ("w_hh1_frag", vp), ("b_hh1", vp), ("b_ih1", vp), ("table1", vp), ("rowbias1", vp), ("h0", vp),
@@ -63,6 +68,11 @@ SIGNATURES = {
     "fn_embed_grad_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     "fn_embed_grad_f32": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     vp, vp, C.c_size_t, vp]),
+    "fn_token_sort_ints": (C.c_size_t, [C.c_int64, C.c_int]),
+    "fn_token_sort_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "fn_token_sort": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_size_t, vp]),
+    "fn_embed_grad_sorted_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "fn_embed_grad_sorted": (C.c_int, [C.POINTER(FnEmbedGrad), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_size_t, vp]),
     "fn_time_sum_f32": (C.c_int, [vp, C.c_int, C.c_int64, vp, vp]),
     "fn_vocab_logsoftmax": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_float, vp, vp]),
     "fn_vocab_logsoftmax_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),

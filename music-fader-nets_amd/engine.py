@@ -21,6 +21,13 @@ E_VOCAB, R_DIMS, N_DIMS, C_DIMS = 342, 3, 16, 24
 LOGIT_LD = 344            # 342 padded to a 16-byte multiple so that the logits rows stay float4-aligned
 
 
+def ops_sort(eng, key, tokens, V):
+    """fn_token_sort of one token matrix into a shape-keyed image buffer"""
+    n = tokens.numel() + 2 * (V + 1) + 2
+    img = eng.buf("sort_img_" + key, (n,), torch.int32) if tokens.is_cuda else None
+    return eng.ops.token_sort(tokens, V, img)
+
+
 class Engine:
     def __init__(self, ops, params, hidden, zdim, n_component, device):
         self.ops = ops
@@ -318,10 +325,16 @@ class Engine:
     def forward(self, d, r, n, c, eps_r, eps_n, labels=None, save=True):
         """Full training-mode forward up to logits; everything backward needs stays in named buffers (save=False: forward only,
         the gate tensors are not written)."""
+        sort = None
+        if save:
+            # token sorts for the backward's segment sums (embed.hip): tiny kernels, side stream, beside the encoder scans
+            self.side_wait_main()
+            with self.on_side():
+                sort = {k: ops_sort(self, k, t, V) for k, t, V in (("d", d, E_VOCAB), ("r", r, R_DIMS), ("n", n, N_DIMS))}
         pre = self.encode(d, save)
         lat = self.latent(pre, {"r": eps_r, "n": eps_n}, labels)
         dec = self.decoders(d, r, n, c, lat["r"]["z"], lat["n"]["z"], save)
-        S = dict(d=d, r=r, n=n, c=c, eps={"r": eps_r, "n": eps_n}, labels=labels, pre=pre, lat=lat, dec=dec)
+        S = dict(d=d, r=r, n=n, c=c, eps={"r": eps_r, "n": eps_n}, labels=labels, pre=pre, lat=lat, dec=dec, sort=sort)
         self.saved = S if save else None
         return S
 
@@ -459,10 +472,8 @@ class Engine:
             ops.gemm(dgx2f, hx0f, G["grucell_g_2.weight_ih"], a_k=False, b_k=False, splitk=sk_T)
             ops.colsum(rs2, G["grucell_g_2.bias_ih"])
             self._gru_weight_grads("g", "grucell_g.", "", T, B, dgx1, dghn1, dec["hx0"], dec["h0g"], G, sk_T, drb_g, rsn_g)
-            dWg = G["grucell_g.weight_ih"]                          # [3H][E+ZG]
-            dtab = self.buf("dtab_E_side", (E_VOCAB, 3 * H))
-            ops.embed_grad(dgx1, d, -1, E_VOCAB - 1, 0, E_VOCAB, dtab)
-            ops.transpose(dtab, dWg[:, :E_VOCAB])
+            dWg = G["grucell_g.weight_ih"]                          # [3H][E+ZG]: token columns = segment sums, written in place
+            ops.embed_grad_sorted(S["sort"]["d"], [dict(dgx=dgx1, out=dWg[:, :E_VOCAB], transposed=True, idx_shift=-1, start_token=E_VOCAB - 1)])
             ops.gemm(drb_g, dec["zc"], dWg[:, E_VOCAB:], a_k=False, b_k=False)
             ops.colsum(drb_g, G["grucell_g.bias_ih"])
             ops.gemm(dh0_g, dec["zc"], G["linear_init_global.weight"], a_k=False, b_k=False)
@@ -476,9 +487,7 @@ class Engine:
                 self._gru_weight_grads("d_" + e, pfx, "_l0", Tr, B, sdb[e]["dgx"], sdb[e]["dghn"], sd[e]["h_all"], sd[e]["h0"], G, sk_Tr,
                                        sdb[e]["drb"], sdb[e]["rsn"])
                 dW = G[pfx + "weight_ih_l0"]                        # [3H][Ce+Z]
-                dt = self.buf("dtab_" + e, (Ce, 3 * H))
-                ops.embed_grad(sdb[e]["dgx"], attr, 0, 0, 0, Ce, dt)
-                ops.transpose(dt, dW[:, :Ce])
+                ops.embed_grad_sorted(S["sort"][e], [dict(dgx=sdb[e]["dgx"], out=dW[:, :Ce], transposed=True)])
                 ops.gemm(sdb[e]["drb"], z, dW[:, Ce:], a_k=False, b_k=False)
                 ops.colsum(sdb[e]["drb"], G[pfx + "bias_ih_l0"])
                 ops.gemm(sdb[e]["dh0"], z, G["linear_init_%s.weight" % e], a_k=False, b_k=False)
@@ -517,13 +526,12 @@ class Engine:
                                   gates=pre["gates"][key], dh_last=dh, dgx_all=encb[key]["dgx"], dghn_all=encb[key]["dghn"],
                                   scratch=self.buf("enc_scr_" + key, (B, H)), dgx_rowsum=encb[key]["rs"], dghn_rowsum=encb[key]["rsn"]))
         ops.gru_seq_bwd(scans)        # 4 concurrent reverse scans, one weight-stationary launch
-        for e in ("r", "n"):
-            for key, sfx, rev in ((e, "_l0", 0), (e + "_reverse", "_l0_reverse", 1)):
-                pfx = "gru_%s." % e
-                self._gru_weight_grads(key, pfx, sfx, T, B, encb[key]["dgx"], encb[key]["dghn"], pre["h_all"][key], None, G, sk_T,
-                                       encb[key]["rs"], encb[key]["rsn"])
-                dtab = self.buf("dtab_E", (E_VOCAB, 3 * H))
-                ops.embed_grad(encb[key]["dgx"], d, 0, 0, rev, E_VOCAB, dtab)
-                ops.transpose(dtab, G[pfx + "weight_ih" + sfx])
-                ops.colsum(encb[key]["rs"], G[pfx + "bias_ih" + sfx])
+        enc_keys = [(e, "gru_%s." % e, key, sfx, rev) for e in ("r", "n") for key, sfx, rev in ((e, "_l0", 0), (e + "_reverse", "_l0_reverse", 1))]
+        # one-hot columns of the four W_ih: token-segment sums of the gate gradients (ONE launch pair, the batch's token sort is shared)
+        ops.embed_grad_sorted(S["sort"]["d"], [dict(dgx=encb[key]["dgx"], out=G[pfx + "weight_ih" + sfx], transposed=True, reverse=rev)
+                                               for e, pfx, key, sfx, rev in enc_keys])
+        for e, pfx, key, sfx, rev in enc_keys:
+            self._gru_weight_grads(key, pfx, sfx, T, B, encb[key]["dgx"], encb[key]["dghn"], pre["h_all"][key], None, G, sk_T,
+                                   encb[key]["rs"], encb[key]["rsn"])
+            ops.colsum(encb[key]["rs"], G[pfx + "bias_ih" + sfx])
         self.main_wait_side()

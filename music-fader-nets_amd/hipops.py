@@ -233,6 +233,42 @@ class HipOps:
         _lib.check(self.lib.fn_embed_grad_f32(_p(dgx_all), B, T, N3, _p(idx), idx.shape[1], idx_shift, start_token, int(reverse), V,
                                               _p(out), _p(ws), wsb, self.stream()), "fn_embed_grad_f32")
 
+    def token_sort(self, idx, V, img=None):
+        """counting sort of the (time, batch) positions of idx [B][T] by token -> handle for embed_grad_sorted.  ONE sort serves
+        every scan that reads this token matrix (encoder directions, decoder layer 1)."""
+        _dense(idx, torch.int32, "idx")
+        B, T = idx.shape
+        n = int(self.lib.fn_token_sort_ints(B * T, V))
+        if img is None:
+            img = torch.empty(n, dtype=torch.int32, device=self.device)
+        _dense(img, torch.int32, "img")
+        if img.numel() < n:
+            raise RuntimeError("token_sort: img too small")
+        wsb = int(self.lib.fn_token_sort_ws_bytes(B * T, V))
+        ws = self.workspace(wsb, "toksort")
+        _lib.check(self.lib.fn_token_sort(_p(idx), B, T, idx.shape[1], V, _p(img), _p(ws), wsb, self.stream()), "fn_token_sort")
+        return dict(img=img, B=B, T=T, V=V)
+
+    def embed_grad_sorted(self, handle, jobs):
+        """jobs: dicts(dgx [T][B][N3], out = [V][N3] table view, or with transposed=True the [N3][V] view (e.g. dW_ih[:, :V]),
+        reverse, idx_shift, start_token) - all reading the token matrix behind `handle`; one launch pair for all jobs."""
+        B, T, V = handle["B"], handle["T"], handle["V"]
+        arr = (_lib.FnEmbedGrad * len(jobs))()
+        N3 = jobs[0]["dgx"].shape[2]
+        for d, j in zip(arr, jobs):
+            _dense(j["dgx"], name="dgx")
+            if tuple(j["dgx"].shape) != (T, B, N3):
+                raise RuntimeError("embed_grad_sorted: dgx must be [T][B][N3] of the sorted token matrix")
+            po, r, c, ld = _mat(j["out"], "out")
+            tr = bool(j.get("transposed", False))
+            if (r, c) != ((N3, V) if tr else (V, N3)):
+                raise RuntimeError("embed_grad_sorted: out has shape %s" % ((r, c),))
+            d.dgx_all, d.out, d.out_ld, d.transposed = _p(j["dgx"]), po, ld, int(tr)
+            d.reverse, d.idx_shift, d.start_token = int(j.get("reverse", 0)), int(j.get("idx_shift", 0)), int(j.get("start_token", 0))
+        wsb = int(self.lib.fn_embed_grad_sorted_ws_bytes(B * T, B, V, N3, len(jobs)))
+        ws = self.workspace(wsb, "embed")
+        _lib.check(self.lib.fn_embed_grad_sorted(arr, len(jobs), B, T, N3, V, _p(handle["img"]), _p(ws), wsb, self.stream()), "fn_embed_grad_sorted")
+
     def time_sum(self, X, out):
         """out[...] = sum over the leading (time) axis of X."""
         _dense(X, name="X"), _dense(out, name="out")

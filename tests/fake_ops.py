@@ -145,6 +145,18 @@ class FakeOps:
         for p in range(T):
             out.index_add_(0, self._tok(fake, p), dgx_all[p])
 
+    def token_sort(self, idx, V, img=None):
+        """handle of a sorted token matrix (the HIP backend keeps the sort image of fn_token_sort)"""
+        return dict(idx=idx.clone(), V=V)
+
+    def embed_grad_sorted(self, handle, jobs):
+        """jobs: dict(dgx, out, reverse, idx_shift, start_token, transposed): out = table [V][N3], or its transpose"""
+        V = handle["V"]
+        for j in jobs:
+            tab = torch.zeros(V, j["dgx"].shape[2])
+            self.embed_grad(j["dgx"], handle["idx"], j.get("idx_shift", 0), j.get("start_token", 0), j.get("reverse", 0), V, tab)
+            j["out"].copy_(tab.t() if j.get("transposed") else tab)
+
     def time_sum(self, X, out):
         out.copy_(X.sum(0).view_as(out))
 

@@ -288,6 +288,20 @@ def test_embed_grad_full_vocab(ops):
         ops.embed_grad(g(dgx), g(idx2), shift, start, rev, V, out)
         close(out, ref, 2e-5)
         assert float(out[100].abs().max()) == 0.0
+    # one sort, several scans per launch, tables written TRANSPOSED into a wider matrix (dW_ih[:, :V] in place)
+    for Bx, Tx in ((130, 33), (256, 70), (3, 5)):
+        dg = [torch.randn(Tx, Bx, N3) for _ in range(3)]
+        ix = torch.randint(0, V, (Bx, Tx), dtype=torch.int32)
+        ix[:, Tx // 2:] = 0
+        h = ops.token_sort(g(ix), V)
+        dW = [torch.full((N3, V + 10), 7.0, device=DEV) for _ in range(3)]
+        cfg = [dict(reverse=0), dict(reverse=1), dict(idx_shift=-1, start_token=V - 1)]
+        ops.embed_grad_sorted(h, [dict(dgx=g(dg[i]), out=dW[i][:, :V], transposed=True, **cfg[i]) for i in range(3)])
+        for i in range(3):
+            ref = torch.zeros(V, N3)
+            FakeOps().embed_grad(dg[i], ix, cfg[i].get("idx_shift", 0), cfg[i].get("start_token", 0), cfg[i].get("reverse", 0), V, ref)
+            close(dW[i][:, :V].t(), ref, 2e-5, "sorted job %d (%d x %d)" % (i, Bx, Tx))
+            assert float((dW[i][:, V:] - 7.0).abs().max()) == 0.0          # columns beyond V untouched
 
 
 def test_head_kernels(ops):
