@@ -83,9 +83,9 @@ def _classify(name, a, k):
     if name == "gru_dwhh":
         rows, Hh = a[2].shape
         return ("dwhh_gemm_tn", 2.0 * rows * 3 * Hh * Hh) if rows >= 4096 else None
-    if name in ("embed_grad", "embed_grad_sorted"):
-        dgx = a[0]
-        return ("embed_grad", float(dgx.numel() * 4)) if dgx.shape[0] * dgx.shape[1] >= 4096 else None
+    if name == "embed_grad_sorted":                        # HBM-bound: every gate-gradient row of every job is read once
+        nbytes = float(sum(j["dgx"].numel() for j in a[1]) * 4)
+        return ("embed_grad", nbytes) if nbytes >= 1e8 else None
     if name == "gemm":
         A, Bm, Cm = a[0], a[1], a[2]
         M, N = Cm.shape
@@ -109,7 +109,7 @@ ROW_INFO = {   # row -> (bound, unit of work, kernel, peak share of the chip)
     "gemm_tn": ("mfma", "flop", "gemm_tn_kernel (dW of dense layers)", 1.0),
     "gemm_nt": ("mfma", "flop", "gemm_kernel (X W^T: W_ih2 projection, output layer)", 1.0),
     "gemm_nn": ("mfma", "flop", "gemm_kernel (dY W: input gradients)", 1.0),
-    "embed_grad": ("hbm", "bytes", "token-segment sum of the gate-gradient rows (embed.hip)", 1.0),
+    "embed_grad": ("hbm", "bytes", "eg_piece_kernel + eg_final_kernel: token-segment sums of the gate-gradient rows (embed.hip)", 1.0),
 }
 
 
