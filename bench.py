@@ -75,8 +75,8 @@ def _classify(name, a, k):
         kind = "fwd" if name == "gru_seq_fwd" else "bwd"
         if len(scans) == 4:
             return "enc_%s_scan" % kind, work
-        if len(scans) == 1 and scans[0]["T"] > 1:
-            return "dec_%s_scan_chunk" % kind, work
+        if all(str(s_.get("tag", "")).startswith("dec_l") for s_ in scans):
+            return ("dec_%s_scan_chunk" % kind, work) if len(scans) == 2 else None      # steady state: layer 1 + layer 2 in one launch
         if len(scans) == 2:
             return "subdec_%s_scan" % kind, work
         return None
@@ -101,8 +101,8 @@ def _classify(name, a, k):
 ROW_INFO = {   # row -> (bound, unit of work, kernel, peak share of the chip)
     "enc_fwd_scan": ("mfma", "flop", "gru_fwd_persist_kernel (4 encoder scans x 256 steps, one launch)", 1.0),
     "enc_bwd_scan": ("mfma", "flop", "gru_bwd_persist_kernel (4 encoder scans x 256 steps, one launch)", 1.0),
-    "dec_fwd_scan_chunk": ("mfma", "flop", "gru_fwd_persist_kernel (one decoder layer, one time chunk, HALF of the CUs)", 0.5),
-    "dec_bwd_scan_chunk": ("mfma", "flop", "gru_bwd_persist_kernel (one decoder layer, one time chunk, HALF of the CUs)", 0.5),
+    "dec_fwd_scan_chunk": ("mfma", "flop", "gru_fwd_persist_kernel (decoder layer 1 chunk k + layer 2 chunk k-2, one launch)", 1.0),
+    "dec_bwd_scan_chunk": ("mfma", "flop", "gru_bwd_persist_kernel (decoder layer 2 chunk k + layer 1 chunk k+2, one launch)", 1.0),
     "subdec_fwd_scan": ("mfma", "flop", "gru_fwd_persist_kernel (both sub-decoders, 64 steps)", 1.0),
     "subdec_bwd_scan": ("mfma", "flop", "gru_bwd_persist_kernel (both sub-decoders, 64 steps)", 1.0),
     "dwhh_gemm_tn": ("mfma", "flop", "gemm_tn_kernel via fn_gru_dwhh_f32 (dW_hh, K = T*B rows)", 1.0),

@@ -41,13 +41,10 @@ class Engine:
         self.whh_t = {}                 # W_hh^T, fragment-major (backward scans)
         self.packs = {}                 # fragment-major W_ih2 / W_out (single-launch greedy decode)
         self.saved = None
-        self.chunk = int(__import__("os").environ.get("FN_CHUNK", "64"))                 # time steps per pipeline chunk of the two decoder layers
-        # decoder scans as weight-stationary launches: the two sub-decoders on the whole chip, then layer 1 || layer 2 on half
-        # of the CUs each (two single-launch scans that overlap must fit on the chip TOGETHER, see FnGruFwd.cu_budget)
-        self.persist_dec = __import__("os").environ.get("FN_PERSIST_DEC", "1") == "1"
+        self.chunk = 32                 # time steps per pipeline chunk of the two decoder layers (layer 2 lags layer 1 by two chunks)
+        self.persist_dec = True         # decoder scans as weight-stationary launches (False: per-step kernels; debug / tests)
         self.single_launch_decode = __import__("os").environ.get("FN_DECODE_PERSIST", "1") == "1"    # decode.py: <= 32 sequences as one launch
-        self._lane_alias = {}           # lane -> lane it is folded into (debug / tuning: FN_AUX=0 runs the aux lane on the side stream)
-        self._aux_mode = __import__("os").environ.get("FN_AUX", "1")      # 1 | 0 | fwd | bwd
+        self._lane_alias = {}           # lane -> lane it is folded into (debug)
         if hidden % 32 != 0:
             raise ValueError("hidden_dims must be a multiple of 32 (K chunks of the MFMA step kernels)")
         if n_component > 8:
@@ -258,28 +255,33 @@ class Engine:
         hx1 = self.buf("g_hx1", (T, B, H))
         g2 = self.buf("g_gates2", (T, ops.gates_floats(B, H))) if save else None
         l2 = dict(B=B, T=T, H=H, w_hh_frag=self.whh_f["g2"], b_hh=P["grucell_g_2.bias_hh"], h0=None, gx_dense=gx2, h_all=hx1, gates=g2)
-        # Time is cut into chunks: layer 1 runs on the main stream; behind it, on the side stream, chunk c of layer 2 = batched
-        # W_ih2 projection of hx0[chunk] (one GEMM) + the recurrent scan (h_init = hx0[0], gmm_model.py:134-135).  Layer 2 thus
-        # lags layer 1 by one chunk; each layer is a weight-stationary launch on half of the CUs.
+        # Time is cut into chunks and the two layers run as ONE weight-stationary launch per chunk step k:
+        #     launch k = [layer 1, chunk k] + [layer 2, chunk k-2]      (two independent scans: 8 row groups of 64 = one per XCD, so a
+        #                                                                row group's state exchange stays inside one XCD's L2)
+        #     aux lane  : gx2[chunk k] = hx0[chunk k] W_ih2^T + b_ih2   (one GEMM, beside launch k+1)
+        # Layer 2 lags layer 1 by two chunks; its state starts from hx0[0] (gmm_model.py:134-135).
         CH = self.chunk
-        half = self._cu_count() // 2
         pd = self.persist_dec
-        self._lane_alias = {} if self._aux_mode in ("1", "fwd") else {"aux": "side"}
-        for t0 in range(0, T, CH):
-            ops.gru_seq_fwd([self._fwd_chunk(l1, t0, t0 + CH)], persistent=pd, cu_budget=half)
-            t1 = min(T, t0 + CH)
-            # three lanes: layer 1 (main) -> input projection of layer 2 (aux) -> layer 2 (side); chunk c+1 of a lane runs
-            # beside chunk c of the next one
-            self.lane_wait("aux", "main")
-            with self.on_aux():
-                ops.gemm(hx0[t0:t1].view(-1, H), P["grucell_g_2.weight_ih"], gx2[t0:t1].view(-1, 3 * H), bias=P["grucell_g_2.bias_ih"])
-            self.lane_wait("side", "aux")
-            with self.on_side():
-                c2 = self._fwd_chunk(l2, t0, t1)
-                if t0 == 0:
+        l1["tag"], l2["tag"] = "dec_l1", "dec_l2"
+        starts = list(range(0, T, CH))
+        nch = len(starts)
+        for k in range(nch + 2):
+            part = []
+            if k < nch:
+                part.append(self._fwd_chunk(l1, starts[k], starts[k] + CH))
+            if k >= 2:
+                c2 = self._fwd_chunk(l2, starts[k - 2], starts[k - 2] + CH)
+                if k == 2:
                     c2["h0"] = hx0[0]
-                ops.gru_seq_fwd([c2], persistent=pd, cu_budget=half)
-        self.main_wait_side()
+                part.append(c2)
+                self.lane_wait("main", "aux%d" % (k & 1))            # the projection of chunk k-2 (issued two launches ago)
+            ops.gru_seq_fwd(part, persistent=pd)
+            if k < nch:
+                t0, t1 = starts[k], min(T, starts[k] + CH)
+                lane = "aux%d" % (k & 1)
+                self.lane_wait(lane, "main")
+                with Engine._Lane(self, True, lane):
+                    ops.gemm(hx0[t0:t1].view(-1, H), P["grucell_g_2.weight_ih"], gx2[t0:t1].view(-1, 3 * H), bias=P["grucell_g_2.bias_ih"])
         logits = self.buf("g_logits", (T * B, LOGIT_LD))
         ops.gemm(hx1.view(T * B, H), P["linear_out_g.weight"], logits[:, :E_VOCAB], bias=P["linear_out_g.bias"])
         return dict(zc=zc, h0g=h0g, rbg=rbg, hx0=hx0, g1=g1, gx2=gx2, hx1=hx1, g2=g2, logits=logits)
@@ -334,6 +336,7 @@ class Engine:
         pre = self.encode(d, save)
         lat = self.latent(pre, {"r": eps_r, "n": eps_n}, labels)
         dec = self.decoders(d, r, n, c, lat["r"]["z"], lat["n"]["z"], save)
+        self.main_wait_side()
         S = dict(d=d, r=r, n=n, c=c, eps={"r": eps_r, "n": eps_n}, labels=labels, pre=pre, lat=lat, dec=dec, sort=sort)
         self.saved = S if save else None
         return S
@@ -432,23 +435,30 @@ class Engine:
                 part.append(self._bwd_chunk(sc, t0, t1, cin, carry[name][slot]))
             return part
 
-        half = self._cu_count() // 2
         pd = self.persist_dec
-        self._lane_alias = {} if self._aux_mode in ("1", "bwd") else {"aux2": "side"}
-        self.side_wait_main()
-        for i, t0 in enumerate(reversed(starts)):
-            with self.on_side():
-                ops.gru_seq_bwd(chunk_call([("l2", l2)], t0, i == 0), persistent=pd, cu_budget=half)
-            # layer 2 (side) -> dhx0[chunk] = dgx2[chunk] W_ih2 (aux) -> layer 1 (main)
-            self.lane_wait("aux2", "side")
-            t1 = min(T, t0 + CH)
-            with Engine._Lane(self, True, "aux2"):
-                ops.gemm(dgx2[t0:t1].view(-1, 3 * H), P["grucell_g_2.weight_ih"], dhx0[t0:t1].view(-1, H), a_k=True, b_k=False)
-                if t0 == 0:
-                    ops.axpy(1.0, carry["l2"][0], dhx0[0])          # hx1 was initialised with hx0[0]: dL/dh_init of layer 2
-            self.lane_wait("main", "aux2")
-            ops.gru_seq_bwd(chunk_call([("l1", l1)], t0, i == 0), persistent=pd, cu_budget=half)
-        # both sub-decoders, all Tr steps, whole chip (layer 2 has finished on the side stream)
+        l1["tag"], l2["tag"] = "dec_l1", "dec_l2"
+        # launch k = [layer 2, chunk js[k]] + [layer 1, chunk js[k-2]] (time runs backwards: js = last chunk .. first), ONE weight-
+        # stationary launch of two independent scans (8 row groups = one per XCD); beside launch k+1 the aux lane turns the layer-2
+        # gate gradients of chunk js[k] into layer 1's incoming state gradient: dhx0[chunk] = dgx2[chunk] W_ih2 (one GEMM)
+        js = list(reversed(starts))
+        nch = len(js)
+        for k in range(nch + 2):
+            part = []
+            if k < nch:
+                part += chunk_call([("l2", l2)], js[k], k == 0)
+            if k >= 2:
+                self.lane_wait("main", "auxb%d" % (k & 1))
+                part += chunk_call([("l1", l1)], js[k - 2], k == 2)
+            ops.gru_seq_bwd(part, persistent=pd)
+            if k < nch:
+                t0, t1 = js[k], min(T, js[k] + CH)
+                lane = "auxb%d" % (k & 1)
+                self.lane_wait(lane, "main")
+                with Engine._Lane(self, True, lane):
+                    ops.gemm(dgx2[t0:t1].view(-1, 3 * H), P["grucell_g_2.weight_ih"], dhx0[t0:t1].view(-1, H), a_k=True, b_k=False)
+                    if t0 == 0:
+                        ops.axpy(1.0, carry["l2"][0], dhx0[0])          # hx1 was initialised with hx0[0]: dL/dh_init of layer 2
+        # both sub-decoders, all Tr steps, whole chip
         ops.gru_seq_bwd([self._bwd_chunk(sds[e], 0, Tr, None, carry[e][0]) for e in ("r", "n")], persistent=pd)
         dh0_g = carry["l1"][0]
         for e in ("r", "n"):
