@@ -12,7 +12,7 @@
  *   - all pointers are DEVICE pointers (fp32 unless stated, int32 for token ids), owned by the
  *     caller; nothing is allocated, freed or synchronised inside (graph-capture safe);
  *   - `stream` is a hipStream_t passed as void*; work is stream-ordered;
- *   - functions are re-entrant; the library keeps no mutable global state;
+ *   - functions are re-entrant; the library keeps no mutable global state and reads no environment variables;
  *   - per-step tensors are TIME-MAJOR: [T][B][...] so that one step is one contiguous slab;
  *     token tensors are batch-major [B][T] int32 exactly as the data loader yields them.
  */
@@ -37,7 +37,7 @@ extern "C" {
 
 #define FN_MAX_SCANS 8
 
-int fn_version(void);                 /* ABI version, currently 1 */
+int fn_version(void);                 /* ABI version, currently 2 */
 const char* fn_strerror(int code);    /* static string for FN_E_* / hipError_t */
 
 /* ------------------------------------------------------------------------------------------
@@ -104,6 +104,9 @@ typedef struct FnGruFwd {
     const float* h0_frag;     /* optional: h0 already in the fragment-major operand layout (fn_frag_floats(B,H)  */
                               /* floats) - saves the packing launch of step-by-step decoding; h0 is still needed */
     float* h_last_frag;       /* optional: the final state, fragment-major (the next call's h0_frag)       */
+    int32_t variant;          /* 0 = automatic (scans[0]'s is used).  Tuning / tests: low byte = force this many batch rows per   */
+                              /* workgroup of the single launch (16/32/64/128; not eligible -> per-step kernels), bit 8 = the     */
+                              /* alternative wave tiling of the 64-row configuration.  Results never depend on it.               */
 } FnGruFwd;
 
 /* fragment-major operand image: floats needed for a [rows][K] matrix, and the packing kernel
@@ -146,6 +149,7 @@ typedef struct FnGruBwd {
     float* frag_ws;           /* 2 * fn_frag_floats(B, 3H) floats, 16-byte aligned             */
     void* sync_ws;            /* as in FnGruFwd (NULL = per-step launches; then scratch is required) */
     int32_t cu_budget;        /* as in FnGruFwd                                                */
+    int32_t variant;          /* as in FnGruFwd                                                */
 } FnGruBwd;
 
 int fn_gru_seq_bwd(const FnGruBwd* scans, int n_scans, void* stream);

@@ -439,17 +439,9 @@ int launch_pack(const float* src, int rows, int K, long ld, float* dst, hipStrea
 namespace {
 
 // ---- launch configuration -------------------------------------------------------------------------------
-// (TM, TN, D) = M-tiles per workgroup, N-tiles (backward only), chunks in flight per wave.  Defaults were picked by
-// measurement on MI355X (profiles/); FN_FWD_CFG / FN_BWD_CFG = "TM,TN,D" override them for tuning runs.
+// (TM, TN, D) = M-tiles per workgroup, N-tiles (backward only), chunks in flight per wave.  Picked by measurement on MI355X
+// (profiles/).
 struct Cfg { int tm, tn, d; };
-
-bool env_cfg(const char* name, Cfg& c) {
-    const char* e = getenv(name);
-    Cfg t;
-    if (!e || sscanf(e, "%d,%d,%d", &t.tm, &t.tn, &t.d) != 3) return false;
-    c = t;
-    return true;
-}
 
 template <int TM, int D>
 void launch_fwd_ns(const FwdArgs& a, int tiles, hipStream_t st) {
@@ -524,7 +516,6 @@ int fn_gru_seq_fwd(const FnGruFwd* scans, int n_scans, void* stream) {
         for (int s = 0; s < n_scans; ++s)
             if (p < scans[s].T) big_tiles += (long)((scans[s].B + 63) / 64) * (scans[s].H / 16);
         Cfg cfg = big_tiles >= 256 ? Cfg{4, 0, 1} : Cfg{2, 0, 3};
-        env_cfg(big_tiles >= 256 ? "FN_FWD_CFG" : "FN_FWD_CFG1", cfg);
         const int bm = 16 * cfg.tm;
         FwdArgs a;
         a.n = 0;
@@ -585,7 +576,6 @@ int fn_gru_seq_bwd(const FnGruBwd* scans, int n_scans, void* stream) {
         }
         if (big_tiles == 0) continue;
         Cfg cfg = big_tiles >= 192 ? Cfg{4, 1, 2} : Cfg{2, 1, 3};
-        env_cfg(big_tiles >= 192 ? "FN_BWD_CFG" : "FN_BWD_CFG1", cfg);
         const int bm = 16 * cfg.tm, bn = 16 * cfg.tn;
         BwdArgs a;
         a.n = 0;

@@ -589,8 +589,6 @@ int launch_k(const Args& a, int grid, size_t lds, hipStream_t st) {
 extern "C" size_t fn_gru_sync_ws_bytes() { return ((size_t)FN_MAX_GROUPS * 32 + 32) * 4; }
 
 int fn_gru_fwd_persist(const FnGruFwd* scans, int n_scans, hipStream_t st) {
-    const char* e = getenv("FN_PERSIST");
-    if (e && atoi(e) == 0) return FN_PERSIST_NA;
     const int H = scans[0].H;
     if (H > 512 || !scans[0].sync_ws) return FN_PERSIST_NA;
     int Tmax = 0;
@@ -612,9 +610,9 @@ int fn_gru_fwd_persist(const FnGruFwd* scans, int n_scans, hipStream_t st) {
     // smallest row block whose group count fits on the chip with one workgroup per CU
     int rpw = 0;
     const int cand[4] = {16, 32, 64, 128};
-    const char* er = getenv("FN_PERSIST_ROWS");
+    const int force_rows = scans[0].variant & 0xFF;         // tuning / tests: take this row block or none
     for (int c = 0; c < 4 && !rpw; ++c) {
-        if (er && atoi(er) != cand[c]) continue;
+        if (force_rows && force_rows != cand[c]) continue;
         long groups = 0;
         for (int s = 0; s < n_scans; ++s) groups += (scans[s].B + cand[c] - 1) / cand[c];
         if (groups <= maxgroups) rpw = cand[c];
@@ -645,19 +643,19 @@ int fn_gru_fwd_persist(const FnGruFwd* scans, int n_scans, hipStream_t st) {
     hipError_t me = hipMemsetAsync(a.sync, 0, (size_t)FN_MAX_GROUPS * 32 * 4, st);      // counters only: err is sticky
     if (me != hipSuccess) return (int)me;
     const int grid = groups * nslices;
-    const int wk = rpw == 16 ? 4 : rpw == 32 ? 2 : 1;
+    const int wk = rpw == 16 ? 4 : rpw == 32 ? 2 : (rpw == 64 && !(scans[0].variant & 0x100)) ? 2 : 1;     // K split of the chosen tiling
     const size_t lds = ((size_t)3 * H * 16 + (size_t)wk * (rpw / 16) * 3 * RT) * 4 + 16;
     switch (rpw) {
         case 128: return launch_k<PArgs, gru_fwd_persist_kernel<4, 1, 2, 4>>(a, grid, lds, st);
-        case 64: return launch_k<PArgs, gru_fwd_persist_kernel<4, 1, 1, 4>>(a, grid, lds, st);
+        case 64:
+            if (scans[0].variant & 0x100) return launch_k<PArgs, gru_fwd_persist_kernel<4, 1, 1, 4>>(a, grid, lds, st);
+            return launch_k<PArgs, gru_fwd_persist_kernel<2, 2, 2, 4>>(a, grid, lds, st);
         case 32: return launch_k<PArgs, gru_fwd_persist_kernel<2, 2, 1, 4>>(a, grid, lds, st);
         default: return launch_k<PArgs, gru_fwd_persist_kernel<1, 4, 1, 4>>(a, grid, lds, st);
     }
 }
 
 int fn_gru_bwd_persist(const FnGruBwd* scans, int n_scans, hipStream_t st) {
-    const char* e = getenv("FN_PERSIST_BWD");
-    if (e && atoi(e) == 0) return FN_PERSIST_NA;
     const int H = scans[0].H;
     if (H > 512 || !scans[0].sync_ws) return FN_PERSIST_NA;
     int Tmax = 0;
@@ -677,9 +675,9 @@ int fn_gru_bwd_persist(const FnGruBwd* scans, int n_scans, hipStream_t st) {
     const int maxgroups = cus / nslices < FN_MAX_GROUPS ? cus / nslices : FN_MAX_GROUPS;
     int rpw = 0;
     const int cand[4] = {16, 32, 64, 128};
-    const char* er = getenv("FN_PERSIST_ROWS");
+    const int force_rows = scans[0].variant & 0xFF;         // tuning / tests: take this row block or none
     for (int c = 0; c < 4 && !rpw; ++c) {
-        if (er && atoi(er) != cand[c]) continue;
+        if (force_rows && force_rows != cand[c]) continue;
         long groups = 0;
         for (int s = 0; s < n_scans; ++s) groups += (scans[s].B + cand[c] - 1) / cand[c];
         if (groups <= maxgroups) rpw = cand[c];
@@ -706,11 +704,13 @@ int fn_gru_bwd_persist(const FnGruBwd* scans, int n_scans, hipStream_t st) {
     hipError_t me = hipMemsetAsync(a.sync, 0, (size_t)FN_MAX_GROUPS * 32 * 4, st);
     if (me != hipSuccess) return (int)me;
     const int grid = groups * nslices;
-    const int wk = rpw == 16 ? 4 : rpw == 32 ? 2 : 1;
+    const int wk = rpw == 16 ? 4 : rpw == 32 ? 2 : (rpw == 64 && !(scans[0].variant & 0x100)) ? 2 : 1;
     const size_t lds = ((size_t)3 * H * 16 + (size_t)wk * (rpw / 16) * RT) * 4 + 16;
     switch (rpw) {
         case 128: return launch_k<QArgs, gru_bwd_persist_kernel<4, 1, 2, 8>>(a, grid, lds, st);
-        case 64: return launch_k<QArgs, gru_bwd_persist_kernel<4, 1, 1, 8>>(a, grid, lds, st);
+        case 64:
+            if (scans[0].variant & 0x100) return launch_k<QArgs, gru_bwd_persist_kernel<4, 1, 1, 8>>(a, grid, lds, st);
+            return launch_k<QArgs, gru_bwd_persist_kernel<2, 2, 2, 8>>(a, grid, lds, st);
         case 32: return launch_k<QArgs, gru_bwd_persist_kernel<2, 2, 1, 8>>(a, grid, lds, st);
         default: return launch_k<QArgs, gru_bwd_persist_kernel<1, 4, 1, 8>>(a, grid, lds, st);
     }

@@ -43,7 +43,7 @@ class Engine:
         self.saved = None
         self.chunk = 32                 # time steps per pipeline chunk of the two decoder layers (layer 2 lags layer 1 by two chunks)
         self.persist_dec = True         # decoder scans as weight-stationary launches (False: per-step kernels; debug / tests)
-        self.single_launch_decode = __import__("os").environ.get("FN_DECODE_PERSIST", "1") == "1"    # decode.py: <= 32 sequences as one launch
+        self.single_launch_decode = True   # decode.py: <= 32 sequences decode as ONE launch (False: per-token kernels; tests)
         self._lane_alias = {}           # lane -> lane it is folded into (debug)
         if hidden % 32 != 0:
             raise ValueError("hidden_dims must be a multiple of 32 (K chunks of the MFMA step kernels)")
@@ -275,7 +275,8 @@ class Engine:
                     c2["h0"] = hx0[0]
                 part.append(c2)
                 self.lane_wait("main", "aux%d" % (k & 1))            # the projection of chunk k-2 (issued two launches ago)
-            ops.gru_seq_fwd(part, persistent=pd)
+            if part:
+                ops.gru_seq_fwd(part, persistent=pd)
             if k < nch:
                 t0, t1 = starts[k], min(T, starts[k] + CH)
                 lane = "aux%d" % (k & 1)
@@ -449,7 +450,8 @@ class Engine:
             if k >= 2:
                 self.lane_wait("main", "auxb%d" % (k & 1))
                 part += chunk_call([("l1", l1)], js[k - 2], k == 2)
-            ops.gru_seq_bwd(part, persistent=pd)
+            if part:
+                ops.gru_seq_bwd(part, persistent=pd)
             if k < nch:
                 t0, t1 = js[k], min(T, js[k] + CH)
                 lane = "auxb%d" % (k & 1)

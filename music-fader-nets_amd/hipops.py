@@ -53,6 +53,7 @@ class HipOps:
             raise RuntimeError("HipOps needs a GPU device")
         self._ws = {}
         self._retired = []
+        self.variant = 0          # FnGruFwd.variant of every scan launch (tuning / tests only; results do not depend on it)
         self.lane = ""            # scratch namespace: kernels enqueued on different streams must not share workspaces
 
     # -- plumbing -------------------------------------------------------------------------------
@@ -153,8 +154,9 @@ class HipOps:
                 t[-32:].zero_()
         return bad
 
-    def gru_seq_fwd(self, scans, persistent=True, cu_budget=0):
+    def gru_seq_fwd(self, scans, persistent=True, cu_budget=0, variant=None):
         arr = (_lib.FnGruFwd * len(scans))()
+        variant = self.variant if variant is None else variant
         for i, (d, s) in enumerate(zip(arr, scans)):
             for k in ("w_hh_frag", "b_hh", "b_ih", "h0", "gx_dense", "gx_table", "gx_rowbias", "h_all", "gates", "h0_frag", "h_last_frag"):
                 _dense(s.get(k), name=k)
@@ -164,6 +166,7 @@ class HipOps:
             d.frag_ws = _p(self._frag_ws("fragf", i, 2 * self.frag_floats(s["B"], s["H"])))
             d.sync_ws = _p(self._sync_ws()) if persistent else None
             d.cu_budget = int(cu_budget)
+            d.variant = int(variant)
             _dense(s.get("idx"), torch.int32, "idx")
             d.B, d.T, d.H, d.reverse = s["B"], s["T"], s["H"], int(s.get("reverse", 0))
             d.w_hh_frag, d.b_hh, d.b_ih, d.h0 = _p(s["w_hh_frag"]), _p(s["b_hh"]), _p(s.get("b_ih")), _p(s.get("h0"))
@@ -174,14 +177,16 @@ class HipOps:
             d.h0_frag, d.h_last_frag = _p(s.get("h0_frag")), _p(s.get("h_last_frag"))
         _lib.check(self.lib.fn_gru_seq_fwd(arr, len(scans), self.stream()), "fn_gru_seq_fwd")
 
-    def gru_seq_bwd(self, scans, persistent=True, cu_budget=0):
+    def gru_seq_bwd(self, scans, persistent=True, cu_budget=0, variant=None):
         arr = (_lib.FnGruBwd * len(scans))()
+        variant = self.variant if variant is None else variant
         for i, (d, s) in enumerate(zip(arr, scans)):
             for k in ("w_hh_t_frag", "h0", "h_all", "gates", "dh_last", "dh_ext", "dgx_all", "dghn_all", "dh0", "dgx_rowsum", "dghn_rowsum", "scratch"):
                 _dense(s.get(k), name=k)
             d.frag_ws = _p(self._frag_ws("fragb", i, 2 * self.frag_floats(s["B"], 3 * s["H"])))
             d.sync_ws = _p(self._sync_ws()) if persistent else None
             d.cu_budget = int(cu_budget)
+            d.variant = int(variant)
             d.B, d.T, d.H = s["B"], s["T"], s["H"]
             d.w_hh_t_frag, d.h0, d.h_all, d.gates = _p(s["w_hh_t_frag"]), _p(s.get("h0")), _p(s["h_all"]), _p(s["gates"])
             d.dh_last, d.dh_ext = _p(s.get("dh_last")), _p(s.get("dh_ext"))

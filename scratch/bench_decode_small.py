@@ -16,10 +16,10 @@ def t(fn, reps=3):
     return best
 for Bi, steps in ((1, 100), (8, 100), (16, 300), (24, 100), (32, 300)):
     z = torch.randn(Bi, 280, device=dev)
-    os.environ["FN_DECODE_PERSIST"] = "0"
+    m.engine().single_launch_decode = False
     lp0, tk0 = pkg.greedy_decode(m, z, steps)
     t0 = t(lambda: pkg.greedy_decode(m, z, steps))
-    os.environ["FN_DECODE_PERSIST"] = "1"
+    m.engine().single_launch_decode = True
     lp1, tk1 = pkg.greedy_decode(m, z, steps)
     t1 = t(lambda: pkg.greedy_decode(m, z, steps))
     same = bool((tk0 == tk1).all())

@@ -76,6 +76,8 @@ class FakeOps:
 
     def gru_seq_fwd(self, scans, persistent=True, cu_budget=0):
         self.calls.append("gru_seq_fwd")
+        if not scans or len(scans) > 8:
+            raise RuntimeError("fn_gru_seq_fwd failed: too many scans in one call (code -5)")      # FN_E_COUNT, as the library
         for s in scans:
             B, T, H = s["B"], s["T"], s["H"]
             h = s["h0"] if s.get("h0") is not None else torch.zeros(B, H)
