@@ -278,6 +278,16 @@ int fn_latent_bwd(const float* pre, const float* eps, const float* mu_lk, const 
 int fn_pairwise_reg(const float* z0_all, const double* attr_all, int n_all, int row0, int nrows, float* loss_rows,
                     float grad_scale, float* dz0, void* stream);
 
+/* Adversarial heads of the Fader-Networks sibling (model_v2.py:572-575, trainer_fader.py:105-110), forward + gradient in one pass,
+ * one wavefront per row.  For a in {0: rhythm, 1: note}:  pre = w_a . z[b] + b_a ;  o[b][a] = relu(pre) * mask[b][a] (mask = the
+ * dropout keep-mask already scaled by 1/(1-p)) ;  loss_rows[b][a] = (o - dens[b][a])^2 ;
+ * da[b][a] = lam * 2 (o - dens) * inv_global_batch * mask * [pre > 0]  (lam read from DEVICE memory, fn_step_params out[6]) ;
+ * g_z[b][:] -= sum_a da[b][a] w_a   - MINUS: ReverseLayerF hands the encoder the negated gradient (model_v2.py:426-435).
+ * z [B][ldz], g_z [B][ldg] (may be NULL), w_a [Z], b_a [1], mask / dens / o / loss_rows / da [B][2]. */
+int fn_adv_head(const float* z, int ldz, int Z, int B, const float* w_r, const float* w_n, const float* b_r, const float* b_n,
+                const float* mask, const float* dens, const float* lam_dev, float inv_global_batch, float* o, float* loss_rows, float* da,
+                float* g_z, int ldg, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * clip_grad_norm_(., max_norm) + Adam (trainer_gmm.py:250-251, torch.optim.Adam defaults) over a
  * flat fp32 buffer.  fn_sumsq writes sum(g^2) to out[0]; fn_clip_adam reads the (all-reduced)
@@ -286,8 +296,10 @@ int fn_pairwise_reg(const float* z0_all, const double* attr_all, int n_all, int 
  * fn_step_params keeps the step counters ON THE DEVICE (counters[0] = training step, counters[1] = Adam t; int64) and
  * derives every step-dependent scalar from them: out[0..2] = {w_lat, w_cls, w_clf} for fn_latent_bwd with
  * beta0 = 0 if step < 1000 else min((step-10000)/10000*beta, beta)  (trainer_gmm.py:125-128), out[3] = lr/(1-beta1^t),
- * out[4] = 1/sqrt(1-beta2^t), out[5] = beta0; advance != 0 increments both counters (t is advanced BEFORE use, the step
- * AFTER).  fn_clip_adam takes hyper = &out[3].  The whole training step is therefore capturable in one hipGraph.
+ * out[4] = 1/sqrt(1-beta2^t), out[5] = beta0, out[6] = min(step/2000*1e-4, 1e-4) (adversarial weight of the Fader-Networks
+ * sibling, trainer_fader.py:105), out[7] = beta * inv_global_batch (the constant KL weight of trainer_singlevae.py:104); out has
+ * 8 floats.  advance != 0 increments both counters (t is advanced BEFORE use, the step AFTER).  fn_clip_adam takes
+ * hyper = &out[3].  The whole training step is therefore capturable in one hipGraph.
  * ------------------------------------------------------------------------------------------ */
 int fn_step_params(int64_t* counters, float beta, float lr, float beta1, float beta2, int supervised, float inv_global_batch,
                    int advance, float* out, void* stream);

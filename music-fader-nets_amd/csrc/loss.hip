@@ -353,6 +353,49 @@ __global__ __launch_bounds__(256) void pairwise_reg_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------ adversarial heads of the Fader-Networks sibling -----
+// model_v2.py:572-575 + trainer_fader.py:105-110: per attribute a in {rhythm, note}
+//     o_a = dropout(relu(w_a . reverse(z) + b_a)),   l_adv_a = lam * mean_b (o_a - dens_a)^2
+// One wavefront per row; forward and the gradient of lam * sum_a mean_b(...) in the same pass:
+//     da[b][a] = lam * 2 (o - dens) / Bg * mask * [pre > 0]   (gradient wrt the pre-activation; its column sums / da^T z are
+//                                                              the discriminator's bias / weight gradients)
+//     g_z[b][:] -= sum_a da[b][a] w_a                          (ReverseLayerF: the encoder receives the NEGATED gradient)
+__global__ __launch_bounds__(256) void adv_head_kernel(const float* __restrict__ z, int ldz, int Z, int B, const float* __restrict__ w_r,
+                                                       const float* __restrict__ w_n, const float* __restrict__ b_r,
+                                                       const float* __restrict__ b_n, const float* __restrict__ mask,
+                                                       const float* __restrict__ dens, const float* __restrict__ lam_dev, float inv_bg,
+                                                       float* __restrict__ o, float* __restrict__ loss_rows, float* __restrict__ da,
+                                                       float* __restrict__ g_z, int ldg) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    float sr = 0.f, sn = 0.f;
+    for (int d = lane; d < Z; d += 64) {
+        const float zz = z[(long)b * ldz + d];
+        sr += zz * w_r[d];
+        sn += zz * w_n[d];
+    }
+    sr = fn_wave_sum(sr) + b_r[0];
+    sn = fn_wave_sum(sn) + b_n[0];
+    const float lam = lam_dev ? lam_dev[0] : 0.f;
+    const float pre[2] = {sr, sn};
+    float dav[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const float m = mask[b * 2 + a];
+        const float ov = fmaxf(pre[a], 0.f) * m;
+        const float df = ov - dens[b * 2 + a];
+        dav[a] = lam * 2.0f * df * inv_bg * m * (pre[a] > 0.f ? 1.0f : 0.f);
+        if (lane == 0) {
+            o[b * 2 + a] = ov;
+            loss_rows[b * 2 + a] = df * df;
+            if (da) da[b * 2 + a] = dav[a];
+        }
+    }
+    if (g_z)
+        for (int d = lane; d < Z; d += 64) g_z[(long)b * ldg + d] -= dav[0] * w_r[d] + dav[1] * w_n[d];
+}
+
 __global__ void onehot_to_index_kernel(const float* __restrict__ oh, long rows, int V, int* __restrict__ idx) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -376,6 +419,17 @@ __global__ void onehot_to_index_kernel(const float* __restrict__ oh, long rows, 
 }  // namespace
 
 extern "C" {
+
+int fn_adv_head(const float* z, int ldz, int Z, int B, const float* w_r, const float* w_n, const float* b_r, const float* b_n,
+                const float* mask, const float* dens, const float* lam_dev, float inv_global_batch, float* o, float* loss_rows, float* da,
+                float* g_z, int ldg, void* stream) {
+    if (!z || !w_r || !w_n || !b_r || !b_n || !mask || !dens || !o || !loss_rows) return FN_E_NULL;
+    if (Z <= 0 || B <= 0 || ldz < Z || (g_z && ldg < Z)) return FN_E_SHAPE;
+    hipLaunchKernelGGL(adv_head_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, z, ldz, Z, B, w_r, w_n, b_r, b_n, mask, dens,
+                       lam_dev, inv_global_batch, o, loss_rows, da, g_z, ldg);
+    FN_CHECK_LAUNCH();
+    return FN_OK;
+}
 
 int fn_vocab_logsoftmax(const float* logits, int B, int T, int E, int ld, float* logp_bt, const int32_t* target, float* nll_rows,
                         float grad_scale, float* dlogits, void* stream) {

@@ -41,7 +41,8 @@ __global__ __launch_bounds__(1024) void sumsq_final_kernel(const float* __restri
 // One thread: advances the device-resident counters and derives everything that depends on the step number, so that a
 // captured hipGraph of the whole training step never bakes a step-dependent scalar into a kernel argument.
 //   counters[0] = training step (beta annealing, trainer_gmm.py:125-128), counters[1] = Adam's t
-//   out[0..2] = w_lat, w_cls, w_clf of fn_latent_bwd ; out[3] = lr / (1 - beta1^t) ; out[4] = 1 / sqrt(1 - beta2^t) ; out[5] = beta0
+//   out[0..2] = w_lat, w_cls, w_clf of fn_latent_bwd ; out[3] = lr / (1 - beta1^t) ; out[4] = 1 / sqrt(1 - beta2^t) ; out[5] = beta0 ;
+//   out[6] = adversarial weight of the Fader sibling ; out[7] = beta / Bg
 __global__ void step_params_kernel(long long* __restrict__ counters, float beta, float lr, float beta1, float beta2, int supervised,
                                    float inv_bg, int advance, float* __restrict__ out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -59,6 +60,13 @@ __global__ void step_params_kernel(long long* __restrict__ counters, float beta,
     out[3] = (float)((double)lr / (1.0 - pow((double)beta1, tt)));
     out[4] = (float)(1.0 / sqrt(1.0 - pow((double)beta2, tt)));
     out[5] = (float)beta0;
+    // sibling trainers: Fader-Networks adversarial weight min(step / 2000 * 1e-4, 1e-4) (trainer_fader.py:105) and the CONSTANT
+    // KL weight beta / Bg of the single-encoder VAE, whose loss ignores its own annealed beta0 (trainer_singlevae.py:84-104)
+    {
+        const double l = (double)step / 2000.0 * 1e-4;
+        out[6] = (float)(l < 1e-4 ? l : 1e-4);
+    }
+    out[7] = beta * inv_bg;
     if (advance) {
         counters[0] = step + 1;
         counters[1] = t;

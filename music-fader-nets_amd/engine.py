@@ -366,6 +366,84 @@ class Engine:
     def _splitk(rows):
         return 16 if rows >= 32768 else (8 if rows >= 4096 else (4 if rows >= 1024 else 1))
 
+    def _bwd_global_decoder_scans(self, S):
+        """Backward of global_decoder_tf up to the gate gradients (dlogits must already be in S['dec']['logits'], in place):
+        output layer dX, then the two cells, chunk-pipelined.  Returns the gate-gradient buffers, the per-sequence row sums
+        (drb_g = d(W_ih[:, V:] z) rows, i.e. the gradient wrt the conditioning projection) and dh0_g = dL/d(linear_init_global(z))."""
+        ops, P, H = self.ops, self.p, self.H
+        dec = S["dec"]
+        B, T = S["d"].shape
+        dlog = dec["logits"]                                   # [T*B][344], holds dlogits
+        dhx1 = self.buf("g_dhx1", (T, B, H))
+        ops.gemm(dlog[:, :E_VOCAB], P["linear_out_g.weight"], dhx1.view(T * B, H), a_k=True, b_k=False)
+        dgx2 = self.buf("g_dgx2", (T, B, 3 * H))
+        dghn2 = self.buf("g_dghn2", (T, B, H))
+        dhx0 = self.buf("g_dhx0", (T, B, H))
+        dgx1 = self.buf("g_dgx1", (T, B, 3 * H))
+        dghn1 = self.buf("g_dghn1", (T, B, H))
+        # per-sequence sums over time of the gate gradients (bias / z-projection gradients) are accumulated by the scans
+        rs2, rsn2 = self.zbuf("g_rs2", (B, 3 * H)), self.zbuf("g_rsn2", (B, H))
+        drb_g, rsn_g = self.zbuf("g_drb", (B, 3 * H)), self.zbuf("g_rsn1", (B, H))
+        l2 = dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t["g2"], h0=dec["hx0"][0], h_all=dec["hx1"], gates=dec["g2"], dh_ext=dhx1,
+                  dgx_all=dgx2, dghn_all=dghn2, scratch=self.buf("g_scr2", (B, H)), dgx_rowsum=rs2, dghn_rowsum=rsn2, tag="dec_l2")
+        l1 = dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t["g"], h0=dec["h0g"], h_all=dec["hx0"], gates=dec["g1"], dh_ext=dhx0,
+                  dgx_all=dgx1, dghn_all=dghn1, scratch=self.buf("g_scr1", (B, H)), dgx_rowsum=drb_g, dghn_rowsum=rsn_g, tag="dec_l1")
+        CH = self.chunk
+        carry = {k: [self.buf("carry_%s_%d" % (k, i), (B, H)) for i in range(2)] for k in ("l2", "l1")}
+
+        def chunk(name, sc, t0):
+            """chunk descriptor with ping-pong carries of the state gradient (slot = chunk parity)"""
+            t1 = min(t0 + CH, T)
+            slot = (t0 // CH) & 1
+            return self._bwd_chunk(sc, t0, t1, None if t1 >= T else carry[name][slot ^ 1], carry[name][slot])
+
+        pd = self.persist_dec
+        # launch k = [layer 2, chunk js[k]] + [layer 1, chunk js[k-2]] (time runs backwards: js = last chunk .. first), ONE weight-
+        # stationary launch of two independent scans (8 row groups = one per XCD); beside launch k+1 the aux lane turns the layer-2
+        # gate gradients of chunk js[k] into layer 1's incoming state gradient: dhx0[chunk] = dgx2[chunk] W_ih2 (one GEMM)
+        js = list(reversed(range(0, T, CH)))
+        nch = len(js)
+        for k in range(nch + 2):
+            part = []
+            if k < nch:
+                part.append(chunk("l2", l2, js[k]))
+            if k >= 2:
+                self.lane_wait("main", "auxb%d" % (k & 1))
+                part.append(chunk("l1", l1, js[k - 2]))
+            if part:
+                ops.gru_seq_bwd(part, persistent=pd)
+            if k < nch:
+                t0, t1 = js[k], min(T, js[k] + CH)
+                lane = "auxb%d" % (k & 1)
+                self.lane_wait(lane, "main")
+                with Engine._Lane(self, True, lane):
+                    ops.gemm(dgx2[t0:t1].view(-1, 3 * H), P["grucell_g_2.weight_ih"], dhx0[t0:t1].view(-1, H), a_k=True, b_k=False)
+                    if t0 == 0:
+                        ops.axpy(1.0, carry["l2"][0], dhx0[0])          # hx1 was initialised with hx0[0]: dL/dh_init of layer 2
+        return dict(dgx1=dgx1, dghn1=dghn1, dgx2=dgx2, dghn2=dghn2, rs2=rs2, rsn2=rsn2, drb_g=drb_g, rsn_g=rsn_g, dh0_g=carry["l1"][0])
+
+    def _bwd_global_decoder_params(self, G, S, gd):
+        """parameter gradients of the global decoder (linear_out_g, grucell_g_2, grucell_g, linear_init_global) from the gate gradients"""
+        ops, H = self.ops, self.H
+        dec = S["dec"]
+        B, T = S["d"].shape
+        sk_T = self._splitk(T * B)
+        dlog = dec["logits"]
+        hx1f, hx0f = dec["hx1"].view(T * B, H), dec["hx0"].view(T * B, H)
+        dgx1, dghn1, dgx2, dghn2, rs2, rsn2, drb_g, rsn_g, dh0_g = (gd[k] for k in ("dgx1", "dghn1", "dgx2", "dghn2", "rs2", "rsn2", "drb_g", "rsn_g", "dh0_g"))
+        ops.gemm(dlog[:, :E_VOCAB], hx1f, G["linear_out_g.weight"], a_k=False, b_k=False, splitk=sk_T)
+        ops.colsum(dlog[:, :E_VOCAB], G["linear_out_g.bias"])
+        self._gru_weight_grads("g2", "grucell_g_2.", "", T, B, dgx2, dghn2, dec["hx1"], dec["hx0"][0], G, sk_T, rs2, rsn2)
+        ops.gemm(dgx2.view(T * B, 3 * H), hx0f, G["grucell_g_2.weight_ih"], a_k=False, b_k=False, splitk=sk_T)
+        ops.colsum(rs2, G["grucell_g_2.bias_ih"])
+        self._gru_weight_grads("g", "grucell_g.", "", T, B, dgx1, dghn1, dec["hx0"], dec["h0g"], G, sk_T, drb_g, rsn_g)
+        dWg = G["grucell_g.weight_ih"]                          # [3H][E+ZG]: token columns = segment sums, written in place
+        ops.embed_grad_sorted(S["sort"]["d"], [dict(dgx=dgx1, out=dWg[:, :E_VOCAB], transposed=True, idx_shift=-1, start_token=E_VOCAB - 1)])
+        ops.gemm(drb_g, dec["zc"], dWg[:, E_VOCAB:], a_k=False, b_k=False)
+        ops.colsum(drb_g, G["grucell_g.bias_ih"])
+        ops.gemm(dh0_g, dec["zc"], G["linear_init_global.weight"], a_k=False, b_k=False)
+        ops.colsum(dh0_g, G["linear_init_global.bias"])
+
     def backward(self, G, dlogits_sd, lat_up, w3=None, after_decoders=None):
         """Backward of forward().
 
@@ -386,85 +464,24 @@ class Engine:
         Tr = r.shape[1]
         sk_T, sk_Tr = self._splitk(T * B), self._splitk(Tr * B)
 
-        # ---- global decoder output layer ----------------------------------------------------------
-        dlog = dec["logits"]                                   # [T*B][344], holds dlogits
-        hx1f, hx0f = dec["hx1"].view(T * B, H), dec["hx0"].view(T * B, H)
-        dhx1 = self.buf("g_dhx1", (T, B, H))
-        ops.gemm(dlog[:, :E_VOCAB], P["linear_out_g.weight"], dhx1.view(T * B, H), a_k=True, b_k=False)
-        # ---- decoder scans, chunk-pipelined over two streams ----------------------------------------------------
-        # side stream : layer-2 backward scan, chunks of time from the end to the start
-        # main stream : one chunk behind: dhx0[chunk] = dgx2[chunk] W_ih2 (one GEMM) -> layer-1 (+ sub-decoder) backward scan
-        dgx2 = self.buf("g_dgx2", (T, B, 3 * H))
-        dghn2 = self.buf("g_dghn2", (T, B, H))
-        dgx2f = dgx2.view(T * B, 3 * H)
-        dhx0 = self.buf("g_dhx0", (T, B, H))
+        # ---- global decoder: output layer + both cells, chunk-pipelined (see _bwd_global_decoder_scans) ----------------
+        gd = self._bwd_global_decoder_scans(S)
+        dgx1, dghn1, dgx2, dghn2, rs2, rsn2, drb_g, rsn_g, dh0_g = (gd[k] for k in ("dgx1", "dghn1", "dgx2", "dghn2", "rs2", "rsn2", "drb_g", "rsn_g", "dh0_g"))
+        dlog = dec["logits"]
+        pd = self.persist_dec
+        # ---- sub-decoders: both attribute decoders, all Tr steps, ONE whole-chip launch ----------------------------------
         sd = dec["sd"]
-        dh_sd = {}
+        dh_sd, sdb, sds = {}, {}, {}
         for e, Ce in (("r", R_DIMS), ("n", N_DIMS)):
             dl = dlogits_sd[e].view(Tr * B, Ce)
             dh_sd[e] = self.buf("sd_dh_" + e, (Tr, B, H))
             ops.gemm(dl, P["linear_out_%s.weight" % e], dh_sd[e].view(Tr * B, H), a_k=True, b_k=False)
-        dgx1 = self.buf("g_dgx1", (T, B, 3 * H))
-        dghn1 = self.buf("g_dghn1", (T, B, H))
-        # per-sequence sums over time of the gate gradients (bias / z-projection gradients) are accumulated by the scans
-        rs2, rsn2 = self.zbuf("g_rs2", (B, 3 * H)), self.zbuf("g_rsn2", (B, H))
-        drb_g, rsn_g = self.zbuf("g_drb", (B, 3 * H)), self.zbuf("g_rsn1", (B, H))
-        l2 = dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t["g2"], h0=dec["hx0"][0], h_all=dec["hx1"], gates=dec["g2"], dh_ext=dhx1,
-                  dgx_all=dgx2, dghn_all=dghn2, scratch=self.buf("g_scr2", (B, H)), dgx_rowsum=rs2, dghn_rowsum=rsn2)
-        l1 = dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t["g"], h0=dec["h0g"], h_all=dec["hx0"], gates=dec["g1"], dh_ext=dhx0,
-                  dgx_all=dgx1, dghn_all=dghn1, scratch=self.buf("g_scr1", (B, H)), dgx_rowsum=drb_g, dghn_rowsum=rsn_g)
-        sdb, sds = {}, {}
-        for e in ("r", "n"):
             sdb[e] = dict(dgx=self.buf("sd_dgx_" + e, (Tr, B, 3 * H)), dghn=self.buf("sd_dghn_" + e, (Tr, B, H)),
-                          drb=self.zbuf("sd_drb_" + e, (B, 3 * H)), rsn=self.zbuf("sd_rsn_" + e, (B, H)))
+                          drb=self.zbuf("sd_drb_" + e, (B, 3 * H)), rsn=self.zbuf("sd_rsn_" + e, (B, H)), dh0=self.buf("sd_dh0_" + e, (B, H)))
             sds[e] = dict(B=B, T=Tr, H=H, w_hh_t_frag=self.whh_t["d_" + e], h0=sd[e]["h0"], h_all=sd[e]["h_all"], gates=sd[e]["gates"],
                           dh_ext=dh_sd[e], dgx_all=sdb[e]["dgx"], dghn_all=sdb[e]["dghn"], scratch=self.buf("sd_scr_" + e, (B, H)),
                           dgx_rowsum=sdb[e]["drb"], dghn_rowsum=sdb[e]["rsn"])
-        CH = self.chunk
-        starts = list(range(0, T, CH))
-        carry = {k: [self.buf("carry_%s_%d" % (k, i), (B, H)) for i in range(2)] for k in ("l2", "l1", "r", "n")}
-
-        def chunk_call(items, t0, last):
-            """items: (name, descriptor); builds the chunk descriptors with ping-pong carries (slot = chunk parity)"""
-            part = []
-            for name, sc in items:
-                if t0 >= sc["T"]:
-                    continue
-                t1 = min(t0 + CH, sc["T"])
-                slot = (t0 // CH) & 1
-                cin = None if t1 >= sc["T"] else carry[name][slot ^ 1]
-                part.append(self._bwd_chunk(sc, t0, t1, cin, carry[name][slot]))
-            return part
-
-        pd = self.persist_dec
-        l1["tag"], l2["tag"] = "dec_l1", "dec_l2"
-        # launch k = [layer 2, chunk js[k]] + [layer 1, chunk js[k-2]] (time runs backwards: js = last chunk .. first), ONE weight-
-        # stationary launch of two independent scans (8 row groups = one per XCD); beside launch k+1 the aux lane turns the layer-2
-        # gate gradients of chunk js[k] into layer 1's incoming state gradient: dhx0[chunk] = dgx2[chunk] W_ih2 (one GEMM)
-        js = list(reversed(starts))
-        nch = len(js)
-        for k in range(nch + 2):
-            part = []
-            if k < nch:
-                part += chunk_call([("l2", l2)], js[k], k == 0)
-            if k >= 2:
-                self.lane_wait("main", "auxb%d" % (k & 1))
-                part += chunk_call([("l1", l1)], js[k - 2], k == 2)
-            if part:
-                ops.gru_seq_bwd(part, persistent=pd)
-            if k < nch:
-                t0, t1 = js[k], min(T, js[k] + CH)
-                lane = "auxb%d" % (k & 1)
-                self.lane_wait(lane, "main")
-                with Engine._Lane(self, True, lane):
-                    ops.gemm(dgx2[t0:t1].view(-1, 3 * H), P["grucell_g_2.weight_ih"], dhx0[t0:t1].view(-1, H), a_k=True, b_k=False)
-                    if t0 == 0:
-                        ops.axpy(1.0, carry["l2"][0], dhx0[0])          # hx1 was initialised with hx0[0]: dL/dh_init of layer 2
-        # both sub-decoders, all Tr steps, whole chip
-        ops.gru_seq_bwd([self._bwd_chunk(sds[e], 0, Tr, None, carry[e][0]) for e in ("r", "n")], persistent=pd)
-        dh0_g = carry["l1"][0]
-        for e in ("r", "n"):
-            sdb[e]["dh0"] = carry[e][0]
+        ops.gru_seq_bwd([self._bwd_chunk(sds[e], 0, Tr, None, sdb[e]["dh0"]) for e in ("r", "n")], persistent=pd)
         # ---- what the encoder side needs from the decoders (main stream, critical path): dz ---------------------
         Wz_g, Wig = P["grucell_g.weight_ih"], P["linear_init_global.weight"]
         for e, c0 in (("r", 0), ("n", Z)):
@@ -478,18 +495,7 @@ class Engine:
         # ---- decoder-side PARAMETER gradients: side stream, overlapping the latent block and the encoder scans ---
         self.side_wait_main()
         with self.on_side():
-            ops.gemm(dlog[:, :E_VOCAB], hx1f, G["linear_out_g.weight"], a_k=False, b_k=False, splitk=sk_T)
-            ops.colsum(dlog[:, :E_VOCAB], G["linear_out_g.bias"])
-            self._gru_weight_grads("g2", "grucell_g_2.", "", T, B, dgx2, dghn2, dec["hx1"], dec["hx0"][0], G, sk_T, rs2, rsn2)
-            ops.gemm(dgx2f, hx0f, G["grucell_g_2.weight_ih"], a_k=False, b_k=False, splitk=sk_T)
-            ops.colsum(rs2, G["grucell_g_2.bias_ih"])
-            self._gru_weight_grads("g", "grucell_g.", "", T, B, dgx1, dghn1, dec["hx0"], dec["h0g"], G, sk_T, drb_g, rsn_g)
-            dWg = G["grucell_g.weight_ih"]                          # [3H][E+ZG]: token columns = segment sums, written in place
-            ops.embed_grad_sorted(S["sort"]["d"], [dict(dgx=dgx1, out=dWg[:, :E_VOCAB], transposed=True, idx_shift=-1, start_token=E_VOCAB - 1)])
-            ops.gemm(drb_g, dec["zc"], dWg[:, E_VOCAB:], a_k=False, b_k=False)
-            ops.colsum(drb_g, G["grucell_g.bias_ih"])
-            ops.gemm(dh0_g, dec["zc"], G["linear_init_global.weight"], a_k=False, b_k=False)
-            ops.colsum(dh0_g, G["linear_init_global.bias"])
+            self._bwd_global_decoder_params(G, S, gd)
             for e, attr, Ce in (("r", r, R_DIMS), ("n", n, N_DIMS)):
                 pfx = "gru_d_%s." % e
                 z = lat[e]["z"]

@@ -84,13 +84,17 @@ class MusicAttrRegGMVAE(nn.Module):
         if self._engine is None or self._engine_key != key:
             from .hipops import HipOps
             ops = self._ops_override if getattr(self, "_ops_override", None) is not None else HipOps(dev)
-            self._engine = Engine(ops, self._engine_params(), self.hidden_dims, self.latent_dim, self.n_component, dev)
+            self._engine = self._make_engine(ops, dev)
             self._engine_key = key
             self._weights_version = -1
         if self._weights_version != self._version:
             self._engine.refresh_weights()
             self._weights_version = self._version
         return self._engine
+
+    def _make_engine(self, ops, dev):
+        """the schedule object of this model family (subclasses with another topology return their own)"""
+        return Engine(ops, self._engine_params(), self.hidden_dims, self.latent_dim, self.n_component, dev)
 
     def _engine_params(self):
         """name -> tensor table the engine works on (subclasses may add tensors that are not parameters)"""

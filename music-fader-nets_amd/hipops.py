@@ -344,6 +344,21 @@ class HipOps:
                                           _p(g_sigma), _p(g_ll), _p(g_qy), _p(w3), _p(dpre), _p(dmu_lk_rows),
                                           self.stream()), "fn_latent_bwd")
 
+    def adv_head(self, z, w_r, w_n, b_r, b_n, mask, dens, lam_dev, inv_global_batch, o, loss_rows, da=None, g_z=None):
+        """adversarial heads of the Fader sibling (fn_adv_head): z [B][>=Z] row view, g_z likewise (gradient is SUBTRACTED)"""
+        pz, B, Zc, ldz = _mat(z, "z")
+        for t, nm in ((w_r, "w_r"), (w_n, "w_n"), (b_r, "b_r"), (b_n, "b_n"), (mask, "mask"), (dens, "dens"), (o, "o"), (loss_rows, "loss_rows"),
+                      (da, "da"), (lam_dev, "lam_dev")):
+            _dense(t, name=nm)
+        Z = w_r.numel()
+        if Zc < Z or tuple(mask.shape) != (B, 2) or tuple(dens.shape) != (B, 2):
+            raise RuntimeError("adv_head shape mismatch")
+        pg, ldg = (None, 0)
+        if g_z is not None:
+            pg, _, _, ldg = _mat(g_z, "g_z")
+        _lib.check(self.lib.fn_adv_head(pz, ldz, Z, B, _p(w_r), _p(w_n), _p(b_r), _p(b_n), _p(mask), _p(dens), _p(lam_dev), inv_global_batch,
+                                        _p(o), _p(loss_rows), _p(da), pg, ldg, self.stream()), "fn_adv_head")
+
     def pairwise_reg(self, z0_all, attr_all, row0, nrows, loss_rows, grad_scale=0.0, dz0=None):
         _dense(z0_all, name="z0_all"), _dense(attr_all, torch.float64, "attr_all"), _dense(loss_rows, name="loss_rows"), _dense(dz0, name="dz0")
         _lib.check(self.lib.fn_pairwise_reg(_p(z0_all), _p(attr_all), z0_all.numel(), row0, nrows, _p(loss_rows), grad_scale, _p(dz0),
@@ -359,8 +374,8 @@ class HipOps:
     def step_params(self, counters, beta, lr, beta1, beta2, supervised, inv_global_batch, advance, out):
         """device-resident step counters -> {w_lat, w_cls, w_clf, lr/(1-b1^t), 1/sqrt(1-b2^t), beta0} (see fn_step_params)"""
         _dense(counters, torch.int64, "counters"), _dense(out, name="out")
-        if counters.numel() < 2 or out.numel() < 6:
-            raise RuntimeError("step_params: counters[2] / out[6] expected")
+        if counters.numel() < 2 or out.numel() < 8:
+            raise RuntimeError("step_params: counters[2] / out[8] expected")
         _lib.check(self.lib.fn_step_params(_p(counters), beta, lr, beta1, beta2, int(supervised), inv_global_batch, int(advance), _p(out),
                                            self.stream()), "fn_step_params")
 

@@ -189,10 +189,14 @@ class GMVAETrainer:
         supervised = batch[6] is not None
         Bg = batch[0].shape[0] if self.dist is None else self.dist.global_batch(batch[0].shape[0])
         eng.ops.step_params(self.counters, self.beta, self.lr, 0.9, 0.999, supervised, 1.0 / Bg, False, self.sp)
-        dl_sd, lat_up, w3, beta0, Bg = self._forward_losses(step, batch, eps, want_grads=True)
-        eng.backward(self.flat.G, dl_sd, lat_up, w3)
+        fw = self._forward_losses(step, batch, eps, want_grads=True)
+        self._run_backward(fw, None)
         eng.ops.sumsq(self.flat.grad, self.sumsq)
-        return self._tuple8(beta0, Bg, supervised)
+        return self._tuple8(fw[3], fw[4], supervised)
+
+    def _run_backward(self, fw, hook):
+        """fw = what _forward_losses returned; fills flat.G"""
+        self.model.engine().backward(self.flat.G, fw[0], fw[1], fw[2], after_decoders=hook)
 
     def _sync_step_counter(self, step):
         """the caller owns `step` (trainer_gmm.py:60,252); the device counter follows it (one tiny copy only when they differ)"""
@@ -208,11 +212,12 @@ class GMVAETrainer:
         supervised = batch[6] is not None
         Bg = batch[0].shape[0] if self.dist is None else self.dist.global_batch(batch[0].shape[0])
         ops.step_params(self.counters, self.beta, self.lr, 0.9, 0.999, supervised, 1.0 / Bg, advance, self.sp)
-        dl_sd, lat_up, w3, beta0, Bg = self._forward_losses(step, batch, eps, want_grads=True)
+        fw = self._forward_losses(step, batch, eps, want_grads=True)
+        beta0, Bg = fw[3], fw[4]
         hook = None
         if self.dist is not None:
             hook = lambda: self.dist.start_bucket(self.flat.grad[:self.flat.bucket_split])
-        eng.backward(self.flat.G, dl_sd, lat_up, w3, after_decoders=hook)
+        self._run_backward(fw, hook)
         if self.dist is not None:
             self.dist.start_bucket(self.flat.grad[self.flat.bucket_split:])
             self.dist.finish_buckets()
@@ -242,7 +247,7 @@ class GMVAETrainer:
         key = (tuple(batch[0].shape), tuple(batch[1].shape), batch[6] is not None)
         st = self._static.get(key)
         if st is None:                              # first call with these shapes: static input buffers + one eager run
-            st = dict(batch=[None if t is None else t.clone() for t in batch], eps=[e.clone() for e in eps], runs=0)
+            st = dict(batch=[None if t is None else t.clone() for t in batch], eps=[None if e is None else e.clone() for e in eps], runs=0)
             self._static[key] = st
         for dst, src in zip(st["batch"] + st["eps"], list(batch) + list(eps)):
             if dst is not None and dst.data_ptr() != src.data_ptr():

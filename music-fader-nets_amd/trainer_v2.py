@@ -1,0 +1,219 @@
+"""Fused training / evaluation steps of the single-encoder siblings: ``train`` / ``evaluate`` of the reference's
+``trainer_singlevae.py:84-160``, ``trainer_cvae.py:84-135`` and ``trainer_fader.py:84-146`` (same argument lists and returned tuples),
+on ``SingleEncEngine`` + the fused clip / Adam kernel of ``GMVAETrainer``.
+
+    SingleVAETrainer   loss = 5 CE_X + beta * KL(q || N(0,1)).mean() + l_r + l_n       (the reference adds its CONSTANT beta, not the
+                       annealed beta0 it computes, trainer_singlevae.py:90-104); the pairwise regulariser acts on z[:, 0] (rhythm
+                       density) and z[:, 1] (note density) (:107-120);        -> (loss, CE_X, l_r, l_n)
+    CVAETrainer        loss = CE_X + beta0(step) * KL.mean()  (trainer_cvae.py:84-103)  -> (loss, CE_X);  ``evaluate`` takes no step, re-derives
+                       the two densities from the rhythm / note tokens (:122-126) and reads the module-level ``step`` (= 0 for the whole run)
+    FaderTrainer       loss = CE_X + beta0 * KL.mean() + l_adv_r + l_adv_n,  l_adv = min(step / 2000 * 1e-4, 1e-4) * MSE(head(reverse(z)), density)
+                       (trainer_fader.py:84-110)                              -> (loss, CE_X, l_adv_r, l_adv_n)
+"""
+import math
+
+import numpy as np
+import torch
+
+from .engine import E_VOCAB
+from .trainer import GMVAETrainer, S_CE_X, S_L_N, S_L_R, S_TERMS_R, beta_schedule
+
+S_ADV = 9                     # stats[9:11] = sum_b (o - density)^2 of the two adversarial heads
+
+
+class _SingleEncTrainer(GMVAETrainer):
+    CE_WEIGHT = 1.0
+
+    def prepare_batch(self, d, r, n, c, r_density, n_density, y_label=None):
+        b = super().prepare_batch(d, r, n, c, r_density, n_density, None)
+        return b
+
+    def draw_eps(self, B, T):
+        eps, extra = self.model._draw(B, T)
+        dev = self.flat.param.device
+        return (eps.to(dev), None if extra is None else extra.to(dev))
+
+    # hooks --------------------------------------------------------------------------------------
+    def _cond(self, batch):
+        raise NotImplementedError
+
+    def _enc_extra(self, batch):
+        return None
+
+    def _kl_weight(self):
+        return self.sp[0:3]           # {beta0 / Bg, ., .}: only w_lat acts (one component: the class term is constant)
+
+    def _extra_terms(self, eng, batch, eps, lat, g_z, Bg, want_grads):
+        pass
+
+    # ---------------------------------------------------------------------------------------------
+    def _forward_losses(self, step, batch, eps, want_grads):
+        m = self.model
+        eng = m.engine()
+        ops = eng.ops
+        d = batch[0]
+        B, T = d.shape
+        Bg = B if self.dist is None else self.dist.global_batch(B)
+        S = eng.forward(d, self._cond(batch), eps[0], self._enc_extra(batch), save=True)
+        dec, lat = S["dec"], S["lat"]
+        st = self.stats
+        nll = eng.buf("nll_rows", (T * B,))
+        ops.vocab_logsoftmax(dec["logits"], B, T, E_VOCAB, target=d, nll_rows=nll,
+                             grad_scale=self.CE_WEIGHT / (Bg * T) if want_grads else 0.0, dlogits=dec["logits"] if want_grads else None)
+        ops.sum(nll, st[S_CE_X:S_CE_X + 1], 1.0 / (Bg * T))
+        ops.colsum(lat["terms"], st[S_TERMS_R:S_TERMS_R + 4])
+        g_z = eng.zbuf("g_z_e", (B, eng.Z)) if want_grads else None
+        self._extra_terms(eng, batch, eps, lat, g_z, Bg, want_grads)
+        return g_z, self._kl_weight(), None, beta_schedule(step, self.beta), Bg
+
+    def _run_backward(self, fw, hook):
+        self.model.engine().backward(self.flat.G, fw[0], fw[1], after_decoders=hook)
+
+    def _pairwise(self, eng, lat, g_z, col, attr, slot, Bg, want_grads, tag):
+        """the regulariser of GMVAETrainer._forward_losses on latent column `col`"""
+        ops = eng.ops
+        B = attr.shape[0]
+        z0 = eng.buf("reg_z0_" + tag, (B,))
+        z0.copy_(lat["z"][:, col])
+        if self.dist is not None:
+            z0_all, a_all, row0 = self.dist.gather_rows(z0, attr)
+        else:
+            z0_all, a_all, row0 = z0, attr, 0
+        lrow = eng.buf("reg_rows_" + tag, (B,))
+        dz0 = eng.buf("reg_dz0_" + tag, (B,)) if want_grads else None
+        ops.pairwise_reg(z0_all, a_all, row0, B, lrow, 1.0 / (Bg * Bg), dz0)
+        ops.sum(lrow, self.stats[slot:slot + 1], 1.0 / (Bg * Bg))
+        if want_grads:
+            g_z[:, col].copy_(dz0)
+
+    def _stats(self):
+        if self.dist is not None:
+            self.dist.all_reduce_sum(self.stats)
+        s = self.stats.tolist()
+        check = getattr(self.model.engine().ops, "gru_sync_error", None)
+        if check is not None and check():
+            raise RuntimeError("GRU scan launch timed out waiting for its row group (sync_ws error flag set); results are invalid")
+        return s
+
+    def train(self, step, d_oh, r_oh, n_oh, d, r, n, c, r_density, n_density, eps=None):
+        batch = self.prepare_batch(d if d is not None else d_oh, r if r is not None else r_oh, n if n is not None else n_oh, c, r_density, n_density)
+        if eps is None:
+            eps = self.draw_eps(*batch[0].shape)
+        beta0, Bg = self.step_device(step, batch, eps)
+        return step + 1, self._tuple8(beta0, Bg, False, step)
+
+    def _evaluate(self, step, batch, eps):
+        if eps is None:
+            eps = self.draw_eps(*batch[0].shape)
+        self._sync_step_counter(step)
+        Bg = batch[0].shape[0] if self.dist is None else self.dist.global_batch(batch[0].shape[0])
+        self.model.engine().ops.step_params(self.counters, self.beta, self.lr, 0.9, 0.999, False, 1.0 / Bg, False, self.sp)
+        fw = self._forward_losses(step, batch, eps, want_grads=False)
+        return self._tuple8(fw[3], fw[4], False, step)
+
+    def loss_and_grads(self, step, batch, eps):
+        """forward + losses + backward WITHOUT the optimiser update (parity tests): fills flat.grad, returns the model's tuple"""
+        eng = self.model.engine()
+        self._sync_step_counter(step)
+        Bg = batch[0].shape[0] if self.dist is None else self.dist.global_batch(batch[0].shape[0])
+        eng.ops.step_params(self.counters, self.beta, self.lr, 0.9, 0.999, False, 1.0 / Bg, False, self.sp)
+        fw = self._forward_losses(step, batch, eps, want_grads=True)
+        self._run_backward(fw, None)
+        eng.ops.sumsq(self.flat.grad, self.sumsq)
+        return self._tuple8(fw[3], fw[4], False, step)
+
+
+class SingleVAETrainer(_SingleEncTrainer):
+    CE_WEIGHT = 5.0
+
+    def _cond(self, batch):
+        return batch[3]
+
+    def _kl_weight(self):
+        w = self.__dict__.get("_w3")
+        if w is None:
+            w = self._w3 = torch.zeros(3, device=self.flat.param.device)
+        w[0:1].copy_(self.sp[7:8])            # beta / Bg, device-side copy (graph safe)
+        return w
+
+    def _extra_terms(self, eng, batch, eps, lat, g_z, Bg, want_grads):
+        self._pairwise(eng, lat, g_z, 0, batch[4], S_L_R, Bg, want_grads, "r")
+        self._pairwise(eng, lat, g_z, 1, batch[5], S_L_N, Bg, want_grads, "n")
+
+    def _tuple8(self, beta0, Bg, supervised=False, step=0, cached=None):
+        s = self._stats()
+        ce_x, l_r, l_n, kld = s[S_CE_X], s[S_L_R], s[S_L_N], s[S_TERMS_R] / Bg
+        return (5 * ce_x + self.beta * kld + l_r + l_n, ce_x, l_r, l_n)
+
+    @torch.no_grad()
+    def evaluate(self, step, d_oh, r_oh, n_oh, d, r, n, c, r_density, n_density, eps=None):
+        batch = self.prepare_batch(d if d is not None else d_oh, r if r is not None else r_oh, n if n is not None else n_oh, c, r_density, n_density)
+        return self._evaluate(step, batch, eps)
+
+
+class CVAETrainer(_SingleEncTrainer):
+    def prepare_batch(self, d, r, n, c, r_density, n_density, y_label=None):
+        b = list(super().prepare_batch(d, r, n, c, r_density, n_density))
+        dev = self.flat.param.device
+        # the densities enter the MODEL here (float32 columns of the encoder / decoder inputs, trainer_cvae.py:199-200)
+        b.append(torch.stack([b[4].float(), b[5].float()], dim=1).to(dev).contiguous())
+        return tuple(b)
+
+    def _cond(self, batch):
+        return batch[7]
+
+    def _enc_extra(self, batch):
+        return batch[7]
+
+    def _tuple8(self, beta0, Bg, supervised=False, step=0, cached=None):
+        s = self._stats()
+        ce_x, kld = s[S_CE_X], s[S_TERMS_R] / Bg
+        return (ce_x + beta0 * kld, ce_x)
+
+    @torch.no_grad()
+    def evaluate(self, d_oh, r_oh, n_oh, d, r, n, c, r_density, n_density, eps=None):
+        """trainer_cvae.py:120-135: densities re-derived from the tokens (share of 1s in r; mean of n), float32; beta0 of step 0"""
+        rt = torch.as_tensor(r if r is not None else r_oh)
+        nt = torch.as_tensor(n if n is not None else n_oh)
+        if rt.dim() == 3:
+            rt, nt = rt.argmax(-1), nt.argmax(-1)
+        rd = torch.tensor([float((k == 1).sum()) / len(k) for k in rt.cpu().numpy()])
+        nd = torch.tensor([float(k.sum()) / len(k) for k in nt.cpu().numpy()])
+        batch = self.prepare_batch(d if d is not None else d_oh, rt, nt, c, rd, nd)
+        return self._evaluate(0, batch, eps)
+
+
+class FaderTrainer(CVAETrainer):
+    def _enc_extra(self, batch):
+        return None
+
+    def _extra_terms(self, eng, batch, eps, lat, g_z, Bg, want_grads):
+        ops, P = eng.ops, eng.p
+        B = batch[0].shape[0]
+        o, lrow = eng.buf("adv_o", (B, 2)), eng.buf("adv_rows", (B, 2))
+        da = eng.buf("adv_da", (B, 2)) if want_grads else None
+        mask = eps[1] if eps[1] is not None else torch.ones(B, 2, device=o.device)
+        ops.adv_head(lat["z"], P["discriminator_r.weight"], P["discriminator_n.weight"], P["discriminator_r.bias"], P["discriminator_n.bias"],
+                     mask.contiguous(), batch[7], self.sp[6:7], 1.0 / Bg, o, lrow, da, g_z)
+        ops.colsum(lrow, self.stats[S_ADV:S_ADV + 2])
+        self._adv = (da, lat["z"])
+
+    def _run_backward(self, fw, hook):
+        super()._run_backward(fw, hook)
+        ops, G = self.model.engine().ops, self.flat.G
+        da, z = self._adv
+        for a, e in enumerate(("r", "n")):                         # dW = da^T z, db = column sum of da
+            ops.gemm(da[:, a:a + 1], z, G["discriminator_%s.weight" % e], a_k=False, b_k=False)
+            ops.colsum(da[:, a:a + 1], G["discriminator_%s.bias" % e])
+
+    def _tuple8(self, beta0, Bg, supervised=False, step=0, cached=None):
+        s = self._stats()
+        lam = min(step / 2000 * 1e-4, 1e-4)
+        ce_x, kld = s[S_CE_X], s[S_TERMS_R] / Bg
+        l_adv_r, l_adv_n = lam * s[S_ADV] / Bg, lam * s[S_ADV + 1] / Bg
+        return (ce_x + beta0 * kld + l_adv_r + l_adv_n, ce_x, l_adv_r, l_adv_n)
+
+    @torch.no_grad()
+    def evaluate(self, step, d_oh, r_oh, n_oh, d, r, n, c, r_density, n_density, eps=None):
+        batch = self.prepare_batch(d if d is not None else d_oh, r if r is not None else r_oh, n if n is not None else n_oh, c, r_density, n_density)
+        return self._evaluate(step, batch, eps)

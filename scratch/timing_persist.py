@@ -20,7 +20,7 @@ def mk(n):
     return fw
 buf = (ctypes.c_ulonglong * 64)()
 lib.fn_pdbg_read.argtypes = [ctypes.c_void_p]
-for n in (1, 4):
+for n in (1, 2, 4):
     fw = mk(n)
     for rep in range(3):
         ops.gru_seq_fwd(fw); torch.cuda.synchronize()
@@ -28,4 +28,4 @@ for n in (1, 4):
         a = np.array(list(buf), dtype=np.int64).reshape(8, 8)[:, :7]
         d = a - a[:, :1]
         print("scans=%d rep %d  step-10 stamps (ticks since step start) [gx issued, polled, kloop, red, epi, drained, arrived]:" % (n, rep))
-        for r in d[:4]: print("    ", r.tolist())
+        for r in d[:3]: print("    ", r.tolist())

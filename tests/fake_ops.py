@@ -287,9 +287,26 @@ class FakeOps:
         out[3] = lr / (1 - beta1 ** tt)
         out[4] = 1.0 / math.sqrt(1 - beta2 ** tt)
         out[5] = beta0
+        out[6] = min(step / 2000 * 1e-4, 1e-4)
+        out[7] = beta * inv_global_batch
         if advance:
             counters[0] = step + 1
             counters[1] = t
+
+    def adv_head(self, z, w_r, w_n, b_r, b_n, mask, dens, lam_dev, inv_global_batch, o, loss_rows, da=None, g_z=None):
+        Z = w_r.numel()
+        zz = z[:, :Z]
+        pre = torch.stack([zz @ w_r.view(-1) + b_r.view(()), zz @ w_n.view(-1) + b_n.view(())], dim=1)
+        ov = torch.relu(pre) * mask
+        df = ov - dens
+        o.copy_(ov)
+        loss_rows.copy_(df * df)
+        lam = float(lam_dev[0]) if lam_dev is not None else 0.0
+        dav = lam * 2.0 * df * inv_global_batch * mask * (pre > 0).float()
+        if da is not None:
+            da.copy_(dav)
+        if g_z is not None:
+            g_z[:, :Z].sub_(dav[:, 0:1] * w_r.view(1, -1) + dav[:, 1:2] * w_n.view(1, -1))
 
     def clip_adam(self, p, g, m, v, sumsq, max_norm, hyper, beta1, beta2, eps):
         coef = min(1.0, max_norm / (math.sqrt(float(sumsq[0])) + 1e-6))

@@ -264,3 +264,90 @@ def check_eval_side(pkg, m, g, dev, rtol=2e-5):
     zc = torch.cat([z_out[0], z_out[1], c], dim=1).detach()
     o2 = m.global_decoder(zc, steps=T)
     np.testing.assert_allclose(o2.cpu().numpy(), o_tf.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+# ---- single-encoder siblings (tests/golden/siblings.npz = the reference's model_v2 classes + their own trainers) ----------------------
+SIBLINGS = {"single": ("MusicAttrSingleVAE", "SingleVAETrainer"), "cvae": ("MusicAttrCVAE", "CVAETrainer"), "fader": ("MusicAttrFaderNets", "FaderTrainer")}
+
+
+def sibling_golden(kind):
+    return {k[len(kind) + 1:]: v for k, v in load_golden("siblings").items() if k.startswith(kind + "/")}
+
+
+def make_sibling(kind, hidden, zdim, device="cpu", ops=None, seed=1234):
+    pkg = load_package()
+    torch.manual_seed(seed)
+    m = getattr(pkg, SIBLINGS[kind][0])(roll_dims=342, rhythm_dims=3, note_dims=16, chroma_dims=24, hidden_dims=hidden, z_dims=zdim, n_step=20)
+    if ops is not None:
+        m._ops_override = ops
+    return m.to(device)
+
+
+def check_sibling(pkg, kind, m, g, dev, rtol_fw=5e-5, tol_grad=5e-4, rtol_tuple=5e-4):
+    """drop-in forward (train and eval mode), fused gradients, three train() steps and evaluate() of one sibling against the reference run"""
+    H, Z, B, T, Tr = (int(x) for x in g["dims"])
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    d, r, n, c = t("d"), t("r"), t("n"), t("c")
+    rd32, nd32 = torch.from_numpy(g["r_density"]).float().unsqueeze(-1).to(dev), torch.from_numpy(g["n_density"]).float().unsqueeze(-1).to(dev)
+    for k, v in m.state_dict().items():
+        vd = v.double()
+        np.testing.assert_allclose([vd.sum().item(), vd.abs().sum().item(), (vd * vd).sum().item()], g["w0sum/" + k], rtol=1e-9, atol=1e-9, err_msg=k)
+    assert set(m.state_dict()) == {k[len("w0sum/"):] for k in g if k.startswith("w0sum/")}
+    call = (lambda: m(pkg.convert_to_one_hot(d, 342), c)) if kind == "single" else \
+           (lambda: m(pkg.convert_to_one_hot(d, 342), pkg.convert_to_one_hot(r, 3), pkg.convert_to_one_hot(n, 16), c, rd32, nd32))
+    # train-mode forward, the reference's nesting, random draws from the seeded global generator
+    m.train()
+    torch.manual_seed(99)
+    res = call()
+    if kind == "fader":
+        (o, r_out, n_out), dis, z = res
+        np.testing.assert_allclose(r_out.cpu().numpy(), g["fw_r_out"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(n_out.cpu().numpy(), g["fw_n_out"], rtol=1e-4, atol=1e-5)
+    else:
+        o, dis, z = res
+    for k, v in (("out", o), ("mu", dis.mean), ("sigma", dis.stddev), ("z", z)):
+        np.testing.assert_allclose(v.cpu().numpy(), g["fw_" + k], rtol=rtol_fw, atol=rtol_fw, err_msg=k)
+    # fused gradients
+    tr = getattr(pkg, SIBLINGS[kind][1])(m, lr=1e-3, beta=0.2)
+    batch = tr.prepare_batch(g["d"], g["r"], g["n"], g["c"], g["r_density"], g["n_density"])
+    for step in ((20000, 500) if kind == "fader" else (20000,)):
+        torch.manual_seed(99)
+        eps = tr.draw_eps(B, T)
+        tup = tr.loss_and_grads(step, batch, eps)
+        np.testing.assert_allclose(tup, g["loss_terms_%d" % step], rtol=rtol_tuple, atol=1e-9)
+        ref_keys = {k[len("grad_%d/" % step):] for k in g if k.startswith("grad_%d/" % step)}
+        assert set(tr.flat.names) == ref_keys, (set(tr.flat.names) ^ ref_keys)
+        for k in tr.flat.names:
+            ref = g["grad_%d/%s" % (step, k)]
+            e = relerr(tr.flat.G[k].cpu().numpy(), ref)
+            assert e < tol_grad or np.abs(ref).max() < 1e-7, (kind, step, k, e)
+        np.testing.assert_allclose(tr.grad_norm(), g["gradnorm_%d" % step][0], rtol=1e-3)
+    # the reference's own train() x3 and evaluate()
+    step = 19999
+    for it in range(3):
+        torch.manual_seed(99 + it)
+        step, tup = tr.train(step, None, None, None, g["d"], g["r"], g["n"], g["c"], g["r_density"], g["n_density"])
+        np.testing.assert_allclose(tup, g["train_tuples"][it], rtol=rtol_tuple, atol=1e-9, err_msg="step %d" % it)
+    assert step == 20002
+    for k, v in m.state_dict().items():
+        vd = v.double()
+        np.testing.assert_allclose([vd.abs().sum().item()], g["w3sum/" + k][1:2], rtol=1e-3, err_msg=k)
+    torch.manual_seed(123)
+    if kind == "cvae":
+        ev = tr.evaluate(None, None, None, g["d"], g["r"], g["n"], g["c"], g["r_density"], g["n_density"])
+    else:
+        ev = tr.evaluate(step - 1, None, None, None, g["d"], g["r"], g["n"], g["c"], g["r_density"], g["n_density"])
+    np.testing.assert_allclose(ev, g["eval_tuple"], rtol=rtol_tuple, atol=1e-9)
+    # eval-mode forward on fresh weights: greedy decoder
+    m2 = make_sibling(kind, H, Z, device=dev, ops=getattr(m, "_ops_override", None))
+    m2.eval()
+    d, r, n, c = (x.to(dev) for x in (d, r, n, c))
+    torch.manual_seed(7)
+    res = (m2(pkg.convert_to_one_hot(d, 342), c) if kind == "single" else
+           m2(pkg.convert_to_one_hot(d, 342), pkg.convert_to_one_hot(r, 3), pkg.convert_to_one_hot(n, 16), c, rd32, nd32))
+    o = res[0][0] if kind == "fader" else res[0]
+    np.testing.assert_allclose(res[2].cpu().numpy(), g["evalfw_z"], rtol=rtol_fw, atol=rtol_fw)
+    np.testing.assert_allclose(o[:, 0].cpu().numpy(), g["evalfw_logp0"], rtol=1e-4, atol=1e-4)
+    assert tokens_match_upto_near_tie(o.argmax(-1).cpu().numpy(), g["evalfw_tokens"], g["evalfw_gap"]) >= B * T // 2
+    if kind == "fader":
+        np.testing.assert_allclose(res[0][1].cpu().numpy(), g["evalfw_r_out"], rtol=1e-4, atol=1e-5)

@@ -839,3 +839,36 @@ def test_dataloader_batches_feed_the_hip_trainer():
               a=a.long().numpy())
     loss, ref, _ = orc.total_loss(sd1, ob, eps[0], eps[1], 20001, 0.2, is_supervised=True)
     np.testing.assert_allclose(tup, [float(x) for x in ref], rtol=5e-4)
+
+
+# ----------------------------------------------------------------------------------------------
+# single-encoder siblings of model_v2.py on the HIP kernels (SingleEncEngine, adv_head_kernel)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["single", "cvae", "fader"])
+def test_siblings_vs_reference(kind):
+    from helpers import check_sibling, make_sibling, sibling_golden
+    pkg = load_package()
+    m = make_sibling(kind, 64, 32, device=DEV)
+    check_sibling(pkg, kind, m, sibling_golden(kind), DEV, rtol_fw=1e-4, tol_grad=5e-4, rtol_tuple=5e-4)
+    assert not m.engine().ops.gru_sync_error()
+
+
+def test_adv_head_kernel(ops):
+    torch.manual_seed(21)
+    B, Z = 37, 96
+    z, w_r, w_n = torch.randn(B, Z + 8), torch.randn(1, Z), torch.randn(1, Z)
+    b_r, b_n = torch.randn(1), torch.randn(1)
+    mask = (torch.rand(B, 2) > 0.3).float() / 0.7
+    dens = torch.rand(B, 2)
+    lam = torch.tensor([3e-2])
+    g0 = torch.randn(B, Z + 8)
+    outs_c = [torch.zeros(B, 2) for _ in range(3)]
+    gz_c = g0.clone()
+    FakeOps().adv_head(z[:, :Z], w_r, w_n, b_r, b_n, mask, dens, lam, 1.0 / B, outs_c[0], outs_c[1], outs_c[2], gz_c[:, :Z])
+    outs_d = [torch.zeros(B, 2, device=DEV) for _ in range(3)]
+    zd, gz_d = g(z), g(g0.clone())
+    ops.adv_head(zd[:, :Z], g(w_r), g(w_n), g(b_r), g(b_n), g(mask), g(dens), g(lam), 1.0 / B, outs_d[0], outs_d[1], outs_d[2], gz_d[:, :Z])
+    for a, b in zip(outs_d, outs_c):
+        close(a, b, 1e-5)
+    close(gz_d, gz_c, 1e-5)
+    assert torch.equal(gz_d[:, Z:].cpu(), g0[:, Z:])              # columns beyond Z untouched (row views with a leading dimension)

@@ -182,3 +182,12 @@ def test_eval_side_callers_host_logic():
     pkg = load_package()
     m = make_model(64, 32, ops=FakeOps())
     check_eval_side(pkg, m, eval_golden("s"), "cpu")
+
+
+@pytest.mark.parametrize("kind", ["single", "cvae", "fader"])
+def test_siblings_host_logic(kind):
+    """model_v2 single-encoder siblings + their fused trainers on the CPU test backend vs the reference's own classes / trainers"""
+    from helpers import check_sibling, make_sibling, sibling_golden
+    pkg = load_package()
+    g = sibling_golden(kind)
+    check_sibling(pkg, kind, make_sibling(kind, 64, 32, ops=FakeOps()), g, "cpu", rtol_fw=3e-5, tol_grad=3e-4, rtol_tuple=1e-4)

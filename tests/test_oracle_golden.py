@@ -292,3 +292,34 @@ def test_c1_fixture_is_the_benchmark_batch(golden_dir):
         vd = v.double()
         np.testing.assert_allclose([vd.sum().item(), vd.abs().sum().item(), (vd * vd).sum().item()], g["w0sum/" + k], rtol=1e-12, atol=1e-12)
     assert g["train_tuples"].shape == (2, 8) and np.isfinite(g["train_tuples"]).all()
+
+
+# ---- single-encoder siblings (tests/golden/siblings.npz) ---------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["single", "cvae", "fader"])
+def test_siblings_oracle_vs_reference(golden_dir, kind):
+    from oracle import siblings_oracle as so
+    from helpers import relerr
+    g = {k[len(kind) + 1:]: v for k, v in _load(golden_dir, "siblings").items() if k.startswith(kind + "/")}
+    H, Z, B, T, Tr = (int(x) for x in g["dims"])
+    sd = so.init_state_dict(kind, H, Z)
+    for k, v in sd.items():
+        vd = v.double()
+        np.testing.assert_allclose([vd.sum().item(), vd.abs().sum().item(), (vd * vd).sum().item()], g["w0sum/" + k], rtol=1e-12, atol=1e-12, err_msg=k)
+    assert set(sd) == {k[len("w0sum/"):] for k in g if k.startswith("w0sum/")}
+    batch = {k: g[k] for k in ("d", "r", "n", "c", "r_density", "n_density")}
+    for step in ((20000, 500) if kind == "fader" else (20000,)):
+        torch.manual_seed(99)
+        eps, mask = so.draw(kind, B, Z, T)
+        grads, tup, fw = so.gradients(sd, kind, batch, eps, mask, step, 0.2)
+        np.testing.assert_allclose(tup, g["loss_terms_%d" % step], rtol=2e-5)
+        if step == 20000:
+            for k in ("out", "mu", "sigma", "z"):
+                np.testing.assert_allclose(fw[k].detach().numpy(), g["fw_" + k], rtol=2e-5, atol=2e-5, err_msg=k)
+            if kind == "fader":
+                np.testing.assert_allclose(fw["adv_out"][:, 0:1].detach().numpy(), g["fw_r_out"], rtol=1e-5, atol=1e-6)
+        ref_keys = {k[len("grad_%d/" % step):] for k in g if k.startswith("grad_%d/" % step)}
+        assert set(so.trainable_used_keys(sd)) == ref_keys
+        for k, gr in grads.items():
+            ref = g["grad_%d/%s" % (step, k)]
+            assert relerr(gr.numpy(), ref) < 2e-4 or np.abs(ref).max() < 1e-7, (k, relerr(gr.numpy(), ref))
+    assert set(g["no_grad_params"]) == {k for k in sd if k.startswith(("c_r.", "c_n."))}
