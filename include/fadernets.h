@@ -37,7 +37,7 @@ extern "C" {
 
 #define FN_MAX_SCANS 8
 
-int fn_version(void);                 /* ABI version, currently 2 */
+int fn_version(void);                 /* ABI version, currently 3 */
 const char* fn_strerror(int code);    /* static string for FN_E_* / hipError_t */
 
 /* ------------------------------------------------------------------------------------------
@@ -102,11 +102,16 @@ typedef struct FnGruFwd {
                               /* Launches that can overlap on different streams must share the chip:       */
                               /* the sum of their budgets must not exceed the CU count.                    */
     const float* h0_frag;     /* optional: h0 already in the fragment-major operand layout (fn_frag_floats(B,H)  */
-                              /* floats) - saves the packing launch of step-by-step decoding; h0 is still needed */
+                              /* floats) - saves the packing launch when a scan continues a previous call (time  */
+                              /* chunks, step-by-step decoding); h0 is still needed (row-major, gate epilogue)   */
     float* h_last_frag;       /* optional: the final state, fragment-major (the next call's h0_frag)       */
     int32_t variant;          /* 0 = automatic (scans[0]'s is used).  Tuning / tests: low byte = force this many batch rows per   */
                               /* workgroup of the single launch (16/32/64/128; not eligible -> per-step kernels), bit 8 = the     */
                               /* alternative wave tiling of the 64-row configuration.  Results never depend on it.               */
+                              /* bit 9: sync_ws counters are ALREADY zero (the caller zero-fills a pool of regions once and gives  */
+                              /* every launch its own region: saves one memset node per launch)                                  */
+    void* err_ws;             /* optional: sticky error word outside sync_ws (>= 4 bytes, scans[0]'s is used); NULL = the last     */
+                              /* 128 bytes of sync_ws                                                                            */
 } FnGruFwd;
 
 /* fragment-major operand image: floats needed for a [rows][K] matrix, and the packing kernel
@@ -150,6 +155,7 @@ typedef struct FnGruBwd {
     void* sync_ws;            /* as in FnGruFwd (NULL = per-step launches; then scratch is required) */
     int32_t cu_budget;        /* as in FnGruFwd                                                */
     int32_t variant;          /* as in FnGruFwd                                                */
+    void* err_ws;             /* as in FnGruFwd                                                */
 } FnGruBwd;
 
 int fn_gru_seq_bwd(const FnGruBwd* scans, int n_scans, void* stream);

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfadernets_hip.so")
 
 FN_MAX_SCANS = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 FN_E_UNSUPPORTED = -6
 _f = C.POINTER(C.c_float)
 _i = C.POINTER(C.c_int32)
@@ -21,14 +21,14 @@ class FnGruFwd(C.Structure):
     _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("H", C.c_int32), ("reverse", C.c_int32),
                 ("w_hh_frag", vp), ("b_hh", vp), ("b_ih", vp), ("h0", vp), ("gx_dense", vp), ("gx_table", vp),
                 ("idx", vp), ("idx_ld", C.c_int32), ("idx_shift", C.c_int32), ("start_token", C.c_int32),
-                ("gx_rowbias", vp), ("h_all", vp), ("gates", vp), ("frag_ws", vp), ("sync_ws", vp), ("cu_budget", C.c_int32), ("h0_frag", vp), ("h_last_frag", vp), ("variant", C.c_int32)]
+                ("gx_rowbias", vp), ("h_all", vp), ("gates", vp), ("frag_ws", vp), ("sync_ws", vp), ("cu_budget", C.c_int32), ("h0_frag", vp), ("h_last_frag", vp), ("variant", C.c_int32), ("err_ws", vp)]
 
 
 class FnGruBwd(C.Structure):
     _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("H", C.c_int32),
                 ("w_hh_t_frag", vp), ("h0", vp), ("h_all", vp), ("gates", vp), ("dh_last", vp), ("dh_ext", vp),
                 ("dgx_all", vp), ("dghn_all", vp), ("dh0", vp), ("dgx_rowsum", vp), ("dghn_rowsum", vp), ("scratch", vp), ("frag_ws", vp),
-                ("sync_ws", vp), ("cu_budget", C.c_int32), ("variant", C.c_int32)]
+                ("sync_ws", vp), ("cu_budget", C.c_int32), ("variant", C.c_int32), ("err_ws", vp)]
 
 
 class FnEmbedGrad(C.Structure):

@@ -3,7 +3,7 @@
 
 extern "C" {
 
-int fn_version(void) { return 2; }
+int fn_version(void) { return 3; }
 
 const char* fn_strerror(int code) {
     switch (code) {

@@ -48,6 +48,8 @@ struct PScan {
     float* h_all;
     float* gates;
     float* xf;            // 2 exchange slabs, fragment-major
+    const float* h0f;     // optional: the initial state already in the slab layout (the previous chunk's hlf) - no packing launch
+    float* hlf;           // optional: the final state in the slab layout
     int idx_ld, idx_shift, start_token, reverse;
     int B, T;
     int group0;           // first row group of this scan
@@ -55,7 +57,8 @@ struct PScan {
 struct PArgs {
     PScan s[FN_MAX_SCANS];
     int n, ngroups, H;
-    u32* sync;            // [ngroups * 32] arrival counters (one per 128-byte line), then err at sync[FN_MAX_GROUPS*32]
+    u32* sync;            // [ngroups * 32] arrival counters (one per 128-byte line), zero at launch
+    u32* err;             // sticky error word
 };
 constexpr int FN_MAX_GROUPS = 64;
 
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(NT) void gru_fwd_persist_kernel(const PArgs args) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wk = wave / WM;
     u32* counter = args.sync + g * 32;
-    u32* err = args.sync + FN_MAX_GROUPS * 32;
+    u32* err = args.err;
 
     // ---- one-time: W_hh slice -> LDS (already in fragment order in global memory) -------------------------------------
     if (tid == 0) dead = 0;
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(NT) void gru_fwd_persist_kernel(const PArgs args) {
 #pragma unroll
             for (int n = 0; n < 3; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (has_k && nkw > 0) {
-            const float* xin = S.xf + (long)(p & 1) * FS;
+            const float* xin = (p == 0 && S.h0f) ? S.h0f : S.xf + (long)(p & 1) * FS;
             f32x4 fa[D][MT][2], fb[2][3][2];
             auto loadA = [&](int set, int it) {
                 const long k0 = (long)(c0 + min(it, nkw - 1)) * 512;
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(NT) void gru_fwd_persist_kernel(const PArgs args) {
         // (e) gates and the new state: thread -> items (row, units 4u4 .. 4u4+3)
         float* h_out = S.h_all + (long)p * B * H;
         float* gt = S.gates ? S.gates + (long)p * 4 * H * nrt * 16 : nullptr;
-        float* xout = (p + 1 < T) ? S.xf + (long)((p + 1) & 1) * FS : nullptr;
+        float* xout = (p + 1 < T) ? S.xf + (long)((p + 1) & 1) * FS : S.hlf;     // last step: hand-over slab of the next launch (or none)
         f32x4 o_r[NI], o_z[NI], o_n[NI], o_g[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -326,6 +329,7 @@ struct QArgs {
     QScan s[FN_MAX_SCANS];
     int n, ngroups, H;
     u32* sync;
+    u32* err;
 };
 
 template <int WM, int WK, int MT, int D>
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(NT) void gru_bwd_persist_kernel(const QArgs args) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wk = wave / WM;
     u32* counter = args.sync + g * 32;
-    u32* err = args.sync + FN_MAX_GROUPS * 32;
+    u32* err = args.err;
 
     if (tid == 0) dead = 0;
     {
@@ -594,7 +598,9 @@ int fn_gru_fwd_persist(const FnGruFwd* scans, int n_scans, hipStream_t st) {
     int Tmax = 0;
     for (int s = 0; s < n_scans; ++s) {
         const FnGruFwd& d = scans[s];
-        if (d.H != H || d.h_last_frag) return FN_PERSIST_NA;   // fragment-major hand-over of the last state: per-step path only
+        if (d.H != H) return FN_PERSIST_NA;
+        if (d.h0_frag && !d.h0) return FN_E_NULL;              // the gate epilogue reads the row-major state
+        if ((((uintptr_t)d.h0_frag) | ((uintptr_t)d.h_last_frag)) & 15) return FN_E_ALIGN;
         // the epilogue moves 16-byte vectors
         const uintptr_t al = (uintptr_t)d.b_hh | (uintptr_t)d.b_ih | (uintptr_t)d.h0 | (uintptr_t)d.gx_dense | (uintptr_t)d.gx_table |
                              (uintptr_t)d.gx_rowbias | (uintptr_t)d.h_all | (uintptr_t)d.gates;
@@ -629,19 +635,22 @@ int fn_gru_fwd_persist(const FnGruFwd* scans, int n_scans, hipStream_t st) {
         PScan& f = a.s[s];
         f.w_frag = d.w_hh_frag; f.b_hh = d.b_hh; f.b_ih = d.b_ih; f.h0 = d.h0;
         f.gx_dense = d.gx_dense; f.gx_table = d.gx_table; f.idx = d.idx; f.gx_rowbias = d.gx_rowbias;
-        f.h_all = d.h_all; f.gates = d.gates; f.xf = d.frag_ws;
+        f.h_all = d.h_all; f.gates = d.gates; f.xf = d.frag_ws; f.h0f = d.h0_frag; f.hlf = d.h_last_frag;
         f.idx_ld = d.idx_ld; f.idx_shift = d.idx_shift; f.start_token = d.start_token; f.reverse = d.reverse;
         f.B = d.B; f.T = d.T;
         f.group0 = groups;
         groups += (d.B + rpw - 1) / rpw;
-        if (d.h0) {
+        if (d.h0 && !d.h0_frag) {
             const int rc = launch_pack(d.h0, d.B, d.H, d.H, d.frag_ws, st);
             if (rc != FN_OK) return rc;
         }
     }
     a.ngroups = groups;
-    hipError_t me = hipMemsetAsync(a.sync, 0, (size_t)FN_MAX_GROUPS * 32 * 4, st);      // counters only: err is sticky
-    if (me != hipSuccess) return (int)me;
+    a.err = scans[0].err_ws ? reinterpret_cast<u32*>(scans[0].err_ws) : a.sync + FN_MAX_GROUPS * 32;
+    if (!(scans[0].variant & 0x200)) {                      // bit 9: the caller hands over counters that are already zero
+        hipError_t me = hipMemsetAsync(a.sync, 0, (size_t)FN_MAX_GROUPS * 32 * 4, st);      // counters only: err is sticky
+        if (me != hipSuccess) return (int)me;
+    }
     const int grid = groups * nslices;
     const int wk = rpw == 16 ? 4 : rpw == 32 ? 2 : (rpw == 64 && !(scans[0].variant & 0x100)) ? 2 : 1;     // K split of the chosen tiling
     const size_t lds = ((size_t)3 * H * 16 + (size_t)wk * (rpw / 16) * 3 * RT) * 4 + 16;
@@ -701,8 +710,11 @@ int fn_gru_bwd_persist(const FnGruBwd* scans, int n_scans, hipStream_t st) {
         groups += (d.B + rpw - 1) / rpw;
     }
     a.ngroups = groups;
-    hipError_t me = hipMemsetAsync(a.sync, 0, (size_t)FN_MAX_GROUPS * 32 * 4, st);
-    if (me != hipSuccess) return (int)me;
+    a.err = scans[0].err_ws ? reinterpret_cast<u32*>(scans[0].err_ws) : a.sync + FN_MAX_GROUPS * 32;
+    if (!(scans[0].variant & 0x200)) {
+        hipError_t me = hipMemsetAsync(a.sync, 0, (size_t)FN_MAX_GROUPS * 32 * 4, st);
+        if (me != hipSuccess) return (int)me;
+    }
     const int grid = groups * nslices;
     const int wk = rpw == 16 ? 4 : rpw == 32 ? 2 : (rpw == 64 && !(scans[0].variant & 0x100)) ? 2 : 1;
     const size_t lds = ((size_t)3 * H * 16 + (size_t)wk * (rpw / 16) * RT) * 4 + 16;

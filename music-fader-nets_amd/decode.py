@@ -39,6 +39,7 @@ def greedy_decode(model, z, steps, want_logp=True, use_graph=None):
         _decode_body(eng, zs, min(steps, 2), want_logp, logp, tokens)                # warm-up: allocates every buffer
         g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
+        getattr(eng.ops, "begin_capture", lambda: None)()
         with torch.cuda.graph(g):
             _decode_body(eng, zs, steps, want_logp, logp, tokens)
         ent = cache[key] = (g, zs, logp, tokens)
@@ -101,11 +102,11 @@ def _decode_body(eng, z, steps, want_logp, logp, tokens):
         ops.gru_seq_fwd([dict(B=Bi, T=1, H=H, w_hh_frag=eng.whh_f["g"], b_hh=P["grucell_g.bias_hh"], b_ih=P["grucell_g.bias_ih"],
                               h0=h0g if i == 0 else hx0[prv][0], h0_frag=None if i == 0 else hf0[prv], h_last_frag=hf0[cur],
                               gx_table=eng.tab["g"], idx=tokens, idx_shift=i - 1,
-                              start_token=E_VOCAB - 1, gx_rowbias=rbg, h_all=hx0[cur])])
+                              start_token=E_VOCAB - 1, gx_rowbias=rbg, h_all=hx0[cur])], persistent=False)
         ops.gemm(hx0[cur][0], P["grucell_g_2.weight_ih"], gx2[0], bias=P["grucell_g_2.bias_ih"])
         ops.gru_seq_fwd([dict(B=Bi, T=1, H=H, w_hh_frag=eng.whh_f["g2"], b_hh=P["grucell_g_2.bias_hh"],
                               h0=hx0[cur][0] if i == 0 else hx1[prv][0], h0_frag=hf0[cur] if i == 0 else hf1[prv], h_last_frag=hf1[cur],
-                              gx_dense=gx2, h_all=hx1[cur])])
+                              gx_dense=gx2, h_all=hx1[cur])], persistent=False)
         ops.gemm(hx1[cur][0], P["linear_out_g.weight"], logits[:, :E_VOCAB], bias=P["linear_out_g.bias"])
         ops.vocab_argmax(logits, E_VOCAB, logp[:, i, :] if want_logp else None, tokens[:, i])
     return logp, tokens

@@ -265,12 +265,25 @@ class Engine:
         l1["tag"], l2["tag"] = "dec_l1", "dec_l2"
         starts = list(range(0, T, CH))
         nch = len(starts)
+        # a chunk leaves its final state ALSO in the fragment-major exchange layout; the next chunk of that layer starts from it
+        # without a packing launch (FnGruFwd.h_last_frag -> h0_frag)
+        nf = ops.frag_floats(B, H)
+        hand = {name: [self.buf("g_hand_%s_%d" % (name, i), (nf,)) for i in range(2)] for name in ("l1", "l2")}
+
+        def chunk(name, sc, ci):
+            c = self._fwd_chunk(sc, starts[ci], starts[ci] + CH)
+            if ci > 0:
+                c["h0_frag"] = hand[name][(ci - 1) & 1]
+            if ci + 1 < nch:
+                c["h_last_frag"] = hand[name][ci & 1]
+            return c
+
         for k in range(nch + 2):
             part = []
             if k < nch:
-                part.append(self._fwd_chunk(l1, starts[k], starts[k] + CH))
+                part.append(chunk("l1", l1, k))
             if k >= 2:
-                c2 = self._fwd_chunk(l2, starts[k - 2], starts[k - 2] + CH)
+                c2 = chunk("l2", l2, k - 2)
                 if k == 2:
                     c2["h0"] = hx0[0]
                 part.append(c2)

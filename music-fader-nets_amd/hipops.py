@@ -134,12 +134,44 @@ class HipOps:
     def _frag_ws(self, tag, i, n):
         return self.workspace(4 * n, "%s%d" % (tag, i))[:n]
 
-    def _sync_ws(self):
-        """arrival counters + sticky error flag of the weight-stationary scan launches (zero-filled once)."""
-        syncs = self.__dict__.setdefault("_syncs", {})      # one per lane: launches on different streams may overlap
-        if self.lane not in syncs:
-            syncs[self.lane] = torch.zeros(int(self.lib.fn_gru_sync_ws_bytes()) // 4, dtype=torch.int32, device=self.device)
-        return syncs[self.lane]
+    SYNC_REGIONS = 64
+
+    def begin_capture(self):
+        """call right before a hipGraph capture starts: the captured launches take counter regions 0, 1, ... of a pool whose
+        zero-fill is the first node of the graph (see _sync_region)"""
+        for ent in self.__dict__.get("_sync_pools", {}).values():
+            ent["next"] = 0
+
+    def _sync_region(self):
+        """(counters of this launch, sticky error word, flag bits).  Arrival counters must be zero at launch.
+        Eager launches: one private region per lane, zero-filled by the library in front of every launch (a memset node each).
+        Captured launches (the training step replays ~50 weight-stationary launches): every lane owns a POOL of regions, each launch
+        takes the next one, and ONE fill node zero-fills the whole pool at the start of the graph and whenever the rotation wraps -
+        every replay therefore finds its regions zero, whatever ran in between."""
+        words = int(self.lib.fn_gru_sync_ws_bytes()) // 4
+        syncs = self.__dict__.setdefault("_syncs", {})
+        if self.lane + "err" not in syncs:
+            syncs[self.lane + "err"] = torch.zeros(32, dtype=torch.int32, device=self.device)
+        err = syncs[self.lane + "err"]
+        if not torch.cuda.is_current_stream_capturing():
+            eager = self.__dict__.setdefault("_sync_eager", {})
+            if self.lane not in eager:
+                eager[self.lane] = torch.zeros(words, dtype=torch.int32, device=self.device)
+            pools = self.__dict__.setdefault("_sync_pools", {})
+            if self.lane not in pools:           # allocated here, outside of any capture
+                pools[self.lane] = dict(pool=torch.zeros(self.SYNC_REGIONS, words, dtype=torch.int32, device=self.device), next=0)
+            for ent in pools.values():
+                ent["next"] = 0                  # whatever is captured next starts with the pool fill
+            return eager[self.lane], err, 0
+        pools = self.__dict__.setdefault("_sync_pools", {})
+        ent = pools.get(self.lane)
+        if ent is None:
+            raise RuntimeError("weight-stationary launch captured before its lane ran once eagerly (the counter pool is allocated eagerly)")
+        if ent["next"] == 0:
+            ent["pool"].zero_()
+        region = ent["pool"][ent["next"]]
+        ent["next"] = (ent["next"] + 1) % self.SYNC_REGIONS
+        return region, err, 0x200
 
     def gru_sync_error(self, clear=False):
         """True when a weight-stationary launch (scan or single-launch decode) gave up waiting: ONE D2H copy of all the sticky
@@ -157,6 +189,7 @@ class HipOps:
     def gru_seq_fwd(self, scans, persistent=True, cu_budget=0, variant=None):
         arr = (_lib.FnGruFwd * len(scans))()
         variant = self.variant if variant is None else variant
+        sync = self._sync_region() if persistent else None
         for i, (d, s) in enumerate(zip(arr, scans)):
             for k in ("w_hh_frag", "b_hh", "b_ih", "h0", "gx_dense", "gx_table", "gx_rowbias", "h_all", "gates", "h0_frag", "h_last_frag"):
                 _dense(s.get(k), name=k)
@@ -164,9 +197,8 @@ class HipOps:
                 if s.get(k) is not None and s[k].numel() < self.frag_floats(s["B"], s["H"]):
                     raise RuntimeError("%s needs frag_floats(B, H) floats" % k)
             d.frag_ws = _p(self._frag_ws("fragf", i, 2 * self.frag_floats(s["B"], s["H"])))
-            d.sync_ws = _p(self._sync_ws()) if persistent else None
+            d.sync_ws, d.err_ws, d.variant = (_p(sync[0]), _p(sync[1]), int(variant) | sync[2]) if persistent else (None, None, int(variant))
             d.cu_budget = int(cu_budget)
-            d.variant = int(variant)
             _dense(s.get("idx"), torch.int32, "idx")
             d.B, d.T, d.H, d.reverse = s["B"], s["T"], s["H"], int(s.get("reverse", 0))
             d.w_hh_frag, d.b_hh, d.b_ih, d.h0 = _p(s["w_hh_frag"]), _p(s["b_hh"]), _p(s.get("b_ih")), _p(s.get("h0"))
@@ -180,13 +212,13 @@ class HipOps:
     def gru_seq_bwd(self, scans, persistent=True, cu_budget=0, variant=None):
         arr = (_lib.FnGruBwd * len(scans))()
         variant = self.variant if variant is None else variant
+        sync = self._sync_region() if persistent else None
         for i, (d, s) in enumerate(zip(arr, scans)):
             for k in ("w_hh_t_frag", "h0", "h_all", "gates", "dh_last", "dh_ext", "dgx_all", "dghn_all", "dh0", "dgx_rowsum", "dghn_rowsum", "scratch"):
                 _dense(s.get(k), name=k)
             d.frag_ws = _p(self._frag_ws("fragb", i, 2 * self.frag_floats(s["B"], 3 * s["H"])))
-            d.sync_ws = _p(self._sync_ws()) if persistent else None
+            d.sync_ws, d.err_ws, d.variant = (_p(sync[0]), _p(sync[1]), int(variant) | sync[2]) if persistent else (None, None, int(variant))
             d.cu_budget = int(cu_budget)
-            d.variant = int(variant)
             d.B, d.T, d.H = s["B"], s["T"], s["H"]
             d.w_hh_t_frag, d.h0, d.h_all, d.gates = _p(s["w_hh_t_frag"]), _p(s.get("h0")), _p(s["h_all"]), _p(s["gates"])
             d.dh_last, d.dh_ext = _p(s.get("dh_last")), _p(s.get("dh_ext"))

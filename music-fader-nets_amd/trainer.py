@@ -261,6 +261,7 @@ class GMVAETrainer:
         else:
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
+            getattr(m.engine().ops, "begin_capture", lambda: None)()
             try:
                 with torch.cuda.graph(g):
                     self._step_body(step, sbatch, seps)

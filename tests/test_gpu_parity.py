@@ -872,3 +872,32 @@ def test_adv_head_kernel(ops):
         close(a, b, 1e-5)
     close(gz_d, gz_c, 1e-5)
     assert torch.equal(gz_d[:, Z:].cpu(), g0[:, Z:])              # columns beyond Z untouched (row views with a leading dimension)
+
+
+@pytest.mark.parametrize("B,H,rows", [(256, 512, 0), (256, 512, 64), (40, 96, 0)])
+def test_chunked_scan_with_fragment_handover_is_bit_identical(ops, B, H, rows):
+    """a forward scan cut into time chunks whose state travels in the exchange layout (h_last_frag -> h0_frag, no packing launch)
+    gives bit-identical states / gates to the same scan in one launch"""
+    torch.manual_seed(B + H)
+    T, V = 24, 50
+    w = (torch.randn(3 * H, H) / H ** 0.5).to(DEV)
+    wf = torch.zeros(ops.frag_floats(3 * H, H), device=DEV)
+    ops.frag_pack(w, wf)
+    base = dict(B=B, H=H, w_hh_frag=wf, b_hh=torch.randn(3 * H, device=DEV) * 0.1, b_ih=torch.randn(3 * H, device=DEV) * 0.1,
+                h0=torch.randn(B, H, device=DEV) * 0.3, gx_table=torch.randn(V, 3 * H, device=DEV) * 0.3,
+                idx=torch.randint(0, V, (B, T), dtype=torch.int32, device=DEV), idx_shift=-1, start_token=V - 1)
+    ref = dict(base, T=T, h_all=torch.zeros(T, B, H, device=DEV), gates=torch.zeros(T, ops.gates_floats(B, H), device=DEV))
+    ops.gru_seq_fwd([ref], variant=rows)
+    h_all = torch.zeros(T, B, H, device=DEV)
+    gates = torch.zeros(T, ops.gates_floats(B, H), device=DEV)
+    hand = [torch.zeros(ops.frag_floats(B, H), device=DEV) for _ in range(2)]
+    for ci, t0 in enumerate(range(0, T, 7)):
+        t1 = min(T, t0 + 7)
+        c = dict(base, T=t1 - t0, h_all=h_all[t0:t1], gates=gates[t0:t1], idx_shift=-1 + t0)
+        if t0 > 0:
+            c["h0"], c["h0_frag"] = h_all[t0 - 1], hand[(ci - 1) & 1]
+        if t1 < T:
+            c["h_last_frag"] = hand[ci & 1]
+        ops.gru_seq_fwd([c], variant=rows)
+    assert not ops.gru_sync_error()
+    assert torch.equal(h_all, ref["h_all"]) and torch.equal(gates, ref["gates"])
