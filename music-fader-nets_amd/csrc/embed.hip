@@ -10,6 +10,7 @@
 //      i.e. straight into dW_ih[:, v].
 // Also: fn_time_sum_f32, the sum over time of a [T][M] tensor.
 #include "common.h"
+#include "mma_core.h"
 
 namespace {
 
@@ -121,7 +122,7 @@ __device__ __forceinline__ int eg_row(int pos, int B, int T, int reverse, int sh
 
 // one workgroup = one piece (<= EG_PIECE sorted positions of one token, or EG_PIECE start-token rows) x all N3 columns
 __global__ __launch_bounds__(EG_NT) void eg_piece_kernel(const EgArgs a) {
-    __shared__ int rows_l[EG_PIECE];
+    __shared__ __attribute__((aligned(16))) int rows_l[EG_PIECE];
     const EgJob& J = a.job[blockIdx.y];
     const int slot = blockIdx.x, V = a.V, B = a.B, T = a.T, N3 = a.N3;
     int cnt = 0;
@@ -150,28 +151,49 @@ __global__ __launch_bounds__(EG_NT) void eg_piece_kernel(const EgArgs a) {
     }
     __syncthreads();
     float* dst = J.partial + (long)slot * N3;
+    // pad the row list to a multiple of 8 with "row 0, weight 0" so that every load below is unconditional (a branch per row
+    // made the compiler serialise: LDS read -> wait -> branch -> load, eight times per batch, with nothing in flight meanwhile)
+    for (int j = cnt + threadIdx.x; j < ((cnt + 7) & ~7); j += EG_NT) rows_l[j] = -1;
+    __syncthreads();
+    const int cnt8 = (cnt + 7) >> 3;
     for (int c = threadIdx.x * 4; c < N3; c += EG_NT * 4) {
         const float* src = J.dgx + c;
         float4 acc[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        int j = 0;
-        for (; j + 8 <= cnt; j += 8) {                     // eight independent row loads in flight per thread
-            float4 x[8];
+        // 32 rows per iteration: four batches of eight asm loads (mma_core.h) are issued back to back, then added batch by batch
+        // behind counted waits (24 / 16 / 8 / 0 loads still in flight).  Nothing is in flight across the loop back-edge: hipcc
+        // is free to copy registers there, and a copy of a still-loading asm destination would read garbage.  (hipcc's own
+        // s_waitcnt placement drained everything before the first add and serialised LDS read -> branch -> load per row.)
+        for (int g8 = 0; g8 < cnt8; g8 += 4) {
+            f32x4 x[4][8];
+            float w[4][8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int r = rows_l[j + u];
-                x[u] = r >= 0 ? *reinterpret_cast<const float4*>(src + (long)r * N3) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            for (int q = 0; q < 4; ++q) {
+                const int gc = min(g8 + q, cnt8 - 1);    // batches past the end re-load the last one with weight 0
+                const int4 r0 = *reinterpret_cast<const int4*>(rows_l + gc * 8), r1 = *reinterpret_cast<const int4*>(rows_l + gc * 8 + 4);
+                const int rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { acc[u].x += x[u].x; acc[u].y += x[u].y; acc[u].z += x[u].z; acc[u].w += x[u].w; }
-        }
-        for (; j < cnt; ++j) {
-            const int r = rows_l[j];
-            if (r >= 0) {
-                const float4 x = *reinterpret_cast<const float4*>(src + (long)r * N3);
-                acc[0].x += x.x; acc[0].y += x.y; acc[0].z += x.z; acc[0].w += x.w;
+                for (int u = 0; u < 8; ++u) {
+                    w[q][u] = (rr[u] >= 0 && g8 + q < cnt8) ? 1.0f : 0.0f;
+                    fn_gld4_asm(x[q][u], src + (long)max(rr[u], 0) * N3);
+                }
             }
+            auto consume = [&](int q) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    acc[u].x += w[q][u] * x[q][u][0]; acc[u].y += w[q][u] * x[q][u][1];
+                    acc[u].z += w[q][u] * x[q][u][2]; acc[u].w += w[q][u] * x[q][u][3];
+                }
+            };
+            fn_wait_vm<24>(); consume(0);
+            fn_wait_vm<16>(); consume(1);
+            fn_wait_vm<8>(); consume(2);
+            fn_wait_vm<0>(); consume(3);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) fn_keep(x[q][u]);
         }
         float4 s;
         s.x = ((acc[0].x + acc[1].x) + (acc[2].x + acc[3].x)) + ((acc[4].x + acc[5].x) + (acc[6].x + acc[7].x));

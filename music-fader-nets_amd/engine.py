@@ -444,7 +444,8 @@ class Engine:
         dlog = dec["logits"]
         hx1f, hx0f = dec["hx1"].view(T * B, H), dec["hx0"].view(T * B, H)
         dgx1, dghn1, dgx2, dghn2, rs2, rsn2, drb_g, rsn_g, dh0_g = (gd[k] for k in ("dgx1", "dghn1", "dgx2", "dghn2", "rs2", "rsn2", "drb_g", "rsn_g", "dh0_g"))
-        ops.gemm(dlog[:, :E_VOCAB], hx1f, G["linear_out_g.weight"], a_k=False, b_k=False, splitk=sk_T)
+        # 342 x 512 output: only 12 tiles of 128 x 128 - a deeper K split fills the chip (42 x 12 = 504 workgroups: 258 vs 325 us)
+        ops.gemm(dlog[:, :E_VOCAB], hx1f, G["linear_out_g.weight"], a_k=False, b_k=False, splitk=42 if T * B >= 32768 else sk_T)
         ops.colsum(dlog[:, :E_VOCAB], G["linear_out_g.bias"])
         self._gru_weight_grads("g2", "grucell_g_2.", "", T, B, dgx2, dghn2, dec["hx1"], dec["hx0"][0], G, sk_T, rs2, rsn2)
         ops.gemm(dgx2.view(T * B, 3 * H), hx0f, G["grucell_g_2.weight_ih"], a_k=False, b_k=False, splitk=sk_T)
