@@ -336,13 +336,19 @@ __global__ __launch_bounds__(NT) void decode_greedy_kernel(const DArgs a) {
 template <int MT>
 int launch_decode(const DArgs& a, int grid, hipStream_t st) {
     auto k = decode_greedy_kernel<MT>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static int fits[32] = {0};                     // per device: 1 = at least one workgroup of this kernel fits a CU, -1 = it does not
     const size_t lds = ((size_t)3 * a.H * 16 + (size_t)4 * MT * 3 * RT) * 4 + 16 + 64 * 4;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return FN_E_UNSUPPORTED;
+    if (fits[dev] == 0) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        if (e != hipSuccess) return (int)e;
+        int nb = 0;                                // every role workgroup must be resident (one per CU): ask the occupancy calculator
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), NT, 160 * 1024 - 64);
+        if (e != hipSuccess) return (int)e;
+        fits[dev] = nb > 0 ? 1 : -1;
+    }
+    if (fits[dev] < 0) return FN_E_UNSUPPORTED;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, a);
     FN_CHECK_LAUNCH();
     return FN_OK;

@@ -563,26 +563,42 @@ __global__ __launch_bounds__(NT) void gru_bwd_persist_kernel(const QArgs args) {
     }
 }
 
+constexpr int FN_MAX_DEVICES = 32;
+
 int cu_count() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
+    static int n[FN_MAX_DEVICES] = {0};              // per device: a process may drive several GPUs
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= FN_MAX_DEVICES) return 0;
+    if (n[dev] == 0) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-        n = prop.multiProcessorCount;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        n[dev] = prop.multiProcessorCount;
     }
-    return n;
+    return n[dev];
 }
 
+// The weight-stationary kernels spin on counters that OTHER workgroups of the same launch advance: every workgroup of the grid
+// must be resident at the same time.  This is what a cooperative launch would assert; here the occupancy calculator is asked how
+// many workgroups of this kernel (with its dynamic LDS) fit one CU, and a grid beyond cus x that is refused (FN_PERSIST_NA -> the
+// caller takes the per-step kernels).  Kernels of OTHER streams can still delay residency; that case is covered by the bounded
+// spins (sticky error word), never by a hang.
 template <class Args, void (*K)(const Args)>
-int launch_k(const Args& a, int grid, size_t lds, hipStream_t st) {
+int launch_k(const Args& a, int grid, size_t lds, int cus, hipStream_t st) {
     auto k = K;
-    static bool attr_done = false;
-    if (!attr_done) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    static int blocks_per_cu[FN_MAX_DEVICES] = {0};  // 0 = not asked yet for this device
+    static size_t lds_asked[FN_MAX_DEVICES] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= FN_MAX_DEVICES) return FN_PERSIST_NA;
+    if (blocks_per_cu[dev] == 0 || lds_asked[dev] != lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        int nb = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), NT, lds);
+        if (e != hipSuccess) return (int)e;
+        blocks_per_cu[dev] = nb > 0 ? nb : -1;
+        lds_asked[dev] = lds;
     }
+    if (blocks_per_cu[dev] < 0 || (long)grid > (long)cus * blocks_per_cu[dev]) return FN_PERSIST_NA;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, a);
     FN_CHECK_LAUNCH();
     return FN_OK;
@@ -655,12 +671,12 @@ int fn_gru_fwd_persist(const FnGruFwd* scans, int n_scans, hipStream_t st) {
     const int wk = rpw == 16 ? 4 : rpw == 32 ? 2 : (rpw == 64 && !(scans[0].variant & 0x100)) ? 2 : 1;     // K split of the chosen tiling
     const size_t lds = ((size_t)3 * H * 16 + (size_t)wk * (rpw / 16) * 3 * RT) * 4 + 16;
     switch (rpw) {
-        case 128: return launch_k<PArgs, gru_fwd_persist_kernel<4, 1, 2, 4>>(a, grid, lds, st);
+        case 128: return launch_k<PArgs, gru_fwd_persist_kernel<4, 1, 2, 4>>(a, grid, lds, cus, st);
         case 64:
-            if (scans[0].variant & 0x100) return launch_k<PArgs, gru_fwd_persist_kernel<4, 1, 1, 4>>(a, grid, lds, st);
-            return launch_k<PArgs, gru_fwd_persist_kernel<2, 2, 2, 4>>(a, grid, lds, st);
-        case 32: return launch_k<PArgs, gru_fwd_persist_kernel<2, 2, 1, 4>>(a, grid, lds, st);
-        default: return launch_k<PArgs, gru_fwd_persist_kernel<1, 4, 1, 4>>(a, grid, lds, st);
+            if (scans[0].variant & 0x100) return launch_k<PArgs, gru_fwd_persist_kernel<4, 1, 1, 4>>(a, grid, lds, cus, st);
+            return launch_k<PArgs, gru_fwd_persist_kernel<2, 2, 2, 4>>(a, grid, lds, cus, st);
+        case 32: return launch_k<PArgs, gru_fwd_persist_kernel<2, 2, 1, 4>>(a, grid, lds, cus, st);
+        default: return launch_k<PArgs, gru_fwd_persist_kernel<1, 4, 1, 4>>(a, grid, lds, cus, st);
     }
 }
 
@@ -719,11 +735,11 @@ int fn_gru_bwd_persist(const FnGruBwd* scans, int n_scans, hipStream_t st) {
     const int wk = rpw == 16 ? 4 : rpw == 32 ? 2 : (rpw == 64 && !(scans[0].variant & 0x100)) ? 2 : 1;
     const size_t lds = ((size_t)3 * H * 16 + (size_t)wk * (rpw / 16) * RT) * 4 + 16;
     switch (rpw) {
-        case 128: return launch_k<QArgs, gru_bwd_persist_kernel<4, 1, 2, 8>>(a, grid, lds, st);
+        case 128: return launch_k<QArgs, gru_bwd_persist_kernel<4, 1, 2, 8>>(a, grid, lds, cus, st);
         case 64:
-            if (scans[0].variant & 0x100) return launch_k<QArgs, gru_bwd_persist_kernel<4, 1, 1, 8>>(a, grid, lds, st);
-            return launch_k<QArgs, gru_bwd_persist_kernel<2, 2, 2, 8>>(a, grid, lds, st);
-        case 32: return launch_k<QArgs, gru_bwd_persist_kernel<2, 2, 1, 8>>(a, grid, lds, st);
-        default: return launch_k<QArgs, gru_bwd_persist_kernel<1, 4, 1, 8>>(a, grid, lds, st);
+            if (scans[0].variant & 0x100) return launch_k<QArgs, gru_bwd_persist_kernel<4, 1, 1, 8>>(a, grid, lds, cus, st);
+            return launch_k<QArgs, gru_bwd_persist_kernel<2, 2, 2, 8>>(a, grid, lds, cus, st);
+        case 32: return launch_k<QArgs, gru_bwd_persist_kernel<2, 2, 1, 8>>(a, grid, lds, cus, st);
+        default: return launch_k<QArgs, gru_bwd_persist_kernel<1, 4, 1, 8>>(a, grid, lds, cus, st);
     }
 }

@@ -163,8 +163,11 @@ class GMVAETrainer:
         # the host is synchronised here anyway: a weight-stationary scan whose workgroups gave up waiting (bounded spins) has left
         # garbage behind - fail loudly instead of returning it
         check = getattr(self.model.engine().ops, "gru_sync_error", None)
-        if check is not None and check():
-            raise RuntimeError("GRU scan launch timed out waiting for its row group (sync_ws error flag set); results are invalid")
+        if check is not None and check(clear=True):
+            # e.g. another process / stream held CUs for seconds.  The flag is cleared so that the NEXT step can run; this one is lost.
+            raise RuntimeError("a weight-stationary GRU launch timed out waiting for its row group (bounded spin, sync error word set): "
+                               "the results of this step are invalid; the error word was cleared, the step can be repeated "
+                               "(Engine.persist_dec = False / HipOps.gru_seq_*(persistent=False) select the per-step kernels)")
         K = self.model.n_component
         ce_x, ce_r, ce_n, l_r, l_n = s[S_CE_X], s[S_CE_R], s[S_CE_N], s[S_L_R], s[S_L_N]
         tr_, tn_ = s[S_TERMS_R:S_TERMS_R + 4], s[S_TERMS_N:S_TERMS_N + 4]

@@ -91,8 +91,9 @@ class _SingleEncTrainer(GMVAETrainer):
             self.dist.all_reduce_sum(self.stats)
         s = self.stats.tolist()
         check = getattr(self.model.engine().ops, "gru_sync_error", None)
-        if check is not None and check():
-            raise RuntimeError("GRU scan launch timed out waiting for its row group (sync_ws error flag set); results are invalid")
+        if check is not None and check(clear=True):
+            raise RuntimeError("a weight-stationary GRU launch timed out waiting for its row group (sync error word set, now cleared): "
+                               "the results of this step are invalid")
         return s
 
     def train(self, step, d_oh, r_oh, n_oh, d, r, n, c, r_density, n_density, eps=None):
