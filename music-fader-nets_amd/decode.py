@@ -40,7 +40,7 @@ def greedy_decode(model, z, steps, want_logp=True, use_graph=None):
         g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
         getattr(eng.ops, "begin_capture", lambda: None)()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             _decode_body(eng, zs, steps, want_logp, logp, tokens)
         ent = cache[key] = (g, zs, logp, tokens)
     g, zs, logp, tokens = ent

@@ -266,7 +266,9 @@ class GMVAETrainer:
             torch.cuda.synchronize()
             getattr(m.engine().ops, "begin_capture", lambda: None)()
             try:
-                with torch.cuda.graph(g):
+                # thread_local: other threads (the RCCL watchdog polls the events of earlier collectives) may keep calling HIP
+                # while this thread captures; in the default "global" mode such a call invalidates the capture (flaky)
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     self._step_body(step, sbatch, seps)
             except Exception as e:                  # e.g. a collective library that cannot be captured: keep training, eagerly
                 import warnings

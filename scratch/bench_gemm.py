@@ -11,10 +11,8 @@ def t(fn, reps=8):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); fn(); e1.record(); torch.cuda.synchronize(); best = min(best, e0.elapsed_time(e1))
     return best
-cases = [("dW all sk%d" % k, False, False, 1536, 512, 65280, k) for k in (8, 11, 16, 21, 32, 43, 64)]
-cases += [("dW out sk%d" % k, False, False, 342, 512, 65536, k) for k in (16, 32, 42, 64, 85)]
-cases += [("fwd proj", True, True, 8192, 1536, 512, 1), ("fwd proj64", True, True, 16384, 1536, 512, 1), ("logits", True, True, 65536, 342, 512, 1),
-          ("dX out", True, False, 65536, 512, 342, 1), ("dX proj", True, False, 8192, 512, 1536, 1)]
+cases = [("TN 64 tiles sk%d" % k, False, False, 2048, 512, 65536, k) for k in (4, 8, 12, 16, 24)]      # 256 / 512 / 768 / 1024 / 1536 workgroups
+cases += [("dW all sk%d" % k, False, False, 1536, 512, 65280, k) for k in (16, 32)]
 for name, ak, bk, M, N, K, sk in cases:
     lda = 344 if (not ak and M == 342) else (M if not ak else (344 if K == 342 else K))
     A = torch.randn((K, lda) if not ak else (M, lda), device=dev)
