@@ -116,27 +116,38 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(int M, int N, int K, float 
         // after them (a copy would be rotated at the back-edge behind s_waitcnt vmcnt(0)), sched_barrier pins that order.
         if (nmain > 0) {
             f32x4 fa[PF], fb[PF];
-            auto load = [&](int set, int ks) {
-                const long kk = kbeg + 4 * min(ks, nmain - 1) + lg;
-                fn_gld4_asm(fa[set], A + kk * lda + ca);
-                fn_gld4_asm(fb[set], B + kk * ldb + cb);
+            // running row pointers, one 64-bit add per load: the multiply-based address of every load (v_mul_lo_u32 / v_mad_u64_u32
+            // are quarter-rate) sat between the last MFMA of a k-step and the first of the next one with the pipe draining
+            const float* pa = A + (long)(kbeg + lg) * lda + ca;
+            const float* pb = B + (long)(kbeg + lg) * ldb + cb;
+            const long sa = 4 * lda, sb = 4 * ldb;
+            auto load = [&](int set) {
+                fn_gld4_asm(fa[set], pa);
+                fn_gld4_asm(fb[set], pb);
+                pa += sa;
+                pb += sb;
+            };
+            auto mma = [&](int u) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(fa[u], a), f4c(fb[u], b), acc[a][b], 0, 0, 0);
             };
 #pragma unroll
-            for (int s = 0; s < PF; ++s) load(s, s);
-            for (int base = 0; base < nmain; base += PF) {
+            for (int s = 0; s < PF; ++s) load(s);
+            for (int base = 0; base + PF < nmain; base += PF) {   // steady state: every step refills its own ring slot
 #pragma unroll
                 for (int u = 0; u < PF; ++u) {
                     fn_wait_vm<2 * (PF - 1)>();          // the two loads of set u have landed; 2(PF-1) younger ones stay in flight
-#pragma unroll
-                    for (int a = 0; a < 4; ++a)
-#pragma unroll
-                        for (int b = 0; b < 4; ++b)
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(fa[u], a), f4c(fb[u], b), acc[a][b], 0, 0, 0);
-                    load(u, base + u + PF);
+                    mma(u);
+                    load(u);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            fn_wait_vm<0>();                             // the last PF prefetches (clamped re-loads) must land before reuse
+            fn_wait_vm<0>();                             // last PF steps: everything has been requested
+#pragma unroll
+            for (int u = 0; u < PF; ++u) mma(u);
 #pragma unroll
             for (int s = 0; s < PF; ++s) { fn_keep(fa[s]); fn_keep(fb[s]); }
         }
@@ -318,7 +329,7 @@ int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha, co
     // 128 x 128 tiles only when they fill the chip (one workgroup per CU); below that the 64 x 64 kernel's 4x more workgroups win
     // (decode at 2048 rows: 192 big tiles -> 55 us, 768 small ones -> 40 us per W_ih2 projection)
     if (tiles128 * (splitk > 1 ? splitk : 1) >= 256)
-        return launch_gemm<128, 128, 16, 2, 2>(a_kmajor, b_kmajor, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, splitk, ws, st);
+        return launch_gemm<128, 128, 32, 2, 2>(a_kmajor, b_kmajor, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, splitk, ws, st);
     return launch_gemm<64, 64, 16, 2, 2>(a_kmajor, b_kmajor, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, splitk, ws, st);
 }
 

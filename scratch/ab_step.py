@@ -2,13 +2,18 @@
 usage: python scratch/ab_step.py 0 256 ...   (values of FnGruFwd.variant; bit 8 = the round-1 64-row tiling <4,1,1>)"""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+import shutil
+libs = [a for a in sys.argv[1:] if a.endswith(".so")]
+if libs:          # A/B of builds inside one gpurun call: python ab_step.py scratch/lib_x.so [variants...]
+    shutil.copy(os.path.join(R, libs[0]), os.path.join(R, "music-fader-nets_amd/libfadernets_hip.so"))
+    sys.argv = [a for a in sys.argv if not a.endswith(".so")]
 import numpy as np, torch
 from mfn_import import load_package
 pkg = load_package()
 from music_fader_nets_amd.synth import synth_batch
 dev = torch.device("cuda:0")
 for variant in [int(x) for x in sys.argv[1:]] or [0]:
-    for chunk in (32, 64):
+    for chunk in (32,):
         torch.manual_seed(1234)
         m = pkg.MusicAttrRegGMVAE(342, 3, 16, 24, 512, 128, 32, n_component=2).to(dev)
         tr = pkg.GMVAETrainer(m, lr=1e-3, beta=0.2)

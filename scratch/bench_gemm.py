@@ -1,5 +1,8 @@
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+import shutil
+if len(sys.argv) > 1:          # A/B of two builds inside one gpurun call: python bench_gemm.py scratch/lib_x.so
+    shutil.copy(os.path.join(R, sys.argv[1]), os.path.join(R, "music-fader-nets_amd/libfadernets_hip.so"))
 import torch
 from mfn_import import load_package
 load_package()
@@ -11,8 +14,9 @@ def t(fn, reps=8):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); fn(); e1.record(); torch.cuda.synchronize(); best = min(best, e0.elapsed_time(e1))
     return best
-cases = [("TN 64 tiles sk%d" % k, False, False, 2048, 512, 65536, k) for k in (4, 8, 12, 16, 24)]      # 256 / 512 / 768 / 1024 / 1536 workgroups
-cases += [("dW all sk%d" % k, False, False, 1536, 512, 65280, k) for k in (16, 32)]
+cases = [("dW all sk16", False, False, 1536, 512, 65280, 16), ("dW out sk42", False, False, 342, 512, 65536, 42),
+         ("fwd proj32", True, True, 8192, 1536, 512, 1), ("fwd proj64", True, True, 16384, 1536, 512, 1), ("logits", True, True, 65536, 342, 512, 1),
+         ("dX out", True, False, 65536, 512, 342, 1), ("dX proj32", True, False, 8192, 512, 1536, 1), ("dX proj64", True, False, 16384, 512, 1536, 1)]
 for name, ak, bk, M, N, K, sk in cases:
     lda = 344 if (not ak and M == 342) else (M if not ak else (344 if K == 342 else K))
     A = torch.randn((K, lda) if not ak else (M, lda), device=dev)
