@@ -222,7 +222,8 @@ def bench_train(args, pkg, ctx, local, rank, world, log):
         dom = dict(rows["enc_fwd_scan"])
         # traffic: HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE with the gfx950 correction + WRITE_SIZE, separate
         # passes) - bench.py itself cannot run the profiler, so this is the committed measurement of the same launch.
-        dom.update(traffic=4.45e9, traffic_source="profiles/r01_pmc_gru_fwd_persist_4scans.txt", flop_per_launch=dom.pop("work_per_launch"),
+        dom.update(traffic=4.33e9, traffic_source="profiles/r02_pmc_training_step.txt (2 x FETCH_SIZE + WRITE_SIZE, separate passes)",
+                   flop_per_launch=dom.pop("work_per_launch"),
                    steps_per_launch=T, step_frac=round(tokens_per_s / world * F_ALG_PER_TOKEN / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
         out["roofline"] = dom
         out["roofline_all"] = rows

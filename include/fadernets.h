@@ -284,6 +284,13 @@ int fn_latent_bwd(const float* pre, const float* eps, const float* mu_lk, const 
 int fn_pairwise_reg(const float* z0_all, const double* attr_all, int n_all, int row0, int nrows, float* loss_rows,
                     float grad_scale, float* dz0, void* stream);
 
+/* Masked probability sums of the GLSR regulariser (trainer_glsr.py:121-139: approx_played_notes / approx_time_separators = the
+ * softmax mass of a token range, per decoder step).  logits [rows][ld], E valid columns; two ranges [lo0,hi0), [lo1,hi1).
+ *   sums [rows][2] (or NULL) = P_0, P_1;   with w [rows][2] and dlogits [rows][ld] (may alias logits):
+ *   dlogits[u] = p_u (w0 [u in range 0] + w1 [u in range 1] - (w0 P_0 + w1 P_1)) = gradient of w0 P_0 + w1 P_1 wrt the logits. */
+int fn_masked_prob(const float* logits, int64_t rows, int E, int ld, int lo0, int hi0, int lo1, int hi1, float* sums, const float* w,
+                   float* dlogits, void* stream);
+
 /* Adversarial heads of the Fader-Networks sibling (model_v2.py:572-575, trainer_fader.py:105-110), forward + gradient in one pass,
  * one wavefront per row.  For a in {0: rhythm, 1: note}:  pre = w_a . z[b] + b_a ;  o[b][a] = relu(pre) * mask[b][a] (mask = the
  * dropout keep-mask already scaled by 1/(1-p)) ;  loss_rows[b][a] = (o - dens[b][a])^2 ;

@@ -82,6 +82,7 @@ SIGNATURES = {
     "fn_time_logsoftmax_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "fn_latent_fwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
     "fn_latent_bwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "fn_masked_prob": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     "fn_adv_head": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, C.c_int, vp]),
     "fn_pairwise_reg": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_float, vp, vp]),
     "fn_sumsq_ws_bytes": (C.c_size_t, [C.c_int64]),

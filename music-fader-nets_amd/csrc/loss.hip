@@ -82,6 +82,43 @@ __global__ __launch_bounds__(256) void vocab_argmax_kernel(const float* __restri
     if (lane == 0) tok_out[(long)b * tok_ld] = am;
 }
 
+// ------------------------------------------------------------------ masked probability sums (GLSR, trainer_glsr.py:121-139) -----
+// per row of logits: P_a = sum over tokens [lo_a, hi_a) of softmax(logits) for two token ranges (played notes 2..89, time separators
+// 180..277 in the reference).  sums [rows][2].  Gradient form: dlogits[u] = p_u (a_u - (w0 P_0 + w1 P_1)),  a_u = w0 [u in range 0] +
+// w1 [u in range 1], i.e. the backward of  w0 P_0 + w1 P_1  through the softmax; w [rows][2].  One wavefront per row.
+__global__ __launch_bounds__(256) void masked_prob_kernel(const float* __restrict__ logits, long rows, int E, int ld, int lo0, int hi0,
+                                                          int lo1, int hi1, float* __restrict__ sums, const float* __restrict__ w,
+                                                          float* __restrict__ dlogits) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* x = logits + row * ld;
+    float mx = -INFINITY;
+    for (int e = lane; e < E; e += 64) mx = fmaxf(mx, x[e]);
+    mx = fn_wave_max(mx);
+    float s = 0.f, s0 = 0.f, s1 = 0.f;
+    for (int e = lane; e < E; e += 64) {
+        const float p = expf(x[e] - mx);
+        s += p;
+        if (e >= lo0 && e < hi0) s0 += p;
+        if (e >= lo1 && e < hi1) s1 += p;
+    }
+    s = fn_wave_sum(s);
+    s0 = fn_wave_sum(s0) / s;
+    s1 = fn_wave_sum(s1) / s;
+    if (sums && lane == 0) { sums[row * 2] = s0; sums[row * 2 + 1] = s1; }
+    if (dlogits) {
+        const float w0 = w[row * 2], w1 = w[row * 2 + 1];
+        const float dot = w0 * s0 + w1 * s1;
+        float* d = dlogits + row * ld;
+        for (int e = lane; e < E; e += 64) {
+            const float p = expf(x[e] - mx) / s;
+            const float a = ((e >= lo0 && e < hi0) ? w0 : 0.f) + ((e >= lo1 && e < hi1) ? w1 : 0.f);
+            d[e] = p * (a - dot);                       // may alias logits: every lane reads x[e] before it writes d[e]
+        }
+    }
+}
+
 // ------------------------------------------------------------------ time axis ----------------
 // one thread per (b, c); loops over Tr.  logits [Tr][B][Cc]
 __global__ void time_logsoftmax_kernel(const float* __restrict__ logits, int B, int Tr, int Cc, float* __restrict__ logp_bt,
@@ -419,6 +456,16 @@ __global__ void onehot_to_index_kernel(const float* __restrict__ oh, long rows, 
 }  // namespace
 
 extern "C" {
+
+int fn_masked_prob(const float* logits, int64_t rows, int E, int ld, int lo0, int hi0, int lo1, int hi1, float* sums, const float* w,
+                   float* dlogits, void* stream) {
+    if (!logits || (!sums && !dlogits) || (dlogits && !w)) return FN_E_NULL;
+    if (rows <= 0 || E <= 0 || ld < E || lo0 < 0 || hi0 > E || lo1 < 0 || hi1 > E) return FN_E_SHAPE;
+    hipLaunchKernelGGL(masked_prob_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, (long)rows, E, ld,
+                       lo0, hi0, lo1, hi1, sums, w, dlogits);
+    FN_CHECK_LAUNCH();
+    return FN_OK;
+}
 
 int fn_adv_head(const float* z, int ldz, int Z, int B, const float* w_r, const float* w_n, const float* b_r, const float* b_n,
                 const float* mask, const float* dens, const float* lam_dev, float inv_global_batch, float* o, float* loss_rows, float* da,

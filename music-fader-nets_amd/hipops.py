@@ -376,6 +376,18 @@ class HipOps:
                                           _p(g_sigma), _p(g_ll), _p(g_qy), _p(w3), _p(dpre), _p(dmu_lk_rows),
                                           self.stream()), "fn_latent_bwd")
 
+    def masked_prob(self, logits, E, ranges, sums=None, w=None, dlogits=None):
+        """softmax mass of two token ranges per logits row (fn_masked_prob) and / or the gradient of w0 P_0 + w1 P_1 wrt the logits"""
+        pl, rows, _, ld = _mat(logits, "logits")
+        _dense(sums, name="sums"), _dense(w, name="w")
+        pd = None
+        if dlogits is not None:
+            pd, r2, _, ld2 = _mat(dlogits, "dlogits")
+            if (r2, ld2) != (rows, ld):
+                raise RuntimeError("masked_prob: dlogits must have the layout of logits")
+        (lo0, hi0), (lo1, hi1) = ranges
+        _lib.check(self.lib.fn_masked_prob(pl, rows, E, ld, lo0, hi0, lo1, hi1, _p(sums), _p(w), pd, self.stream()), "fn_masked_prob")
+
     def adv_head(self, z, w_r, w_n, b_r, b_n, mask, dens, lam_dev, inv_global_batch, o, loss_rows, da=None, g_z=None):
         """adversarial heads of the Fader sibling (fn_adv_head): z [B][>=Z] row view, g_z likewise (gradient is SUBTRACTED)"""
         pz, B, Zc, ldz = _mat(z, "z")

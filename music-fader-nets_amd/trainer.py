@@ -119,6 +119,7 @@ class GMVAETrainer:
         Bg = B if self.dist is None else self.dist.global_batch(B)
         Z = eng.Z
         beta0 = beta_schedule(step, self.beta)
+        self._step_now = step
         S = eng.forward(d, r, n, c, eps[0], eps[1], labels)
         dec, lat = S["dec"], S["lat"]
         st = self.stats
@@ -136,7 +137,16 @@ class GMVAETrainer:
         # latent terms: column sums of the per-row terms written by fn_latent_fwd
         for slot, e in ((S_TERMS_R, "r"), (S_TERMS_N, "n")):
             ops.colsum(lat[e]["terms"], st[slot:slot + 4])
-        # pairwise regulariser on z[:, 0] against the GLOBAL batch
+        lat_up = self._regulariser(eng, S, batch, Bg, want_grads)
+        return dl_sd, lat_up, self.sp[0:3], beta0, Bg
+
+    def _regulariser(self, eng, S, batch, Bg, want_grads):
+        """pairwise regulariser on z[:, 0] against the GLOBAL batch (trainer_gmm.py:199-217): fills stats[S_L_R / S_L_N] and returns
+        the upstream gradient buffers {'r','n'} -> dict(g_z=[B][Z]) the backward accumulates the decoders' dz into"""
+        ops, lat, Z = eng.ops, S["lat"], eng.Z
+        d, r, n, c, rd, nd, labels = batch
+        B = d.shape[0]
+        st = self.stats
         lat_up = {}
         for slot, e, attr in ((S_L_R, "r", rd), (S_L_N, "n", nd)):
             z0 = eng.buf("reg_z0_" + e, (B,))
@@ -153,7 +163,7 @@ class GMVAETrainer:
                 gz = eng.zbuf("g_z_" + e, (B, Z))
                 gz[:, 0].copy_(dz0)
                 lat_up[e] = dict(g_z=gz)
-        return dl_sd, lat_up, self.sp[0:3], beta0, Bg
+        return lat_up
 
     def _tuple8(self, beta0, Bg, supervised):
         """device partial sums -> the reference's 8 numbers (ONE D2H copy; the reference does 8 .item() calls, :257)."""

@@ -218,3 +218,184 @@ class FaderTrainer(CVAETrainer):
     def evaluate(self, step, d_oh, r_oh, n_oh, d, r, n, c, r_density, n_density, eps=None):
         batch = self.prepare_batch(d if d is not None else d_oh, r if r is not None else r_oh, n if n is not None else n_oh, c, r_density, n_density)
         return self._evaluate(step, batch, eps)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+class GLSRTrainer(GMVAETrainer):
+    """``train`` / ``evaluate`` of the reference's ``trainer_glsr.py`` (:267-321) for ``MusicAttrRegVAE``:
+    loss = 5 CE_X + CE_R + CE_N + beta0(step) * (KL_r + KL_n)  (:87-115; here the step argument IS used)  and, once step > 20, the GLSR
+    regulariser of Hadjeres et al. as the reference implements it (:118-264): for the rhythm and then the note latent, z[:, 0] is moved by
+    +-delta (delta = (1 + U(0,1)) * 1e-2 per sample), the TRAIN-mode (teacher-forced) global decoder is run for 100 steps on both, an
+    attribute is read off the output probabilities, and  -log N(0,1)( (attr+ - attr-) / (2 delta) )  is averaged over the batch.
+      note density   = sum_t P_t(note-on tokens 2..89)                                                   (:135-137)
+      rhythm density = a host-side walk over the 100 steps (:139-165): between "time separators" (steps whose time-shift mass
+                       P_t(180..277) >= 0.9) the note-on mass OF SAMPLE 0 (``played_notes[0][i]`` - reproduced) is accumulated; a flush
+                       adds 1 (no gradient) if the accumulated mass exceeds 1e-2, else the mass itself; divided by sum_t P_t(180..277).
+    The four extra decodes and their backward passes run on the HIP kernels (teacher-forced decoder scans, fn_masked_prob); the walk
+    over the 2 x B x 100 masses is host arithmetic exactly as in the reference (it branches on ``.item()`` per step), so the step syncs
+    with the host four times and is not graph-captured.  -> (loss, CE_X, CE_R, CE_N, l_r, l_n).  Not data parallel (sample 0 is global)."""
+    NOTES, SEPS, EPSILON, STEPS = (2, 90), (180, 278), 1e-2, 100
+
+    def __init__(self, model, lr=1e-3, beta=0.1, max_norm=1.0, dist_ctx=None):
+        if dist_ctx is not None:
+            raise ValueError("GLSRTrainer is single-process: the reference's rhythm-density walk reads sample 0 of the batch for every row")
+        super().__init__(model, lr=lr, beta=beta, max_norm=max_norm)
+        self.use_graph = False
+        self.flat2 = torch.zeros_like(self.flat.grad)          # parameter gradients of one extra decoder pass
+        self.acc = torch.zeros_like(self.flat.grad)            # ... summed over the four passes
+        self.G2 = {k: self.flat2[o:o + self.flat.G[k].numel()].view_as(self.flat.G[k]) for k, o in self.flat.offsets.items()}
+        self._glsr_active = False
+
+    def draw_eps(self, B, T, step=None):
+        """forward draws (randn x2, T x rand(1)), then - if the regulariser is active - per latent: rand(B) for the deltas and the
+        2 x 100 rand(1) of the two train-mode decodes (trainer_glsr.py:175-177,183-186, model_v2.py:129-131)"""
+        dev = self.flat.param.device
+        eps = list(self.model._draw_eps(B, T, dev))
+        deltas = []
+        if step is not None and step > 20:
+            for _ in range(2):
+                deltas.append(((1 + torch.rand(B)) * self.EPSILON).to(dev))
+                for _ in range(2 * self.STEPS):
+                    torch.rand(1)
+        return tuple(eps + [deltas])
+
+    # ---------------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _rhythm_density(PN, PS):
+        """host walk of trainer_glsr.py:139-165 on float32 masses PN / PS [steps][B] -> (r [B], dPN0 [steps][B]: d r_b / d PN[i][0] per
+        (i, b), dPS [steps][B]: d r_b / d PS[i][b])"""
+        steps, B = PS.shape
+        r = np.zeros(B, np.float32)
+        dPN0, dPS = np.zeros((steps, B), np.float32), np.zeros((steps, B), np.float32)
+        for b in range(B):
+            total, total_grad_idx, cur, cur_idx, started = np.float32(0), [], np.float32(0), [], False
+            for i in range(steps):
+                if PS[i, b] < 0.9:
+                    cur = np.float32(cur + PN[i, 0])
+                    cur_idx.append(i)
+                    started = True
+                else:
+                    if not started or cur == 0:
+                        continue
+                    if cur > 1e-2:
+                        total = np.float32(total + 1)
+                    else:
+                        total = np.float32(total + cur)
+                        total_grad_idx += cur_idx
+                    cur, cur_idx, started = np.float32(0), [], False
+            S = np.float32(PS[:, b].sum(dtype=np.float32))
+            rb = np.float32(total / S)
+            if rb != 0:
+                r[b] = rb
+                for i in total_grad_idx:
+                    dPN0[i, b] += 1.0 / S
+                dPS[:, b] = -total / (S * S)
+        return r, dPN0, dPS
+
+    def _regulariser(self, eng, S, batch, Bg, want_grads):
+        ops, Z = eng.ops, eng.Z
+        d, r, n, c, rd, nd, labels = batch
+        B, T = d.shape
+        lat = S["lat"]
+        dev = d.device
+        gz = {e: eng.zbuf("g_z_" + e, (B, Z)) for e in ("r", "n")}
+        lat_up = {e: dict(g_z=gz[e]) for e in ("r", "n")}
+        self.stats[S_L_R:S_L_N + 1].zero_()
+        self._glsr_active = False
+        deltas = self._cur_eps[2] if len(self._cur_eps) > 2 else []
+        if self._step_now <= 20 or not deltas:
+            return lat_up
+        if T < self.STEPS:
+            raise IndexError("GLSR decodes %d teacher-forced steps: the batch needs T >= %d (trainer_glsr.py:183)" % (self.STEPS, self.STEPS))
+        st_ = self.STEPS
+        d100 = eng.buf("glsr_d", (B, st_), torch.int32)
+        d100.copy_(d[:, :st_])
+        base = eng.pack_zc(lat["r"]["z"], lat["n"]["z"], c).clone()
+        ranges = (self.NOTES, self.SEPS)
+
+        def decode(attr, sign, save):
+            zc = eng.buf("glsr_zc", base.shape)
+            zc.copy_(base)
+            zc[:, 0 if attr == 0 else Z] += sign * deltas[attr]
+            return eng.global_decoder_tf(d100, zc, save=save)
+
+        sums = eng.buf("glsr_sums", (st_ * B, 2))
+        mass = {}
+        for attr in (0, 1):
+            for sign in (1.0, -1.0):
+                dec = decode(attr, sign, False)
+                ops.masked_prob(dec["logits"], E_VOCAB, ranges, sums=sums)
+                mass[(attr, sign)] = sums.view(st_, B, 2).cpu().numpy().copy()            # host sync (the reference calls .item() per step)
+        # ---- host: attributes, losses, and d loss / d masses ------------------------------------------------------------------
+        half_log_2pi = 0.5 * math.log(2 * math.pi)
+        w = {}
+        dl = [deltas[a].cpu().numpy() for a in (0, 1)]
+        rp = self._rhythm_density(mass[(0, 1.0)][:, :, 0], mass[(0, 1.0)][:, :, 1])
+        rm = self._rhythm_density(mass[(0, -1.0)][:, :, 0], mass[(0, -1.0)][:, :, 1])
+        g_r = ((rp[0] - rm[0]) / (2 * dl[0])).astype(np.float32)
+        l_r = float(np.mean(0.5 * g_r * g_r + half_log_2pi, dtype=np.float32))
+        for sign, (rv, dPN0, dPS) in ((1.0, rp), (-1.0, rm)):
+            coef = sign * g_r / (2 * dl[0]) / Bg                                          # d l_r / d r(sign)_b
+            ww = np.zeros((st_, B, 2), np.float32)
+            ww[:, 0, 0] = (dPN0 * coef[None, :]).sum(1)                                   # every row's walk reads the notes of SAMPLE 0
+            ww[:, :, 1] = dPS * coef[None, :]
+            w[(0, sign)] = ww
+        n_p, n_m = mass[(1, 1.0)][:, :, 0].sum(0, dtype=np.float32), mass[(1, -1.0)][:, :, 0].sum(0, dtype=np.float32)
+        g_n = ((n_p - n_m) / (2 * dl[1])).astype(np.float32)
+        l_n = float(np.mean(0.5 * g_n * g_n + half_log_2pi, dtype=np.float32))
+        for sign in (1.0, -1.0):
+            ww = np.zeros((st_, B, 2), np.float32)
+            ww[:, :, 0] = (sign * g_n / (2 * dl[1]) / Bg)[None, :]
+            w[(1, sign)] = ww
+        self.stats[S_L_R:S_L_N + 1].copy_(torch.tensor([l_r, l_n], dtype=torch.float32))
+        if not want_grads:
+            return lat_up
+        # ---- backward of the four decodes: recompute forward (activations saved), seed dlogits, reverse scans -----------------------
+        from .engine import ops_sort
+        self.acc.zero_()
+        gzc = eng.zbuf("glsr_gzc", base.shape)
+        S2 = dict(d=d100, sort={"d": ops_sort(eng, "d100", d100, E_VOCAB)})
+        P = eng.p
+        wdev = eng.buf("glsr_w", (st_ * B, 2))
+        for attr in (0, 1):
+            for sign in (1.0, -1.0):
+                if not np.any(w[(attr, sign)]):
+                    continue                                                              # constant attribute: no gradient
+                S2["dec"] = decode(attr, sign, True)
+                wdev.copy_(torch.from_numpy(w[(attr, sign)]).view(st_ * B, 2))
+                ops.masked_prob(S2["dec"]["logits"], E_VOCAB, ranges, w=wdev, dlogits=S2["dec"]["logits"])
+                gd = eng._bwd_global_decoder_scans(S2)
+                ops.gemm(gd["drb_g"], P["grucell_g.weight_ih"][:, E_VOCAB:], gzc, a_k=True, b_k=False, beta=1.0)
+                ops.gemm(gd["dh0_g"], P["linear_init_global.weight"], gzc, a_k=True, b_k=False, beta=1.0)
+                self.flat2.zero_()
+                eng._bwd_global_decoder_params(self.G2, S2, gd)
+                ops.axpy(1.0, self.flat2, self.acc)
+        gz["r"].copy_(gzc[:, :Z])
+        gz["n"].copy_(gzc[:, Z:2 * Z])
+        self._glsr_active = True
+        return lat_up
+
+    def _forward_losses(self, step, batch, eps, want_grads):
+        self._cur_eps = eps
+        return super()._forward_losses(step, batch, eps, want_grads)
+
+    def _run_backward(self, fw, hook):
+        super()._run_backward(fw, hook)
+        if self._glsr_active:
+            self.model.engine().ops.axpy(1.0, self.acc, self.flat.grad)
+
+    def train(self, step, d_oh, r_oh, n_oh, d, r, n, c, r_density, n_density, eps=None):
+        batch = self.prepare_batch(d if d is not None else d_oh, r if r is not None else r_oh, n if n is not None else n_oh, c, r_density, n_density)
+        if eps is None:
+            eps = self.draw_eps(*batch[0].shape, step=step)
+        beta0, Bg = self.step_device(step, batch, eps)
+        return step + 1, self._tuple8(beta0, Bg, False)[:6]
+
+    @torch.no_grad()
+    def evaluate(self, step, d_oh, r_oh, n_oh, d, r, n, c, r_density, n_density, eps=None):
+        batch = self.prepare_batch(d if d is not None else d_oh, r if r is not None else r_oh, n if n is not None else n_oh, c, r_density, n_density)
+        if eps is None:
+            eps = self.draw_eps(*batch[0].shape, step=step)
+        self.model.engine()
+        fw = self._forward_losses(step, batch, eps, want_grads=False)
+        return self._tuple8(fw[3], fw[4], False)[:6]

@@ -93,3 +93,84 @@ def gradients(sd, batch, eps_r, eps_n, beta=0.1):
     loss, tup, fw = total_loss(p, batch, eps_r, eps_n, beta)
     grads = torch.autograd.grad(loss, [leaves[k] for k in keys], allow_unused=True)
     return {k: (gr if gr is not None else torch.zeros_like(sd[k])) for k, gr in zip(keys, grads)}, tup, fw
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# GLSR variant of the step (trainer_glsr.py:87-321): same model, the loss uses the PASSED step for beta0, and after step 20 the
+# finite-difference regulariser of :118-264 replaces the pairwise one.  Pinned by tests/golden/glsr.npz (make_golden_glsr.py).
+# ----------------------------------------------------------------------------------------------------------------------------------
+NOTES, SEPS, GLSR_EPS, GLSR_STEPS = (2, 90), (180, 278), 1e-2, 100
+
+
+def draw_glsr(B, Z, T, step):
+    """the draws of one trainer_glsr.train() call on torch's global generator: forward (randn x2, T x rand(1)); if step > 20, per
+    latent rand(B) for the deltas followed by the 2 x 100 rand(1) of the two train-mode decodes"""
+    eps_r, eps_n = torch.randn(B, Z), torch.randn(B, Z)
+    for _ in range(T):
+        torch.rand(1)
+    deltas = []
+    if step > 20:
+        for _ in range(2):
+            deltas.append((1 + torch.rand(B)) * GLSR_EPS)
+            for _ in range(2 * GLSR_STEPS):
+                torch.rand(1)
+    return eps_r, eps_n, deltas
+
+
+def _rhythm_density(probs):
+    """trainer_glsr.py:139-165 incl. its use of ``played_notes[0]`` (sample 0) for every row; probs [B][steps][E]"""
+    played = probs[:, :, NOTES[0]:NOTES[1]].sum(-1)
+    sep = probs[:, :, SEPS[0]:SEPS[1]].sum(-1)
+    res = []
+    for b in range(probs.shape[0]):
+        total, cur, started = 0, 0, False
+        for i in range(probs.shape[1]):
+            if sep[b, i].item() < 0.9:
+                cur = cur + played[0, i]
+                started = True
+            else:
+                if not started or float(cur) == 0:
+                    continue
+                total = total + (cur / cur if float(cur) > 1e-2 else cur)
+                cur, started = 0, False
+        r = total / sep[b].sum()
+        res.append(r if float(r) != 0.0 else torch.zeros(()))
+    return torch.stack(res)
+
+
+def glsr_terms(sd, z_r, z_n, c, d, deltas):
+    """-> (l_r, l_n) of trainer_glsr.py:167-264 (differentiable wrt sd / z)"""
+    import math
+    teacher = d[:, :GLSR_STEPS]
+    out = []
+    for attr, dl in enumerate(deltas):
+        vals = []
+        for sign in (1.0, -1.0):
+            zr, zn = z_r.clone(), z_n.clone()
+            (zr if attr == 0 else zn)[:, 0] += sign * dl
+            probs = g.global_decoder(sd, torch.cat([zr, zn, c], dim=1), GLSR_STEPS, teacher=teacher).exp()
+            vals.append(_rhythm_density(probs) if attr == 0 else probs[:, :, NOTES[0]:NOTES[1]].sum(-1).sum(1))
+        grad_attr = (vals[0] - vals[1]) / (2 * dl)
+        out.append((0.5 * grad_attr ** 2 + 0.5 * math.log(2 * math.pi)).mean())
+    return out[0], out[1]
+
+
+def glsr_total_loss(sd, batch, eps_r, eps_n, deltas, step, beta):
+    d, r, n = (torch.as_tensor(batch[k]).long() for k in ("d", "r", "n"))
+    c = torch.as_tensor(batch["c"]).float()
+    fw = forward(sd, d, r, n, c, eps_r, eps_n)
+    ls = loss_function(fw, d, r, n, beta, global_step=step)
+    zero = torch.zeros(())
+    l_r, l_n = glsr_terms(sd, fw["z_r"], fw["z_n"], c, d, deltas) if step > 20 else (zero, zero)
+    loss = ls[0] + l_r + l_n
+    return loss, (loss, ls[1], ls[2], ls[3], l_r, l_n), fw
+
+
+def glsr_gradients(sd, batch, eps_r, eps_n, deltas, step, beta):
+    keys = trainable_used_keys(sd)
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in keys}
+    p = dict(sd)
+    p.update(leaves)
+    loss, tup, fw = glsr_total_loss(p, batch, eps_r, eps_n, deltas, step, beta)
+    grads = torch.autograd.grad(loss, [leaves[k] for k in keys], allow_unused=True)
+    return {k: (gr if gr is not None else torch.zeros_like(sd[k])) for k, gr in zip(keys, grads)}, tuple(float(t.detach()) for t in tup), fw

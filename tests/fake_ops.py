@@ -293,6 +293,19 @@ class FakeOps:
             counters[0] = step + 1
             counters[1] = t
 
+    def masked_prob(self, logits, E, ranges, sums=None, w=None, dlogits=None):
+        p = torch.softmax(logits[:, :E].double(), dim=1)
+        (lo0, hi0), (lo1, hi1) = ranges
+        s0, s1 = p[:, lo0:hi0].sum(1), p[:, lo1:hi1].sum(1)
+        if sums is not None:
+            sums.copy_(torch.stack([s0, s1], dim=1).float())
+        if dlogits is not None:
+            a = torch.zeros_like(p)
+            a[:, lo0:hi0] += w[:, 0:1].double()
+            a[:, lo1:hi1] += w[:, 1:2].double()
+            dot = w[:, 0].double() * s0 + w[:, 1].double() * s1
+            dlogits[:, :E].copy_((p * (a - dot.unsqueeze(1))).float())
+
     def adv_head(self, z, w_r, w_n, b_r, b_n, mask, dens, lam_dev, inv_global_batch, o, loss_rows, da=None, g_z=None):
         Z = w_r.numel()
         zz = z[:, :Z]

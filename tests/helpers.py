@@ -351,3 +351,52 @@ def check_sibling(pkg, kind, m, g, dev, rtol_fw=5e-5, tol_grad=5e-4, rtol_tuple=
     assert tokens_match_upto_near_tie(o.argmax(-1).cpu().numpy(), g["evalfw_tokens"], g["evalfw_gap"]) >= B * T // 2
     if kind == "fader":
         np.testing.assert_allclose(res[0][1].cpu().numpy(), g["evalfw_r_out"], rtol=1e-4, atol=1e-5)
+
+
+# ---- GLSR trainer (tests/golden/glsr.npz = trainer_glsr.py's own functions on model_v2.MusicAttrRegVAE) ---------------------------------
+def glsr_fixture_weights(g, hidden, zdim):
+    """the seeded MusicAttrRegVAE weights with the fixture's output-layer modification (make_golden_glsr.py)"""
+    from oracle import vae_oracle as vo
+    sd = vo.init_state_dict(hidden, zdim)
+    sd["linear_out_g.weight"] = sd["linear_out_g.weight"] * float(g["out_scale"][0])
+    sd["linear_out_g.bias"] = sd["linear_out_g.bias"] + torch.from_numpy(g["bias_shift"])
+    for k, v in sd.items():
+        vd = v.double()
+        np.testing.assert_allclose([vd.sum().item(), vd.abs().sum().item(), (vd * vd).sum().item()], g["w0sum/" + k], rtol=1e-6, atol=1e-6, err_msg=k)
+    return sd
+
+
+def check_glsr(pkg, m, g, dev, tol_grad=1e-3, rtol_tuple=5e-4):
+    """GLSRTrainer (fused step + four extra teacher-forced decodes + host walk) vs the reference's trainer_glsr.train / evaluate"""
+    H, Z, B, T, Tr = (int(x) for x in g["dims"])
+    tr = pkg.GLSRTrainer(m, lr=1e-3, beta=0.2)
+    batch = tr.prepare_batch(g["d"], g["r"], g["n"], g["c"], g["r_density"], g["n_density"])
+    torch.manual_seed(99)
+    eps = tr.draw_eps(B, T, step=20000)
+    assert len(eps[2]) == 2
+    tup = tr.loss_and_grads(20000, batch, eps)[:6]
+    np.testing.assert_allclose(tup, g["loss_terms_20000"], rtol=rtol_tuple)
+    assert tup[5] > 0.92 and float(g["diag_sep_frac_above"][0]) > 0.2          # the regulariser is not at its constant floor
+    ref_keys = {k[len("grad/"):] for k in g if k.startswith("grad/")}
+    assert set(tr.flat.names) == ref_keys
+    for k in tr.flat.names:
+        ref = g["grad/" + k]
+        e = relerr(tr.flat.G[k].cpu().numpy(), ref)
+        assert e < tol_grad or np.abs(ref).max() < 1e-6, (k, e)
+    np.testing.assert_allclose(tr.grad_norm(), g["gradnorm"][0], rtol=2e-3)
+    # step <= 20: regulariser off, no extra draws (trainer_glsr.py:289-292)
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    torch.manual_seed(50)
+    _, t19 = tr.train(19, None, None, None, g["d"], g["r"], g["n"], g["c"], g["r_density"], g["n_density"])
+    np.testing.assert_allclose(t19, g["train_tuple_step19"], rtol=rtol_tuple, atol=1e-9)
+    # the reference's own train() x3 from the fixture weights, then evaluate()
+    m.load_state_dict(sd0)
+    tr = pkg.GLSRTrainer(m, lr=1e-3, beta=0.2)
+    step = 19999
+    for it in range(3):
+        torch.manual_seed(99 + it)
+        step, tup = tr.train(step, None, None, None, g["d"], g["r"], g["n"], g["c"], g["r_density"], g["n_density"])
+        np.testing.assert_allclose(tup, g["train_tuples"][it], rtol=2e-3 if it else rtol_tuple, err_msg="step %d" % it)
+    torch.manual_seed(123)
+    ev = tr.evaluate(step - 1, None, None, None, g["d"], g["r"], g["n"], g["c"], g["r_density"], g["n_density"])
+    np.testing.assert_allclose(ev, g["eval_tuple"], rtol=2e-3)

@@ -901,3 +901,31 @@ def test_chunked_scan_with_fragment_handover_is_bit_identical(ops, B, H, rows):
         ops.gru_seq_fwd([c], variant=rows)
     assert not ops.gru_sync_error()
     assert torch.equal(h_all, ref["h_all"]) and torch.equal(gates, ref["gates"])
+
+
+def test_masked_prob_kernel(ops):
+    torch.manual_seed(31)
+    rows, E, ld = 203, 342, 344
+    logits = torch.randn(rows, ld) * 3
+    w = torch.randn(rows, 2)
+    ranges = ((2, 90), (180, 278))
+    s_c, d_c = torch.zeros(rows, 2), torch.zeros(rows, ld)
+    FakeOps().masked_prob(logits, E, ranges, sums=s_c, w=w, dlogits=d_c)
+    ld_dev = g(logits.clone())
+    s_d = torch.zeros(rows, 2, device=DEV)
+    ops.masked_prob(ld_dev, E, ranges, sums=s_d)
+    close(s_d, s_c, 1e-5)
+    ops.masked_prob(ld_dev, E, ranges, w=g(w), dlogits=ld_dev)          # in place, as the GLSR backward seeds the decoder
+    close(ld_dev[:, :E], d_c[:, :E], 2e-5)
+
+
+def test_glsr_trainer_vs_reference():
+    """trainer_glsr.py's step (four extra teacher-forced decodes + host walk + their backward) on the HIP kernels"""
+    from helpers import check_glsr, glsr_fixture_weights, make_vae_model
+    pkg = load_package()
+    gold = load_golden("glsr")
+    H, Z = int(gold["dims"][0]), int(gold["dims"][1])
+    m = make_vae_model(H, Z, device=DEV)
+    m.load_state_dict(glsr_fixture_weights(gold, H, Z))
+    check_glsr(pkg, m, gold, DEV, tol_grad=2e-3, rtol_tuple=5e-4)
+    assert not m.engine().ops.gru_sync_error()

@@ -191,3 +191,14 @@ def test_siblings_host_logic(kind):
     pkg = load_package()
     g = sibling_golden(kind)
     check_sibling(pkg, kind, make_sibling(kind, 64, 32, ops=FakeOps()), g, "cpu", rtol_fw=3e-5, tol_grad=3e-4, rtol_tuple=1e-4)
+
+
+def test_glsr_trainer_host_logic():
+    """GLSRTrainer on the CPU test backend vs the reference's trainer_glsr.py run (tests/golden/glsr.npz)"""
+    from helpers import check_glsr, glsr_fixture_weights, load_golden, make_vae_model
+    pkg = load_package()
+    g = load_golden("glsr")
+    H, Z = int(g["dims"][0]), int(g["dims"][1])
+    m = make_vae_model(H, Z, ops=FakeOps())
+    m.load_state_dict(glsr_fixture_weights(g, H, Z))
+    check_glsr(pkg, m, g, "cpu", tol_grad=5e-4, rtol_tuple=1e-4)

@@ -323,3 +323,25 @@ def test_siblings_oracle_vs_reference(golden_dir, kind):
             ref = g["grad_%d/%s" % (step, k)]
             assert relerr(gr.numpy(), ref) < 2e-4 or np.abs(ref).max() < 1e-7, (k, relerr(gr.numpy(), ref))
     assert set(g["no_grad_params"]) == {k for k in sd if k.startswith(("c_r.", "c_n."))}
+
+
+def test_glsr_oracle_vs_reference(golden_dir):
+    """oracle/vae_oracle.py's restatement of trainer_glsr.py (finite-difference regulariser incl. the host walk) vs the reference run"""
+    from oracle import vae_oracle as vo
+    from helpers import glsr_fixture_weights, relerr
+    g = _load(golden_dir, "glsr")
+    H, Z, B, T, Tr = (int(x) for x in g["dims"])
+    sd = glsr_fixture_weights(g, H, Z)
+    batch = {k: g[k] for k in ("d", "r", "n", "c", "r_density", "n_density")}
+    torch.manual_seed(99)
+    eps_r, eps_n, deltas = vo.draw_glsr(B, Z, T, 20000)
+    grads, tup, fw = vo.glsr_gradients(sd, batch, eps_r, eps_n, deltas, 20000, 0.2)
+    np.testing.assert_allclose(tup, g["loss_terms_20000"], rtol=2e-5)
+    for k, gr in grads.items():
+        ref = g["grad/" + k]
+        assert relerr(gr.numpy(), ref) < 3e-4 or np.abs(ref).max() < 1e-6, (k, relerr(gr.numpy(), ref))
+    torch.manual_seed(50)
+    eps_r, eps_n, deltas = vo.draw_glsr(B, Z, T, 19)
+    assert deltas == []
+    _, tup, _ = vo.glsr_gradients(sd, batch, eps_r, eps_n, deltas, 19, 0.2)
+    np.testing.assert_allclose(tup, g["train_tuple_step19"], rtol=2e-5, atol=1e-9)
