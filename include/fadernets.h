@@ -119,6 +119,18 @@ typedef struct FnGruFwd {
 size_t fn_frag_floats(int rows, int K);
 int fn_frag_pack(const float* src, int rows, int K, int ld, float* dst, void* stream);
 
+/* All weight images of one optimiser step in ONE launch (the refresh after every Adam update: ~40 small matrices).
+ *   kind 0: dst [cols][rows] = src^T                       (the one-hot column table W_ih[:, :V]^T; src [rows][cols], leading dim ld)
+ *   kind 1: dst = fn_frag_pack image of src [rows][K = cols]  (cols % 32 == 0)
+ *   kind 2: dst = fn_frag_pack image of src^T, the [cols][K = rows] matrix (rows % 32 == 0): W_hh^T for the backward scans
+ * up to 40 jobs; dst of kinds 1 / 2 16-byte aligned with fn_frag_floats(...) floats. */
+typedef struct FnWeightImage {
+    const float* src;
+    float* dst;
+    int32_t rows, cols, ld, kind;
+} FnWeightImage;
+int fn_weight_images(const FnWeightImage* jobs, int n_jobs, void* stream);
+
 /* floats per time step of the saved-gates buffer (4*H*ceil16(B)) */
 size_t fn_gru_gates_floats(int B, int H);
 

@@ -36,6 +36,10 @@ class FnEmbedGrad(C.Structure):
                 ("idx_shift", C.c_int32), ("start_token", C.c_int32)]
 
 
+class FnWeightImage(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("rows", C.c_int32), ("cols", C.c_int32), ("ld", C.c_int32), ("kind", C.c_int32)]
+
+
 class FnDecode(C.Structure):
     _fields_ = [("B", C.c_int32), ("steps", C.c_int32), ("H", C.c_int32), ("V", C.c_int32), ("start_token", C.c_int32),
                 ("w_hh1_frag", vp), ("b_hh1", vp), ("b_ih1", vp), ("table1", vp), ("rowbias1", vp), ("h0", vp),
@@ -58,6 +62,7 @@ SIGNATURES = {
     "fn_gru_gates_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "fn_frag_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "fn_frag_pack": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "fn_weight_images": (C.c_int, [C.POINTER(FnWeightImage), C.c_int, vp]),
     "fn_gru_sync_ws_bytes": (C.c_size_t, []),
     "fn_gru_seq_fwd": (C.c_int, [C.POINTER(FnGruFwd), C.c_int, vp]),
     "fn_gru_seq_bwd": (C.c_int, [C.POINTER(FnGruBwd), C.c_int, vp]),

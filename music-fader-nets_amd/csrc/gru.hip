@@ -426,7 +426,86 @@ __global__ void frag_pack_kernel(const float* __restrict__ src, int rows, int K,
     }
 }
 
+// ---- all weight images of one optimiser step in ONE launch (fn_weight_images) -------------------------------------------------------
+// job kinds: 0 = dst [C][R] = src^T (src [R][C], leading dimension ld): the one-hot column table W_ih[:, :V]^T
+//            1 = fragment-major image of src [rows = R][K = C]                           (forward scans: W_hh, W_ih2, W_out)
+//            2 = fragment-major image of src^T, i.e. of the [rows = C][K = R] matrix    (backward scans: W_hh^T) - no intermediate
+// The refresh after every Adam update used to be ~40 dependent launches of a few microseconds of work each (0.5 ms of the step).
+constexpr int WI_MAX_JOBS = 40;
+struct WiJob {
+    const float* src;
+    float* dst;
+    int R, C, ld, kind;
+};
+struct WiArgs {
+    WiJob job[WI_MAX_JOBS];
+};
+
+__global__ __launch_bounds__(256) void weight_images_kernel(const WiArgs a) {
+    const WiJob& J = a.job[blockIdx.y];
+    if (J.kind == 0) {
+        // LDS-tiled transpose, 32 x 32 tiles, grid-stride over tiles
+        __shared__ float t[32][33];
+        const int tr = (J.R + 31) / 32, tc = (J.C + 31) / 32;
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        for (int tile = blockIdx.x; tile < tr * tc; tile += gridDim.x) {
+            const int r0 = (tile / tc) * 32, c0 = (tile % tc) * 32;
+            for (int j = ty; j < 32; j += 8) {
+                const int r = r0 + j, c = c0 + tx;
+                t[j][tx] = (r < J.R && c < J.C) ? J.src[(long)r * J.ld + c] : 0.f;
+            }
+            __syncthreads();
+            for (int j = ty; j < 32; j += 8) {
+                const int c = c0 + j, r = r0 + tx;
+                if (r < J.R && c < J.C) J.dst[(long)c * J.R + r] = t[tx][j];
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    const int rows = J.kind == 1 ? J.R : J.C, K = J.kind == 1 ? J.C : J.R;
+    const int rows16 = (rows + 15) & ~15, NC = K >> 5;
+    const long total4 = (long)rows16 * (K >> 2);          // one item = 4 consecutive k of one row = 16 contiguous bytes of the image
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total4; i += (long)gridDim.x * 256L) {
+        // walk the IMAGE linearly (coalesced 16-byte stores): invert frag_off for the item's first float
+        const long o = i * 4;
+        const int lane = (int)((o >> 2) & 63), half = (int)((o >> 8) & 1);
+        const long blk = o >> 9;                            // (row >> 4) * NC + (k >> 5)
+        const int row = (int)(blk / NC) * 16 + (lane & 15);
+        const int k = (int)(blk % NC) * 32 + half * 16 + (lane >> 4) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < rows) {
+            if (J.kind == 1) {
+                const float* p = J.src + (long)row * J.ld + k;
+                v = make_float4(p[0], p[1], p[2], p[3]);
+            } else {
+                const float* p = J.src + (long)k * J.ld + row;
+                v = make_float4(p[0], p[J.ld], p[2L * J.ld], p[3L * J.ld]);
+            }
+        }
+        *reinterpret_cast<float4*>(J.dst + o) = v;
+    }
+}
+
 }  // namespace
+
+extern "C" int fn_weight_images(const FnWeightImage* jobs, int n_jobs, void* stream) {
+    if (!jobs) return FN_E_NULL;
+    if (n_jobs <= 0 || n_jobs > WI_MAX_JOBS) return FN_E_COUNT;
+    WiArgs a;
+    for (int j = 0; j < n_jobs; ++j) {
+        const FnWeightImage& d = jobs[j];
+        if (!d.src || !d.dst) return FN_E_NULL;
+        if (d.rows <= 0 || d.cols <= 0 || d.ld < d.cols || d.kind < 0 || d.kind > 2) return FN_E_SHAPE;
+        if (d.kind == 1 && (d.cols % 32)) return FN_E_SHAPE;
+        if (d.kind == 2 && (d.rows % 32)) return FN_E_SHAPE;
+        if (d.kind != 0 && (((uintptr_t)d.dst) & 15)) return FN_E_ALIGN;
+        a.job[j] = WiJob{d.src, d.dst, d.rows, d.cols, d.ld, d.kind};
+    }
+    hipLaunchKernelGGL(weight_images_kernel, dim3(128, n_jobs), dim3(256), 0, (hipStream_t)stream, a);
+    FN_CHECK_LAUNCH();
+    return FN_OK;
+}
 
 int launch_pack(const float* src, int rows, int K, long ld, float* dst, hipStream_t st) {
     const long total = (long)((rows + 15) & ~15) * (K >> 2);

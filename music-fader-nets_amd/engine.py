@@ -141,32 +141,29 @@ class Engine:
         }
 
     def refresh_weights(self, need_backward=True):
-        """Re-derive the transposed weight images after the parameters changed (once per optimiser step)."""
+        """Re-derive the transposed / fragment-major weight images after the parameters changed (once per optimiser step): ONE launch
+        for all of them (fn_weight_images)."""
         H = self.H
+        jobs = []
         for key, (pfx, sfx, V) in self._gru_sets().items():
             w_ih = self.p[pfx + "weight_ih" + sfx]
             if V > 0:
-                tab = self.buf("tab_" + key, (V, 3 * H))
-                self.ops.transpose(w_ih[:, :V], tab)
-                self.tab[key] = tab
+                self.tab[key] = self.buf("tab_" + key, (V, 3 * H))
+                jobs.append(("transpose", w_ih[:, :V], self.tab[key]))
             w_hh = self.p[pfx + "weight_hh" + sfx]
-            wf = self.buf("whhf_" + key, (self.ops.frag_floats(3 * H, H),))
-            self.ops.frag_pack(w_hh, wf)
-            self.whh_f[key] = wf
+            self.whh_f[key] = self.buf("whhf_" + key, (self.ops.frag_floats(3 * H, H),))
+            jobs.append(("frag", w_hh, self.whh_f[key]))
             if need_backward:
-                wt = self.buf("whht_rm_" + key, (H, 3 * H))
-                self.ops.transpose(w_hh, wt)
-                wtf = self.buf("whht_" + key, (self.ops.frag_floats(H, 3 * H),))
-                self.ops.frag_pack(wt, wtf)
-                self.whh_t[key] = wtf
+                self.whh_t[key] = self.buf("whht_" + key, (self.ops.frag_floats(H, 3 * H),))
+                jobs.append(("frag_t", w_hh, self.whh_t[key]))
         # operand images of the two dense matrices of the single-launch greedy decode (decode.py): refreshed here so that the
         # captured training step keeps them current - a decode after training must not see the weights of an earlier step
         for key, name in (("ih2", "grucell_g_2.weight_ih"), ("out", "linear_out_g.weight")):
             w = self.p[name]
-            img = self.packs.get(key)
-            if img is None:
-                img = self.packs[key] = torch.zeros(self.ops.frag_floats(w.shape[0], w.shape[1]), device=self.dev)
-            self.ops.frag_pack(w, img)
+            if key not in self.packs:
+                self.packs[key] = torch.zeros(self.ops.frag_floats(w.shape[0], w.shape[1]), device=self.dev)
+            jobs.append(("frag", w, self.packs[key]))
+        self.ops.weight_images(jobs)
 
     # ------------------------------------------------------------------------------------------
     # forward

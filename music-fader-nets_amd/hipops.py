@@ -131,6 +131,22 @@ class HipOps:
             raise RuntimeError("frag_pack: dst too small")
         _lib.check(self.lib.fn_frag_pack(ps, rows, K, ld, _p(dst), self.stream()), "fn_frag_pack")
 
+    def weight_images(self, jobs):
+        """jobs: (kind, src 2-D view, dst) with kind "transpose" (dst [C][R] contiguous), "frag" (fragment-major image of src) or
+        "frag_t" (fragment-major image of src^T) - all in ONE launch (fn_weight_images)"""
+        kinds = {"transpose": 0, "frag": 1, "frag_t": 2}
+        for i0 in range(0, len(jobs), 40):
+            part = jobs[i0:i0 + 40]
+            arr = (_lib.FnWeightImage * len(part))()
+            for d, (kind, src, dst) in zip(arr, part):
+                ps, R, Cc, ld = _mat(src, "src")
+                _dense(dst, name="dst")
+                need = R * Cc if kind == "transpose" else (self.frag_floats(R, Cc) if kind == "frag" else self.frag_floats(Cc, R))
+                if dst.numel() < need:
+                    raise RuntimeError("weight_images: dst too small for %s of %s" % (kind, tuple(src.shape)))
+                d.src, d.dst, d.rows, d.cols, d.ld, d.kind = ps, _p(dst), R, Cc, ld, kinds[kind]
+            _lib.check(self.lib.fn_weight_images(arr, len(part), self.stream()), "fn_weight_images")
+
     def _frag_ws(self, tag, i, n):
         return self.workspace(4 * n, "%s%d" % (tag, i))[:n]
 

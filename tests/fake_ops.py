@@ -147,6 +147,15 @@ class FakeOps:
         for p in range(T):
             out.index_add_(0, self._tok(fake, p), dgx_all[p])
 
+    def weight_images(self, jobs):
+        for kind, src, dst in jobs:
+            if kind == "transpose":
+                dst.view(src.shape[1], src.shape[0]).copy_(src.t())
+            elif kind == "frag":
+                self.frag_pack(src, dst)
+            else:
+                self.frag_pack(src.t().contiguous(), dst)
+
     def token_sort(self, idx, V, img=None):
         """handle of a sorted token matrix (the HIP backend keeps the sort image of fn_token_sort)"""
         return dict(idx=idx.clone(), V=V)

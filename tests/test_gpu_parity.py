@@ -929,3 +929,22 @@ def test_glsr_trainer_vs_reference():
     m.load_state_dict(glsr_fixture_weights(gold, H, Z))
     check_glsr(pkg, m, gold, DEV, tol_grad=2e-3, rtol_tuple=5e-4)
     assert not m.engine().ops.gru_sync_error()
+
+
+def test_weight_images_one_launch(ops):
+    """fn_weight_images (every transposed / fragment-major weight image of a step in one launch) == the single-matrix entry points"""
+    torch.manual_seed(17)
+    H, V = 96, 342
+    w_ih = torch.randn(3 * H, V + 40, device=DEV)
+    w_hh = torch.randn(3 * H, H, device=DEV)
+    w_out = torch.randn(V, H, device=DEV)
+    tab = torch.zeros(V, 3 * H, device=DEV)
+    f1, f2 = torch.zeros(ops.frag_floats(3 * H, H), device=DEV), torch.zeros(ops.frag_floats(H, 3 * H), device=DEV)
+    f3 = torch.zeros(ops.frag_floats(V, H), device=DEV)
+    ops.weight_images([("transpose", w_ih[:, :V], tab), ("frag", w_hh, f1), ("frag_t", w_hh, f2), ("frag", w_out, f3)])
+    assert torch.equal(tab, w_ih[:, :V].t())
+    r1, r2, r3 = torch.zeros_like(f1), torch.zeros_like(f2), torch.zeros_like(f3)
+    ops.frag_pack(w_hh, r1)
+    ops.frag_pack(w_hh.t().contiguous(), r2)
+    ops.frag_pack(w_out, r3)
+    assert torch.equal(f1, r1) and torch.equal(f2, r2) and torch.equal(f3, r3)
