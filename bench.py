@@ -137,18 +137,20 @@ def roofline_rows(records):
 
 
 def per_kernel_rooflines(trainer, batch, eps, reps=5):
-    """`reps` eager fwd+bwd passes (no optimiser update) under the TimedOps proxy -> per-kernel average launch durations (mean of all
-    launches, not the best) and their roofline fractions."""
+    """`reps` eager fwd+bwd passes (no optimiser update) under the TimedOps proxy, all lanes serialised on one stream -> per-kernel
+    average launch durations with each kernel running alone (mean of all launches, not the best) and their roofline fractions."""
     eng = trainer.model.engine()
     real = eng.ops
     proxy = TimedOps(real)
     eng.ops = proxy
-    try:
+    eng.serialize_lanes = True          # every lane on one stream: each kernel is timed running ALONE (as under rocprofv3 --pmc);
+    try:                                # in the real step GEMMs / segment sums overlap each other and the scans' launch tails
         for _ in range(reps):
             trainer.loss_and_grads(20000, batch, eps)
         torch.cuda.synchronize()
     finally:
         eng.ops = real
+        eng.serialize_lanes = False
     if real.gru_sync_error():
         raise RuntimeError("weight-stationary scan: a workgroup gave up waiting (sync error flag set)")
     return roofline_rows(proxy.records)

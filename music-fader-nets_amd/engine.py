@@ -45,6 +45,7 @@ class Engine:
         self.persist_dec = True         # decoder scans as weight-stationary launches (False: per-step kernels; debug / tests)
         self.single_launch_decode = True   # decode.py: <= 32 sequences decode as ONE launch (False: per-token kernels; tests)
         self._lane_alias = {}           # lane -> lane it is folded into (debug)
+        self.serialize_lanes = False    # True: every lane runs on the caller's stream (per-kernel measurements: each kernel alone)
         if hidden % 32 != 0:
             raise ValueError("hidden_dims must be a multiple of 32 (K chunks of the MFMA step kernels)")
         if n_component > 8:
@@ -57,7 +58,7 @@ class Engine:
     # most of the chip idle.  Each lane has its own scratch (ops.lane) so concurrent kernels never share a workspace.
     def _lane_stream(self, lane):
         """lane: "side" or "aux" -> its HIP stream (None on CPU test backends)."""
-        if self.dev.type != "cuda":
+        if self.dev.type != "cuda" or self.serialize_lanes:
             return None
         lane = self._lane_alias.get(lane, lane)
         streams = self.__dict__.setdefault("_streams", {})
@@ -101,7 +102,7 @@ class Engine:
             return
         get = lambda l: torch.cuda.current_stream(self.dev) if l == "main" else self._lane_stream(l)
         a, b = get(waiter), get(waited)
-        if a != b:
+        if a is not None and b is not None and a != b:
             a.wait_stream(b)
 
     def side_wait_main(self):
