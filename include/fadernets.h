@@ -54,6 +54,27 @@ int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha,
                 const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc,
                 const float* bias, int splitk, float* ws, size_t ws_bytes, void* stream);
 
+/* Up to 12 small independent GEMMs in ONE launch, each the sum of up to 4 products over separate operands (the heads of the path are
+ * chains of 256-row GEMMs: e.g. mu_r = [h_fwd | h_rev] W^T is two products into one output, gmm_model.py:85-86):
+ *   C_j[M,N] = sum_i opA(A_ji) opB(B_ji) + beta_j * C_j + bias_j      (a_kmajor / b_kmajor as in fn_gemm_f32, shared by all jobs) */
+typedef struct FnGemmSeg {
+    const float* A;
+    int32_t lda;
+    const float* B;
+    int32_t ldb;
+    int32_t K;
+} FnGemmSeg;
+typedef struct FnGemmJob {
+    int32_t M, N;
+    FnGemmSeg seg[4];
+    int32_t n_seg;
+    float beta;
+    float* C;
+    int32_t ldc;
+    const float* bias;
+} FnGemmJob;
+int fn_gemm_multi(int a_kmajor, int b_kmajor, const FnGemmJob* jobs, int n_jobs, void* stream);
+
 /* dst[c*dst_ld + r] = src[r*src_ld + c]  for r < R, c < C */
 int fn_transpose_f32(const float* src, int R, int C, int src_ld, float* dst, int dst_ld, void* stream);
 /* out[n] = beta*out[n] + sum_m X[m*ld + n]; ws >= fn_colsum_ws_bytes(M,N) */

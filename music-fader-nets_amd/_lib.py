@@ -36,6 +36,15 @@ class FnEmbedGrad(C.Structure):
                 ("idx_shift", C.c_int32), ("start_token", C.c_int32)]
 
 
+class FnGemmSeg(C.Structure):
+    _fields_ = [("A", vp), ("lda", C.c_int32), ("B", vp), ("ldb", C.c_int32), ("K", C.c_int32)]
+
+
+class FnGemmJob(C.Structure):
+    _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("seg", FnGemmSeg * 4), ("n_seg", C.c_int32), ("beta", C.c_float), ("C", vp),
+                ("ldc", C.c_int32), ("bias", vp)]
+
+
 class FnWeightImage(C.Structure):
     _fields_ = [("src", vp), ("dst", vp), ("rows", C.c_int32), ("cols", C.c_int32), ("ld", C.c_int32), ("kind", C.c_int32)]
 
@@ -54,6 +63,7 @@ SIGNATURES = {
     "fn_gemm_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "fn_gemm_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, C.c_int, vp, C.c_int,
                               C.c_float, vp, C.c_int, vp, C.c_int, vp, C.c_size_t, vp]),
+    "fn_gemm_multi": (C.c_int, [C.c_int, C.c_int, C.POINTER(FnGemmJob), C.c_int, vp]),
     "fn_transpose_f32": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     "fn_colsum_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "fn_colsum_f32": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, C.c_size_t, vp]),

@@ -76,6 +76,75 @@ __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alp
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Several small, independent GEMMs in ONE launch (blockIdx.z = job), each the sum of up to 4 (A_i, B_i) products over its own K range:
+//     C_j = sum_i op(A_ji) op(B_ji) + beta_j C_j + bias_j
+// The head / latent / dz phases of the step are chains of 256-row GEMMs that take a few microseconds each but a launch boundary apiece
+// (8 launches for the four mu / var heads alone, each head = forward half + reverse half of the encoder state): 64 x 64 tiles.
+constexpr int GM_MAX_JOBS = 12, GM_MAX_SEG = 4;
+struct GmSeg {
+    const float* A;
+    const float* B;
+    int lda, ldb, K;
+};
+struct GmJob {
+    GmSeg seg[GM_MAX_SEG];
+    float* C;
+    const float* bias;
+    int M, N, ldc, nseg;
+    float beta;
+};
+struct GmArgs {
+    GmJob job[GM_MAX_JOBS];
+};
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(NT) void gemm_multi_kernel(const GmArgs args) {
+    constexpr int BM = 64, BN = 64, BK = 16, WM = 2, WN = 2, TM = BM / WM / 16, TN = BN / WN / 16;
+    using SA = Stage<BM, BK, AKC, NT>;
+    using SB = Stage<BN, BK, BKC, NT>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const GmJob& J = args.job[blockIdx.z];
+    const int ntn = (J.N + BN - 1) / BN, ntm = (J.M + BM - 1) / BM;
+    if ((int)blockIdx.x >= ntn * ntm) return;
+    const int m0 = (blockIdx.x / ntn) * BM, n0 = (blockIdx.x % ntn) * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const RowsPlain ra{m0, J.M}, rb{n0, J.N};
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int sI = 0; sI < J.nseg; ++sI) {
+        const GmSeg& S = J.seg[sI];
+        const float* A = S.A;
+        const float* B = S.B;
+        const long lda = S.lda, ldb = S.ldb;
+        const int K = S.K, nk = (K + BK - 1) / BK;
+        auto loadA = [&](int k0, SA& st) { st.load_checked(A, lda, ra, k0, K); };
+        auto loadB = [&](int k0, SB& st) { st.load_checked(B, ldb, rb, k0, K); };
+        fn_kloop<PF_DEPTH, TM, TN, BK, SA, SB>(smem, nk, loadA, loadB, wm * TM * 16, wn * TN * 16, lane, acc);
+    }
+    const int cj = lane & 15, rq = (lane >> 4) * 4;
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const int col = n0 + (wn * TN + n) * 16 + cj;
+            if (col >= J.N) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = m0 + (wm * TM + m) * 16 + rq + i;
+                if (row >= J.M) continue;
+                float o = acc[m][n][i];
+                if (J.bias) o += J.bias[col];
+                if (J.beta != 0.f) o += J.beta * J.C[(long)row * J.ldc + col];
+                J.C[(long)row * J.ldc + col] = o;
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // "TN" GEMM for the weight gradients  C[M][N] = sum_k A[k][m] B[k][n]  (both operands stored [K][rows], rows contiguous:
 // dgx [T*B][3H], h [T*B][H], dlogits [T*B][344]).  No LDS and no barrier: with this storage the MFMA fragments can be
 // read straight from global memory with full-width coalesced loads - lane (i = l&15, g = l>>4) loads the float4
@@ -296,6 +365,41 @@ int launch_gemm(int ak, int bk, int M, int N, int K, float alpha, const float* A
 }  // namespace
 
 extern "C" {
+
+int fn_gemm_multi(int a_kmajor, int b_kmajor, const FnGemmJob* jobs, int n_jobs, void* stream) {
+    if (!jobs) return FN_E_NULL;
+    if (n_jobs <= 0 || n_jobs > GM_MAX_JOBS) return FN_E_COUNT;
+    GmArgs a;
+    int maxtiles = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const FnGemmJob& d = jobs[j];
+        if (!d.C || d.n_seg <= 0 || d.n_seg > GM_MAX_SEG || d.M <= 0 || d.N <= 0 || d.ldc < d.N) return d.C ? FN_E_SHAPE : FN_E_NULL;
+        GmJob& J = a.job[j];
+        for (int i = 0; i < d.n_seg; ++i) {
+            const FnGemmSeg& sg = d.seg[i];
+            if (!sg.A || !sg.B) return FN_E_NULL;
+            if (sg.K <= 0 || sg.lda < (a_kmajor ? sg.K : d.M) || sg.ldb < (b_kmajor ? sg.K : d.N)) return FN_E_SHAPE;
+            J.seg[i] = GmSeg{sg.A, sg.B, sg.lda, sg.ldb, sg.K};
+        }
+        J.C = d.C; J.bias = d.bias; J.M = d.M; J.N = d.N; J.ldc = d.ldc; J.nseg = d.n_seg; J.beta = d.beta;
+        const int tiles = ((d.M + 63) / 64) * ((d.N + 63) / 64);
+        maxtiles = tiles > maxtiles ? tiles : maxtiles;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(maxtiles, 1, n_jobs);
+#define FN_GM_LAUNCH(AK, BKK)                                                                        \
+    {                                                                                                \
+        const size_t sh = 2 * (Stage<64, 16, AK, NT>::WORDS + Stage<64, 16, BKK, NT>::WORDS) * sizeof(float); \
+        hipLaunchKernelGGL((gemm_multi_kernel<AK, BKK>), grid, dim3(NT), sh, st, a);                 \
+    }
+    if (a_kmajor && b_kmajor) FN_GM_LAUNCH(true, true)
+    else if (a_kmajor && !b_kmajor) FN_GM_LAUNCH(true, false)
+    else if (!a_kmajor && !b_kmajor) FN_GM_LAUNCH(false, false)
+    else FN_GM_LAUNCH(false, true)
+#undef FN_GM_LAUNCH
+    FN_CHECK_LAUNCH();
+    return FN_OK;
+}
 
 size_t fn_gemm_ws_bytes(int M, int N, int splitk) { return splitk > 1 ? (size_t)splitk * M * N * sizeof(float) : 0; }
 

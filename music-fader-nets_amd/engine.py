@@ -183,13 +183,14 @@ class Engine:
                                   h_all=hall[key], gates=self.buf("enc_g_" + key, (T, ops.gates_floats(B, H))) if save else None))
         ops.gru_seq_fwd(scans)
         pre = {"h_all": hall, "gates": {sc_key: sc["gates"] for sc_key, sc in zip(hall, scans)}}
+        jobs = []
         for e in ("r", "n"):
             hf, hb = hall[e][T - 1], hall[e + "_reverse"][T - 1]
             pre[e] = self.buf("pre_" + e, (B, 2 * Z))
-            for head, c0 in (("mu_", 0), ("var_", Z)):
-                W, bias = P[head + e + ".weight"], P[head + e + ".bias"]
-                ops.gemm(hf, W[:, :H], pre[e][:, c0:c0 + Z], bias=bias)
-                ops.gemm(hb, W[:, H:], pre[e][:, c0:c0 + Z], beta=1.0)
+            for head, c0 in (("mu_", 0), ("var_", Z)):          # [h_fwd | h_rev] W^T + b: two products into one output (gmm_model.py:85-86)
+                W = P[head + e + ".weight"]
+                jobs.append(dict(C=pre[e][:, c0:c0 + Z], segs=[(hf, W[:, :H]), (hb, W[:, H:])], bias=P[head + e + ".bias"]))
+        ops.gemm_multi(jobs)                                     # the four heads of both encoders: one launch
         return pre
 
     def latent(self, pre, eps, labels=None):
@@ -209,17 +210,19 @@ class Engine:
         ops, P, H = self.ops, self.p, self.H
         B, Tr = r.shape
         scans, sd = [], {}
+        jobs = []
         for e, attr, Ce, z in (("r", r, R_DIMS, z_r), ("n", n, N_DIMS, z_n)):
             h0 = self.buf("sd_h0_" + e, (B, H))
-            ops.gemm(z, P["linear_init_%s.weight" % e], h0, bias=P["linear_init_%s.bias" % e])
+            jobs.append(dict(C=h0, segs=[(z, P["linear_init_%s.weight" % e])], bias=P["linear_init_%s.bias" % e]))
             w_ih = P["gru_d_%s.weight_ih_l0" % e]
             rb = self.buf("sd_rb_" + e, (B, 3 * H))
-            ops.gemm(z, w_ih[:, Ce:], rb)
+            jobs.append(dict(C=rb, segs=[(z, w_ih[:, Ce:])]))
             sd[e] = dict(h0=h0, rb=rb, h_all=self.buf("sd_h_" + e, (Tr, B, H)),
                          gates=self.buf("sd_g_" + e, (Tr, ops.gates_floats(B, H))) if save else None)
             scans.append(dict(B=B, T=Tr, H=H, w_hh_frag=self.whh_f["d_" + e], b_hh=P["gru_d_%s.bias_hh_l0" % e],
                               b_ih=P["gru_d_%s.bias_ih_l0" % e], h0=h0, gx_table=self.tab["d_" + e], idx=attr, gx_rowbias=rb,
                               h_all=sd[e]["h_all"], gates=sd[e]["gates"]))
+        ops.gemm_multi(jobs)                                     # initial states + per-sequence input parts of both decoders: one launch
         ops.gru_seq_fwd(scans)
         for e, Ce in (("r", R_DIMS), ("n", N_DIMS)):
             sd[e]["logits"] = self.buf("sd_logits_" + e, (Tr, B, Ce))
@@ -242,9 +245,9 @@ class Engine:
         ops, P, H = self.ops, self.p, self.H
         B, T = d.shape
         h0g = self.buf("g_h0", (B, H))
-        ops.gemm(zc, P["linear_init_global.weight"], h0g, bias=P["linear_init_global.bias"])
         rbg = self.buf("g_rb", (B, 3 * H))
-        ops.gemm(zc, P["grucell_g.weight_ih"][:, E_VOCAB:], rbg)
+        ops.gemm_multi([dict(C=h0g, segs=[(zc, P["linear_init_global.weight"])], bias=P["linear_init_global.bias"]),
+                        dict(C=rbg, segs=[(zc, P["grucell_g.weight_ih"][:, E_VOCAB:])])])
         hx0 = self.buf("g_hx0", (T, B, H))
         g1 = self.buf("g_gates1", (T, ops.gates_floats(B, H))) if save else None
         l1 = dict(B=B, T=T, H=H, w_hh_frag=self.whh_f["g"], b_hh=P["grucell_g.bias_hh"], b_ih=P["grucell_g.bias_ih"],
@@ -496,14 +499,12 @@ class Engine:
         ops.gru_seq_bwd([self._bwd_chunk(sds[e], 0, Tr, None, sdb[e]["dh0"]) for e in ("r", "n")], persistent=pd)
         # ---- what the encoder side needs from the decoders (main stream, critical path): dz ---------------------
         Wz_g, Wig = P["grucell_g.weight_ih"], P["linear_init_global.weight"]
-        for e, c0 in (("r", 0), ("n", Z)):
-            gz = lat_up[e]["g_z"]
-            ops.gemm(drb_g, Wz_g[:, E_VOCAB + c0:E_VOCAB + c0 + Z], gz, a_k=True, b_k=False, beta=1.0)
-            ops.gemm(dh0_g, Wig[:, c0:c0 + Z], gz, a_k=True, b_k=False, beta=1.0)
-        for e, Ce in (("r", R_DIMS), ("n", N_DIMS)):
-            gz = lat_up[e]["g_z"]
-            ops.gemm(sdb[e]["drb"], P["gru_d_%s.weight_ih_l0" % e][:, Ce:], gz, a_k=True, b_k=False, beta=1.0)
-            ops.gemm(sdb[e]["dh0"], P["linear_init_%s.weight" % e], gz, a_k=True, b_k=False, beta=1.0)
+        jobs = []
+        for e, c0, Ce in (("r", 0, R_DIMS), ("n", Z, N_DIMS)):      # four products into each g_z (it already holds the regulariser's part)
+            jobs.append(dict(C=lat_up[e]["g_z"], beta=1.0,
+                             segs=[(drb_g, Wz_g[:, E_VOCAB + c0:E_VOCAB + c0 + Z]), (dh0_g, Wig[:, c0:c0 + Z]),
+                                   (sdb[e]["drb"], P["gru_d_%s.weight_ih_l0" % e][:, Ce:]), (sdb[e]["dh0"], P["linear_init_%s.weight" % e])]))
+        ops.gemm_multi(jobs, a_k=True, b_k=False)
         # ---- decoder-side PARAMETER gradients: side stream, overlapping the latent block and the encoder scans ---
         self.side_wait_main()
         with self.on_side():
@@ -540,14 +541,13 @@ class Engine:
             hf = pre["h_all"][e][T - 1]
             hb = pre["h_all"][e + "_reverse"][T - 1]
             dhf, dhb = self.buf("enc_dhf_" + e, (B, H)), self.buf("enc_dhb_" + e, (B, H))
-            for i, (head, c0) in enumerate((("mu_", 0), ("var_", Z))):
-                W = P[head + e + ".weight"]                     # [Z][2H]
-                dp = dpre[:, c0:c0 + Z]
-                ops.gemm(dp, W[:, :H], dhf, a_k=True, b_k=False, beta=float(i))
-                ops.gemm(dp, W[:, H:], dhb, a_k=True, b_k=False, beta=float(i))
-                dW = G[head + e + ".weight"]
-                ops.gemm(dp, hf, dW[:, :H], a_k=False, b_k=False)
-                ops.gemm(dp, hb, dW[:, H:], a_k=False, b_k=False)
+            Wm, Wv = P["mu_" + e + ".weight"], P["var_" + e + ".weight"]      # [Z][2H]
+            dpm, dpv = dpre[:, :Z], dpre[:, Z:]
+            ops.gemm_multi([dict(C=dhf, segs=[(dpm, Wm[:, :H]), (dpv, Wv[:, :H])]), dict(C=dhb, segs=[(dpm, Wm[:, H:]), (dpv, Wv[:, H:])])],
+                           a_k=True, b_k=False)
+            ops.gemm_multi([dict(C=G[head + e + ".weight"][:, c0:c0 + H], segs=[(dp, hh)])
+                            for head, dp in (("mu_", dpm), ("var_", dpv)) for c0, hh in ((0, hf), (H, hb))], a_k=False, b_k=False)
+            for head, dp in (("mu_", dpm), ("var_", dpv)):
                 ops.colsum(dp, G[head + e + ".bias"])
             for key, dh in ((e, dhf), (e + "_reverse", dhb)):
                 encb[key] = dict(dgx=self.buf("enc_dgx_" + key, (T, B, 3 * H)), dghn=self.buf("enc_dghn_" + key, (T, B, H)),

@@ -47,10 +47,8 @@ class SingleEncEngine(Engine):
         ops.gru_seq_fwd(scans)
         pre = self.buf("pre_e", (B, 2 * Z))
         hf, hb = hall["e"][T - 1], hall["e_reverse"][T - 1]
-        for head, c0 in (("mu", 0), ("var", Z)):
-            W, bias = P[head + ".weight"], P[head + ".bias"]
-            ops.gemm(hf, W[:, :H], pre[:, c0:c0 + Z], bias=bias)
-            ops.gemm(hb, W[:, H:], pre[:, c0:c0 + Z], beta=1.0)
+        ops.gemm_multi([dict(C=pre[:, c0:c0 + Z], segs=[(hf, P[head + ".weight"][:, :H]), (hb, P[head + ".weight"][:, H:])],
+                             bias=P[head + ".bias"]) for head, c0 in (("mu", 0), ("var", Z))])
         return dict(pre=pre, h_all=hall, gates=gates)
 
     def latent1(self, pre, eps):
@@ -94,8 +92,8 @@ class SingleEncEngine(Engine):
         sk_T = self._splitk(T * B)
         gd = self._bwd_global_decoder_scans(S)
         drb_g, dh0_g = gd["drb_g"], gd["dh0_g"]
-        ops.gemm(drb_g, P["grucell_g.weight_ih"][:, E_VOCAB:E_VOCAB + Z], g_z, a_k=True, b_k=False, beta=1.0)
-        ops.gemm(dh0_g, P["linear_init_global.weight"][:, :Z], g_z, a_k=True, b_k=False, beta=1.0)
+        ops.gemm_multi([dict(C=g_z, beta=1.0, segs=[(drb_g, P["grucell_g.weight_ih"][:, E_VOCAB:E_VOCAB + Z]),
+                                                    (dh0_g, P["linear_init_global.weight"][:, :Z])])], a_k=True, b_k=False)
         self.side_wait_main()
         with self.on_side():
             self._bwd_global_decoder_params(G, S, gd)

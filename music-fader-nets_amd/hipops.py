@@ -89,6 +89,27 @@ class HipOps:
         _lib.check(self.lib.fn_gemm_f32(int(a_k), int(b_k), M, N, K, alpha, pa, lda, pb, ldb, beta, pc, ldc, _p(bias), splitk,
                                         _p(ws), wsb, self.stream()), "fn_gemm_f32")
 
+    def gemm_multi(self, jobs, a_k=True, b_k=True):
+        """jobs: dicts(C=2-D view, segs=[(A, B), ...] (<= 4 products summed), beta=0.0, bias=None) - independent GEMMs of one
+        (a_k, b_k) form in ONE launch (fn_gemm_multi); more than 12 jobs are split into several launches"""
+        for i0 in range(0, len(jobs), 12):
+            part = jobs[i0:i0 + 12]
+            arr = (_lib.FnGemmJob * len(part))()
+            for d, j in zip(arr, part):
+                pc, M, N, ldc = _mat(j["C"], "C")
+                _chk(j.get("bias"), name="bias")
+                d.M, d.N, d.C, d.ldc, d.bias, d.beta, d.n_seg = M, N, pc, ldc, _p(j.get("bias")), float(j.get("beta", 0.0)), len(j["segs"])
+                if not 1 <= len(j["segs"]) <= 4:
+                    raise RuntimeError("gemm_multi: 1..4 products per job")
+                for sg, (A, B) in zip(d.seg, j["segs"]):
+                    pa, ar, ac, lda = _mat(A, "A")
+                    pb, br, bc, ldb = _mat(B, "B")
+                    K = ac if a_k else ar
+                    if (ar if a_k else ac) != M or (br if b_k else bc) != N or (bc if b_k else br) != K:
+                        raise RuntimeError("gemm_multi shape mismatch A%s B%s C%s" % (tuple(A.shape), tuple(B.shape), (M, N)))
+                    sg.A, sg.lda, sg.B, sg.ldb, sg.K = pa, lda, pb, ldb, K
+            _lib.check(self.lib.fn_gemm_multi(int(a_k), int(b_k), arr, len(part), self.stream()), "fn_gemm_multi")
+
     def transpose(self, src, dst):
         ps, R, Cc, sld = _mat(src, "src")
         pd, dr, dc, dld = _mat(dst, "dst")

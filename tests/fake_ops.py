@@ -147,6 +147,17 @@ class FakeOps:
         for p in range(T):
             out.index_add_(0, self._tok(fake, p), dgx_all[p])
 
+    def gemm_multi(self, jobs, a_k=True, b_k=True):
+        for j in jobs:
+            acc = 0
+            for A, B in j["segs"]:
+                acc = acc + (A if a_k else A.t()) @ (B.t() if b_k else B)
+            beta = float(j.get("beta", 0.0))
+            out = acc + beta * j["C"] if beta != 0.0 else acc          # C may be uninitialised memory when beta == 0
+            if j.get("bias") is not None:
+                out = out + j["bias"]
+            j["C"].copy_(out)
+
     def weight_images(self, jobs):
         for kind, src, dst in jobs:
             if kind == "transpose":

@@ -948,3 +948,30 @@ def test_weight_images_one_launch(ops):
     ops.frag_pack(w_hh.t().contiguous(), r2)
     ops.frag_pack(w_out, r3)
     assert torch.equal(f1, r1) and torch.equal(f2, r2) and torch.equal(f3, r3)
+
+
+@pytest.mark.parametrize("a_k,b_k", [(True, True), (True, False), (False, False)])
+def test_gemm_multi(ops, a_k, b_k):
+    """several small GEMMs, each a sum of products over separate operands, in one launch (odd sizes, strided views, beta, bias)"""
+    torch.manual_seed(77)
+    jobs_d, refs = [], []
+    for M, N, Ks in ((256, 128, (512, 512)), (37, 70, (33,)), (256, 1536, (128,)), (130, 64, (20, 48, 16, 100))):
+        C0 = torch.randn(M, N + 6)
+        bias = torch.randn(N)
+        beta = 0.0 if len(Ks) == 1 else 1.0
+        segs_d, acc = [], beta * C0[:, :N].double() + bias.double()
+        for K in Ks:
+            A = torch.randn((M, K + 4) if a_k else (K, M + 4))
+            Bm = torch.randn((N, K + 8) if b_k else (K, N + 8))
+            Av = A[:, :K] if a_k else A[:, :M]
+            Bv = Bm[:, :K] if b_k else Bm[:, :N]
+            acc = acc + (Av if a_k else Av.t()).double() @ (Bv.t() if b_k else Bv).double()
+            Ad, Bd = g(A), g(Bm)
+            segs_d.append((Ad[:, :K] if a_k else Ad[:, :M], Bd[:, :K] if b_k else Bd[:, :N]))
+        Cd = g(C0.clone())
+        jobs_d.append(dict(C=Cd[:, :N], segs=segs_d, beta=beta, bias=g(bias)))
+        refs.append((Cd, acc.float(), C0, N))
+    ops.gemm_multi(jobs_d, a_k=a_k, b_k=b_k)
+    for Cd, ref, C0, N in refs:
+        close(Cd[:, :N], ref, 2e-5)
+        assert torch.equal(Cd[:, N:].cpu(), C0[:, N:])            # columns beyond N untouched
