@@ -45,6 +45,8 @@ class Engine:
         self.persist_dec = True         # decoder scans as weight-stationary launches (False: per-step kernels; debug / tests)
         self.single_launch_decode = True   # decode.py: <= 32 sequences decode as ONE launch (False: per-token kernels; tests)
         self._lane_alias = {}           # lane -> lane it is folded into (debug)
+        self.losses_on_side = True      # trainer: the small loss-term launches run on the side lane beside the decoder backward's first launches
+        self.buf_ns = ""                # namespace of buf(): a second decoder pass (GLSR) must not overwrite the saved activations of the first
         self.serialize_lanes = False    # True: every lane runs on the caller's stream (per-kernel measurements: each kernel alone)
         if hidden % 32 != 0:
             raise ValueError("hidden_dims must be a multiple of 32 (K chunks of the MFMA step kernels)")
@@ -120,7 +122,7 @@ class Engine:
         buffer is NEVER dropped or reallocated once handed out - another batch shape gets its own set (the epoch driver alternates
         train / validation / ragged-tail shapes, trainer_gmm.py:320-440, and replays the graph of each)."""
         shape = tuple(int(s) for s in shape)
-        key = (name, shape, dtype)
+        key = (self.buf_ns + name, shape, dtype)
         t = self._bufs.get(key)
         if t is None:
             t = torch.empty(shape, dtype=dtype, device=self.dev)
@@ -481,6 +483,7 @@ class Engine:
 
         # ---- global decoder: output layer + both cells, chunk-pipelined (see _bwd_global_decoder_scans) ----------------
         gd = self._bwd_global_decoder_scans(S)
+        self.main_wait_side()            # the caller's loss terms / gradient seeds of the sub-decoders and of z (side lane)
         dgx1, dghn1, dgx2, dghn2, rs2, rsn2, drb_g, rsn_g, dh0_g = (gd[k] for k in ("dgx1", "dghn1", "dgx2", "dghn2", "rs2", "rsn2", "drb_g", "rsn_g", "dh0_g"))
         dlog = dec["logits"]
         pd = self.persist_dec

@@ -13,9 +13,11 @@ ranks simply SUM their gradients and statistics:
   supervised:   + beta0 * mean_b KL_label [r,n] + CrossEntropy(softmax(qy), label) [r,n]            (:181-194)
   + pairwise tanh/sign regulariser on z[:,0] for r and n                                             (:199-217)
 """
+import contextlib
 import math
 
 import numpy as np
+
 import torch
 
 from .engine import E_VOCAB
@@ -127,17 +129,24 @@ class GMVAETrainer:
         nll = eng.buf("nll_rows", (T * B,))
         ops.vocab_logsoftmax(dec["logits"], B, T, E_VOCAB, target=d, nll_rows=nll,
                              grad_scale=5.0 / (Bg * T) if want_grads else 0.0, dlogits=dec["logits"] if want_grads else None)
-        ops.sum(nll, st[S_CE_X:S_CE_X + 1], 1.0 / (Bg * T))
-        dl_sd = {}
-        for slot, e, attr, Ce in ((S_CE_R, "r", r, 3), (S_CE_N, "n", n, 16)):
-            nbc = eng.buf("nll_bc_" + e, (B, Ce))
-            dl_sd[e] = eng.buf("sd_dlogits_" + e, (Tr, B, Ce)) if want_grads else None
-            ops.time_logsoftmax(dec["sd"][e]["logits"], target=attr, nll_bc=nbc, grad_scale=1.0 / (Bg * Tr), dlogits=dl_sd[e])
-            ops.sum(nbc, st[slot:slot + 1], 1.0 / (Bg * Tr))
-        # latent terms: column sums of the per-row terms written by fn_latent_fwd
-        for slot, e in ((S_TERMS_R, "r"), (S_TERMS_N, "n")):
-            ops.colsum(lat[e]["terms"], st[slot:slot + 4])
-        lat_up = self._regulariser(eng, S, batch, Bg, want_grads)
+        # Everything below is ~20 dependent launches of a few microseconds each; the decoder backward only needs the dlogits written
+        # above, so the rest runs on the side lane beside its first launches (Engine.backward joins the lane before it reads these).
+        if eng.losses_on_side:
+            eng.side_wait_main()
+        with (eng.on_side() if eng.losses_on_side else contextlib.nullcontext()):
+            ops.sum(nll, st[S_CE_X:S_CE_X + 1], 1.0 / (Bg * T))
+            dl_sd = {}
+            for slot, e, attr, Ce in ((S_CE_R, "r", r, 3), (S_CE_N, "n", n, 16)):
+                nbc = eng.buf("nll_bc_" + e, (B, Ce))
+                dl_sd[e] = eng.buf("sd_dlogits_" + e, (Tr, B, Ce)) if want_grads else None
+                ops.time_logsoftmax(dec["sd"][e]["logits"], target=attr, nll_bc=nbc, grad_scale=1.0 / (Bg * Tr), dlogits=dl_sd[e])
+                ops.sum(nbc, st[slot:slot + 1], 1.0 / (Bg * Tr))
+            # latent terms: column sums of the per-row terms written by fn_latent_fwd
+            for slot, e in ((S_TERMS_R, "r"), (S_TERMS_N, "n")):
+                ops.colsum(lat[e]["terms"], st[slot:slot + 4])
+            lat_up = self._regulariser(eng, S, batch, Bg, want_grads)
+        if not want_grads:
+            eng.main_wait_side()
         return dl_sd, lat_up, self.sp[0:3], beta0, Bg
 
     def _regulariser(self, eng, S, batch, Bg, want_grads):

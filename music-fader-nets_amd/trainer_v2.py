@@ -317,7 +317,11 @@ class GLSRTrainer(GMVAETrainer):
             zc = eng.buf("glsr_zc", base.shape)
             zc.copy_(base)
             zc[:, 0 if attr == 0 else Z] += sign * deltas[attr]
-            return eng.global_decoder_tf(d100, zc, save=save)
+            eng.buf_ns = "glsr/"             # own buffers: the main pass's saved decoder state (same shapes for B x H tensors) stays intact
+            try:
+                return eng.global_decoder_tf(d100, zc, save=save)
+            finally:
+                eng.buf_ns = ""
 
         sums = eng.buf("glsr_sums", (st_ * B, 2))
         mass = {}
@@ -364,7 +368,11 @@ class GLSRTrainer(GMVAETrainer):
                 S2["dec"] = decode(attr, sign, True)
                 wdev.copy_(torch.from_numpy(w[(attr, sign)]).view(st_ * B, 2))
                 ops.masked_prob(S2["dec"]["logits"], E_VOCAB, ranges, w=wdev, dlogits=S2["dec"]["logits"])
-                gd = eng._bwd_global_decoder_scans(S2)
+                eng.buf_ns = "glsr/"
+                try:
+                    gd = eng._bwd_global_decoder_scans(S2)
+                finally:
+                    eng.buf_ns = ""
                 ops.gemm(gd["drb_g"], P["grucell_g.weight_ih"][:, E_VOCAB:], gzc, a_k=True, b_k=False, beta=1.0)
                 ops.gemm(gd["dh0_g"], P["linear_init_global.weight"], gzc, a_k=True, b_k=False, beta=1.0)
                 self.flat2.zero_()
