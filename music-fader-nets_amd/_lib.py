@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libfadernets_hip.so")
 
 FN_MAX_SCANS = 8
 ABI_VERSION = 3
+GEMM_LEAN = 0x10000          # FN_GEMM_LEAN
 FN_E_UNSUPPORTED = -6
 _f = C.POINTER(C.c_float)
 _i = C.POINTER(C.c_int32)

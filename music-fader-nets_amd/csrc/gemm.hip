@@ -156,10 +156,10 @@ __global__ __launch_bounds__(NT) void gemm_multi_kernel(const GmArgs args) {
 FN_DEVINL float f4c(const f32x4& v, int j) { return v[j]; }
 
 template <int PF>
-__global__ __launch_bounds__(NT) void gemm_tn_kernel(int M, int N, int K, float alpha, const float* __restrict__ A, long lda,
-                                                     const float* __restrict__ B, long ldb, float beta, float* __restrict__ C, long ldc,
-                                                     const float* __restrict__ bias, int ksplit_len, float* __restrict__ slabs,
-                                                     const float* __restrict__ A2, long lda2, int msplit) {
+FN_DEVINL void gemm_tn_body(int M, int N, int K, float alpha, const float* __restrict__ A, long lda,
+                            const float* __restrict__ B, long ldb, float beta, float* __restrict__ C, long ldc,
+                            const float* __restrict__ bias, int ksplit_len, float* __restrict__ slabs,
+                            const float* __restrict__ A2, long lda2, int msplit) {
     const int ntn = (N + 127) / 128, ntm = (M + 127) / 128;
     const int tile = fn_xcd_remap(blockIdx.x, ntn * ntm);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -254,6 +254,24 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(int M, int N, int K, float 
                 }
             }
         }
+}
+
+__global__ __launch_bounds__(NT) void gemm_tn_kernel(int M, int N, int K, float alpha, const float* __restrict__ A, long lda,
+                                                     const float* __restrict__ B, long ldb, float beta, float* __restrict__ C, long ldc,
+                                                     const float* __restrict__ bias, int ksplit_len, float* __restrict__ slabs,
+                                                     const float* __restrict__ A2, long lda2, int msplit) {
+    gemm_tn_body<8>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, ksplit_len, slabs, A2, lda2, msplit);
+}
+
+// The same product for the idle MFMA cycles of a weight-stationary scan: <= 128 vector registers per wavefront (4 wavefronts per SIMD
+// requested), so that one fits beside a scan wavefront (336-376 of the SIMD's 512 registers); 4 k-steps of operands in flight instead
+// of 8 - beside a scan it is issue-starved, not latency-bound.  s_setprio 0 (the scans run at 3): it only takes what they leave.
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void gemm_tn_lean_kernel(int M, int N, int K, float alpha, const float* __restrict__ A, long lda,
+                         const float* __restrict__ B, long ldb, float beta, float* __restrict__ C, long ldc,
+                         const float* __restrict__ bias, int ksplit_len, float* __restrict__ slabs,
+                         const float* __restrict__ A2, long lda2, int msplit) {
+    gemm_tn_body<4>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, ksplit_len, slabs, A2, lda2, msplit);
 }
 
 // C = alpha * sum_s slabs[s] + beta*C + bias
@@ -407,6 +425,8 @@ int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha, co
                 float beta, float* C, int ldc, const float* bias, int splitk, float* ws, size_t ws_bytes, void* stream) {
     if (!A || !B || !C) return FN_E_NULL;
     if (M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return FN_E_SHAPE;
+    const bool lean = (splitk & FN_GEMM_LEAN) != 0;
+    splitk &= ~FN_GEMM_LEAN;
     if (splitk > 1 && (!ws || ws_bytes < fn_gemm_ws_bytes(M, N, splitk))) return FN_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (!a_kmajor && !b_kmajor && (lda % 4) == 0 && (ldb % 4) == 0 && lda >= 4 && ldb >= 4 &&
@@ -418,7 +438,7 @@ int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha, co
         }
         const int ntm = (M + 127) / 128, ntn = (N + 127) / 128;
         float* slabs = splitk > 1 ? ws : nullptr;
-        hipLaunchKernelGGL(gemm_tn_kernel<8>, dim3(ntm * ntn, 1, splitk > 1 ? splitk : 1), dim3(NT), 0, st, M, N, K, alpha, A, (long)lda, B,
+        hipLaunchKernelGGL(lean ? gemm_tn_lean_kernel : gemm_tn_kernel, dim3(ntm * ntn, 1, splitk > 1 ? splitk : 1), dim3(NT), 0, st, M, N, K, alpha, A, (long)lda, B,
                            (long)ldb, beta, C, (long)ldc, bias, klen, slabs, (const float*)nullptr, 0L, 0);
         FN_CHECK_LAUNCH();
         if (splitk > 1) {
@@ -443,6 +463,8 @@ int fn_gru_dwhh_f32(const float* dgx, const float* dghn, const float* hprev, int
                     float* ws, size_t ws_bytes, void* stream) {
     if (!dgx || !dghn || !hprev || !dW) return FN_E_NULL;
     if (rows <= 0 || rows > 0x7fffffff || H <= 0) return FN_E_SHAPE;
+    const bool lean = (splitk & FN_GEMM_LEAN) != 0;
+    splitk &= ~FN_GEMM_LEAN;
     if (splitk > 1 && (!ws || ws_bytes < fn_gru_dwhh_ws_bytes(H, splitk))) return FN_E_WORKSPACE;
     const int M = 3 * H, N = H, K = (int)rows;
     const bool one_launch = (2 * H) % 128 == 0 && (H % 4) == 0 && (((((uintptr_t)dgx) | ((uintptr_t)dghn) | ((uintptr_t)hprev)) & 15) == 0);
@@ -459,7 +481,7 @@ int fn_gru_dwhh_f32(const float* dgx, const float* dghn, const float* hprev, int
     }
     const int ntm = (M + 127) / 128, ntn = (N + 127) / 128;
     float* slabs = splitk > 1 ? ws : nullptr;
-    hipLaunchKernelGGL(gemm_tn_kernel<8>, dim3(ntm * ntn, 1, splitk > 1 ? splitk : 1), dim3(NT), 0, st, M, N, K, 1.0f, dgx, (long)3 * H, hprev,
+    hipLaunchKernelGGL(lean ? gemm_tn_lean_kernel : gemm_tn_kernel, dim3(ntm * ntn, 1, splitk > 1 ? splitk : 1), dim3(NT), 0, st, M, N, K, 1.0f, dgx, (long)3 * H, hprev,
                        (long)H, beta, dW, (long)H, (const float*)nullptr, klen, slabs, dghn, (long)H, 2 * H);
     FN_CHECK_LAUNCH();
     if (splitk > 1) {

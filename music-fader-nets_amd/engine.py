@@ -45,6 +45,7 @@ class Engine:
         self.persist_dec = True         # decoder scans as weight-stationary launches (False: per-step kernels; debug / tests)
         self.single_launch_decode = True   # decode.py: <= 32 sequences decode as ONE launch (False: per-token kernels; tests)
         self._lane_alias = {}           # lane -> lane it is folded into (debug)
+        self.lean_dw = True             # decoder-side weight-gradient GEMMs as the <= 128-register instance: one of its wavefronts fits on a SIMD beside an encoder-scan wavefront (374 of 512 registers), the 194-register instance waits for the scan to end
         self.losses_on_side = True      # trainer: the small loss-term launches run on the side lane beside the decoder backward's first launches
         self.buf_ns = ""                # namespace of buf(): a second decoder pass (GLSR) must not overwrite the saved activations of the first
         self.serialize_lanes = False    # True: every lane runs on the caller's stream (per-kernel measurements: each kernel alone)
@@ -361,7 +362,7 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     # backward
     # ------------------------------------------------------------------------------------------
-    def _gru_weight_grads(self, key, pfx, sfx, T, B, dgx, dghn, h_all, h0, G, splitk, rs, rsn):
+    def _gru_weight_grads(self, key, pfx, sfx, T, B, dgx, dghn, h_all, h0, G, splitk, rs, rsn, lean=False):
         """dW_hh / db_hh of one scan from the saved per-step gate gradients (batched over all steps); the bias gradients
         are column sums of the per-sequence row sums rs [B][3H] / rsn [B][H] accumulated by the backward scan."""
         ops, H = self.ops, self.H
@@ -369,7 +370,7 @@ class Engine:
         dgx2 = dgx.view(T * B, 3 * H)
         dgn2 = dghn.view(T * B, H)
         if T > 1:
-            ops.gru_dwhh(dgx2[B:], dgn2[B:], h_all.view(T * B, H)[: (T - 1) * B], dW, splitk=splitk)
+            ops.gru_dwhh(dgx2[B:], dgn2[B:], h_all.view(T * B, H)[: (T - 1) * B], dW, splitk=splitk, lean=lean)
         else:
             dW.zero_()
         if h0 is not None:
@@ -448,12 +449,13 @@ class Engine:
         hx1f, hx0f = dec["hx1"].view(T * B, H), dec["hx0"].view(T * B, H)
         dgx1, dghn1, dgx2, dghn2, rs2, rsn2, drb_g, rsn_g, dh0_g = (gd[k] for k in ("dgx1", "dghn1", "dgx2", "dghn2", "rs2", "rsn2", "drb_g", "rsn_g", "dh0_g"))
         # 342 x 512 output: only 12 tiles of 128 x 128 - a deeper K split fills the chip (42 x 12 = 504 workgroups: 258 vs 325 us)
-        ops.gemm(dlog[:, :E_VOCAB], hx1f, G["linear_out_g.weight"], a_k=False, b_k=False, splitk=42 if T * B >= 32768 else sk_T)
+        ln = self.lean_dw
+        ops.gemm(dlog[:, :E_VOCAB], hx1f, G["linear_out_g.weight"], a_k=False, b_k=False, splitk=42 if T * B >= 32768 else sk_T, lean=ln)
         ops.colsum(dlog[:, :E_VOCAB], G["linear_out_g.bias"])
-        self._gru_weight_grads("g2", "grucell_g_2.", "", T, B, dgx2, dghn2, dec["hx1"], dec["hx0"][0], G, sk_T, rs2, rsn2)
-        ops.gemm(dgx2.view(T * B, 3 * H), hx0f, G["grucell_g_2.weight_ih"], a_k=False, b_k=False, splitk=sk_T)
+        self._gru_weight_grads("g2", "grucell_g_2.", "", T, B, dgx2, dghn2, dec["hx1"], dec["hx0"][0], G, sk_T, rs2, rsn2, lean=ln)
+        ops.gemm(dgx2.view(T * B, 3 * H), hx0f, G["grucell_g_2.weight_ih"], a_k=False, b_k=False, splitk=sk_T, lean=ln)
         ops.colsum(rs2, G["grucell_g_2.bias_ih"])
-        self._gru_weight_grads("g", "grucell_g.", "", T, B, dgx1, dghn1, dec["hx0"], dec["h0g"], G, sk_T, drb_g, rsn_g)
+        self._gru_weight_grads("g", "grucell_g.", "", T, B, dgx1, dghn1, dec["hx0"], dec["h0g"], G, sk_T, drb_g, rsn_g, lean=ln)
         dWg = G["grucell_g.weight_ih"]                          # [3H][E+ZG]: token columns = segment sums, written in place
         ops.embed_grad_sorted(S["sort"]["d"], [dict(dgx=dgx1, out=dWg[:, :E_VOCAB], transposed=True, idx_shift=-1, start_token=E_VOCAB - 1)])
         ops.gemm(drb_g, dec["zc"], dWg[:, E_VOCAB:], a_k=False, b_k=False)
@@ -519,7 +521,7 @@ class Engine:
                 ops.gemm(dl, sd[e]["h_all"].view(Tr * B, H), G["linear_out_%s.weight" % e], a_k=False, b_k=False, splitk=sk_Tr)
                 ops.colsum(dl, G["linear_out_%s.bias" % e])
                 self._gru_weight_grads("d_" + e, pfx, "_l0", Tr, B, sdb[e]["dgx"], sdb[e]["dghn"], sd[e]["h_all"], sd[e]["h0"], G, sk_Tr,
-                                       sdb[e]["drb"], sdb[e]["rsn"])
+                                       sdb[e]["drb"], sdb[e]["rsn"], lean=self.lean_dw)
                 dW = G[pfx + "weight_ih_l0"]                        # [3H][Ce+Z]
                 ops.embed_grad_sorted(S["sort"][e], [dict(dgx=sdb[e]["dgx"], out=dW[:, :Ce], transposed=True)])
                 ops.gemm(sdb[e]["drb"], z, dW[:, Ce:], a_k=False, b_k=False)

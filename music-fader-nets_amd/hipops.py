@@ -74,7 +74,7 @@ class HipOps:
         return cur
 
     # -- dense ----------------------------------------------------------------------------------
-    def gemm(self, A, B, Cm, a_k=True, b_k=True, alpha=1.0, beta=0.0, bias=None, splitk=1):
+    def gemm(self, A, B, Cm, a_k=True, b_k=True, alpha=1.0, beta=0.0, bias=None, splitk=1, lean=False):
         pa, ar, ac, lda = _mat(A, "A")
         pb, br, bc, ldb = _mat(B, "B")
         pc, M, N, ldc = _mat(Cm, "C")
@@ -84,9 +84,10 @@ class HipOps:
         _chk(bias, name="bias")
         ws, wsb = None, 0
         if splitk > 1:
-            wsb = self.lib.fn_gemm_ws_bytes(M, N, splitk)
+            wsb = self.lib.fn_gemm_ws_bytes(M, N, splitk & 0xffff)
             ws = self.workspace(wsb, "gemm")
-        _lib.check(self.lib.fn_gemm_f32(int(a_k), int(b_k), M, N, K, alpha, pa, lda, pb, ldb, beta, pc, ldc, _p(bias), splitk,
+        _lib.check(self.lib.fn_gemm_f32(int(a_k), int(b_k), M, N, K, alpha, pa, lda, pb, ldb, beta, pc, ldc, _p(bias),
+                                        splitk | (_lib.GEMM_LEAN if lean else 0),
                                         _p(ws), wsb, self.stream()), "fn_gemm_f32")
 
     def gemm_multi(self, jobs, a_k=True, b_k=True):
@@ -263,7 +264,7 @@ class HipOps:
             d.dgx_rowsum, d.dghn_rowsum, d.scratch = _p(s.get("dgx_rowsum")), _p(s.get("dghn_rowsum")), _p(s["scratch"])
         _lib.check(self.lib.fn_gru_seq_bwd(arr, len(scans), self.stream()), "fn_gru_seq_bwd")
 
-    def gru_dwhh(self, dgx, dghn, hprev, dW, beta=0.0, splitk=1):
+    def gru_dwhh(self, dgx, dghn, hprev, dW, beta=0.0, splitk=1, lean=False):
         """dW [3H][H] = beta*dW + [dgx[:, :2H] | dghn]^T hprev  (dgx [rows][3H], dghn / hprev [rows][H])."""
         for t, nm in ((dgx, "dgx"), (dghn, "dghn"), (hprev, "hprev"), (dW, "dW")):
             _dense(t, name=nm)
@@ -272,7 +273,8 @@ class HipOps:
             raise RuntimeError("gru_dwhh shape mismatch")
         wsb = int(self.lib.fn_gru_dwhh_ws_bytes(H, splitk))
         ws = self.workspace(wsb, "gemm") if wsb else None
-        _lib.check(self.lib.fn_gru_dwhh_f32(_p(dgx), _p(dghn), _p(hprev), rows, H, beta, _p(dW), splitk, _p(ws), wsb, self.stream()), "fn_gru_dwhh_f32")
+        _lib.check(self.lib.fn_gru_dwhh_f32(_p(dgx), _p(dghn), _p(hprev), rows, H, beta, _p(dW), splitk | (_lib.GEMM_LEAN if lean else 0),
+                                            _p(ws), wsb, self.stream()), "fn_gru_dwhh_f32")
 
     def decode_greedy(self, B, steps, H, V, start_token, w_hh1_frag, b_hh1, b_ih1, table1, rowbias1, h0, w_ih2_frag, b_ih2, w_hh2_frag, b_hh2,
                       w_out_frag, b_out, tokens, logp=None):

@@ -20,7 +20,7 @@ class FakeOps:
         self.lane = ""
 
     # -- dense --------------------------------------------------------------------------------------
-    def gemm(self, A, B, Cm, a_k=True, b_k=True, alpha=1.0, beta=0.0, bias=None, splitk=1):
+    def gemm(self, A, B, Cm, a_k=True, b_k=True, alpha=1.0, beta=0.0, bias=None, splitk=1, lean=False):
         self.calls.append("gemm")
         a = A if a_k else A.t()
         b = B.t() if b_k else B
@@ -135,7 +135,7 @@ class FakeOps:
             if s.get("dh0") is not None:
                 s["dh0"].copy_(carry)
 
-    def gru_dwhh(self, dgx, dghn, hprev, dW, beta=0.0, splitk=1):
+    def gru_dwhh(self, dgx, dghn, hprev, dW, beta=0.0, splitk=1, lean=False):
         H = hprev.shape[1]
         g = torch.cat([dgx[:, : 2 * H], dghn], dim=1)
         dW.copy_(beta * dW + g.t() @ hprev)

@@ -64,6 +64,26 @@ def test_gemm(ops, a_k, b_k, M, N, K, splitk):
     close(Cd, ref.float(), 1e-5, "gemm")
 
 
+@pytest.mark.parametrize("M,N,K,splitk", [(1536, 512, 4099, 8), (342, 512, 2048, 4), (200, 130, 515, 1)])
+def test_gemm_lean_instance(ops, M, N, K, splitk):
+    """fn_gemm_f32 with splitk | FN_GEMM_LEAN (the <= 128-register weight-gradient instance that fits beside a scan wavefront): same k
+    order, so the result is bit-identical to the default instance; also through fn_gru_dwhh_f32."""
+    torch.manual_seed(M + K)
+    A, B = g(torch.randn(K, M)), g(torch.randn(K, N))
+    C0, C1 = torch.zeros(M, N, device=DEV), torch.zeros(M, N, device=DEV)
+    ops.gemm(A, B, C0, a_k=False, b_k=False, splitk=splitk)
+    ops.gemm(A, B, C1, a_k=False, b_k=False, splitk=splitk, lean=True)
+    assert torch.equal(C0, C1)
+    close(C1, (A.double().t() @ B.double()).float(), 1e-5, "lean gemm")
+    if M == 1536:
+        H = 512
+        dgx, dghn, hp = g(torch.randn(K, 3 * H)), g(torch.randn(K, H)), g(torch.randn(K, H))
+        W0, W1 = torch.zeros(3 * H, H, device=DEV), torch.zeros(3 * H, H, device=DEV)
+        ops.gru_dwhh(dgx, dghn, hp, W0, splitk=splitk)
+        ops.gru_dwhh(dgx, dghn, hp, W1, splitk=splitk, lean=True)
+        assert torch.equal(W0, W1)
+
+
 def test_gemm_is_transpose_detecting(ops):
     """identity A with an ASYMMETRIC B: catches a swapped C-write (cdna guide rule 16)."""
     n = 96
