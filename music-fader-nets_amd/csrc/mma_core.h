@@ -229,10 +229,12 @@ FN_DEVINL void fn_kloop(float* __restrict__ smem, int nk, const FA& loadA, const
 // Gate non-linearities on the hardware transcendental units: exp2 (v_exp_f32) + reciprocal (v_rcp_f32), ~1 ulp each.
 // |error| <= ~2e-7 absolute, far below the fp32 tolerance of the parity tests, and ~10x fewer instructions than
 // expf / tanhf / IEEE division - the gate epilogue was measured at 1.8 us of a 10 us step otherwise.
-FN_DEVINL float fn_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+// __builtin_amdgcn_rcpf IS v_rcp_f32; __frcp_rn (what this used to call) is the correctly rounded 1/x, which hipcc expands into the
+// v_div_scale / v_rcp / 4 fma / v_div_fmas / v_div_fixup sequence - 12 of them per (row, 4 units) item, ~1 k cycles of a 36 k-cycle step.
+FN_DEVINL float fn_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 FN_DEVINL float fn_tanh(float x) {
     const float e = __expf(-2.0f * fabsf(x));            // in (0, 1]: no overflow
-    const float t = (1.0f - e) * __frcp_rn(1.0f + e);
+    const float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
     return copysignf(t, x);
 }
 
