@@ -93,7 +93,10 @@ def _classify(name, a, k):
         if 2.0 * M * N * Kk >= 2e10:
             return ("gemm_nt" if k.get("b_k", True) else ("gemm_nn" if k.get("a_k", True) else "gemm_tn")), 2.0 * M * N * Kk
         return None
-    if name in ("vocab_logsoftmax", "out_head_loss"):
+    if name == "out_head":                                 # fused output head: the projection's flops (the softmax rides in its epilogue)
+        h, W = a[0], a[1]
+        return "out_head", 2.0 * h.shape[0] * W.shape[0] * h.shape[1]
+    if name == "vocab_logsoftmax":
         return "out_head_softmax", None
     return None
 
@@ -109,6 +112,7 @@ ROW_INFO = {   # row -> (bound, unit of work, kernel, peak share of the chip)
     "gemm_tn": ("mfma", "flop", "gemm_tn_kernel (dW of dense layers)", 1.0),
     "gemm_nt": ("mfma", "flop", "gemm_kernel (X W^T: W_ih2 projection, output layer)", 1.0),
     "gemm_nn": ("mfma", "flop", "gemm_kernel (dY W: input gradients)", 1.0),
+    "out_head": ("mfma", "flop", "out_head_kernel (512 -> 342 projection + log-softmax + NLL + gradient seed, logits never written)", 1.0),
     "embed_grad": ("hbm", "bytes", "eg_piece_kernel + eg_final_kernel: token-segment sums of the gate-gradient rows (embed.hip)", 1.0),
 }
 

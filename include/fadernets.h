@@ -275,6 +275,17 @@ int fn_decode_greedy(const FnDecode* d, void* stream);
  *   dlogits  [T*B][ld] or NULL   grad_scale * (softmax - onehot(target))   (may alias logits)  */
 int fn_vocab_logsoftmax(const float* logits, int B, int T, int E, int ld, float* logp_bt, const int32_t* target,
                         float* nll_rows, float grad_scale, float* dlogits, void* stream);
+/* The same head FUSED with its projection (gmm_model.py:137 `log_softmax(linear_out_g(hx[1]))` + trainer_gmm.py:131-132 `nll_loss` and
+ * their autograd): logits = h W^T + bias never reach memory.
+ *   h        [T*B][ldh] time-major rows (row = t*B + b), H valid columns (the layer-2 states)
+ *   W        [V][ldw]   linear_out_g.weight, bias [V];  V <= 384 (else FN_E_UNSUPPORTED)
+ *   target   [B][T] int32
+ *   nll_rows [T*B] or NULL       -log_softmax(logits)[target]
+ *   dlogits  [T*B][ld] or NULL   grad_scale * (softmax - onehot(target)); ld a multiple of 4, V <= ld <= 384, 16-byte aligned;
+ *                                columns [V, ld) are written as zeros
+ * The logits are bit-identical to fn_gemm_f32's (same k order); the row sums run in a different order than fn_vocab_logsoftmax's. */
+int fn_out_head_f32(const float* h, int ldh, const float* W, int ldw, const float* bias, int B, int T, int V, int H,
+                    const int32_t* target, float grad_scale, float* nll_rows, float* dlogits, int ld, void* stream);
 /* generic backward of the same log_softmax: dlogits[row] = g - softmax * sum(g), g = gout_bt[b][t][:] */
 int fn_vocab_logsoftmax_bwd(const float* logp_bt, const float* gout_bt, int B, int T, int E, int ld, float* dlogits,
                             void* stream);

@@ -93,6 +93,7 @@ SIGNATURES = {
     "fn_time_sum_f32": (C.c_int, [vp, C.c_int, C.c_int64, vp, vp]),
     "fn_vocab_logsoftmax": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_float, vp, vp]),
     "fn_vocab_logsoftmax_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "fn_out_head_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_float, vp, vp, C.c_int, vp]),
     "fn_vocab_argmax": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp, C.c_int, vp]),
     "fn_time_logsoftmax": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_float, vp, vp]),
     "fn_time_logsoftmax_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),

@@ -274,6 +274,132 @@ void gemm_tn_lean_kernel(int M, int N, int K, float alpha, const float* __restri
     gemm_tn_body<4>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, ksplit_len, slabs, A2, lda2, msplit);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Output head of the teacher-forced decoder in ONE kernel: logits = h W^T + b (512 -> 342), log-softmax over the vocabulary, NLL of the
+// target token and the gradient seed grad_scale * (softmax - onehot) - gmm_model.py:137 + trainer_gmm.py:131-132 and their autograd.
+// The logits never reach HBM (unfused: 90 MB written by the GEMM, read and rewritten by the softmax kernel at the benchmark shape).
+// Workgroup = 64 rows x all vocabulary columns (384 = 24 column tiles of 16, columns >= V are padding), waves 2 x 2: wave (wm, wn) owns
+// rows [32 wm, 32 wm + 32) x columns [192 wn, 192 wn + 192) - 14 LDS fragment reads per 48 MFMAs (a 4 x 1 layout with complete rows per
+// wave needs 25 and was LDS-bound: 60 TFLOP/s); the row maximum / sum of the two column halves meet through LDS.  Same k order as
+// gemm_kernel -> the logits are bit-identical to the unfused product.  The gradient rows leave through LDS as aligned float4 rows.
+constexpr int OH_BM = 64, OH_BN = 384, OH_BK = 16, OH_LDT = OH_BN + 4;
+size_t out_head_lds_bytes() {
+    const size_t stage = (size_t)2 * (Stage<OH_BM, OH_BK, true, NT>::WORDS + Stage<OH_BN, OH_BK, true, NT>::WORDS) * sizeof(float);
+    const size_t rows = (size_t)(OH_BM / 2) * OH_LDT * sizeof(float) + 4 * OH_BM * sizeof(float);      // half the rows at a time + row statistics
+    return stage > rows ? stage : rows;
+}
+
+__global__ __launch_bounds__(NT, 2) void out_head_kernel(const float* __restrict__ h, long ldh, const float* __restrict__ W, long ldw,
+                                                         const float* __restrict__ bias, int R, int V, int K, int B, int T,
+                                                         const int* __restrict__ target, float grad_scale, float* __restrict__ nll_rows,
+                                                         float* __restrict__ dlogits, long ld) {
+    constexpr int TM = 2, TN = OH_BN / 2 / 16;
+    using SA = Stage<OH_BM, OH_BK, true, NT>;
+    using SB = Stage<OH_BN, OH_BK, true, NT>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int m0 = blockIdx.x * OH_BM;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const RowsPlain ra{m0, R}, rb{0, V};
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nk = (K + OH_BK - 1) / OH_BK;
+    if (SA::can_fast(h, ldh, ra, K) && SB::can_fast(W, ldw, rb, K)) {
+        auto loadA = [&](int k0, SA& st) { st.load_fast(h, ldh, ra, k0); };
+        auto loadB = [&](int k0, SB& st) { st.load_fast(W, ldw, rb, k0); };
+        fn_kloop<PF_DEPTH, TM, TN, OH_BK, SA, SB>(smem, nk, loadA, loadB, wm * 32, wn * (OH_BN / 2), lane, acc);
+    } else {
+        auto loadA = [&](int k0, SA& st) { st.load_checked(h, ldh, ra, k0, K); };
+        auto loadB = [&](int k0, SB& st) { st.load_checked(W, ldw, rb, k0, K); };
+        fn_kloop<PF_DEPTH, TM, TN, OH_BK, SA, SB>(smem, nk, loadA, loadB, wm * 32, wn * (OH_BN / 2), lane, acc);
+    }
+    // (the K loop ended with a barrier: the staging buffers are free)
+    // D[row = 16 m + (lane>>4)*4 + i][col = 192 wn + 16 n + (lane&15)]; row statistics of the two column halves meet in stat[]
+    float* stat = smem + (OH_BM / 2) * OH_LDT;          // [2 halves][64 rows] maxima, then [2][64] sums
+    const int cj = lane & 15, rq = (lane >> 4) * 4, c0 = wn * (OH_BN / 2);
+    float mxr[TM][4], lser[TM][4];
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+        const int col = c0 + 16 * n + cj;
+        const float bv = col < V ? bias[col] : 0.f;
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[m][n][i] += bv;
+    }
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+                if (c0 + 16 * n + cj < V) mx = fmaxf(mx, acc[m][n][i]);
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            if (cj == 0) stat[wn * OH_BM + wm * 32 + 16 * m + rq + i] = mx;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rl = wm * 32 + 16 * m + rq + i;
+            const float mx = fmaxf(stat[rl], stat[OH_BM + rl]);
+            mxr[m][i] = mx;
+            float sum = 0.f;
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+                if (c0 + 16 * n + cj < V) sum += expf(acc[m][n][i] - mx);
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+            if (cj == 0) stat[2 * OH_BM + wn * OH_BM + rl] = sum;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rl = wm * 32 + 16 * m + rq + i;
+            const int row = m0 + rl;
+            const float lse = mxr[m][i] + logf(stat[2 * OH_BM + rl] + stat[3 * OH_BM + rl]);    // half 0 + half 1: the same order in both waves
+            lser[m][i] = lse;
+            const int rc = min(row, R - 1);
+            const int tg = target[(long)(rc % B) * T + rc / B];
+#pragma unroll
+            for (int n = 0; n < TN; ++n) {
+                const int col = c0 + 16 * n + cj;
+                const float l = acc[m][n][i] - lse;
+                if (col == tg && row < R && nll_rows) nll_rows[row] = -l;
+                acc[m][n][i] = col < V ? grad_scale * (expf(l) - (col == tg ? 1.0f : 0.0f)) : 0.f;
+            }
+        }
+    if (!dlogits) return;
+    // gradient rows -> LDS -> aligned float4 rows, 32 rows (one wm) at a time: half the LDS, two workgroups per CU
+    const int nq = (int)(ld >> 2);                      // float4 per output row (ld is a multiple of 4, <= OH_BN)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();                                // statistics read / previous half written out
+        if (wm == half) {
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) smem[(16 * m + rq + i) * OH_LDT + c0 + 16 * n + cj] = acc[m][n][i];
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 32 * nq; idx += NT) {
+            const int r = idx / nq, c4 = idx - r * nq;
+            const int row = m0 + half * 32 + r;
+            if (row < R) *reinterpret_cast<float4*>(dlogits + (long)row * ld + 4 * c4) = *reinterpret_cast<const float4*>(smem + r * OH_LDT + 4 * c4);
+        }
+    }
+}
+
 // C = alpha * sum_s slabs[s] + beta*C + bias
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, int S, int M, int N, float alpha, float beta,
                                    float* __restrict__ C, long ldc, const float* __restrict__ bias) {
@@ -383,6 +509,30 @@ int launch_gemm(int ak, int bk, int M, int N, int K, float alpha, const float* A
 }  // namespace
 
 extern "C" {
+
+int fn_out_head_f32(const float* h, int ldh, const float* W, int ldw, const float* bias, int B, int T, int V, int H, const int32_t* target,
+                    float grad_scale, float* nll_rows, float* dlogits, int ld, void* stream) {
+    if (!h || !W || !bias || !target) return FN_E_NULL;
+    if (B <= 0 || T <= 0 || V <= 0 || H <= 0 || ldh < H || ldw < H) return FN_E_SHAPE;
+    if (V > OH_BN) return FN_E_UNSUPPORTED;
+    if (dlogits && (ld < V || ld > OH_BN || (ld & 3))) return FN_E_SHAPE;
+    if (dlogits && (((uintptr_t)dlogits) & 15)) return FN_E_ALIGN;
+    const long R = (long)B * T;
+    if (R > 0x7fffffff) return FN_E_SHAPE;
+    static bool attr_set[32] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return FN_E_SHAPE;
+    const size_t lds = out_head_lds_bytes();
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(out_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(out_head_kernel, dim3((unsigned)((R + OH_BM - 1) / OH_BM)), dim3(NT), lds, (hipStream_t)stream, h, (long)ldh, W, (long)ldw,
+                       bias, (int)R, V, H, B, T, target, grad_scale, nll_rows, dlogits, (long)ld);
+    FN_CHECK_LAUNCH();
+    return FN_OK;
+}
 
 int fn_gemm_multi(int a_kmajor, int b_kmajor, const FnGemmJob* jobs, int n_jobs, void* stream) {
     if (!jobs) return FN_E_NULL;

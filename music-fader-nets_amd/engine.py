@@ -45,6 +45,7 @@ class Engine:
         self.persist_dec = True         # decoder scans as weight-stationary launches (False: per-step kernels; debug / tests)
         self.single_launch_decode = True   # decode.py: <= 32 sequences decode as ONE launch (False: per-token kernels; tests)
         self._lane_alias = {}           # lane -> lane it is folded into (debug)
+        self.fused_head = True          # trainers: output projection + log-softmax + NLL + gradient seed as ONE kernel (fn_out_head_f32); False: GEMM -> logits in HBM -> fn_vocab_logsoftmax
         self.lean_dw = True             # decoder-side weight-gradient GEMMs as the <= 128-register instance: one of its wavefronts fits on a SIMD beside an encoder-scan wavefront (374 of 512 registers), the 194-register instance waits for the scan to end
         self.losses_on_side = True      # trainer: the small loss-term launches run on the side lane beside the decoder backward's first launches
         self.buf_ns = ""                # namespace of buf(): a second decoder pass (GLSR) must not overwrite the saved activations of the first
@@ -242,9 +243,10 @@ class Engine:
         zc[:, 2 * Z:].copy_(c)
         return zc
 
-    def global_decoder_tf(self, d, zc, save=True):
+    def global_decoder_tf(self, d, zc, save=True, head=True):
         """gmm_model.py:119-149 in train mode (teacher forced with d, start token 341, input shifted by one step) up to the
-        pre-softmax logits [T*B][LOGIT_LD]."""
+        pre-softmax logits [T*B][LOGIT_LD].  head=False: the output projection is left to the caller's fused head
+        (ops.out_head on dec['hx1'], which writes the gradient seed into dec['logits']); the buffer is returned unwritten."""
         ops, P, H = self.ops, self.p, self.H
         B, T = d.shape
         h0g = self.buf("g_h0", (B, H))
@@ -301,13 +303,14 @@ class Engine:
                 with Engine._Lane(self, True, lane):
                     ops.gemm(hx0[t0:t1].view(-1, H), P["grucell_g_2.weight_ih"], gx2[t0:t1].view(-1, 3 * H), bias=P["grucell_g_2.bias_ih"])
         logits = self.buf("g_logits", (T * B, LOGIT_LD))
-        ops.gemm(hx1.view(T * B, H), P["linear_out_g.weight"], logits[:, :E_VOCAB], bias=P["linear_out_g.bias"])
+        if head:
+            ops.gemm(hx1.view(T * B, H), P["linear_out_g.weight"], logits[:, :E_VOCAB], bias=P["linear_out_g.bias"])
         return dict(zc=zc, h0g=h0g, rbg=rbg, hx0=hx0, g1=g1, gx2=gx2, hx1=hx1, g2=g2, logits=logits)
 
-    def decoders(self, d, r, n, c, z_r, z_n, save=True):
+    def decoders(self, d, r, n, c, z_r, z_n, save=True, head=True):
         """sub-decoders + teacher-forced global decoder up to the (pre-softmax) logits."""
         sd = self.sub_decoders_fwd(r, n, z_r, z_n, save)
-        dec = self.global_decoder_tf(d, self.pack_zc(z_r, z_n, c), save)
+        dec = self.global_decoder_tf(d, self.pack_zc(z_r, z_n, c), save, head)
         dec["sd"] = sd
         return dec
 
@@ -342,9 +345,9 @@ class Engine:
         c["dh0"] = carry_out
         return c
 
-    def forward(self, d, r, n, c, eps_r, eps_n, labels=None, save=True):
+    def forward(self, d, r, n, c, eps_r, eps_n, labels=None, save=True, head=True):
         """Full training-mode forward up to logits; everything backward needs stays in named buffers (save=False: forward only,
-        the gate tensors are not written)."""
+        the gate tensors are not written).  head=False: see global_decoder_tf."""
         sort = None
         if save:
             # token sorts for the backward's segment sums (embed.hip): tiny kernels, side stream, beside the encoder scans
@@ -353,7 +356,7 @@ class Engine:
                 sort = {k: ops_sort(self, k, t, V) for k, t, V in (("d", d, E_VOCAB), ("r", r, R_DIMS), ("n", n, N_DIMS))}
         pre = self.encode(d, save)
         lat = self.latent(pre, {"r": eps_r, "n": eps_n}, labels)
-        dec = self.decoders(d, r, n, c, lat["r"]["z"], lat["n"]["z"], save)
+        dec = self.decoders(d, r, n, c, lat["r"]["z"], lat["n"]["z"], save, head)
         self.main_wait_side()
         S = dict(d=d, r=r, n=n, c=c, eps={"r": eps_r, "n": eps_n}, labels=labels, pre=pre, lat=lat, dec=dec, sort=sort)
         self.saved = S if save else None

@@ -66,7 +66,7 @@ class SingleEncEngine(Engine):
         zc[:, Z:].copy_(cond)
         return zc
 
-    def forward(self, d, cond, eps, extra=None, save=True):
+    def forward(self, d, cond, eps, extra=None, save=True, head=True):
         sort = None
         if save:
             self.side_wait_main()
@@ -74,7 +74,7 @@ class SingleEncEngine(Engine):
                 sort = {"d": ops_sort(self, "d", d, E_VOCAB)}
         enc = self.encode(d, extra, save)
         lat = self.latent1(enc["pre"], eps)
-        dec = self.global_decoder_tf(d, self.pack_zc(lat["z"], cond), save)
+        dec = self.global_decoder_tf(d, self.pack_zc(lat["z"], cond), save, head)
         self.main_wait_side()
         S = dict(d=d, cond=cond, extra=extra, eps=eps, enc=enc, lat=lat, dec=dec, sort=sort)
         self.saved = S if save else None

@@ -363,6 +363,22 @@ class HipOps:
         _lib.check(self.lib.fn_vocab_logsoftmax(pl, B, T, E, ld, _p(logp_bt), _p(target), _p(nll_rows), grad_scale, _p(dlogits),
                                                 self.stream()), "fn_vocab_logsoftmax")
 
+    def out_head(self, h, W, bias, B, T, target, nll_rows=None, grad_scale=0.0, dlogits=None):
+        """fused output head (fn_out_head_f32): h [T*B][H] time-major rows, W [V][H], bias [V], target [B][T] int32 ->
+        nll_rows [T*B] and / or dlogits [T*B][ld] = grad_scale * (softmax(h W^T + b) - onehot); the logits are not materialised"""
+        ph, R, H, ldh = _mat(h, "h")
+        pw, V, Hw, ldw = _mat(W, "W")
+        if R != B * T or Hw != H:
+            raise RuntimeError("out_head shape mismatch h%s W%s B=%d T=%d" % (tuple(h.shape), tuple(W.shape), B, T))
+        _dense(bias, name="bias"), _dense(target, torch.int32, "target"), _dense(nll_rows, name="nll_rows")
+        pd, ld = None, 0
+        if dlogits is not None:
+            pd, rows, _, ld = _mat(dlogits, "dlogits")
+            if rows != R:
+                raise RuntimeError("out_head: dlogits has %d rows, expected %d" % (rows, R))
+        _lib.check(self.lib.fn_out_head_f32(ph, ldh, pw, ldw, _p(bias), B, T, V, H, _p(target), grad_scale, _p(nll_rows), pd, ld,
+                                            self.stream()), "fn_out_head_f32")
+
     def vocab_logsoftmax_bwd(self, logp_bt, gout_bt, dlogits):
         _dense(logp_bt, name="logp_bt"), _dense(gout_bt, name="gout_bt")
         B, T, E = logp_bt.shape

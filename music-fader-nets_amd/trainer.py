@@ -122,13 +122,18 @@ class GMVAETrainer:
         Z = eng.Z
         beta0 = beta_schedule(step, self.beta)
         self._step_now = step
-        S = eng.forward(d, r, n, c, eps[0], eps[1], labels)
+        fused = eng.fused_head
+        S = eng.forward(d, r, n, c, eps[0], eps[1], labels, head=not fused)
         dec, lat = S["dec"], S["lat"]
         st = self.stats
-        # reconstruction terms; the gradient seeds overwrite the logits in place
+        # reconstruction terms; the gradient seeds land where the logits would be (fused head: the logits are never written)
         nll = eng.buf("nll_rows", (T * B,))
-        ops.vocab_logsoftmax(dec["logits"], B, T, E_VOCAB, target=d, nll_rows=nll,
-                             grad_scale=5.0 / (Bg * T) if want_grads else 0.0, dlogits=dec["logits"] if want_grads else None)
+        gs = 5.0 / (Bg * T) if want_grads else 0.0
+        if fused:
+            ops.out_head(dec["hx1"].view(T * B, eng.H), eng.p["linear_out_g.weight"], eng.p["linear_out_g.bias"], B, T, d, nll_rows=nll,
+                         grad_scale=gs, dlogits=dec["logits"] if want_grads else None)
+        else:
+            ops.vocab_logsoftmax(dec["logits"], B, T, E_VOCAB, target=d, nll_rows=nll, grad_scale=gs, dlogits=dec["logits"] if want_grads else None)
         # Everything below is ~20 dependent launches of a few microseconds each; the decoder backward only needs the dlogits written
         # above, so the rest runs on the side lane beside its first launches (Engine.backward joins the lane before it reads these).
         if eng.losses_on_side:

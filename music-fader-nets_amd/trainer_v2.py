@@ -54,12 +54,17 @@ class _SingleEncTrainer(GMVAETrainer):
         d = batch[0]
         B, T = d.shape
         Bg = B if self.dist is None else self.dist.global_batch(B)
-        S = eng.forward(d, self._cond(batch), eps[0], self._enc_extra(batch), save=True)
+        fused = eng.fused_head
+        S = eng.forward(d, self._cond(batch), eps[0], self._enc_extra(batch), save=True, head=not fused)
         dec, lat = S["dec"], S["lat"]
         st = self.stats
         nll = eng.buf("nll_rows", (T * B,))
-        ops.vocab_logsoftmax(dec["logits"], B, T, E_VOCAB, target=d, nll_rows=nll,
-                             grad_scale=self.CE_WEIGHT / (Bg * T) if want_grads else 0.0, dlogits=dec["logits"] if want_grads else None)
+        gs = self.CE_WEIGHT / (Bg * T) if want_grads else 0.0
+        if fused:
+            ops.out_head(dec["hx1"].view(T * B, eng.H), eng.p["linear_out_g.weight"], eng.p["linear_out_g.bias"], B, T, d, nll_rows=nll,
+                         grad_scale=gs, dlogits=dec["logits"] if want_grads else None)
+        else:
+            ops.vocab_logsoftmax(dec["logits"], B, T, E_VOCAB, target=d, nll_rows=nll, grad_scale=gs, dlogits=dec["logits"] if want_grads else None)
         ops.sum(nll, st[S_CE_X:S_CE_X + 1], 1.0 / (Bg * T))
         ops.colsum(lat["terms"], st[S_TERMS_R:S_TERMS_R + 4])
         g_z = eng.zbuf("g_z_e", (B, eng.Z)) if want_grads else None

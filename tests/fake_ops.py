@@ -197,6 +197,13 @@ class FakeOps:
                 g.scatter_add_(2, tg.unsqueeze(-1), -torch.ones(T, B, 1))
                 dlogits[:, :E].copy_((grad_scale * g).view(T * B, E))
 
+    def out_head(self, h, W, bias, B, T, target, nll_rows=None, grad_scale=0.0, dlogits=None):
+        V = W.shape[0]
+        logits = h @ W.t() + bias
+        if dlogits is not None:
+            dlogits.zero_()
+        self.vocab_logsoftmax(logits, B, T, V, target=target, nll_rows=nll_rows, grad_scale=grad_scale, dlogits=dlogits)
+
     def vocab_logsoftmax_bwd(self, logp_bt, gout_bt, dlogits):
         B, T, E = logp_bt.shape
         g = gout_bt - logp_bt.exp() * gout_bt.sum(-1, keepdim=True)

@@ -84,6 +84,32 @@ def test_gemm_lean_instance(ops, M, N, K, splitk):
         assert torch.equal(W0, W1)
 
 
+@pytest.mark.parametrize("B,T,H,V,ld", [(256, 8, 512, 342, 344), (5, 7, 64, 342, 344), (3, 4, 96, 19, 20), (64, 1, 512, 384, 384)])
+def test_out_head_fused(ops, B, T, H, V, ld):
+    """fn_out_head_f32 (projection + log-softmax + NLL + gradient seed in one kernel) against the unfused pair fn_gemm_f32 ->
+    fn_vocab_logsoftmax and against fp64 torch; rows that do not fill a 64-row workgroup, padding columns, V = the tile width."""
+    torch.manual_seed(B * 31 + T)
+    h = g(torch.randn(T * B, H))
+    W, bias = g(torch.randn(V, H) * 0.2), g(torch.randn(V))
+    tgt = g(torch.randint(0, V, (B, T), dtype=torch.int32))
+    logits = torch.zeros(T * B, ld, device=DEV)
+    ops.gemm(h, W, logits[:, :V], bias=bias)
+    nll0, nll1 = torch.zeros(T * B, device=DEV), torch.full((T * B,), -1.0, device=DEV)
+    dl0 = torch.zeros(T * B, ld, device=DEV)
+    ops.vocab_logsoftmax(logits, B, T, V, target=tgt, nll_rows=nll0, grad_scale=0.37, dlogits=dl0)
+    dl1 = torch.full((T * B, ld), 7.0, device=DEV)
+    ops.out_head(h, W, bias, B, T, tgt, nll_rows=nll1, grad_scale=0.37, dlogits=dl1)
+    close(nll1, nll0, 2e-6, "fused nll vs unfused")
+    close(dl1[:, :V], dl0[:, :V], 2e-6, "fused dlogits vs unfused")
+    assert float(dl1[:, V:].abs().max()) == 0.0 if ld > V else True
+    ref = torch.log_softmax(h.double() @ W.double().t() + bias.double(), dim=-1).view(T, B, V)
+    tg = tgt.long().t()
+    close(nll1.view(T, B), -ref.gather(2, tg.unsqueeze(-1)).squeeze(-1).float(), 1e-5, "fused nll vs fp64")
+    nll2 = torch.zeros(T * B, device=DEV)
+    ops.out_head(h, W, bias, B, T, tgt, nll_rows=nll2)                       # evaluation form: no gradient seed
+    assert torch.equal(nll1, nll2)
+
+
 def test_gemm_is_transpose_detecting(ops):
     """identity A with an ASYMMETRIC B: catches a swapped C-write (cdna guide rule 16)."""
     n = 96
