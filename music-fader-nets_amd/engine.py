@@ -18,7 +18,7 @@ import math
 import torch
 
 E_VOCAB, R_DIMS, N_DIMS, C_DIMS = 342, 3, 16, 24
-LOGIT_LD = 344            # 342 padded to a 16-byte multiple so that the logits rows stay float4-aligned
+LOGIT_LD = 352            # 342 padded to a multiple of the GEMM K tile (32): the input gradient dlogits W_out then takes the branch-free operand loads (K = 344 did not: 308 -> 250 us); the pad columns are zero
 
 
 def ops_sort(eng, key, tokens, V):
@@ -119,7 +119,7 @@ class Engine:
         if st is not None:
             torch.cuda.current_stream(self.dev).wait_stream(st)
 
-    def buf(self, name, shape, dtype=torch.float32):
+    def buf(self, name, shape, dtype=torch.float32, zero_init=False):
         """Named scratch tensor.  The key includes the shape: a captured hipGraph holds raw pointers into these buffers, so a
         buffer is NEVER dropped or reallocated once handed out - another batch shape gets its own set (the epoch driver alternates
         train / validation / ragged-tail shapes, trainer_gmm.py:320-440, and replays the graph of each)."""
@@ -127,7 +127,7 @@ class Engine:
         key = (self.buf_ns + name, shape, dtype)
         t = self._bufs.get(key)
         if t is None:
-            t = torch.empty(shape, dtype=dtype, device=self.dev)
+            t = (torch.zeros if zero_init else torch.empty)(shape, dtype=dtype, device=self.dev)
             self._bufs[key] = t
         return t
 
@@ -168,7 +168,12 @@ class Engine:
             if key not in self.packs:
                 self.packs[key] = torch.zeros(self.ops.frag_floats(w.shape[0], w.shape[1]), device=self.dev)
             jobs.append(("frag", w, self.packs[key]))
+        if need_backward:                                    # linear_out_g.weight^T [H][LOGIT_LD], pad columns zero: B operand of the input gradient of the output layer
+            if getattr(self, "wout_t", None) is None:
+                self.wout_t = torch.zeros(H, LOGIT_LD, device=self.dev)
         self.ops.weight_images(jobs)
+        if need_backward:
+            self.ops.transpose(self.p["linear_out_g.weight"], self.wout_t[:, :E_VOCAB])
 
     # ------------------------------------------------------------------------------------------
     # forward
@@ -302,7 +307,7 @@ class Engine:
                 self.lane_wait(lane, "main")
                 with Engine._Lane(self, True, lane):
                     ops.gemm(hx0[t0:t1].view(-1, H), P["grucell_g_2.weight_ih"], gx2[t0:t1].view(-1, 3 * H), bias=P["grucell_g_2.bias_ih"])
-        logits = self.buf("g_logits", (T * B, LOGIT_LD))
+        logits = self.buf("g_logits", (T * B, LOGIT_LD), zero_init=True)     # columns [342, 352) stay zero: every writer leaves them alone or writes zeros
         if head:
             ops.gemm(hx1.view(T * B, H), P["linear_out_g.weight"], logits[:, :E_VOCAB], bias=P["linear_out_g.bias"])
         return dict(zc=zc, h0g=h0g, rbg=rbg, hx0=hx0, g1=g1, gx2=gx2, hx1=hx1, g2=g2, logits=logits)
@@ -393,9 +398,9 @@ class Engine:
         ops, P, H = self.ops, self.p, self.H
         dec = S["dec"]
         B, T = S["d"].shape
-        dlog = dec["logits"]                                   # [T*B][344], holds dlogits
+        dlog = dec["logits"]                                   # [T*B][LOGIT_LD], holds dlogits
         dhx1 = self.buf("g_dhx1", (T, B, H))
-        ops.gemm(dlog[:, :E_VOCAB], P["linear_out_g.weight"], dhx1.view(T * B, H), a_k=True, b_k=False)
+        ops.gemm(dlog, self.wout_t, dhx1.view(T * B, H), a_k=True, b_k=True)         # K = LOGIT_LD incl. the zero pad columns: whole K tiles
         dgx2 = self.buf("g_dgx2", (T, B, 3 * H))
         dghn2 = self.buf("g_dghn2", (T, B, H))
         dhx0 = self.buf("g_dhx0", (T, B, H))
