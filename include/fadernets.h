@@ -167,6 +167,35 @@ size_t fn_gru_gates_floats(int B, int H);
 size_t fn_gru_sync_ws_bytes(void);
 int fn_gru_seq_fwd(const FnGruFwd* scans, int n_scans, void* stream);
 
+/* ONE GRU cell step for a large batch (nn.GRUCell, gmm_model.py:131-136 in the eval-mode decode loop of thousands of rows):
+ *    gi = x W_ih^T + b_ih + gx_table[tok] + gx_rowbias[b]      (every term optional)       gh = h_prev W_hh^T + b_hh
+ *    r = sigmoid(gi_r + gh_r), z = sigmoid(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h_out = (1 - z) n + z h_prev
+ * as a staged MFMA GEMM (128 rows x 32 hidden units per workgroup, both products in one K loop) with the gates in its epilogue:
+ * layer 2 of the decoder needs no separate W_ih projection launch and no [B][3H] round trip.  Weights are the torch matrices
+ * themselves ([3H][K] row-major), states row-major; h_out must not alias h_prev.  H % 32 == 0.
+ * tok = idx ? idx[b * idx_ld] : start_token (point idx at the column of the previous step's tokens). */
+typedef struct FnGruCell {
+    int32_t B, H;
+    const float* x;           /* [B][ldx] dense input, K1 valid columns, or NULL              */
+    int32_t ldx, K1;
+    const float* w_ih;        /* [3H][ldw_ih], K1 valid columns (required with x)             */
+    int32_t ldw_ih;
+    const float* gx_table;    /* [V][3H] (= W_ih[:, :V]^T) or NULL                            */
+    const int32_t* idx;       /* token of row b at idx[b * idx_ld], or NULL = start_token     */
+    int32_t idx_ld, start_token;
+    const float* gx_rowbias;  /* [B][3H] or NULL                                              */
+    const float* h_prev;      /* [B][ldh]                                                     */
+    int32_t ldh;
+    const float* w_hh;        /* [3H][ldw_hh]                                                 */
+    int32_t ldw_hh;
+    const float* b_ih;        /* [3H] or NULL                                                 */
+    const float* b_hh;        /* [3H]                                                         */
+    float* h_out;             /* [B][ldo]                                                     */
+    int32_t ldo;
+    int32_t variant;          /* 0 = default tiling (64 rows x 32 units, waves 2 x 2); 1-3: other tilings (measurements) */
+} FnGruCell;
+int fn_gru_cell_f32(const FnGruCell* c, void* stream);
+
 /* Backward of the same scans (autograd of nn.GRU / GRUCell in loss.backward(), trainer_gmm.py:249).
  *   dh_p = dh_ext[p] (+ dh_last at p = T-1) + carried gradient
  *   outputs: dgx_all [T][B][3H] = d(pre-activations r,z,n) (= d gx, also d(W_hh h + b_hh) for r,z)

@@ -489,6 +489,158 @@ __global__ __launch_bounds__(256) void weight_images_kernel(const WiArgs a) {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------
+// One GRU cell step for a LARGE batch (eval-mode greedy decode of thousands of rows, gmm_model.py:131-136) as a staged GEMM with the
+// gate non-linearities in its epilogue.  The per-step scan kernel above splits K over the 4 waves of a 64-row tile and re-reads
+// its W_hh slice and state tile from L2 with 14 flop per byte (70 TFLOP/s at 2048 rows), and layer 2 needed a separate W_ih
+// projection launch.  Here a workgroup owns 128 rows x 32 hidden units: the 96 weight rows of the three gates are gathered by the
+// row map, the x part (x W_ih^T, optional) and the h part (h W_hh^T) run through the same LDS-staged K loop into separate
+// accumulators (the n gate needs them apart: tanh(gi_n + r * gh_n)), and every lane ends up holding r, z, n of its (row, unit)
+// pairs - no reduction, no exchange.
+struct RowsGate {                                    // local B-tile row r = 32 gate + unit -> weight row gate * H + u0 + unit (shifts only: it runs in every operand load)
+    int u0, H;
+    FN_DEVINL bool valid(int r) const { return true; }
+    FN_DEVINL long clamped(int r) const { return (long)(r >> 5) * H + u0 + (r & 31); }
+    FN_DEVINL bool all_valid(int rows) const { return true; }
+};
+
+struct CellArgs {
+    const float* x; long ldx; int K1;                // dense input [B][K1] (NULL: none)
+    const float* w_ih; long ldw_ih;                  // [3H][K1]
+    const float* gx_table; const int* idx; long idx_ld; int tok_const;    // optional token row gx_table[tok][3H]; idx NULL -> tok_const
+    const float* gx_rowbias;                         // [B][3H] or NULL
+    const float* h_prev; long ldh;                   // [B][H]
+    const float* w_hh; long ldw_hh;                  // [3H][H]
+    const float* b_ih; const float* b_hh;            // [3H] (b_ih may be NULL)
+    float* h_out; long ldo;
+    int B, H;
+};
+
+constexpr int GC_BN = 96, GC_BK = 32;
+// BM rows x 32 units per workgroup, waves WM x WN: WN = 2 gives each wave one 16-unit tile (all three gates of it)
+template <int BM, int WM, int WN>
+__global__ __launch_bounds__(NT, 2) void gru_cell_kernel(const CellArgs a) {
+    static_assert(WM * WN == 4 && (WN == 1 || WN == 2), "4 waves");
+    constexpr int TM = BM / WM / 16, TN = GC_BN / WN / 16, UT = 2 / WN;      // a wave's TN = 3 UT column tiles: tile n = UT * gate + ut, B rows 32 gate + 16 (wn + ut)
+    constexpr int BST = WN == 2 ? 32 : 16;             // B-tile rows between consecutive column tiles of a wave
+    using SA = Stage<BM, GC_BK, true, NT>;
+    using SB = Stage<GC_BN, GC_BK, true, NT>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nut = a.H >> 5;
+    // 4 x 8 super-tiles (row panels x unit tiles) in consecutive virtual ids = on one XCD
+    const int v = fn_xcd_remap(blockIdx.x, gridDim.x);
+    const int ntm = (a.B + BM - 1) / BM;
+    int tm, tu;
+    if ((ntm % 4) == 0 && (nut % 8) == 0) {
+        const int sb = v >> 5, l = v & 31, sbu = nut >> 3;
+        tm = (sb / sbu) * 4 + (l >> 3);
+        tu = (sb % sbu) * 8 + (l & 7);
+    } else {
+        tm = v / nut;
+        tu = v % nut;
+    }
+    const int m0 = tm * BM, u0 = tu * 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int arow0 = wm * (BM / WM), brow0 = WN == 2 ? 16 * wn : 0;
+    const RowsPlain ra{m0, a.B};
+    const RowsGate rb{u0, a.H};
+    f32x4 ax[TM][TN], ah[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) ax[m][n] = ah[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.x) {
+        const int nk = (a.K1 + GC_BK - 1) / GC_BK;
+        if (SA::can_fast(a.x, a.ldx, ra, a.K1) && SB::can_fast(a.w_ih, a.ldw_ih, rb, a.K1)) {
+            auto loadA = [&](int k0, SA& st) { st.load_fast(a.x, a.ldx, ra, k0); };
+            auto loadB = [&](int k0, SB& st) { st.load_fast(a.w_ih, a.ldw_ih, rb, k0); };
+            fn_kloop<2, TM, TN, GC_BK, SA, SB, BST>(smem, nk, loadA, loadB, arow0, brow0, lane, ax);
+        } else {
+            auto loadA = [&](int k0, SA& st) { st.load_checked(a.x, a.ldx, ra, k0, a.K1); };
+            auto loadB = [&](int k0, SB& st) { st.load_checked(a.w_ih, a.ldw_ih, rb, k0, a.K1); };
+            fn_kloop<2, TM, TN, GC_BK, SA, SB, BST>(smem, nk, loadA, loadB, arow0, brow0, lane, ax);
+        }
+    }
+    {
+        const int nk = (a.H + GC_BK - 1) / GC_BK;
+        if (SA::can_fast(a.h_prev, a.ldh, ra, a.H) && SB::can_fast(a.w_hh, a.ldw_hh, rb, a.H)) {
+            auto loadA = [&](int k0, SA& st) { st.load_fast(a.h_prev, a.ldh, ra, k0); };
+            auto loadB = [&](int k0, SB& st) { st.load_fast(a.w_hh, a.ldw_hh, rb, k0); };
+            fn_kloop<2, TM, TN, GC_BK, SA, SB, BST>(smem, nk, loadA, loadB, arow0, brow0, lane, ah);
+        } else {
+            auto loadA = [&](int k0, SA& st) { st.load_checked(a.h_prev, a.ldh, ra, k0, a.H); };
+            auto loadB = [&](int k0, SB& st) { st.load_checked(a.w_hh, a.ldw_hh, rb, k0, a.H); };
+            fn_kloop<2, TM, TN, GC_BK, SA, SB, BST>(smem, nk, loadA, loadB, arow0, brow0, lane, ah);
+        }
+    }
+    // D[row = 16 m + (lane>>4)*4 + i][col = lane&15] of tile n = UT * gate + ut.
+    // Every operand of the epilogue is loaded WITHOUT a branch (an absent source reads b_hh and is dropped by a select; rows past the
+    // batch read the last row): inside `if (table) {...}` hipcc waits for each load at the end of its block - 96 serialised memory
+    // latencies per lane, 35 us of a 56 us layer-1 launch.
+    const int cj = lane & 15, rq = (lane >> 4) * 4;
+    const bool has_tab = a.gx_table != nullptr, has_rb = a.gx_rowbias != nullptr, has_bi = a.b_ih != nullptr;
+    const float* tabp = has_tab ? a.gx_table : a.b_hh;
+    const float* rbp = has_rb ? a.gx_rowbias : a.b_hh;
+    const float* bip = has_bi ? a.b_ih : a.b_hh;
+    const long H3 = 3L * a.H;
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = m0 + arow0 + 16 * m + rq + i;
+            const int rc = min(row, a.B - 1);
+            const int tok = (has_tab && a.idx) ? a.idx[(long)rc * a.idx_ld] : a.tok_const;
+            const long toff = has_tab ? (long)tok * H3 : 0, roff = has_rb ? (long)rc * H3 : 0;
+            float tv[UT][3], rv[UT][3], hv[UT];
+#pragma unroll
+            for (int ut = 0; ut < UT; ++ut) {
+                const int u = u0 + 16 * ((WN == 2 ? wn : 0) + ut) + cj;
+                hv[ut] = a.h_prev[(long)rc * a.ldh + u];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    tv[ut][q] = tabp[toff + q * a.H + u];
+                    rv[ut][q] = rbp[roff + q * a.H + u];
+                }
+            }
+#pragma unroll
+            for (int ut = 0; ut < UT; ++ut) {
+                const int u = u0 + 16 * ((WN == 2 ? wn : 0) + ut) + cj;
+                float gi[3], gh[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    float e = (has_bi ? bip[q * a.H + u] : 0.f) + ax[m][UT * q + ut][i];   // same association as the scan kernels: ((b_ih + x part) + token row) + row constant
+                    e = has_tab ? e + tv[ut][q] : e;
+                    e = has_rb ? e + rv[ut][q] : e;
+                    gi[q] = e;
+                    gh[q] = ah[m][UT * q + ut][i] + a.b_hh[q * a.H + u];
+                }
+                const float r = fn_sigmoid(gi[0] + gh[0]);
+                const float z = fn_sigmoid(gi[1] + gh[1]);
+                const float n = fn_tanh(gi[2] + r * gh[2]);
+                if (row < a.B) a.h_out[(long)row * a.ldo + u] = (1.0f - z) * n + z * hv[ut];
+            }
+        }
+}
+
+template <int BM, int WM, int WN>
+int launch_cell(const CellArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)2 * (Stage<BM, GC_BK, true, NT>::WORDS + Stage<GC_BN, GC_BK, true, NT>::WORDS) * sizeof(float);
+    static bool attr_set[32] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return FN_E_SHAPE;
+    auto k = gru_cell_kernel<BM, WM, WN>;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set[dev] = true;
+    }
+    const int tiles = ((a.B + BM - 1) / BM) * (a.H / 32);
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(NT), lds, st, a);
+    FN_CHECK_LAUNCH();
+    return FN_OK;
+}
+
 extern "C" int fn_weight_images(const FnWeightImage* jobs, int n_jobs, void* stream) {
     if (!jobs) return FN_E_NULL;
     if (n_jobs <= 0 || n_jobs > WI_MAX_JOBS) return FN_E_COUNT;
@@ -554,6 +706,25 @@ bool launch_bwd(const Cfg& c, const BwdArgs& a, int tiles, hipStream_t st) {
 }  // namespace
 
 extern "C" {
+
+int fn_gru_cell_f32(const FnGruCell* c, void* stream) {
+    if (!c || !c->h_prev || !c->w_hh || !c->b_hh || !c->h_out) return FN_E_NULL;
+    if (c->B <= 0 || c->H <= 0 || (c->H % 32) != 0 || c->ldh < c->H || c->ldo < c->H || c->ldw_hh < c->H) return FN_E_SHAPE;
+    if (c->x && (!c->w_ih || c->K1 <= 0 || c->ldx < c->K1 || c->ldw_ih < c->K1)) return FN_E_SHAPE;
+    if (c->gx_table && c->idx && c->idx_ld <= 0) return FN_E_SHAPE;
+    if (c->h_out == c->h_prev) return FN_E_SHAPE;              // other workgroups still read the old state
+    CellArgs a;
+    a.x = c->x; a.ldx = c->ldx; a.K1 = c->x ? c->K1 : 0; a.w_ih = c->w_ih; a.ldw_ih = c->ldw_ih;
+    a.gx_table = c->gx_table; a.idx = c->idx; a.idx_ld = c->idx_ld; a.tok_const = c->start_token; a.gx_rowbias = c->gx_rowbias;
+    a.h_prev = c->h_prev; a.ldh = c->ldh; a.w_hh = c->w_hh; a.ldw_hh = c->ldw_hh; a.b_ih = c->b_ih; a.b_hh = c->b_hh;
+    a.h_out = c->h_out; a.ldo = c->ldo; a.B = c->B; a.H = c->H;
+    switch (c->variant) {                                  // tuning / tests; results do not depend on it
+        case 1: return launch_cell<128, 4, 1>(a, (hipStream_t)stream);
+        case 2: return launch_cell<128, 2, 2>(a, (hipStream_t)stream);
+        case 3: return launch_cell<64, 4, 1>(a, (hipStream_t)stream);
+        default: return launch_cell<64, 2, 2>(a, (hipStream_t)stream);
+    }
+}
 
 size_t fn_gru_gates_floats(int B, int H) { return (size_t)4 * H * (((size_t)B + 15) / 16 * 16); }
 

@@ -168,7 +168,7 @@ struct Stage {
 };
 
 // One BK-deep slab of MFMAs for a wave computing TM x TN tiles of 16x16.
-template <int TM, int TN, int BK, class SA, class SB>
+template <int TM, int TN, int BK, class SA, class SB, int BSTRIDE = 16>
 FN_DEVINL void mma_slab(const float* __restrict__ ldsA, const float* __restrict__ ldsB, int arow0, int brow0, int lane,
                         f32x4 (&acc)[TM][TN]) {
 #pragma unroll
@@ -177,7 +177,7 @@ FN_DEVINL void mma_slab(const float* __restrict__ ldsA, const float* __restrict_
 #pragma unroll
         for (int m = 0; m < TM; ++m) a[m] = SA::frag(ldsA, arow0 + 16 * m, kb, lane);
 #pragma unroll
-        for (int n = 0; n < TN; ++n) b[n] = SB::frag(ldsB, brow0 + 16 * n, kb, lane);
+        for (int n = 0; n < TN; ++n) b[n] = SB::frag(ldsB, brow0 + BSTRIDE * n, kb, lane);      // BSTRIDE: B-tile rows between a wave's column tiles
 #pragma unroll
         for (int m = 0; m < TM; ++m)
 #pragma unroll
@@ -193,7 +193,7 @@ FN_DEVINL void mma_slab(const float* __restrict__ ldsA, const float* __restrict_
 // multiplied, LDS is double buffered, one barrier per K tile.  The steady state has NO branch around the loads (hipcc falls
 // back to s_waitcnt vmcnt(0) at control-flow merges, which would serialise the ring): tiles past the end are re-loads of
 // the last tile (clamped index, at most D redundant tiles) that are never stored.
-template <int D, int TM, int TN, int BK, class SA, class SB, class FA, class FB>
+template <int D, int TM, int TN, int BK, class SA, class SB, int BSTRIDE = 16, class FA, class FB>
 FN_DEVINL void fn_kloop(float* __restrict__ smem, int nk, const FA& loadA, const FB& loadB, int arow0, int brow0, int lane,
                         f32x4 (&acc)[TM][TN]) {
     constexpr int BUFW = SA::WORDS + SB::WORDS;   // buffer b: A at smem + b*BUFW, B right behind it
@@ -217,7 +217,7 @@ FN_DEVINL void fn_kloop(float* __restrict__ smem, int nk, const FA& loadA, const
             const int cur = kt & 1;
             loadA(min(kt + D, last) * BK, sa[u]);           // set u held tile kt (already in LDS): refill with tile kt + D
             loadB(min(kt + D, last) * BK, sb[u]);
-            if (kt < nk) mma_slab<TM, TN, BK, SA, SB>(smem + cur * BUFW, smem + cur * BUFW + SA::WORDS, arow0, brow0, lane, acc);
+            if (kt < nk) mma_slab<TM, TN, BK, SA, SB, BSTRIDE>(smem + cur * BUFW, smem + cur * BUFW + SA::WORDS, arow0, brow0, lane, acc);
             sa[(u + 1) % D].store(smem + (cur ^ 1) * BUFW);  // tile kt + 1 (or a harmless duplicate of the last tile)
             sb[(u + 1) % D].store(smem + (cur ^ 1) * BUFW + SA::WORDS);
             __syncthreads();

@@ -97,6 +97,18 @@ def _decode_body(eng, z, steps, want_logp, logp, tokens):
     nf = ops.frag_floats(Bi, H)
     hf0 = [eng.buf("dec_hf0_a", (nf,)), eng.buf("dec_hf0_b", (nf,))]
     hf1 = [eng.buf("dec_hf1_a", (nf,)), eng.buf("dec_hf1_b", (nf,))]
+    if Bi >= eng.cell_decode_rows:
+        # thousands of rows: every cell is ONE staged-GEMM launch with the gates in its epilogue (fn_gru_cell_f32); layer 2 takes its input
+        # projection in the same K loop - 3 launches + argmax per token instead of 4 + argmax, and no [B][3H] round trip
+        for i in range(steps):
+            cur, prv = i & 1, (i & 1) ^ 1
+            ops.gru_cell(h0g if i == 0 else hx0[prv][0], P["grucell_g.weight_hh"], P["grucell_g.bias_hh"], hx0[cur][0], b_ih=P["grucell_g.bias_ih"],
+                         gx_table=eng.tab["g"], idx=tokens[:, i - 1] if i > 0 else None, start_token=E_VOCAB - 1, gx_rowbias=rbg)
+            ops.gru_cell(hx0[cur][0] if i == 0 else hx1[prv][0], P["grucell_g_2.weight_hh"], P["grucell_g_2.bias_hh"], hx1[cur][0],
+                         x=hx0[cur][0], w_ih=P["grucell_g_2.weight_ih"], b_ih=P["grucell_g_2.bias_ih"])
+            ops.gemm(hx1[cur][0], P["linear_out_g.weight"], logits[:, :E_VOCAB], bias=P["linear_out_g.bias"])
+            ops.vocab_argmax(logits, E_VOCAB, logp[:, i, :] if want_logp else None, tokens[:, i])
+        return logp, tokens
     for i in range(steps):
         cur, prv = i & 1, (i & 1) ^ 1
         ops.gru_seq_fwd([dict(B=Bi, T=1, H=H, w_hh_frag=eng.whh_f["g"], b_hh=P["grucell_g.bias_hh"], b_ih=P["grucell_g.bias_ih"],

@@ -53,6 +53,7 @@ class HipOps:
             raise RuntimeError("HipOps needs a GPU device")
         self._ws = {}
         self._retired = []
+        self.cell_variant = 0     # FnGruCell.variant (tuning / tests)
         self.variant = 0          # FnGruFwd.variant of every scan launch (tuning / tests only; results do not depend on it)
         self.lane = ""            # scratch namespace: kernels enqueued on different streams must not share workspaces
 
@@ -246,6 +247,32 @@ class HipOps:
             d.gx_rowbias, d.h_all, d.gates = _p(s.get("gx_rowbias")), _p(s["h_all"]), _p(s.get("gates"))
             d.h0_frag, d.h_last_frag = _p(s.get("h0_frag")), _p(s.get("h_last_frag"))
         _lib.check(self.lib.fn_gru_seq_fwd(arr, len(scans), self.stream()), "fn_gru_seq_fwd")
+
+    def gru_cell(self, h_prev, w_hh, b_hh, h_out, x=None, w_ih=None, b_ih=None, gx_table=None, idx=None, start_token=0, gx_rowbias=None, variant=None):
+        """one GRUCell step of a large batch (fn_gru_cell_f32): h_out [B][H] from h_prev [B][H], optional dense input x [B][K1] with the
+        torch matrix w_ih [3H][K1], optional token rows gx_table [V][3H] picked by idx (a [B] int32 column view, e.g. tokens[:, i - 1];
+        None = start_token) and per-row constants gx_rowbias [B][3H]; w_hh [3H][H] is the torch matrix itself"""
+        c = _lib.FnGruCell()
+        ph, B, H, ldh = _mat(h_prev, "h_prev")
+        pw, r3, Hw, ldw = _mat(w_hh, "w_hh")
+        po, Bo, Ho, ldo = _mat(h_out, "h_out")
+        if r3 != 3 * H or Hw != H or (Bo, Ho) != (B, H):
+            raise RuntimeError("gru_cell shape mismatch h_prev%s w_hh%s h_out%s" % (tuple(h_prev.shape), tuple(w_hh.shape), tuple(h_out.shape)))
+        _dense(b_hh, name="b_hh"), _dense(b_ih, name="b_ih"), _dense(gx_table, name="gx_table"), _dense(gx_rowbias, name="gx_rowbias")
+        c.B, c.H, c.h_prev, c.ldh, c.w_hh, c.ldw_hh, c.b_hh, c.b_ih, c.h_out, c.ldo = B, H, ph, ldh, pw, ldw, _p(b_hh), _p(b_ih), po, ldo
+        if x is not None:
+            px, Bx, K1, ldx = _mat(x, "x")
+            pwi, r3i, K1w, ldwi = _mat(w_ih, "w_ih")
+            if Bx != B or r3i != 3 * H or K1w != K1:
+                raise RuntimeError("gru_cell: x%s / w_ih%s do not match" % (tuple(x.shape), tuple(w_ih.shape)))
+            c.x, c.ldx, c.K1, c.w_ih, c.ldw_ih = px, ldx, K1, pwi, ldwi
+        c.gx_table, c.gx_rowbias, c.start_token = _p(gx_table), _p(gx_rowbias), int(start_token)
+        c.variant = int(self.cell_variant if variant is None else variant)
+        if idx is not None:
+            if idx.dtype != torch.int32 or idx.dim() != 1 or idx.shape[0] != B:
+                raise RuntimeError("gru_cell: idx must be a [B] int32 column")
+            c.idx, c.idx_ld = idx.data_ptr(), idx.stride(0)
+        _lib.check(self.lib.fn_gru_cell_f32(C.byref(c), self.stream()), "fn_gru_cell_f32")
 
     def gru_seq_bwd(self, scans, persistent=True, cu_budget=0, variant=None):
         arr = (_lib.FnGruBwd * len(scans))()

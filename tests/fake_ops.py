@@ -135,6 +135,24 @@ class FakeOps:
             if s.get("dh0") is not None:
                 s["dh0"].copy_(carry)
 
+    def gru_cell(self, h_prev, w_hh, b_hh, h_out, x=None, w_ih=None, b_ih=None, gx_table=None, idx=None, start_token=0, gx_rowbias=None, variant=None):
+        B, H = h_prev.shape
+        gi = torch.zeros(B, 3 * H)
+        if x is not None:
+            gi = gi + x @ w_ih.t()
+        if b_ih is not None:
+            gi = gi + b_ih
+        if gx_table is not None:
+            tok = idx.long() if idx is not None else torch.full((B,), int(start_token), dtype=torch.long)
+            gi = gi + gx_table[tok]
+        if gx_rowbias is not None:
+            gi = gi + gx_rowbias
+        gh = h_prev @ w_hh.t() + b_hh
+        r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+        z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+        n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+        h_out.copy_((1.0 - z) * n + z * h_prev)
+
     def gru_dwhh(self, dgx, dghn, hprev, dW, beta=0.0, splitk=1, lean=False):
         H = hprev.shape[1]
         g = torch.cat([dgx[:, : 2 * H], dghn], dim=1)

@@ -110,6 +110,30 @@ def test_out_head_fused(ops, B, T, H, V, ld):
     assert torch.equal(nll1, nll2)
 
 
+@pytest.mark.parametrize("B,H,K1,mode", [(300, 64, 64, "dense"), (2048, 512, 512, "dense"), (130, 96, 0, "table"), (1030, 512, 0, "table0")])
+def test_gru_cell_dense(ops, B, H, K1, mode):
+    """fn_gru_cell_f32 (one GRUCell step of a large batch as a staged GEMM with the gates in its epilogue) against tests/fake_ops.py
+    (= torch nn.GRUCell semantics with the optional token-row / row-constant input parts), ragged row / unit tiles."""
+    from fake_ops import FakeOps
+    torch.manual_seed(B + H)
+    V = 50
+    hp = torch.randn(B, H) * 0.5
+    whh, bhh, bih = torch.randn(3 * H, H) / H ** 0.5, torch.randn(3 * H) * 0.1, torch.randn(3 * H) * 0.1
+    kw = dict(b_ih=bih)
+    if mode == "dense":
+        kw.update(x=torch.randn(B, K1), w_ih=torch.randn(3 * H, K1) / K1 ** 0.5)
+    else:
+        toks = torch.randint(0, V, (B, 7), dtype=torch.int32)
+        kw.update(gx_table=torch.randn(V, 3 * H) * 0.3, gx_rowbias=torch.randn(B, 3 * H) * 0.3, start_token=V - 1,
+                  idx=toks[:, 3] if mode == "table" else None)
+    ref = torch.zeros(B, H)
+    FakeOps().gru_cell(hp, whh, bhh, ref, **kw)
+    out = torch.zeros(B, H, device=DEV)
+    ops.gru_cell(g(hp), g(whh), g(bhh), out, **{k: (g(v) if torch.is_tensor(v) and k != "idx" else v) for k, v in kw.items() if k != "idx"},
+                 idx=(g(toks)[:, 3] if mode == "table" else None) if mode != "dense" else None)
+    close(out, ref, 2e-5, "gru_cell")
+
+
 def test_gemm_is_transpose_detecting(ops):
     """identity A with an ASYMMETRIC B: catches a swapped C-write (cdna guide rule 16)."""
     n = 96
@@ -661,6 +685,32 @@ def test_single_launch_decode_matches_per_token_kernels(H, Bi, steps, monkeypatc
     upto = int(first_unclear[0]) if len(first_unclear) else steps
     assert torch.equal(tk0[:, :upto], tk1[:, :upto])
     close(lp1[:, :upto], lp0[:, :upto], 2e-5)
+
+
+@pytest.mark.parametrize("H,Bi,steps", [(64, 1100, 14), (512, 1024, 10)])
+def test_large_batch_decode_cells_match_per_token_kernels(H, Bi, steps):
+    """decode of >= Engine.cell_decode_rows sequences (fn_gru_cell_f32: every cell one staged-GEMM launch, layer 2's input projection in
+    the same K loop) vs the scan-step kernels + projection GEMM: per row the same tokens and log-probabilities up to that row's first
+    near-tie (the two paths sum the gate pre-activations in different orders)."""
+    pkg = load_package()
+    m = make_model(H, 32 if H == 64 else 128, device=DEV, seed=11)
+    m.eval()
+    torch.manual_seed(5)
+    z = torch.randn(Bi, 2 * m.latent_dim + 24, device=DEV)
+    eng = m.engine()
+    eng.cell_decode_rows = 1 << 30
+    lp0, tk0 = pkg.greedy_decode(m, z, steps)
+    eng.cell_decode_rows = 1024
+    lp1, tk1 = pkg.greedy_decode(m, z, steps)
+    lp2, tk2 = pkg.greedy_decode(m, z, steps)
+    assert torch.equal(tk1, tk2) and torch.equal(lp1, lp2)
+    gap = lp0.topk(2, dim=-1).values
+    unclear = ((gap[..., 0] - gap[..., 1]) <= 1e-4)                           # [Bi][steps]
+    first = torch.where(unclear.any(1), unclear.float().argmax(1), torch.full((Bi,), steps, device=DEV))    # per row: first near-tie step
+    keep = torch.arange(steps, device=DEV).view(1, -1) < first.view(-1, 1)
+    assert bool(keep.float().mean() > 0.9)
+    assert torch.equal(tk0[keep], tk1[keep])
+    close(lp1[keep], lp0[keep], 2e-5)
 
 
 def test_full_size_properties():
