@@ -29,24 +29,6 @@ FN_DEVINL void stv4_sc1(float* p, const f32x4& v) { asm volatile("global_store_d
 FN_DEVINL f32x4 ldv4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 FN_DEVINL void stv4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
 FN_DEVINL u32 ld_cnt(u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// The same through the scalar unit (wave-uniform address): the answer comes back on lgkmcnt, so a poll does not have to wait for the
-// vector stores / gathers the wavefront still has in flight (vmcnt returns in order).  glc: served by L2, where the counter's atomics execute.
-FN_DEVINL const u32* fn_uniform(const u32* p) {       // a wave-uniform pointer in scalar registers
-    const unsigned long long v = (unsigned long long)p;
-    const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
-    return reinterpret_cast<const u32*>(((unsigned long long)hi << 32) | lo);
-}
-FN_DEVINL u32 ld_cnt_s(const u32* p) {
-    u32 v;
-    asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
-    return v;
-}
-
-// Workgroup barrier that only settles LDS traffic.  __syncthreads() is a fence + barrier: hipcc drains vmcnt(0) in front of it, i.e. every
-// barrier of the time loop would wait for the gathers / operand prefetches a step has in flight on purpose.  Global hand-overs
-// are ordered explicitly where they happen (s_waitcnt vmcnt(0) before the arrival atomic).
-FN_DEVINL void fn_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 // host-side entry points of gru_persist.hip: return FN_OK when the persistent kernel was launched,
 // FN_PERSIST_NA when the configuration is not eligible (the caller then uses the per-step kernels).
 #define FN_PERSIST_NA 1000000

@@ -39,20 +39,6 @@ FN_DEVINL void fn_wait_vm() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// the same with a count that is only known after unrolling (folds to one s_waitcnt)
-FN_DEVINL void fn_wait_vm_n(int n) {
-    switch (n) {
-#define FN_WVM_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-        FN_WVM_CASE(0) FN_WVM_CASE(1) FN_WVM_CASE(2) FN_WVM_CASE(3) FN_WVM_CASE(4) FN_WVM_CASE(5) FN_WVM_CASE(6) FN_WVM_CASE(7)
-        FN_WVM_CASE(8) FN_WVM_CASE(9) FN_WVM_CASE(10) FN_WVM_CASE(11) FN_WVM_CASE(12) FN_WVM_CASE(13) FN_WVM_CASE(14) FN_WVM_CASE(15)
-        FN_WVM_CASE(16) FN_WVM_CASE(17) FN_WVM_CASE(18) FN_WVM_CASE(19) FN_WVM_CASE(20) FN_WVM_CASE(21) FN_WVM_CASE(22) FN_WVM_CASE(23)
-        FN_WVM_CASE(24) FN_WVM_CASE(25) FN_WVM_CASE(26) FN_WVM_CASE(27) FN_WVM_CASE(28) FN_WVM_CASE(29) FN_WVM_CASE(30) FN_WVM_CASE(31)
-#undef FN_WVM_CASE
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-}
-
 FN_DEVINL bool fn_aligned16(const void* p, long ld) { return ((((uintptr_t)p) & 15) == 0) && ((ld & 3) == 0); }
 
 // Row maps: local tile row r -> source row.  valid(r) says whether the row exists; clamped(r) is always a legal row
