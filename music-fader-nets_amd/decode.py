@@ -30,7 +30,7 @@ def greedy_decode(model, z, steps, want_logp=True, use_graph=None):
     if not use_graph:
         return _decode_body(eng, z, steps, want_logp, None, None)
     cache = eng.__dict__.setdefault("_decode_graphs", {})
-    key = (z.shape[0], steps, bool(want_logp))
+    key = (z.shape[0], steps, bool(want_logp), z.shape[0] >= eng.cell_decode_rows)     # the captured launches depend on the path taken
     ent = cache.get(key)
     if ent is None:
         zs = z.clone()

@@ -45,7 +45,7 @@ class Engine:
         self.persist_dec = True         # decoder scans as weight-stationary launches (False: per-step kernels; debug / tests)
         self.single_launch_decode = True   # decode.py: <= 32 sequences decode as ONE launch (False: per-token kernels; tests)
         self._lane_alias = {}           # lane -> lane it is folded into (debug)
-        self.cell_decode_rows = 1024    # decode.py: from this many sequences on, the per-token cells are staged-GEMM launches (fn_gru_cell_f32)
+        self.cell_decode_rows = 768     # decode.py: from this many sequences on, the per-token cells are staged-GEMM launches (fn_gru_cell_f32); measured crossover (scratch/bench_decode_rows.py): 512 rows 67 vs 87 us per token, 768 rows 97 vs 88
         self.fused_head = True          # trainers: output projection + log-softmax + NLL + gradient seed as ONE kernel (fn_out_head_f32); False: GEMM -> logits in HBM -> fn_vocab_logsoftmax
         self.lean_dw = True             # decoder-side weight-gradient GEMMs as the <= 128-register instance: one of its wavefronts fits on a SIMD beside an encoder-scan wavefront (374 of 512 registers), the 194-register instance waits for the scan to end
         self.losses_on_side = True      # trainer: the small loss-term launches run on the side lane beside the decoder backward's first launches
