@@ -16,7 +16,8 @@ def greedy_decode(model, z, steps, want_logp=True, use_graph=None):
     """z (Bi, 2Z+24) -> (log-probs (Bi, steps, 342) or None, tokens (Bi, steps) int32).
 
     Bi <= 32: ONE launch for the whole decode (fn_decode_greedy).  Larger batches: steps x {layer-1 cell, W_ih2 projection,
-    layer-2 cell, output GEMM, log_softmax+argmax} captured once per (Bi, steps) into a hipGraph and replayed.  The captured
+    layer-2 cell, output GEMM, log_softmax+argmax} (from Engine.cell_decode_rows sequences on: steps x {layer-1 cell, layer-2 cell incl.
+    its projection - fn_gru_cell_f32 -, output GEMM, argmax}) captured once per (Bi, steps) into a hipGraph and replayed.  The captured
     kernels read the parameters and the engine's weight images IN PLACE (stable addresses, refreshed by Engine.refresh_weights
     after every optimiser step / load_state_dict), so a graph stays valid when the weights change."""
     eng = model.engine()
