@@ -15,6 +15,7 @@ ranks simply SUM their gradients and statistics:
 """
 import contextlib
 import math
+import os
 
 import numpy as np
 
@@ -86,6 +87,12 @@ class GMVAETrainer:
         self.sp = torch.zeros(8, device=dev)
         self._dev_step = 0                          # host mirror of counters[0]
         self.use_graph = dev.type == "cuda"          # replay the whole step as ONE hipGraph (no per-launch host cost)
+        if dist_ctx is not None and os.environ.get("FN_DP_GRAPH", "0") != "1":
+            # Data parallel: eager launches.  With the RCCL collectives inside the captured step, about 1 capture in 25 ended with
+            # hipErrorStreamCaptureUnjoined on this stack (torch 2.10 / RCCL 2.26), after which the process-group watchdog died on an event
+            # "last recorded in a capturing stream" - 150 single-rank runs of bench.py, see DESIGN.md.  The launches of a step cost
+            # less host time than the GPU needs to run them, so the eager step is GPU-bound as well.  FN_DP_GRAPH=1 captures anyway.
+            self.use_graph = False
         self._graphs = {}
         self._static = {}
         model.train()
