@@ -91,6 +91,25 @@ def test_fused_step_gradients(small, sup, chunk):
     np.testing.assert_allclose(tr.grad_norm(), small["gradnorm_%s_20000" % tag][0], rtol=1e-4)
 
 
+@pytest.mark.parametrize("fused,lean", [(False, False), (True, True)])
+def test_fused_step_schedule_switches(small, fused, lean):
+    """Engine.fused_head (projection + log-softmax + NLL + gradient seed as one op, logits never written) and Engine.lean_dw (the
+    <= 128-register weight-gradient instance) change which ops run, never what comes out: the reference's gradients either way."""
+    pkg = load_package()
+    m = make_model(64, 32, sd_from(small, "w0/"), ops=FakeOps())
+    tr = pkg.GMVAETrainer(m, lr=1e-3, beta=0.2)
+    m.engine().fused_head, m.engine().lean_dw = fused, lean
+    b = batch_of(small)
+    batch = tr.prepare_batch(b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"])
+    eps = (torch.from_numpy(small["eps_r"]), torch.from_numpy(small["eps_n"]))
+    tup = tr.loss_and_grads(20000, batch, eps)
+    np.testing.assert_allclose(tup[0], small["total_loss_unsup_20000"][0], rtol=1e-5)
+    for k in tr.flat.names:
+        ref = small["grad_unsup/%s" % k]
+        e = relerr(tr.flat.G[k].numpy(), ref)
+        assert e < 3e-4 or np.abs(ref).max() < 1e-6, (k, e)
+
+
 def test_three_fused_train_steps(small):
     """GMVAETrainer.train == the reference's train() (trainer_gmm.py:220) for 3 steps from step 19999."""
     pkg = load_package()
