@@ -317,6 +317,37 @@ def test_weight_stationary_scans_random_configurations(ops):
     assert not ops.gru_sync_error()
 
 
+@pytest.mark.parametrize("B,T,H", [(5, 7, 64), (200, 6, 512), (256, 33, 512)])
+def test_exchange_slabs_are_all_sentinel_between_launches(ops, B, T, H):
+    """Flag-in-data hand-over of the weight-stationary scans: their three exchange slabs must be all 0xFFFFFFFF again when a launch ends
+    (forward incl. the packed initial state and pad rows, backward incl. the dh0 iteration), with and without the caller's
+    "already clean" hint (without it the library memsets in front of the launch), and the results must not depend on the hint."""
+    fake = FakeOps()
+    c = _scan_inputs(B, T, H, 21, 4, True, shift=-1)
+    d = _to_dev(c)
+    c["w_hh_frag"], d["w_hh_frag"] = _pack(fake, c["w_hh"], "cpu"), _pack(ops, c["w_hh"], DEV)
+    fake.gru_seq_fwd([c])
+    outs = []
+    for hint in (True, False, True):
+        ops.frag_clean_hint = hint
+        d["h_all"].fill_(float("nan"))
+        ops.gru_seq_fwd([d])
+        close(d["h_all"], c["h_all"], 2e-5, "h_all hint=%s" % hint)
+        outs.append(d["h_all"].clone())
+        torch.manual_seed(3)
+        b = dict(B=B, T=T, H=H, w_hh_t_frag=_pack(ops, c["w_hh"].t().contiguous(), DEV), h0=d.get("h0"), h_all=d["h_all"], gates=d["gates"],
+                 dh_last=g(torch.randn(B, H)), dh_ext=g(torch.randn(T, B, H)), dgx_all=torch.zeros(T, B, 3 * H, device=DEV),
+                 dghn_all=torch.zeros(T, B, H, device=DEV), dh0=torch.zeros(B, H, device=DEV), scratch=torch.zeros(B, H, device=DEV))
+        ops.gru_seq_bwd([b])
+        outs.append(b["dgx_all"].clone())
+        torch.cuda.synchronize()
+        for tag, ws in ops._frag_clean.items():
+            assert bool((ws.view(torch.int32) == -1).all()), "exchange scratch %s is not all-sentinel after the launch (hint=%s)" % (tag, hint)
+    ops.frag_clean_hint = True
+    assert not ops.gru_sync_error()
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[4]) and torch.equal(outs[1], outs[3]) and torch.equal(outs[1], outs[5])
+
+
 @pytest.mark.parametrize("rows,H,splitk,beta", [(37, 64, 1, 0.0), (1030, 64, 4, 1.0), (300, 96, 4, 0.0), (5000, 512, 8, 1.0)])
 def test_gru_weight_gradient(ops, rows, H, splitk, beta):
     """fn_gru_dwhh_f32: dW_hh = beta dW_hh + [dgx[:, :2H] | dghn]^T hprev (one split-A launch when 2H % 128 == 0, else two products)."""
