@@ -798,11 +798,6 @@ int fn_gru_seq_fwd(const FnGruFwd* scans, int n_scans, void* stream) {
         if (!launch_fwd(cfg, a, tiles, st)) return FN_E_SHAPE;
         FN_CHECK_LAUNCH();
     }
-    if (scans[0].variant & 0x400)              // the caller keeps frag_ws all-sentinel for the weight-stationary launches: restore that
-        for (int s = 0; s < n_scans; ++s) {
-            hipError_t me = hipMemsetAsync(scans[s].frag_ws, 0xFF, 3 * fn_frag_floats(scans[s].B, scans[s].H) * sizeof(float), st);
-            if (me != hipSuccess) return (int)me;
-        }
     return FN_OK;
 }
 
@@ -874,11 +869,6 @@ int fn_gru_seq_bwd(const FnGruBwd* scans, int n_scans, void* stream) {
         if (!launch_bwd(cfg, a, tiles, st)) return FN_E_SHAPE;
         FN_CHECK_LAUNCH();
     }
-    if (scans[0].variant & 0x400)
-        for (int s = 0; s < n_scans; ++s) {
-            hipError_t me = hipMemsetAsync(scans[s].frag_ws, 0xFF, 3 * fn_frag_floats(scans[s].B, 3 * scans[s].H) * sizeof(float), st);
-            if (me != hipSuccess) return (int)me;
-        }
     return FN_OK;
 }
 

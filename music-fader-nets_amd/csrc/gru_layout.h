@@ -29,17 +29,6 @@ FN_DEVINL void stv4_sc1(float* p, const f32x4& v) { asm volatile("global_store_d
 FN_DEVINL f32x4 ldv4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 FN_DEVINL void stv4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
 FN_DEVINL u32 ld_cnt(u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// flag-in-data hand-over of gru_persist.hip: a dword of an exchange slab that still holds FN_SENTINEL has not been published yet
-constexpr u32 FN_SENTINEL = 0xFFFFFFFFu;
-FN_DEVINL f32x4 fn_sentinel4() {
-    const float s = __uint_as_float(FN_SENTINEL);
-    return (f32x4){s, s, s, s};
-}
-// orders every later use of v behind the preceding (volatile) wait: the value of an asm load must not be looked at before it
-FN_DEVINL void fn_touch(f32x4& v) { asm volatile("" : "+v"(v)); }
-FN_DEVINL u32 fn_umax4(u32 m, const f32x4& v) {
-    return max(max(m, __float_as_uint(v[0])), max(max(__float_as_uint(v[1]), __float_as_uint(v[2])), __float_as_uint(v[3])));
-}
 // host-side entry points of gru_persist.hip: return FN_OK when the persistent kernel was launched,
 // FN_PERSIST_NA when the configuration is not eligible (the caller then uses the per-step kernels).
 #define FN_PERSIST_NA 1000000

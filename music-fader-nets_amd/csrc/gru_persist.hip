@@ -11,22 +11,11 @@
 //   * every step the recurrent operand h_{p-1}[rows of g][0..H) is read from a fragment-major exchange slab in global memory
 //     (asm dwordx4 loads kept D chunks in flight) and multiplied against the LDS-resident slice;
 //   * the gate epilogue is element-wise; the new state slice goes to h_all (row-major, for the backward pass and the heads)
-//     and, write-through (sc1), to the exchange slab of this step;
-//   * hand-over = FLAG IN DATA (no arrival counter on the critical path): the exchange is THREE rotating slabs that hold the
-//     bit pattern FN_SENTINEL (0xFFFFFFFF, a NaN no kernel of this library produces) wherever the producer has not written yet.
-//     Step p reads slab (p-1) % 3, publishes into slab p % 3 and, once its K loop is through (= every slice of the row group has
-//     published step p-1, hence has finished READING slab (p-2) % 3 = (p+1) % 3), re-fills its own part of slab (p+1) % 3 with the
-//     sentinel; those stores are drained (they are ~3 k cycles old by then) before the step's own data is published, so a consumer
-//     that sees step p of a slice can never find that slice's stale step p-2 values in the slab it polls next.  A consumer simply
-//     loads the operand chunk and looks at the dwords it got: K chunk c (32 k-values = slices 2c, 2c+1) is multiplied as soon as ITS
-//     two producers are through - the K loop starts on published chunks instead of waiting for the slowest of 32 slices, and the
-//     drain -> barrier -> atomic -> poll -> barrier -> first load chain of a counter hand-over (three L2 round trips) becomes one.
-//     Every dword validates itself, so no multi-dword store atomicity is assumed.  Pad rows (up to the 16-row tile) are published too.
-//   * the slabs are all-sentinel between launches: at the end every workgroup arrives ONCE at its row group's counter (off the
-//     critical path), waits for the group and re-fills its part of all three slabs.  (FnGruFwd.variant bit 10 tells the library
-//     that the caller keeps that invariant; otherwise a memset node in front of the launch establishes it.)
-//   * Block ids are dealt so that a row group sits on ONE XCD when there are 8 groups (speed only, correctness never depends on
-//     placement: payload stores are write-through, loads bypass the L1).
+//     and, write-through (sc1), to the other exchange slab;
+//   * the 32 workgroups of a row group then meet at a monotonic arrival counter (cdna_hip_programming.md G16, recipe R1:
+//     sc1 payload stores -> every wave drains vmcnt -> barrier -> one relaxed agent-scope atomic; consumer: one lane polls,
+//     barrier, sc1 loads).  Block ids are dealt so that a row group sits on ONE XCD when there are 8 groups (speed only,
+//     correctness never depends on placement).
 //   * every spin is bounded: on timeout (or when another workgroup has timed out) the workgroup raises err and leaves.
 #include "gru_layout.h"
 
@@ -58,7 +47,7 @@ struct PScan {
     const float* gx_rowbias;
     float* h_all;
     float* gates;
-    float* xf;            // 3 exchange slabs, fragment-major (all FN_SENTINEL at launch)
+    float* xf;            // 2 exchange slabs, fragment-major
     const float* h0f;     // optional: the initial state already in the slab layout (the previous chunk's hlf) - no packing launch
     float* hlf;           // optional: the final state in the slab layout
     int idx_ld, idx_shift, start_token, reverse;
@@ -68,21 +57,10 @@ struct PScan {
 struct PArgs {
     PScan s[FN_MAX_SCANS];
     int n, ngroups, H;
-    u32* sync;            // [ngroups * 32] end-of-launch arrival counters (one per 128-byte line), zero at launch
+    u32* sync;            // [ngroups * 32] arrival counters (one per 128-byte line), zero at launch
     u32* err;             // sticky error word
 };
 constexpr int FN_MAX_GROUPS = 64;
-
-// bounded wait of the slow path: true = give up (this or another workgroup timed out)
-FN_DEVINL bool fn_spin_expired(u32& spins, u32* err, volatile int& dead) {
-    __builtin_amdgcn_s_sleep(2);
-    if ((++spins & 63u) == 0 && (spins > SPIN_LIMIT || ld_cnt(err) != 0)) {
-        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        dead = 1;
-        return true;
-    }
-    return false;
-}
 
 
 // waves = WM (row blocks of MT tiles) x WK (K split); rows per workgroup RPW = 16 * WM * MT
@@ -93,9 +71,8 @@ __global__ __launch_bounds__(NT) void gru_fwd_persist_kernel(const PArgs args) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = args.H, nk = H >> 5;
     float* wl = smem;                                // [3][nk][2][64][4]  W_hh slice, B-fragment order
-    float* red0 = smem + 3 * H * 16;                 // [2][WK][EM][3][RT] accumulator exchange, double buffered (one barrier per step)
-    constexpr int REDW = WK * EM * 3 * RT;
-    volatile int& dead = *reinterpret_cast<volatile int*>(red0 + 2 * REDW);   // all LDS is dynamic (16-byte aligned base)
+    float* red = smem + 3 * H * 16;                  // [WK][EM][3][RT]    accumulator exchange
+    volatile int& dead = *reinterpret_cast<volatile int*>(red + WK * EM * 3 * RT);   // all LDS is dynamic (16-byte aligned base)
 
     const int g = blockIdx.x % args.ngroups, slice = blockIdx.x / args.ngroups;
     int si = 0;
@@ -126,7 +103,7 @@ __global__ __launch_bounds__(NT) void gru_fwd_persist_kernel(const PArgs args) {
     //      the epilogue is a 16-byte vector (scalar sc1 stores cost ~6x per byte, MI355X_MICROARCH.md price list) -------
     constexpr int NI = (EM * 64 + NT - 1) / NT;      // items per thread
     int ib[NI], iu4[NI], icoff[NI];
-    bool iact[NI], ipub[NI];
+    bool iact[NI];
     f32x4 bh[3], bi[3], e_rb[NI][3], hp[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -134,16 +111,11 @@ __global__ __launch_bounds__(NT) void gru_fwd_persist_kernel(const PArgs args) {
         const int rl = item >> 2;                    // row inside the workgroup's row block
         iu4[i] = item & 3;
         iact[i] = item < EM * 64 && m0 + rl < B;
-        ipub[i] = item < EM * 64 && m0 + rl < nrt * 16;      // pad rows of the last tile are published too (consumers look at every dword)
         ib[i] = min(m0 + rl, B - 1);
-
         // accumulator tile (rl >> 4) in padded MFMA C layout: lane' = ((r&15)>>2)*16 + unit, reg = r & 3, +4 floats per 64
         icoff[i] = (min(rl >> 4, EM - 1) * 3) * RT + ((rl & 15) >> 2) * 68 + iu4[i] * 16 + (rl & 3);
     }
     const int jj0 = hh0 + 4 * (tid & 3);
-    // slab offset of item i = (row m0 + (tid >> 2) + 64 i, units jj0..jj0+3): consecutive items of a thread are 4 row tiles apart
-    const long ixoff0 = frag_off(m0 + (tid >> 2), jj0, nk);
-    const long ixstep = (long)4 * nk * 512;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         bh[q] = ldv4(S.b_hh + q * H + jj0);
@@ -188,19 +160,34 @@ __global__ __launch_bounds__(NT) void gru_fwd_persist_kernel(const PArgs args) {
         }
 
         FN_PSTAMP(0);
-        // (b)+(c) gh = h_{p-1} W_hh^T slice; for p > 0 the operand is polled in place (flag in data): a chunk is multiplied as soon
-        //         as no dword of it holds the sentinel any more
+        // (b) wait until every slice of this row group has published h_{p-1}
         const bool has_k = p > 0 || S.h0 != nullptr;
-        const bool chk = p > 0;
-        float* red = red0 + (p & 1) * REDW;
+        if (p > 0) {
+            if (tid == 0) {
+                const u32 target = (u32)nslices * (u32)p;
+                u32 spins = 0;
+                while (ld_cnt(counter) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 63u) == 0 && (spins > SPIN_LIMIT || ld_cnt(err) != 0)) {
+                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        dead = 1;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            if (dead) return;
+        }
+
         FN_PSTAMP(1);
+        // (c) gh = h_{p-1} W_hh^T slice
         f32x4 acc[MT][3];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int n = 0; n < 3; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (has_k && nkw > 0) {
-            const float* xin = (p == 0 && S.h0f) ? S.h0f : S.xf + (long)((p + 2) % 3) * FS;
+            const float* xin = (p == 0 && S.h0f) ? S.h0f : S.xf + (long)(p & 1) * FS;
             f32x4 fa[D][MT][2], fb[2][3][2];
             auto loadA = [&](int set, int it) {
                 const long k0 = (long)(c0 + min(it, nkw - 1)) * 512;
@@ -225,39 +212,15 @@ __global__ __launch_bounds__(NT) void gru_fwd_persist_kernel(const PArgs args) {
                             acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4at(fa[set][m][j >> 2], j & 3), f4at(fb[bs][n][j >> 2], j & 3),
                                                                              acc[m][n], 0, 0, 0);
             };
-            auto stale = [&](int set) -> bool {          // wave-uniform: some lane still sees an unpublished dword in this chunk
-                u32 mx = 0;
 #pragma unroll
-                for (int m = 0; m < MT; ++m) { fn_touch(fa[set][m][0]); fn_touch(fa[set][m][1]); mx = fn_umax4(fn_umax4(mx, fa[set][m][0]), fa[set][m][1]); }
-                return __any(mx == FN_SENTINEL) != 0;
-            };
-            // poll chunk `it` alone until its producers are through (drains the ring first; the younger entries stay as requested and
-            // are looked at when their turn comes - re-requesting them here costs 7 x 16 live registers at every merge point)
-            auto refetch = [&](int set, int it) {
-                u32 spins = 0;
-                do {
-                    fn_wait_vm<0>();
-                    loadA(set, it);
-                    fn_wait_vm<0>();
-                } while (stale(set) && !fn_spin_expired(spins, err, dead));
-            };
-            // the step starts by polling its FIRST chunk only; the rest of the ring is requested once that one is published (the slices
-            // of a row group finish within a fraction of a chunk's MFMA time of each other)
-            loadA(0, 0);
+            for (int s = 0; s < D; ++s) loadA(s, s);
             loadB(0, 0);
-            if (chk) {
-                fn_wait_vm<0>();
-                if (stale(0)) refetch(0, 0);
-            }
-#pragma unroll
-            for (int s = 1; s < D; ++s) loadA(s, s);
             const int nmain = nkw / D * D;
             for (int base = 0; base < nmain; base += D) {
 #pragma unroll
                 for (int uu = 0; uu < D; ++uu) {
                     loadB((uu + 1) & 1, base + uu + 1);
                     fn_wait_vm<NLA * (D - 1)>();
-                    if (chk && stale(uu)) refetch(uu, base + uu);
                     mma(uu, uu & 1);
                     loadA(uu, base + uu + D);
                     __builtin_amdgcn_sched_barrier(0);
@@ -268,21 +231,12 @@ __global__ __launch_bounds__(NT) void gru_fwd_persist_kernel(const PArgs args) {
             for (int uu = 0; uu < D; ++uu)
                 if (nmain + uu < nkw) {
                     loadB((uu + 1) & 1, nmain + uu + 1);
-                    if (chk && stale(uu)) refetch(uu, nmain + uu);
                     mma(uu, uu & 1);
                 }
 #pragma unroll
             for (int s = 0; s < D; ++s)
 #pragma unroll
                 for (int m = 0; m < MT; ++m) { fn_keep(fa[s][m][0]); fn_keep(fa[s][m][1]); }
-        }
-        // every slice of the row group has published step p-1, i.e. nobody reads slab (p+1) % 3 (step p-2) any more: sentinel again
-        {
-            float* xclr = S.xf + (long)((p + 1) % 3) * FS;
-            const f32x4 sv = fn_sentinel4();
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-                if (ipub[i]) stv4_sc1(xclr + ixoff0 + i * ixstep, sv);
         }
 
         FN_PSTAMP(2);
@@ -299,10 +253,7 @@ __global__ __launch_bounds__(NT) void gru_fwd_persist_kernel(const PArgs args) {
         // (e) gates and the new state: thread -> items (row, units 4u4 .. 4u4+3)
         float* h_out = S.h_all + (long)p * B * H;
         float* gt = S.gates ? S.gates + (long)p * 4 * H * nrt * 16 : nullptr;
-        float* xout = (p + 1 < T) ? S.xf + (long)(p % 3) * FS : S.hlf;     // last step: hand-over slab of the next launch (or none)
-        if (dead) return;                                                  // a wave gave up in the K loop (uniform: read after the barrier)
-        if (p + 1 == T && tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // this workgroup has read its last operand
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the sentinel stores above are in L2 before any data of this step
+        float* xout = (p + 1 < T) ? S.xf + (long)((p + 1) & 1) * FS : S.hlf;     // last step: hand-over slab of the next launch (or none)
         f32x4 o_r[NI], o_z[NI], o_n[NI], o_g[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -325,12 +276,18 @@ __global__ __launch_bounds__(NT) void gru_fwd_persist_kernel(const PArgs args) {
                 hp[i][c] = (1.0f - z) * n + z * hp[i][c];
                 o_r[i][c] = r; o_z[i][c] = z; o_n[i][c] = n; o_g[i][c] = gh[2][c];
             }
-            // the exchange slab first: it is all the other workgroups wait for (pad rows carry the clamped row's finite values)
-            if (xout && ipub[i]) stv4_sc1(xout + ixoff0 + i * ixstep, hp[i]);
+            // the exchange slab first: it is all the other workgroups wait for
+            if (xout && iact[i]) stv4_sc1(xout + frag_off(ib[i], jj0, nk), hp[i]);
         }
 
         FN_PSTAMP(4);
-        FN_PSTAMP(5);
+        // (f) publish: every wave drains its stores, then ONE lane arrives at the group counter
+        if (p + 1 < T) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FN_PSTAMP(5);
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         FN_PSTAMP(6);
         // (g) outputs nobody in this launch waits for
 #pragma unroll
@@ -344,21 +301,6 @@ __global__ __launch_bounds__(NT) void gru_fwd_persist_kernel(const PArgs args) {
                 stv4(gt + gate_off(ib[i], 3, jj0, nrt), o_g[i]);
             }
         }
-    }
-    // leave the exchange all-sentinel for the next launch: once every slice of the row group has read its last operand
-    if (tid == 0) {
-        u32 spins = 0;
-        while (ld_cnt(counter) < (u32)nslices && !fn_spin_expired(spins, err, dead)) {}
-    }
-    __syncthreads();
-    if (dead) return;
-    {
-        const f32x4 sv = fn_sentinel4();
-#pragma unroll
-        for (int sl = 0; sl < 3; ++sl)
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-                if (ipub[i]) stv4_sc1(S.xf + (long)sl * FS + ixoff0 + i * ixstep, sv);
     }
 }
 
@@ -379,7 +321,7 @@ struct QScan {
     float* dh0;
     float* rowsum;
     float* rowsum_n;
-    float* xf;            // 3 exchange slabs [rows][3H], fragment-major (all FN_SENTINEL at launch)
+    float* xf;            // 2 exchange slabs [rows][3H], fragment-major
     int B, T;
     int group0;
 };
@@ -397,9 +339,8 @@ __global__ __launch_bounds__(NT) void gru_bwd_persist_kernel(const QArgs args) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = args.H, nk3 = (3 * H) >> 5;
     float* wl = smem;                                // [nk3][2][64][4]  W_hh^T slice, B-fragment order
-    float* red0 = smem + 3 * H * 16;                 // [2][WK][EM][RT], double buffered (one barrier per iteration)
-    constexpr int REDW = WK * EM * RT;
-    volatile int& dead = *reinterpret_cast<volatile int*>(red0 + 2 * REDW);
+    float* red = smem + 3 * H * 16;                  // [WK][EM][RT]
+    volatile int& dead = *reinterpret_cast<volatile int*>(red + WK * EM * RT);
 
     const int g = blockIdx.x % args.ngroups, slice = blockIdx.x / args.ngroups;
     int si = 0;
@@ -428,20 +369,15 @@ __global__ __launch_bounds__(NT) void gru_bwd_persist_kernel(const QArgs args) {
 
     constexpr int NI = (EM * 64 + NT - 1) / NT;
     int ib[NI], icoff[NI];
-    bool iact[NI], ipub[NI];
+    bool iact[NI];
     f32x4 carry[NI], rs[NI][3], rsn[NI];
     const int jj0 = hh0 + 4 * (tid & 3);
-    // slab offset of item i inside the r third of a slab (z / n thirds follow `third` floats further); items are 4 row tiles apart
-    const long ixoff0 = frag_off(m0 + (tid >> 2), jj0, nk3);
-    const long ixstep = (long)4 * nk3 * 512;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int item = tid + NT * i;
         const int rl = item >> 2;
         iact[i] = item < EM * 64 && m0 + rl < B;
-        ipub[i] = item < EM * 64 && m0 + rl < nrt * 16;
         ib[i] = min(m0 + rl, B - 1);
-
         icoff[i] = min(rl >> 4, EM - 1) * RT + ((rl & 15) >> 2) * 68 + (item & 3) * 16 + (rl & 3);
         carry[i] = S.dh_last ? ldv4(S.dh_last + (long)ib[i] * H + jj0) : (f32x4){0.f, 0.f, 0.f, 0.f};
         rsn[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -477,13 +413,30 @@ __global__ __launch_bounds__(NT) void gru_bwd_persist_kernel(const QArgs args) {
             }
         }
 
-        // (b)+(c) dh partial = df_{q+1} W_hh (columns of this slice); the operand of iteration it-1 is polled in place (flag in data)
-        float* red = red0 + (it & 1) * REDW;
+        // (b) wait for every slice's gradient slab of the previous iteration
+        if (it > 0) {
+            if (tid == 0) {
+                const u32 target = (u32)nslices * (u32)it;
+                u32 spins = 0;
+                while (ld_cnt(counter) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 63u) == 0 && (spins > SPIN_LIMIT || ld_cnt(err) != 0)) {
+                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        dead = 1;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            if (dead) return;
+        }
+
+        // (c) dh partial = df_{q+1} W_hh (columns of this slice)
         f32x4 acc[MT][2];
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[m][0] = acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (it > 0 && nkw > 0) {
-            const float* xin = S.xf + (long)((it + 2) % 3) * FS3;
+            const float* xin = S.xf + (long)((it - 1) & 1) * FS3;
             f32x4 fa[D][MT][2], fb[2][2];
             auto loadA = [&](int set, int k) {
                 const long k0 = (long)(c0 + min(k, nkw - 1)) * 512;
@@ -503,33 +456,15 @@ __global__ __launch_bounds__(NT) void gru_bwd_persist_kernel(const QArgs args) {
                         acc[m][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4at(fa[set][m][j >> 2], j & 3), f4at(fb[bs][j >> 2], j & 3),
                                                                              acc[m][j & 1], 0, 0, 0);
             };
-            auto stale = [&](int set) -> bool {
-                u32 mx = 0;
 #pragma unroll
-                for (int m = 0; m < MT; ++m) { fn_touch(fa[set][m][0]); fn_touch(fa[set][m][1]); mx = fn_umax4(fn_umax4(mx, fa[set][m][0]), fa[set][m][1]); }
-                return __any(mx == FN_SENTINEL) != 0;
-            };
-            auto refetch = [&](int set, int k) {          // see the forward kernel
-                u32 spins = 0;
-                do {
-                    fn_wait_vm<0>();
-                    loadA(set, k);
-                    fn_wait_vm<0>();
-                } while (stale(set) && !fn_spin_expired(spins, err, dead));
-            };
-            loadA(0, 0);
+            for (int s = 0; s < D; ++s) loadA(s, s);
             loadB(0, 0);
-            fn_wait_vm<0>();
-            if (stale(0)) refetch(0, 0);
-#pragma unroll
-            for (int s = 1; s < D; ++s) loadA(s, s);
             const int nmain = nkw / D * D;
             for (int base = 0; base < nmain; base += D) {
 #pragma unroll
                 for (int uu = 0; uu < D; ++uu) {
                     loadB((uu + 1) & 1, base + uu + 1);
                     fn_wait_vm<NLA * (D - 1)>();
-                    if (stale(uu)) refetch(uu, base + uu);
                     mma(uu, uu & 1);
                     loadA(uu, base + uu + D);
                     __builtin_amdgcn_sched_barrier(0);
@@ -540,26 +475,12 @@ __global__ __launch_bounds__(NT) void gru_bwd_persist_kernel(const QArgs args) {
             for (int uu = 0; uu < D; ++uu)
                 if (nmain + uu < nkw) {
                     loadB((uu + 1) & 1, nmain + uu + 1);
-                    if (stale(uu)) refetch(uu, nmain + uu);
                     mma(uu, uu & 1);
                 }
 #pragma unroll
             for (int s = 0; s < D; ++s)
 #pragma unroll
                 for (int m = 0; m < MT; ++m) { fn_keep(fa[s][m][0]); fn_keep(fa[s][m][1]); }
-        }
-        // every slice has published iteration it-1, i.e. nobody reads slab (it+1) % 3 (iteration it-2) any more: sentinel again
-        const long third = (long)(H >> 5) * 512;          // floats between the r, z and n parts of one row tile's chunks
-        {
-            float* xclr = S.xf + (long)((it + 1) % 3) * FS3;
-            const f32x4 sv = fn_sentinel4();
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-                if (ipub[i]) {
-                    stv4_sc1(xclr + ixoff0 + i * ixstep, sv);
-                    stv4_sc1(xclr + ixoff0 + i * ixstep + third, sv);
-                    stv4_sc1(xclr + ixoff0 + i * ixstep + 2 * third, sv);
-                }
         }
 
         // (d) accumulators -> LDS (padded MFMA C layout)
@@ -569,11 +490,9 @@ __global__ __launch_bounds__(NT) void gru_bwd_persist_kernel(const QArgs args) {
         __syncthreads();
 
         // (e) gate backward, element-wise
-        const bool publish = it + 1 < iters;
-        float* xout = S.xf + (long)(it % 3) * FS3;
-        if (dead) return;
-        if (it + 1 == iters && tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the sentinel stores above are in L2 before any data of this iteration
+        const bool publish = q > 0 || (q == 0 && S.dh0 != nullptr);
+        float* xout = S.xf + (long)(it & 1) * FS3;
+        const int nkc = nk3;
         f32x4 o_r[NI], o_z[NI], o_n[NI], o_g[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -602,13 +521,19 @@ __global__ __launch_bounds__(NT) void gru_bwd_persist_kernel(const QArgs args) {
                 o_g[i][c] = dnp * r;
                 carry[i][c] = dh[c] * z;
             }
-            if (publish && ipub[i]) {
-                stv4_sc1(xout + ixoff0 + i * ixstep, o_r[i]);
-                stv4_sc1(xout + ixoff0 + i * ixstep + third, o_z[i]);
-                stv4_sc1(xout + ixoff0 + i * ixstep + 2 * third, o_g[i]);
+            if (publish && iact[i]) {
+                stv4_sc1(xout + frag_off(ib[i], jj0, nkc), o_r[i]);
+                stv4_sc1(xout + frag_off(ib[i], H + jj0, nkc), o_z[i]);
+                stv4_sc1(xout + frag_off(ib[i], 2 * H + jj0, nkc), o_g[i]);
             }
         }
 
+        // (f) publish
+        if (publish) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         // (g) outputs nobody in this launch waits for
         if (q >= 0) {
 #pragma unroll
@@ -622,27 +547,6 @@ __global__ __launch_bounds__(NT) void gru_bwd_persist_kernel(const QArgs args) {
                 stv4(S.dghn_all + (long)q * BH + (long)ib[i] * H + jj0, o_g[i]);
             }
         }
-    }
-    // leave the exchange all-sentinel for the next launch: once every slice of the row group has read its last operand
-    if (tid == 0) {
-        u32 spins = 0;
-        while (ld_cnt(counter) < (u32)nslices && !fn_spin_expired(spins, err, dead)) {}
-    }
-    __syncthreads();
-    if (dead) return;
-    {
-        const f32x4 sv = fn_sentinel4();
-        const long third = (long)(H >> 5) * 512;
-#pragma unroll
-        for (int sl = 0; sl < 3; ++sl)
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-                if (ipub[i]) {
-                    float* x = S.xf + (long)sl * FS3 + ixoff0 + i * ixstep;
-                    stv4_sc1(x, sv);
-                    stv4_sc1(x + third, sv);
-                    stv4_sc1(x + 2 * third, sv);
-                }
     }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -752,13 +656,8 @@ int fn_gru_fwd_persist(const FnGruFwd* scans, int n_scans, hipStream_t st) {
         f.B = d.B; f.T = d.T;
         f.group0 = groups;
         groups += (d.B + rpw - 1) / rpw;
-        const size_t FS = fn_frag_floats(d.B, d.H);
-        if (!(scans[0].variant & 0x400)) {                      // bit 10: the caller keeps the exchange slabs all-sentinel between launches
-            hipError_t me = hipMemsetAsync(d.frag_ws, 0xFF, 3 * FS * sizeof(float), st);
-            if (me != hipSuccess) return (int)me;
-        }
-        if (d.h0 && !d.h0_frag) {                               // step 0 reads slab 2 (= slab of "step -1")
-            const int rc = launch_pack(d.h0, d.B, d.H, d.H, d.frag_ws + 2 * FS, st);
+        if (d.h0 && !d.h0_frag) {
+            const int rc = launch_pack(d.h0, d.B, d.H, d.H, d.frag_ws, st);
             if (rc != FN_OK) return rc;
         }
     }
@@ -770,7 +669,7 @@ int fn_gru_fwd_persist(const FnGruFwd* scans, int n_scans, hipStream_t st) {
     }
     const int grid = groups * nslices;
     const int wk = rpw == 16 ? 4 : rpw == 32 ? 2 : (rpw == 64 && !(scans[0].variant & 0x100)) ? 2 : 1;     // K split of the chosen tiling
-    const size_t lds = ((size_t)3 * H * 16 + (size_t)2 * wk * (rpw / 16) * 3 * RT) * 4 + 16;
+    const size_t lds = ((size_t)3 * H * 16 + (size_t)wk * (rpw / 16) * 3 * RT) * 4 + 16;
     switch (rpw) {
         case 128: return launch_k<PArgs, gru_fwd_persist_kernel<4, 1, 2, 4>>(a, grid, lds, cus, st);
         case 64:
@@ -825,10 +724,6 @@ int fn_gru_bwd_persist(const FnGruBwd* scans, int n_scans, hipStream_t st) {
         f.B = d.B; f.T = d.T;
         f.group0 = groups;
         groups += (d.B + rpw - 1) / rpw;
-        if (!(scans[0].variant & 0x400)) {
-            hipError_t me = hipMemsetAsync(d.frag_ws, 0xFF, 3 * fn_frag_floats(d.B, 3 * d.H) * sizeof(float), st);
-            if (me != hipSuccess) return (int)me;
-        }
     }
     a.ngroups = groups;
     a.err = scans[0].err_ws ? reinterpret_cast<u32*>(scans[0].err_ws) : a.sync + FN_MAX_GROUPS * 32;
@@ -838,7 +733,7 @@ int fn_gru_bwd_persist(const FnGruBwd* scans, int n_scans, hipStream_t st) {
     }
     const int grid = groups * nslices;
     const int wk = rpw == 16 ? 4 : rpw == 32 ? 2 : (rpw == 64 && !(scans[0].variant & 0x100)) ? 2 : 1;
-    const size_t lds = ((size_t)3 * H * 16 + (size_t)2 * wk * (rpw / 16) * RT) * 4 + 16;
+    const size_t lds = ((size_t)3 * H * 16 + (size_t)wk * (rpw / 16) * RT) * 4 + 16;
     switch (rpw) {
         case 128: return launch_k<QArgs, gru_bwd_persist_kernel<4, 1, 2, 8>>(a, grid, lds, cus, st);
         case 64:

@@ -66,7 +66,10 @@ def arousal_transfer(model, d, c, lmbda=1.0, low_to_high=True, steps=300):
     -> (out (1, steps, 342) log-probabilities, z (1, 2Z+24))."""
     dev = model.mu_r.weight.device
     model.eval()
-    x = torch.as_tensor(d).to(dev).unsqueeze(0)
+    x = torch.as_tensor(d).to(dev)
+    if x.dim() == 1 and x.is_floating_point():
+        x = x.long()                         # the loaders yield float32 ids (cast like the reference's `.long()`, test_class.py:240)
+    x = x.unsqueeze(0)
     Z = model.latent_dim
     dis_r, dis_n = model.encode(x)
     z_r = dis_r.mean + dis_r.stddev * torch.randn(1, Z).to(dev)

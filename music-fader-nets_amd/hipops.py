@@ -56,7 +56,6 @@ class HipOps:
         self.cell_variant = 0     # FnGruCell.variant (tuning / tests)
         self.variant = 0          # FnGruFwd.variant of every scan launch (tuning / tests only; results do not depend on it)
         self.lane = ""            # scratch namespace: kernels enqueued on different streams must not share workspaces
-        self.frag_clean_hint = True   # tell the scans that their exchange scratch is all-sentinel (False: the library memsets it per launch; tests)
 
     # -- plumbing -------------------------------------------------------------------------------
     def stream(self):
@@ -171,19 +170,8 @@ class HipOps:
                 d.src, d.dst, d.rows, d.cols, d.ld, d.kind = ps, _p(dst), R, Cc, ld, kinds[kind]
             _lib.check(self.lib.fn_weight_images(arr, len(part), self.stream()), "fn_weight_images")
 
-    FRAG_CLEAN = 0x400            # FnGruFwd.variant bit 10: frag_ws is all-sentinel between launches (kept so by the kernels themselves)
-
-    def _frag_ws(self, tag, i, n, persistent=True):
-        """exchange scratch of scan i of a launch.  The weight-stationary kernels hand their operands over with a flag-in-data protocol:
-        their three slabs hold the sentinel bit pattern 0xFFFFFFFF between launches (filled here once, restored by every launch), which
-        saves a memset node per launch.  The per-step kernels ping-pong plain data, so they get a scratch of their own."""
-        tag = "%s%s%d" % (tag, "" if persistent else "step", i)
-        cur = self._ws.get(self.lane + tag)
-        ws = self.workspace(4 * n, tag)
-        if persistent and ws is not cur:                      # new (or outgrown and replaced) buffer
-            ws.view(torch.int32).fill_(-1)
-            self.__dict__.setdefault("_frag_clean", {})[self.lane + tag] = ws
-        return ws[:n]
+    def _frag_ws(self, tag, i, n):
+        return self.workspace(4 * n, "%s%d" % (tag, i))[:n]
 
     SYNC_REGIONS = 64
 
@@ -235,14 +223,11 @@ class HipOps:
         if bad and clear:
             for t in syncs:
                 t[-32:].zero_()
-            for ws in self.__dict__.get("_frag_clean", {}).values():      # a launch that gave up has left its exchange slabs half written
-                ws.view(torch.int32).fill_(-1)
         return bad
 
     def gru_seq_fwd(self, scans, persistent=True, cu_budget=0, variant=None):
         arr = (_lib.FnGruFwd * len(scans))()
         variant = self.variant if variant is None else variant
-        persistent = persistent and max(s["T"] for s in scans) >= 2      # single steps (token-by-token decode) are per-step launches anyway
         sync = self._sync_region() if persistent else None
         for i, (d, s) in enumerate(zip(arr, scans)):
             for k in ("w_hh_frag", "b_hh", "b_ih", "h0", "gx_dense", "gx_table", "gx_rowbias", "h_all", "gates", "h0_frag", "h_last_frag"):
@@ -250,8 +235,8 @@ class HipOps:
             for k in ("h0_frag", "h_last_frag"):
                 if s.get(k) is not None and s[k].numel() < self.frag_floats(s["B"], s["H"]):
                     raise RuntimeError("%s needs frag_floats(B, H) floats" % k)
-            d.frag_ws = _p(self._frag_ws("fragf", i, 3 * self.frag_floats(s["B"], s["H"]), persistent))
-            d.sync_ws, d.err_ws, d.variant = (_p(sync[0]), _p(sync[1]), int(variant) | sync[2] | (self.FRAG_CLEAN if self.frag_clean_hint else 0)) if persistent else (None, None, int(variant))
+            d.frag_ws = _p(self._frag_ws("fragf", i, 2 * self.frag_floats(s["B"], s["H"])))
+            d.sync_ws, d.err_ws, d.variant = (_p(sync[0]), _p(sync[1]), int(variant) | sync[2]) if persistent else (None, None, int(variant))
             d.cu_budget = int(cu_budget)
             _dense(s.get("idx"), torch.int32, "idx")
             d.B, d.T, d.H, d.reverse = s["B"], s["T"], s["H"], int(s.get("reverse", 0))
@@ -292,13 +277,12 @@ class HipOps:
     def gru_seq_bwd(self, scans, persistent=True, cu_budget=0, variant=None):
         arr = (_lib.FnGruBwd * len(scans))()
         variant = self.variant if variant is None else variant
-        persistent = persistent and max(s["T"] for s in scans) >= 2
         sync = self._sync_region() if persistent else None
         for i, (d, s) in enumerate(zip(arr, scans)):
             for k in ("w_hh_t_frag", "h0", "h_all", "gates", "dh_last", "dh_ext", "dgx_all", "dghn_all", "dh0", "dgx_rowsum", "dghn_rowsum", "scratch"):
                 _dense(s.get(k), name=k)
-            d.frag_ws = _p(self._frag_ws("fragb", i, 3 * self.frag_floats(s["B"], 3 * s["H"]), persistent))
-            d.sync_ws, d.err_ws, d.variant = (_p(sync[0]), _p(sync[1]), int(variant) | sync[2] | (self.FRAG_CLEAN if self.frag_clean_hint else 0)) if persistent else (None, None, int(variant))
+            d.frag_ws = _p(self._frag_ws("fragb", i, 2 * self.frag_floats(s["B"], 3 * s["H"])))
+            d.sync_ws, d.err_ws, d.variant = (_p(sync[0]), _p(sync[1]), int(variant) | sync[2]) if persistent else (None, None, int(variant))
             d.cu_budget = int(cu_budget)
             d.B, d.T, d.H = s["B"], s["T"], s["H"]
             d.w_hh_t_frag, d.h0, d.h_all, d.gates = _p(s["w_hh_t_frag"]), _p(s.get("h0")), _p(s["h_all"]), _p(s["gates"])

@@ -104,6 +104,14 @@ class _SingleEncModel(MusicAttrRegGMVAE):
     @torch.no_grad()
     def _forward_core(self, x, cond, extra, eps):
         """encode -> z -> global decoder (teacher forced in train mode, greedy in eval mode) -> (out, dis, z_lat)"""
+        if self.training and not getattr(self, "_warned_no_autograd", False):
+            # forward-only drop-in: a reference-style `loss.backward(); optimizer.step()` on these outputs would fail with
+            # "does not require grad" - say so once, where the user can see why
+            import warnings
+            warnings.warn("%s.forward returns tensors without an autograd graph (forward-only drop-in); train through the fused "
+                          "%s classes of music_fader_nets_amd.trainer_v2, which reproduce the reference trainers' train()/evaluate()"
+                          % (type(self).__name__, "SingleVAETrainer / CVAETrainer / FaderTrainer"), stacklevel=3)
+            self._warned_no_autograd = True
         eng = self.engine()
         d = self._indices(x, self.roll_dims)
         B, T = d.shape
@@ -225,7 +233,12 @@ class MusicAttrFaderNets(_SingleEncModel):
 
     def _draw_extra(self, B):
         """the two dropout keep-masks, scaled by 1/(1-p), drawn as the reference's nn.Dropout draws them on the CPU generator
-        (rhythm head first, model_v2.py:574-575); all ones in eval mode"""
+        (rhythm head first, model_v2.py:574-575); all ones in eval mode.
+
+        RNG contract: the parity pin is the reference's CPU path on identical seeds (tests/golden/siblings.npz), where nn.Dropout
+        consumes the CPU generator between randn(B, Z) and the T x rand(1) draws - reproduced here.  The reference run on a GPU draws
+        its masks from the CUDA generator instead (whose Philox stream cannot be reproduced by another kernel anyway), so after the
+        first Fader forward its CPU generator is 2 x B draws behind ours; pass eps / mask explicitly to be independent of that."""
         if not self.training:
             return torch.ones(B, 2)
         one = torch.ones(B, 1)

@@ -162,6 +162,8 @@ class CVAETrainer(_SingleEncTrainer):
         b = list(super().prepare_batch(d, r, n, c, r_density, n_density))
         dev = self.flat.param.device
         # the densities enter the MODEL here (float32 columns of the encoder / decoder inputs, trainer_cvae.py:199-200)
+        # (the reference's loops hand them over as (B, 1) float tensors, trainer_cvae.py:171 / trainer_fader.py:180; (B,) arrays work too)
+        b[4], b[5] = b[4].reshape(-1), b[5].reshape(-1)
         b.append(torch.stack([b[4].float(), b[5].float()], dim=1).to(dev).contiguous())
         return tuple(b)
 
@@ -390,6 +392,10 @@ class GLSRTrainer(GMVAETrainer):
 
     def _forward_losses(self, step, batch, eps, want_grads):
         self._cur_eps = eps
+        # The regulariser runs four more decoder passes (weight-stationary, whole-chip launches that spin on each other's progress).  On the
+        # side lane they would be in flight together with the main pass's decoder backward on the main stream: two such grids of 256
+        # workgroups cannot be resident at once at hidden 512 / batch 256 and would starve each other into the bounded-spin error.
+        self.model.engine().losses_on_side = False
         return super()._forward_losses(step, batch, eps, want_grads)
 
     def _run_backward(self, fw, hook):

@@ -326,7 +326,10 @@ def check_sibling(pkg, kind, m, g, dev, rtol_fw=5e-5, tol_grad=5e-4, rtol_tuple=
     step = 19999
     for it in range(3):
         torch.manual_seed(99 + it)
-        step, tup = tr.train(step, None, None, None, g["d"], g["r"], g["n"], g["c"], g["r_density"], g["n_density"])
+        # the densities as the reference's own loops hand them over: float64 arrays (trainer_singlevae.py:107-120), (B, 1) float32
+        # device tensors for the conditional models (trainer_cvae.py:171, trainer_fader.py:180)
+        dens = (g["r_density"], g["n_density"]) if kind == "single" or it == 2 else (rd32, nd32)
+        step, tup = tr.train(step, None, None, None, g["d"], g["r"], g["n"], g["c"], *dens)
         np.testing.assert_allclose(tup, g["train_tuples"][it], rtol=rtol_tuple, atol=1e-9, err_msg="step %d" % it)
     assert step == 20002
     for k, v in m.state_dict().items():
@@ -334,7 +337,9 @@ def check_sibling(pkg, kind, m, g, dev, rtol_fw=5e-5, tol_grad=5e-4, rtol_tuple=
         np.testing.assert_allclose([vd.abs().sum().item()], g["w3sum/" + k][1:2], rtol=1e-3, err_msg=k)
     torch.manual_seed(123)
     if kind == "cvae":
-        ev = tr.evaluate(None, None, None, g["d"], g["r"], g["n"], g["c"], g["r_density"], g["n_density"])
+        ev = tr.evaluate(None, None, None, g["d"], g["r"], g["n"], g["c"], rd32, nd32)
+    elif kind == "fader":
+        ev = tr.evaluate(step - 1, None, None, None, g["d"], g["r"], g["n"], g["c"], rd32, nd32)
     else:
         ev = tr.evaluate(step - 1, None, None, None, g["d"], g["r"], g["n"], g["c"], g["r_density"], g["n_density"])
     np.testing.assert_allclose(ev, g["eval_tuple"], rtol=rtol_tuple, atol=1e-9)

@@ -317,37 +317,6 @@ def test_weight_stationary_scans_random_configurations(ops):
     assert not ops.gru_sync_error()
 
 
-@pytest.mark.parametrize("B,T,H", [(5, 7, 64), (200, 6, 512), (256, 33, 512)])
-def test_exchange_slabs_are_all_sentinel_between_launches(ops, B, T, H):
-    """Flag-in-data hand-over of the weight-stationary scans: their three exchange slabs must be all 0xFFFFFFFF again when a launch ends
-    (forward incl. the packed initial state and pad rows, backward incl. the dh0 iteration), with and without the caller's
-    "already clean" hint (without it the library memsets in front of the launch), and the results must not depend on the hint."""
-    fake = FakeOps()
-    c = _scan_inputs(B, T, H, 21, 4, True, shift=-1)
-    d = _to_dev(c)
-    c["w_hh_frag"], d["w_hh_frag"] = _pack(fake, c["w_hh"], "cpu"), _pack(ops, c["w_hh"], DEV)
-    fake.gru_seq_fwd([c])
-    outs = []
-    for hint in (True, False, True):
-        ops.frag_clean_hint = hint
-        d["h_all"].fill_(float("nan"))
-        ops.gru_seq_fwd([d])
-        close(d["h_all"], c["h_all"], 2e-5, "h_all hint=%s" % hint)
-        outs.append(d["h_all"].clone())
-        torch.manual_seed(3)
-        b = dict(B=B, T=T, H=H, w_hh_t_frag=_pack(ops, c["w_hh"].t().contiguous(), DEV), h0=d.get("h0"), h_all=d["h_all"], gates=d["gates"],
-                 dh_last=g(torch.randn(B, H)), dh_ext=g(torch.randn(T, B, H)), dgx_all=torch.zeros(T, B, 3 * H, device=DEV),
-                 dghn_all=torch.zeros(T, B, H, device=DEV), dh0=torch.zeros(B, H, device=DEV), scratch=torch.zeros(B, H, device=DEV))
-        ops.gru_seq_bwd([b])
-        outs.append(b["dgx_all"].clone())
-        torch.cuda.synchronize()
-        for tag, ws in ops._frag_clean.items():
-            assert bool((ws.view(torch.int32) == -1).all()), "exchange scratch %s is not all-sentinel after the launch (hint=%s)" % (tag, hint)
-    ops.frag_clean_hint = True
-    assert not ops.gru_sync_error()
-    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[4]) and torch.equal(outs[1], outs[3]) and torch.equal(outs[1], outs[5])
-
-
 @pytest.mark.parametrize("rows,H,splitk,beta", [(37, 64, 1, 0.0), (1030, 64, 4, 1.0), (300, 96, 4, 0.0), (5000, 512, 8, 1.0)])
 def test_gru_weight_gradient(ops, rows, H, splitk, beta):
     """fn_gru_dwhh_f32: dW_hh = beta dW_hh + [dgx[:, :2H] | dghn]^T hprev (one split-A launch when 2H % 128 == 0, else two products)."""
@@ -1102,3 +1071,119 @@ def test_gemm_multi(ops, a_k, b_k):
     for Cd, ref, C0, N in refs:
         close(Cd[:, :N], ref, 2e-5)
         assert torch.equal(Cd[:, N:].cpu(), C0[:, N:])            # columns beyond N untouched
+
+
+def test_glsr_full_size_keeps_the_scans_apart():
+    """GLSRTrainer at hidden 512, B=256 (T=128 >= its 100 decode steps), step > 20: the four extra decoder passes are whole-chip weight-
+    stationary launches; queued on a side stream they would be in flight together with the main decoder backward and starve each other
+    into the bounded-spin error.  Two steps must finish with finite numbers and a clear sync-error word."""
+    from helpers import make_vae_model
+    from music_fader_nets_amd.synth import synth_batch
+    pkg = load_package()
+    m = make_vae_model(512, 128, device=DEV)
+    tr = pkg.GLSRTrainer(m, lr=1e-3, beta=0.2)
+    b = synth_batch(np.random.RandomState(3), 256, 128, 32)
+    step = 5000
+    for it in range(2):
+        torch.manual_seed(11 + it)
+        step, tup = tr.train(step, None, None, None, b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"])
+        assert all(np.isfinite(tup)), tup
+    assert m.engine().losses_on_side is False
+    assert not m.engine().ops.gru_sync_error()
+    assert tup[4] > 0 and tup[5] > 0            # both regularisers were active
+
+
+# ----------------------------------------------------------------------------------------------
+# element-wise gradient slices at hidden 512 (tests/golden/slices.npz, made by the reference itself): c0 / c1 hold per-parameter
+# checksums only, which a row permutation or a sign pattern inside one tensor would pass
+# ----------------------------------------------------------------------------------------------
+def _check_grad_slices(g, pfx, named_grads, tol=5e-4, skip=()):
+    """first 2 + last 2 rows and every 97th element of each parameter gradient, at `tol` of the tensor's max"""
+    n_rows = n_stride = 0
+    for k, G in named_grads:
+        got = G.detach().cpu().numpy()
+        scale = float(np.abs(got).max())
+        if k in skip:
+            continue
+        ref = g[pfx + "gstride/" + k]
+        assert np.abs(got.reshape(-1)[::97] - ref).max() <= tol * max(scale, np.abs(ref).max()) + 1e-7, (pfx, k, "stride-97 sample")
+        n_stride += ref.size
+        if pfx + "grad/" + k in g:
+            ref = g[pfx + "grad/" + k]
+            mine = np.concatenate([got[:2], got[-2:]], 0) if (got.ndim == 2 and got.shape[0] >= 8) else got
+            assert mine.shape == ref.shape, (k, mine.shape, ref.shape)
+            assert np.abs(mine - ref).max() <= tol * max(scale, np.abs(ref).max()) + 1e-7, (pfx, k, "rows")
+            n_rows += ref.size
+    return n_rows, n_stride
+
+
+@pytest.mark.parametrize("pfx,sup", [("c0u/", False), ("c0s/", True), ("c1u/", False)])
+def test_gradient_slices_vs_reference_at_hidden_512(pfx, sup):
+    """hidden 512: per-parameter gradient ROWS and a stride-97 sample of every gradient, plus d loss / d (encoder input) at sampled
+    (batch, time) positions = both directions' gate-gradient rows of gru_r / gru_n projected through W_ih, against the reference's own
+    backward (unsupervised and supervised loss at B=8, the benchmark shape B=256 / T=256: 128-row tiles, K = 65 280 weight-gradient GEMMs)"""
+    pkg = load_package()
+    from music_fader_nets_amd.synth import synth_batch
+    g = load_golden("slices")
+    H, Z, K, B, T, Tr = (int(x) for x in g[pfx + "dims"])
+    m = make_model(H, Z, device=DEV)
+    tr = pkg.GMVAETrainer(m, lr=1e-3, beta=0.2)
+    b = synth_batch(np.random.RandomState(0), B, T, Tr)
+    lab = b["a"] if sup else None
+    batch = tr.prepare_batch(b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"], lab)
+    torch.manual_seed(99)
+    eps = tr.draw_eps(B, T)
+    tup = tr.loss_and_grads(20000, batch, eps)
+    np.testing.assert_allclose(tup[0], g[pfx + "loss"][0], rtol=2e-5)
+    np.testing.assert_allclose(tr.grad_norm(), g[pfx + "gradnorm"][0], rtol=1e-3)
+    ref_keys = {k[len(pfx + "gstride/"):] for k in g if k.startswith(pfx + "gstride/")}
+    assert set(tr.flat.names) == ref_keys
+    # linear_out_{r,n}.bias: mathematically zero gradient (time-axis softmax), pure rounding noise in both implementations
+    n_rows, n_stride = _check_grad_slices(g, pfx, [(k, tr.flat.G[k]) for k in tr.flat.names], skip=("linear_out_r.bias", "linear_out_n.bias"))
+    assert n_rows > 30000 and n_stride > 50000
+    # encoder input gradient: dgx rows of both directions through W_ih (dgx is stored in PROCESSING order: reverse scans run t = T-1 .. 0)
+    eng = m.engine()
+    bs, ts = g[pfx + "xg_b"], g[pfx + "xg_t"]
+    for e in ("r", "n"):
+        ref = g[pfx + "xgrad_" + e]                                # [len(bs)][len(ts)][342]
+        dgx_f = eng.buf("enc_dgx_" + e, (T, B, 3 * H))
+        dgx_b = eng.buf("enc_dgx_" + e + "_reverse", (T, B, 3 * H))
+        Wf, Wb = eng.p["gru_%s.weight_ih_l0" % e].double(), eng.p["gru_%s.weight_ih_l0_reverse" % e].double()
+        got = np.zeros_like(ref, dtype=np.float64)
+        for i, bi in enumerate(bs):
+            for j, t in enumerate(ts):
+                got[i, j] = (dgx_f[int(t), int(bi)].double() @ Wf + dgx_b[T - 1 - int(t), int(bi)].double() @ Wb).cpu().numpy()
+        assert np.abs(got - ref).max() <= 5e-4 * np.abs(ref).max(), (pfx, e, np.abs(got - ref).max(), np.abs(ref).max())
+
+
+def test_fader_sibling_at_hidden_512_batch_256_vs_reference():
+    """MusicAttrFaderNets at hidden 512, B=256, T=64 (the 128-row tiles of the single-encoder engine) against trainer_fader.py's own
+    loss / backward / train() at that size: loss terms, gradient rows + stride-97 samples, one optimisation step"""
+    from helpers import make_sibling
+    pkg = load_package()
+    g = load_golden("slices")
+    pfx = "fader/"
+    H, Z, B, T, Tr = (int(x) for x in g[pfx + "dims"])
+    m = make_sibling("fader", H, Z, device=DEV)
+    for k, v in m.state_dict().items():
+        vd = v.double()
+        np.testing.assert_allclose([vd.sum().item(), vd.abs().sum().item(), (vd * vd).sum().item()], g[pfx + "w0sum/" + k], rtol=1e-9, atol=1e-9, err_msg=k)
+    from music_fader_nets_amd.synth import synth_batch
+    b = synth_batch(np.random.RandomState(5), B, T, Tr)
+    tr = pkg.FaderTrainer(m, lr=1e-3, beta=0.2)
+    rd32 = torch.from_numpy(b["r_density"]).float().unsqueeze(-1).to(DEV)       # (B, 1) float32 device tensors, trainer_fader.py:180
+    nd32 = torch.from_numpy(b["n_density"]).float().unsqueeze(-1).to(DEV)
+    batch = tr.prepare_batch(b["d"], b["r"], b["n"], b["c"], rd32, nd32)
+    torch.manual_seed(99)
+    eps = tr.draw_eps(B, T)
+    tup = tr.loss_and_grads(20000, batch, eps)
+    np.testing.assert_allclose(tup, g[pfx + "loss_terms"], rtol=5e-4, atol=1e-9)
+    np.testing.assert_allclose(tr.grad_norm(), g[pfx + "gradnorm"][0], rtol=1e-3)
+    assert set(tr.flat.names) == {k[len(pfx + "gstride/"):] for k in g if k.startswith(pfx + "gstride/")}
+    _check_grad_slices(g, pfx, [(k, tr.flat.G[k]) for k in tr.flat.names])
+    torch.manual_seed(99)
+    step, t1 = tr.train(19999, None, None, None, b["d"], b["r"], b["n"], b["c"], rd32, nd32)
+    np.testing.assert_allclose(t1, g[pfx + "train_tuple"], rtol=5e-4, atol=1e-9)
+    for k, v in m.state_dict().items():
+        np.testing.assert_allclose([v.double().abs().sum().item()], g[pfx + "w1sum/" + k][1:2], rtol=1e-3, err_msg=k)
+    assert not m.engine().ops.gru_sync_error()

@@ -128,6 +128,26 @@ def test_gradients_c0(c0):
         np.testing.assert_allclose(got[2], ref[2], rtol=4e-4, atol=1e-9, err_msg=k)
 
 
+@pytest.mark.parametrize("pfx,sup", [("c0u/", False), ("c0s/", True)])
+def test_gradient_slices_c0(c0, pfx, sup, golden_dir):
+    """hidden 512: the oracle's gradients against ROWS and stride-97 samples of the reference's (tests/golden/slices.npz) - checksums
+    alone would pass a row permutation or a sign pattern inside one tensor"""
+    g = dict(np.load(os.path.join(golden_dir, "slices.npz")))
+    sd = orc.init_state_dict(512, 128)
+    grads, tup, _ = orc.gradients(sd, _batch(c0), torch.from_numpy(c0["eps_r"]), torch.from_numpy(c0["eps_n"]), 20000, 0.2, is_supervised=sup)
+    np.testing.assert_allclose(float(tup[0].detach()), g[pfx + "loss"][0], rtol=2e-6)
+    assert set(grads) == {k[len(pfx + "gstride/"):] for k in g if k.startswith(pfx + "gstride/")}
+    for k, gr in grads.items():
+        got = gr.numpy()
+        scale = max(1e-6, float(np.abs(got).max()))
+        if k in ("linear_out_r.bias", "linear_out_n.bias"):      # mathematically zero (time-axis softmax): rounding noise
+            continue
+        assert np.abs(got.reshape(-1)[::97] - g[pfx + "gstride/" + k]).max() <= 2e-4 * scale + 1e-7, k
+        if pfx + "grad/" + k in g:
+            mine = np.concatenate([got[:2], got[-2:]], 0) if (got.ndim == 2 and got.shape[0] >= 8) else got
+            assert np.abs(mine - g[pfx + "grad/" + k]).max() <= 2e-4 * scale + 1e-7, k
+
+
 @pytest.mark.parametrize("case", ["small", "c0"])
 def test_three_train_steps(case, small, c0):
     """The reference's own train() (trainer_gmm.py:220) run 3x from step 19999."""
