@@ -12,7 +12,9 @@ mode train (default; BASELINE configs[1], configs[2-3] with N>1): a "step" = for
 mode decode (BASELINE configs[4]): a "step" = encode 256 sequences (T=256), 8 fader values each on z_r[:, 0], greedy decode of the
   2048 rows for 300 steps (test_class.py:233-254 batched; replicas only, no collective).
 
-Prints ONE JSON line on rank 0 with the contract fields plus `roofline`, `roofline_all` and (N=1) `cpu_baseline`.
+Prints ONE JSON line on rank 0 with the contract fields plus `roofline` (the kernel with the largest time per step), `roofline_all`,
+(N=1) `cpu_baseline`, `decode` (the configs[4] measurement, so that the default run records it too) and, with collectives in place,
+`comm` (per-bucket all-reduce time and how long the step's stream stood still for them).
 """
 import argparse
 import json
@@ -82,7 +84,8 @@ def _classify(name, a, k):
         return None
     if name == "gru_dwhh":
         rows, Hh = a[2].shape
-        return ("dwhh_gemm_tn", 2.0 * rows * 3 * Hh * Hh) if rows >= 4096 else None
+        # two kernel symbols: the <= 128-register instance (decoder side, beside the encoder backward scan) and the full one
+        return ("dwhh_gemm_tn_lean" if k.get("lean") else "dwhh_gemm_tn", 2.0 * rows * 3 * Hh * Hh) if rows >= 4096 else None
     if name == "embed_grad_sorted":                        # HBM-bound: every gate-gradient row of every job is read once
         nbytes = float(sum(j["dgx"].numel() for j in a[1]) * 4)
         return ("embed_grad", nbytes) if nbytes >= 1e8 else None
@@ -108,13 +111,20 @@ ROW_INFO = {   # row -> (bound, unit of work, kernel, peak share of the chip)
     "dec_bwd_scan_chunk": ("mfma", "flop", "gru_bwd_persist_kernel (decoder layer 2 chunk k + layer 1 chunk k+2, one launch)", 1.0),
     "subdec_fwd_scan": ("mfma", "flop", "gru_fwd_persist_kernel (both sub-decoders, 64 steps)", 1.0),
     "subdec_bwd_scan": ("mfma", "flop", "gru_bwd_persist_kernel (both sub-decoders, 64 steps)", 1.0),
-    "dwhh_gemm_tn": ("mfma", "flop", "gemm_tn_kernel via fn_gru_dwhh_f32 (dW_hh, K = T*B rows)", 1.0),
+    "dwhh_gemm_tn": ("mfma", "flop", "gemm_tn_kernel via fn_gru_dwhh_f32 (dW_hh of the encoder scans, K = T*B rows)", 1.0),
+    "dwhh_gemm_tn_lean": ("mfma", "flop", "gemm_tn_lean_kernel via fn_gru_dwhh_f32 (dW_hh of the decoder-side scans, <= 128 registers)", 1.0),
     "gemm_tn": ("mfma", "flop", "gemm_tn_kernel (dW of dense layers)", 1.0),
     "gemm_nt": ("mfma", "flop", "gemm_kernel (X W^T: W_ih2 projection, output layer)", 1.0),
     "gemm_nn": ("mfma", "flop", "gemm_kernel (dY W: input gradients)", 1.0),
     "out_head": ("mfma", "flop", "out_head_kernel (512 -> 342 projection + log-softmax + NLL + gradient seed, logits never written)", 1.0),
     "embed_grad": ("hbm", "bytes", "eg_piece_kernel + eg_final_kernel: token-segment sums of the gate-gradient rows (embed.hip)", 1.0),
 }
+
+
+# HBM bytes per launch from rocprofv3 PMC passes (2 x FETCH_SIZE with the gfx950 correction + WRITE_SIZE, separate passes): bench.py
+# itself cannot run the profiler, so these are the committed measurements of the same launches
+PMC_TRAFFIC = {"enc_fwd_scan": 4.33e9, "enc_bwd_scan": 7.91e9}
+PMC_SOURCE = "profiles/r02_pmc_training_step.txt (2 x FETCH_SIZE + WRITE_SIZE, separate passes; kernels unchanged since)"
 
 
 def roofline_rows(records):
@@ -136,7 +146,7 @@ def roofline_rows(records):
         else:
             ach, peak, u = work / (ms * 1e-3) / 1e9, PEAK_HBM_GBS * share, "GB/s"
         rows[row] = dict(bound=bound, kernel=kernel, launches=cnt, avg_launch_us=round(ms / cnt * 1e3, 1), achieved=round(ach, 2),
-                         peak=peak, unit=u, frac=round(ach / peak, 4), work_per_launch=work / cnt)
+                         peak=peak, unit=u, frac=round(ach / peak, 4), work_per_launch=work / cnt, total_us=ms * 1e3)
     return rows
 
 
@@ -157,7 +167,42 @@ def per_kernel_rooflines(trainer, batch, eps, reps=5):
         eng.serialize_lanes = False
     if real.gru_sync_error():
         raise RuntimeError("weight-stationary scan: a workgroup gave up waiting (sync error flag set)")
-    return roofline_rows(proxy.records)
+    rows = roofline_rows(proxy.records)
+    for r in rows.values():
+        r["us_per_step"] = round(r.pop("total_us") / reps, 1)        # kernel time of this row in ONE training step
+    return rows
+
+
+def _max_over_ranks(x, dev):
+    """MAX over ranks of a host scalar through the control-plane process group (gloo: CPU tensor; nccl: device tensor)"""
+    on_dev = torch.distributed.get_backend() == "nccl"
+    t = torch.tensor([x], dtype=torch.float64, device=dev if on_dev else "cpu")
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    return float(t.item())
+
+
+def comm_times(trainer, ctx, batch, eps, step, reps=3):
+    """per-bucket all-reduce durations and the time the step's stream waits for the last bucket, from `reps` EAGER steps (events on
+    the communicator's stream; a captured step cannot carry timing events)"""
+    use_graph = trainer.use_graph
+    trainer.use_graph = False
+    ctx.timing = {}
+    try:
+        for i in range(reps):
+            trainer.step_device(step + i, batch, eps)
+        torch.cuda.synchronize()
+        out = {}
+        for key, name in (("bucket1", "bucket1_ms"), ("bucket2", "bucket2_ms"), ("exposed", "exposed_ms")):
+            evs = ctx.timing.get(key, [])
+            out[name] = round(float(np.mean([a.elapsed_time(b) for a, b in evs])), 4) if evs else None
+        out["bucket1_MB"] = round(trainer.flat.bucket_split * 4 / 1e6, 2)
+        out["bucket2_MB"] = round((trainer.flat.n - trainer.flat.bucket_split) * 4 / 1e6, 2)
+        out["note"] = ("bucket 1 (decoder-side gradients) is issued behind the decoder weight-gradient GEMMs and runs beside the latent block / encoder "
+                       "backward; bucket 2 follows the encoder weight gradients; exposed = wait of the step's stream in front of clip+Adam")
+        return out
+    finally:
+        ctx.timing = None
+        trainer.use_graph = use_graph
 
 
 def respawn_under_launcher(n):
@@ -206,9 +251,7 @@ def bench_train(args, pkg, ctx, local, rank, world, log):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if ctx is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt = _max_over_ranks(dt, dev)
     tup = trainer._tuple8(0.2, B * world, False)            # one sync: the loss numbers of the last step (finite check)
     assert all(np.isfinite(tup)), tup
     tokens_per_s = world * B * T * args.steps / dt
@@ -224,13 +267,16 @@ def bench_train(args, pkg, ctx, local, rank, world, log):
                    "global_batch": B * world, "seq_len": T, "parallelism": "dp%d" % world},
         "last_loss": round(tup[0], 4),
     }
+    if ctx is not None and getattr(ctx, "rccl", None) is not None:
+        comm = comm_times(trainer, ctx, batch, eps, step)
+        if rank == 0:
+            out["comm"] = comm
     if rank == 0:
-        dom = dict(rows["enc_fwd_scan"])
-        # traffic: HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE with the gfx950 correction + WRITE_SIZE, separate
-        # passes) - bench.py itself cannot run the profiler, so this is the committed measurement of the same launch.
-        dom.update(traffic=4.33e9, traffic_source="profiles/r02_pmc_training_step.txt (2 x FETCH_SIZE + WRITE_SIZE, separate passes)",
-                   flop_per_launch=dom.pop("work_per_launch"),
-                   steps_per_launch=T, step_frac=round(tokens_per_s / world * F_ALG_PER_TOKEN / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
+        dom_row = max(rows, key=lambda r: rows[r]["us_per_step"])          # the kernel (symbol) the step spends most of its time in
+        dom = dict(rows[dom_row])
+        dom.update(row=dom_row, traffic=PMC_TRAFFIC.get(dom_row), traffic_source=PMC_SOURCE if dom_row in PMC_TRAFFIC else None,
+                   flop_per_launch=dom.pop("work_per_launch"), steps_per_launch=T,
+                   step_frac=round(tokens_per_s / world * F_ALG_PER_TOKEN / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
         out["roofline"] = dom
         out["roofline_all"] = rows
         out["roofline_worst"] = min(rows, key=lambda r: rows[r]["frac"])
@@ -244,6 +290,13 @@ def bench_train(args, pkg, ctx, local, rank, world, log):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cpu_baseline
         out["cpu_baseline"] = cpu_baseline.time_baseline(H, Z, B, T, TR)
+    if world == 1 and not args.no_decode:
+        # BASELINE configs[4] rides along in the default line (about 0.3 s of GPU time): 1 warm-up + 3 timed passes
+        del trainer
+        dargs = argparse.Namespace(steps=3, warmup=1, no_cpu_baseline=args.no_cpu_baseline)
+        d = bench_decode(dargs, pkg, None, local, rank, world, log)
+        out["decode"] = dict(metric=d["metric"], value=d["value"], unit=d["unit"], ms_per_pass=d["ms_per_step"], workload=d["config"]["workload"],
+                             roofline=d["roofline"], cpu_baseline=d.get("cpu_baseline"))
     return out
 
 
@@ -277,9 +330,7 @@ def bench_decode(args, pkg, ctx, local, rank, world, log):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if ctx is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt = _max_over_ranks(dt, dev)
     assert int(tok.min()) >= 0 and int(tok.max()) < 342
     tokens_per_s = world * rows * DEC_STEPS * args.steps / dt
     log("timed region done: %.3f ms per pass" % (dt / args.steps * 1e3))
@@ -323,6 +374,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=("train", "decode"), default="train")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="train mode: leave the configs[4] decode measurement out of the line")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn_under_launcher(args.gpus)
@@ -334,7 +386,7 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    ctx, local = parallel.init_from_env("nccl")
+    ctx, local = parallel.init_from_env()       # control plane: gloo; the collectives of the step are RCCL calls through the C ABI
     world = 1 if ctx is None else ctx.world
     rank = 0 if ctx is None else ctx.rank
     if world != args.gpus:
@@ -350,6 +402,8 @@ def main():
         print(json.dumps(out), flush=True)
     if ctx is not None:
         torch.distributed.barrier()
+        if ctx.rccl is not None:
+            ctx.rccl.close()
         torch.distributed.destroy_process_group()
 
 

@@ -12,7 +12,9 @@
  *   - all pointers are DEVICE pointers (fp32 unless stated, int32 for token ids), owned by the
  *     caller; nothing is allocated, freed or synchronised inside (graph-capture safe);
  *   - `stream` is a hipStream_t passed as void*; work is stream-ordered;
- *   - functions are re-entrant; the library keeps no mutable global state and reads no environment variables;
+ *   - functions are re-entrant and thread-safe; the only process-wide state is a handful of write-once caches of immutable facts
+ *     (compute-unit count and kernel attributes per device, the run-time binding of librccl), held in atomics / behind
+ *     std::call_once; no environment variable is read;
  *   - per-step tensors are TIME-MAJOR: [T][B][...] so that one step is one contiguous slab;
  *     token tensors are batch-major [B][T] int32 exactly as the data loader yields them.
  */
@@ -34,10 +36,12 @@ extern "C" {
 #define FN_E_COUNT (-5)     /* too many scans in one call                   */
 #define FN_E_UNSUPPORTED (-6) /* valid arguments, but this single-launch path is not eligible on this device / shape: */
                             /* nothing was enqueued, the caller takes the general path                             */
+#define FN_E_COMM (-7)      /* fn_comm_*: librccl could not be loaded / lacks a symbol                             */
+#define FN_COMM_ERROR_BASE 2000000  /* fn_comm_*: FN_COMM_ERROR_BASE + ncclResult_t                                 */
 
 #define FN_MAX_SCANS 8
 
-int fn_version(void);                 /* ABI version, currently 3 */
+int fn_version(void);                 /* ABI version, currently 4 */
 const char* fn_strerror(int code);    /* static string for FN_E_* / hipError_t */
 
 /* ------------------------------------------------------------------------------------------
@@ -82,6 +86,20 @@ int fn_gemm_multi(int a_kmajor, int b_kmajor, const FnGemmJob* jobs, int n_jobs,
 
 /* dst[c*dst_ld + r] = src[r*src_ld + c]  for r < R, c < C */
 int fn_transpose_f32(const float* src, int R, int C, int src_ld, float* dst, int dst_ld, void* stream);
+/* Column sums of up to FN_COLSUM_MAX_JOBS small matrices in ONE launch: out_j[n] = beta_j*out_j[n] + sum_m X_j[m*ld_j + n].
+ * The bias gradients of a step (autograd of every `+ b` on the path, trainer_gmm.py:249) are ~40 column sums over <= 256-row
+ * matrices; as separate launch pairs they were 76 launches of a few microseconds each on the critical tail of the step.
+ * One workgroup per (job, 64 columns): rows are summed in a fixed order (4 row phases x 4 accumulators, then a fixed
+ * tree) - deterministic.  Meant for M <= a few thousand rows; taller matrices belong to fn_colsum_f32. */
+#define FN_COLSUM_MAX_JOBS 64
+typedef struct FnColsumJob {
+    const float* X;
+    int32_t M, N, ld;
+    float beta;
+    float* out;
+} FnColsumJob;
+int fn_colsum_multi(const FnColsumJob* jobs, int n_jobs, void* stream);
+
 /* out[n] = beta*out[n] + sum_m X[m*ld + n]; ws >= fn_colsum_ws_bytes(M,N) */
 size_t fn_colsum_ws_bytes(int M, int N);
 int fn_colsum_f32(const float* X, int M, int N, int ld, float beta, float* out, float* ws, size_t ws_bytes,
@@ -402,6 +420,29 @@ int fn_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, const 
 /* one-hot (B,T,V) -> int32 indices (argmax along the last axis); used at the class boundary where callers
  * hand over convert_to_one_hot tensors (trainer_gmm.py:296-303) */
 int fn_onehot_to_index(const float* oh, int64_t rows, int V, int32_t* idx, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Data parallelism: RCCL collectives on the CALLER's stream (one process per GPU).
+ * The reference has no distributed code; the step that must see the REDUCED gradient is
+ * clip_grad_norm_ + optimizer.step(), trainer_gmm.py:249-251.  Rank 0 calls fn_comm_unique_id and hands the
+ * FN_COMM_ID_BYTES bytes to the other ranks out of band (music-fader-nets_amd/parallel.py uses the torch.distributed
+ * store); every rank then calls fn_comm_init with the device it will use CURRENT.  The collectives are ordinary
+ * stream-ordered work: they may be captured into a hipGraph together with the kernels of the step, and no helper thread
+ * touches the streams.  librccl is bound at run time (dlopen by SONAME: a copy already in the process is reused);
+ * FN_E_COMM when it is missing.  In-place SUM all-reduce of fp32; all-gather of raw bytes (recv holds world * bytes_per_rank).
+ * ------------------------------------------------------------------------------------------ */
+#define FN_COMM_ID_BYTES 128
+int fn_comm_unique_id(void* id_out);
+int fn_comm_init(void** comm_out, int world, int rank, const void* id);
+int fn_comm_destroy(void* comm);
+int fn_comm_all_reduce_f32(void* comm, float* buf, size_t n, void* stream);
+int fn_comm_all_gather(void* comm, const void* send, void* recv, size_t bytes_per_rank, void* stream);
+
+/* Diagnostic: `blocks` workgroups that each hold `lds_bytes` of LDS (<= 64 KB) and spin for about `cycles` clock ticks - a stand-in
+ * for a foreign kernel (an RCCL channel, another process' launch) that is RESIDENT on some compute units when a weight-stationary
+ * launch starts: the scan's remaining workgroups cannot become resident until it leaves, the resident ones spin at their counters
+ * (bounded).  tests/test_gpu_parity.py uses it to show that such contention delays a step but never changes its results. */
+int fn_occupy_cus(int blocks, int lds_bytes, long long cycles, void* stream);
 
 #ifdef __cplusplus
 }

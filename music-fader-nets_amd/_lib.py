@@ -10,9 +10,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfadernets_hip.so")
 
 FN_MAX_SCANS = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 GEMM_LEAN = 0x10000          # FN_GEMM_LEAN
 FN_E_UNSUPPORTED = -6
+FN_E_COMM = -7
+FN_COMM_ID_BYTES = 128
+FN_COLSUM_MAX_JOBS = 64
 _f = C.POINTER(C.c_float)
 _i = C.POINTER(C.c_int32)
 vp = C.c_void_p
@@ -46,6 +49,10 @@ class FnGemmJob(C.Structure):
                 ("ldc", C.c_int32), ("bias", vp)]
 
 
+class FnColsumJob(C.Structure):
+    _fields_ = [("X", vp), ("M", C.c_int32), ("N", C.c_int32), ("ld", C.c_int32), ("beta", C.c_float), ("out", vp)]
+
+
 class FnGruCell(C.Structure):
     _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("x", vp), ("ldx", C.c_int32), ("K1", C.c_int32), ("w_ih", vp), ("ldw_ih", C.c_int32),
                 ("gx_table", vp), ("idx", vp), ("idx_ld", C.c_int32), ("start_token", C.c_int32), ("gx_rowbias", vp), ("h_prev", vp),
@@ -74,6 +81,7 @@ SIGNATURES = {
     "fn_transpose_f32": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     "fn_colsum_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "fn_colsum_f32": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, C.c_size_t, vp]),
+    "fn_colsum_multi": (C.c_int, [C.POINTER(FnColsumJob), C.c_int, vp]),
     "fn_axpy_f32": (C.c_int, [C.c_int64, C.c_float, vp, vp, vp]),
     "fn_sum_f32": (C.c_int, [vp, C.c_int64, C.c_float, vp, vp]),
     "fn_gru_gates_floats": (C.c_size_t, [C.c_int, C.c_int]),
@@ -114,6 +122,12 @@ SIGNATURES = {
     "fn_step_params": (C.c_int, [vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_int, vp, vp]),
     "fn_clip_adam": (C.c_int, [vp, vp, vp, vp, C.c_int64, vp, C.c_float, vp, C.c_float, C.c_float, C.c_float, vp]),
     "fn_onehot_to_index": (C.c_int, [vp, C.c_int64, C.c_int, vp, vp]),
+    "fn_comm_unique_id": (C.c_int, [vp]),
+    "fn_comm_init": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, vp]),
+    "fn_comm_destroy": (C.c_int, [vp]),
+    "fn_comm_all_reduce_f32": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "fn_comm_all_gather": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
+    "fn_occupy_cus": (C.c_int, [C.c_int, C.c_int, C.c_longlong, vp]),
 }
 
 _lib = None

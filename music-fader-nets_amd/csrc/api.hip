@@ -3,7 +3,7 @@
 
 extern "C" {
 
-int fn_version(void) { return 3; }
+int fn_version(void) { return 4; }
 
 const char* fn_strerror(int code) {
     switch (code) {
@@ -14,8 +14,10 @@ const char* fn_strerror(int code) {
         case FN_E_WORKSPACE: return "workspace too small";
         case FN_E_COUNT: return "too many scans in one call";
         case FN_E_UNSUPPORTED: return "single-launch path not eligible for this device / shape (nothing enqueued)";
+        case FN_E_COMM: return "librccl could not be loaded (or lacks a symbol): fn_comm_* unavailable";
         default: break;
     }
+    if (code >= FN_COMM_ERROR_BASE) return fn_comm_strerror(code);
     if (code > 0) return hipGetErrorString((hipError_t)code);
     return "unknown error";
 }

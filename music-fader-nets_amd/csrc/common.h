@@ -12,6 +12,8 @@
         if (e__ != hipSuccess) return (int)e__;  \
     } while (0)
 
+const char* fn_comm_strerror(int code);      // comm.hip: text of FN_COMM_ERROR_BASE + ncclResult_t
+
 __device__ __forceinline__ float fn_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -454,6 +454,33 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, int chunk
     out[n] = (beta != 0.f ? beta * out[n] : 0.f) + s;
 }
 
+// all small column sums of a step in one launch: workgroup (x, z) = 64 columns [64x, 64x+64) of job z; thread = (column, row phase 0..3)
+struct CsArgs { FnColsumJob job[FN_COLSUM_MAX_JOBS]; };
+__global__ __launch_bounds__(256) void colsum_multi_kernel(const CsArgs a) {
+    const FnColsumJob& J = a.job[blockIdx.z];
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+    __shared__ float part[4][64];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (blockIdx.x * 64 < J.N) {
+        const int nc = n < J.N ? n : J.N - 1;
+        const float* X = J.X + nc;
+        int m = ph;
+        for (; m + 12 < J.M; m += 16) {                       // 4 independent loads in flight per thread
+            s0 += X[(long)m * J.ld];
+            s1 += X[(long)(m + 4) * J.ld];
+            s2 += X[(long)(m + 8) * J.ld];
+            s3 += X[(long)(m + 12) * J.ld];
+        }
+        for (; m < J.M; m += 4) s0 += X[(long)m * J.ld];
+    }
+    part[ph][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ph == 0 && n < J.N) {
+        const float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        J.out[n] = (J.beta != 0.f ? J.beta * J.out[n] : 0.f) + t;
+    }
+}
+
 __global__ void axpy_kernel(long n, float alpha, const float* __restrict__ x, float* __restrict__ y) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] += alpha * x[i];
 }
@@ -652,6 +679,23 @@ int fn_transpose_f32(const float* src, int R, int C, int src_ld, float* dst, int
     if (R <= 0 || C <= 0 || src_ld < C || dst_ld < R) return FN_E_SHAPE;
     hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(32, 8), 0, (hipStream_t)stream, src, R, C,
                        (long)src_ld, dst, (long)dst_ld);
+    FN_CHECK_LAUNCH();
+    return FN_OK;
+}
+
+int fn_colsum_multi(const FnColsumJob* jobs, int n_jobs, void* stream) {
+    if (!jobs) return FN_E_NULL;
+    if (n_jobs <= 0 || n_jobs > FN_COLSUM_MAX_JOBS) return FN_E_COUNT;
+    CsArgs a;
+    int maxn = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const FnColsumJob& d = jobs[j];
+        if (!d.X || !d.out) return FN_E_NULL;
+        if (d.M <= 0 || d.N <= 0 || d.ld < d.N) return FN_E_SHAPE;
+        a.job[j] = d;
+        maxn = d.N > maxn ? d.N : maxn;
+    }
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3((maxn + 63) / 64, 1, n_jobs), dim3(256), 0, (hipStream_t)stream, a);
     FN_CHECK_LAUNCH();
     return FN_OK;
 }

@@ -132,10 +132,65 @@ class Engine:
             self._bufs[key] = t
         return t
 
+    # Accumulators a step starts from zero (per-sequence row sums of the backward scans, upstream latent gradients) live in ONE arena:
+    # begin_step() clears it with a single fill instead of one fill kernel per buffer (19 per step).  A buffer that is asked for a second
+    # time within a step (or was never part of a cleared arena) is still cleared on its own - zbuf() always returns zeros.
+    ARENA_BYTES = 48 << 20
+
     def zbuf(self, name, shape):
-        t = self.buf(name, shape)
-        t.zero_()
+        shape = tuple(int(x) for x in shape)
+        key = (self.buf_ns + name, shape, torch.float32)
+        t = self._bufs.get(key)
+        if t is None:
+            n = 1
+            for x in shape:
+                n *= x
+            n_al = (n + 63) // 64 * 64                       # 256-byte aligned carve-outs
+            ar = self.__dict__.setdefault("_arena", dict(chunks=[], used=0))
+            if not ar["chunks"] or ar["used"] + n_al > ar["chunks"][-1].numel():
+                ar["chunks"].append(torch.zeros(max(self.ARENA_BYTES // 4, n_al), device=self.dev))
+                ar["used"] = 0
+            chunk = ar["chunks"][-1]
+            t = chunk[ar["used"]:ar["used"] + n].view(shape)
+            ar["used"] += n_al
+            ar.setdefault("extent", {})[id(chunk)] = ar["used"]
+            self._bufs[key] = t
+            return t                                         # fresh chunks are zero
+        clean = self.__dict__.get("_arena_clean")
+        if clean is not None and key in clean:
+            clean.discard(key)
+        else:
+            t.zero_()
         return t
+
+    def begin_step(self):
+        """one fill per arena chunk; every zbuf() of this step that has not been handed out since is then served without a fill kernel"""
+        ar = self.__dict__.get("_arena")
+        if ar is None:
+            return
+        for chunk in ar["chunks"]:
+            chunk[:ar["extent"][id(chunk)]].zero_()
+        self._arena_clean = {k for k in self._bufs if k[2] == torch.float32 and self._in_arena(self._bufs[k])}
+
+    def _in_arena(self, t):
+        ar = self.__dict__.get("_arena")
+        if ar is None:
+            return False
+        p = t.data_ptr()
+        return any(c.data_ptr() <= p < c.data_ptr() + c.numel() * 4 for c in ar["chunks"])
+
+    # Bias gradients = column sums of small matrices: collected per lane and issued as ONE launch (fn_colsum_multi) where the lane's
+    # inputs are complete, instead of a launch pair each (76 launches per step).  Tall inputs keep the two-phase kernel.
+    def colsum(self, X, out, beta=0.0):
+        if X.shape[0] > 4096 or not hasattr(self.ops, "colsum_multi"):
+            self.ops.colsum(X, out, beta)
+            return
+        self.__dict__.setdefault("_cs_jobs", {}).setdefault(getattr(self.ops, "lane", ""), []).append((X, out, beta))
+
+    def flush_colsums(self):
+        jobs = self.__dict__.get("_cs_jobs", {}).pop(getattr(self.ops, "lane", ""), None)
+        if jobs:
+            self.ops.colsum_multi(jobs)
 
     # GRU parameter sets on the path: key -> (prefix, suffix, one-hot width V)
     def _gru_sets(self):
@@ -385,8 +440,8 @@ class Engine:
         if h0 is not None:
             ops.gru_dwhh(dgx2[:B], dgn2[:B], h0, dW, beta=1.0)
         db = G[pfx + "bias_hh" + sfx]
-        ops.colsum(rs[:, : 2 * H], db[: 2 * H])
-        ops.colsum(rsn, db[2 * H:])
+        self.colsum(rs[:, : 2 * H], db[: 2 * H])
+        self.colsum(rsn, db[2 * H:])
 
     @staticmethod
     def _splitk(rows):
@@ -448,8 +503,9 @@ class Engine:
                         ops.axpy(1.0, carry["l2"][0], dhx0[0])          # hx1 was initialised with hx0[0]: dL/dh_init of layer 2
         return dict(dgx1=dgx1, dghn1=dghn1, dgx2=dgx2, dghn2=dghn2, rs2=rs2, rsn2=rsn2, drb_g=drb_g, rsn_g=rsn_g, dh0_g=carry["l1"][0])
 
-    def _bwd_global_decoder_params(self, G, S, gd):
-        """parameter gradients of the global decoder (linear_out_g, grucell_g_2, grucell_g, linear_init_global) from the gate gradients"""
+    def _bwd_global_decoder_params(self, G, S, gd, flush=True):
+        """parameter gradients of the global decoder (linear_out_g, grucell_g_2, grucell_g, linear_init_global) from the gate gradients;
+        flush=False: the caller issues the collected bias-gradient column sums itself (together with more of them)"""
         ops, H = self.ops, self.H
         dec = S["dec"]
         B, T = S["d"].shape
@@ -460,17 +516,19 @@ class Engine:
         # 342 x 512 output: only 12 tiles of 128 x 128 - a deeper K split fills the chip (42 x 12 = 504 workgroups: 258 vs 325 us)
         ln = self.lean_dw
         ops.gemm(dlog[:, :E_VOCAB], hx1f, G["linear_out_g.weight"], a_k=False, b_k=False, splitk=42 if T * B >= 32768 else sk_T, lean=ln)
-        ops.colsum(dlog[:, :E_VOCAB], G["linear_out_g.bias"])
+        self.colsum(dlog[:, :E_VOCAB], G["linear_out_g.bias"])
         self._gru_weight_grads("g2", "grucell_g_2.", "", T, B, dgx2, dghn2, dec["hx1"], dec["hx0"][0], G, sk_T, rs2, rsn2, lean=ln)
         ops.gemm(dgx2.view(T * B, 3 * H), hx0f, G["grucell_g_2.weight_ih"], a_k=False, b_k=False, splitk=sk_T, lean=ln)
-        ops.colsum(rs2, G["grucell_g_2.bias_ih"])
+        self.colsum(rs2, G["grucell_g_2.bias_ih"])
         self._gru_weight_grads("g", "grucell_g.", "", T, B, dgx1, dghn1, dec["hx0"], dec["h0g"], G, sk_T, drb_g, rsn_g, lean=ln)
         dWg = G["grucell_g.weight_ih"]                          # [3H][E+ZG]: token columns = segment sums, written in place
         ops.embed_grad_sorted(S["sort"]["d"], [dict(dgx=dgx1, out=dWg[:, :E_VOCAB], transposed=True, idx_shift=-1, start_token=E_VOCAB - 1)])
         ops.gemm(drb_g, dec["zc"], dWg[:, E_VOCAB:], a_k=False, b_k=False)
-        ops.colsum(drb_g, G["grucell_g.bias_ih"])
+        self.colsum(drb_g, G["grucell_g.bias_ih"])
         ops.gemm(dh0_g, dec["zc"], G["linear_init_global.weight"], a_k=False, b_k=False)
-        ops.colsum(dh0_g, G["linear_init_global.bias"])
+        self.colsum(dh0_g, G["linear_init_global.bias"])
+        if flush:
+            self.flush_colsums()
 
     def backward(self, G, dlogits_sd, lat_up, w3=None, after_decoders=None):
         """Backward of forward().
@@ -522,21 +580,22 @@ class Engine:
         # ---- decoder-side PARAMETER gradients: side stream, overlapping the latent block and the encoder scans ---
         self.side_wait_main()
         with self.on_side():
-            self._bwd_global_decoder_params(G, S, gd)
+            self._bwd_global_decoder_params(G, S, gd, flush=False)
             for e, attr, Ce in (("r", r, R_DIMS), ("n", n, N_DIMS)):
                 pfx = "gru_d_%s." % e
                 z = lat[e]["z"]
                 dl = dlogits_sd[e].view(Tr * B, Ce)
                 ops.gemm(dl, sd[e]["h_all"].view(Tr * B, H), G["linear_out_%s.weight" % e], a_k=False, b_k=False, splitk=sk_Tr)
-                ops.colsum(dl, G["linear_out_%s.bias" % e])
+                self.colsum(dl, G["linear_out_%s.bias" % e])
                 self._gru_weight_grads("d_" + e, pfx, "_l0", Tr, B, sdb[e]["dgx"], sdb[e]["dghn"], sd[e]["h_all"], sd[e]["h0"], G, sk_Tr,
                                        sdb[e]["drb"], sdb[e]["rsn"], lean=self.lean_dw)
                 dW = G[pfx + "weight_ih_l0"]                        # [3H][Ce+Z]
                 ops.embed_grad_sorted(S["sort"][e], [dict(dgx=sdb[e]["dgx"], out=dW[:, :Ce], transposed=True)])
                 ops.gemm(sdb[e]["drb"], z, dW[:, Ce:], a_k=False, b_k=False)
-                ops.colsum(sdb[e]["drb"], G[pfx + "bias_ih_l0"])
+                self.colsum(sdb[e]["drb"], G[pfx + "bias_ih_l0"])
                 ops.gemm(sdb[e]["dh0"], z, G["linear_init_%s.weight" % e], a_k=False, b_k=False)
-                ops.colsum(sdb[e]["dh0"], G["linear_init_%s.bias" % e])
+                self.colsum(sdb[e]["dh0"], G["linear_init_%s.bias" % e])
+            self.flush_colsums()
             if after_decoders is not None:
                 after_decoders()           # data parallel: this bucket's all-reduce is ordered behind the side stream
 
@@ -551,7 +610,7 @@ class Engine:
                            lat[e]["z"], lat[e]["qy"], up["g_z"], up.get("g_mu"), up.get("g_sigma"), up.get("g_ll"), up.get("g_qy"),
                            w3, dpre, dmu_rows)
             if "mu_%s_lookup.weight" % e in G:           # the plain-VAE sibling has no component means to train
-                ops.colsum(dmu_rows, G["mu_%s_lookup.weight" % e].view(-1))
+                self.colsum(dmu_rows, G["mu_%s_lookup.weight" % e].view(-1))
             hf = pre["h_all"][e][T - 1]
             hb = pre["h_all"][e + "_reverse"][T - 1]
             dhf, dhb = self.buf("enc_dhf_" + e, (B, H)), self.buf("enc_dhb_" + e, (B, H))
@@ -562,7 +621,7 @@ class Engine:
             ops.gemm_multi([dict(C=G[head + e + ".weight"][:, c0:c0 + H], segs=[(dp, hh)])
                             for head, dp in (("mu_", dpm), ("var_", dpv)) for c0, hh in ((0, hf), (H, hb))], a_k=False, b_k=False)
             for head, dp in (("mu_", dpm), ("var_", dpv)):
-                ops.colsum(dp, G[head + e + ".bias"])
+                self.colsum(dp, G[head + e + ".bias"])
             for key, dh in ((e, dhf), (e + "_reverse", dhb)):
                 encb[key] = dict(dgx=self.buf("enc_dgx_" + key, (T, B, 3 * H)), dghn=self.buf("enc_dghn_" + key, (T, B, H)),
                                  rs=self.zbuf("enc_rs_" + key, (B, 3 * H)), rsn=self.zbuf("enc_rsn_" + key, (B, H)))
@@ -577,5 +636,6 @@ class Engine:
         for e, pfx, key, sfx, rev in enc_keys:
             self._gru_weight_grads(key, pfx, sfx, T, B, encb[key]["dgx"], encb[key]["dghn"], pre["h_all"][key], None, G, sk_T,
                                    encb[key]["rs"], encb[key]["rsn"])
-            ops.colsum(encb[key]["rs"], G[pfx + "bias_ih" + sfx])
+            self.colsum(encb[key]["rs"], G[pfx + "bias_ih" + sfx])
+        self.flush_colsums()
         self.main_wait_side()

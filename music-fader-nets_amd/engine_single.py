@@ -112,7 +112,7 @@ class SingleEncEngine(Engine):
             dW = G[head + ".weight"]
             ops.gemm(dp, hf, dW[:, :H], a_k=False, b_k=False)
             ops.gemm(dp, hb, dW[:, H:], a_k=False, b_k=False)
-            ops.colsum(dp, G[head + ".bias"])
+            self.colsum(dp, G[head + ".bias"])
         scans, encb = [], {}
         for key, dh in (("e", dhf), ("e_reverse", dhb)):
             encb[key] = dict(dgx=self.buf("enc_dgx_" + key, (T, B, 3 * H)), dghn=self.buf("enc_dghn_" + key, (T, B, H)),
@@ -127,7 +127,8 @@ class SingleEncEngine(Engine):
         for key, sfx, rev in keys:
             self._gru_weight_grads(key, self.gru, sfx, T, B, encb[key]["dgx"], encb[key]["dghn"], enc["h_all"][key], None, G, sk_T,
                                    encb[key]["rs"], encb[key]["rsn"])
-            ops.colsum(encb[key]["rs"], G[self.gru + "bias_ih" + sfx])
+            self.colsum(encb[key]["rs"], G[self.gru + "bias_ih" + sfx])
             if self.enc_extra:                               # the dense density columns: (sum over time of the gate gradients)^T extra
                 ops.gemm(encb[key]["rs"], S["extra"], G[self.gru + "weight_ih" + sfx][:, E_VOCAB:], a_k=False, b_k=False)
+        self.flush_colsums()
         self.main_wait_side()

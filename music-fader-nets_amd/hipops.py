@@ -128,6 +128,25 @@ class HipOps:
         ws = self.workspace(wsb, "colsum")
         _lib.check(self.lib.fn_colsum_f32(px, M, N, ld, beta, _p(out), _p(ws), wsb, self.stream()), "fn_colsum_f32")
 
+    def colsum_multi(self, jobs):
+        """jobs: (X 2-D view, out 1-D dense[, beta]) - all column sums in ONE launch per 64 jobs (fn_colsum_multi); meant for the
+        bias gradients of a step (<= a few thousand rows each)"""
+        for i0 in range(0, len(jobs), _lib.FN_COLSUM_MAX_JOBS):
+            part = jobs[i0:i0 + _lib.FN_COLSUM_MAX_JOBS]
+            arr = (_lib.FnColsumJob * len(part))()
+            for d, j in zip(arr, part):
+                X, out = j[0], j[1]
+                px, M, N, ld = _mat(X, "X")
+                _dense(out, name="out")
+                if out.numel() != N:
+                    raise RuntimeError("colsum_multi: out has %d elements, expected %d" % (out.numel(), N))
+                d.X, d.M, d.N, d.ld, d.beta, d.out = px, M, N, ld, float(j[2]) if len(j) > 2 else 0.0, _p(out)
+            _lib.check(self.lib.fn_colsum_multi(arr, len(part), self.stream()), "fn_colsum_multi")
+
+    def occupy_cus(self, blocks, lds_bytes, cycles):
+        """diagnostic (fn_occupy_cus): `blocks` workgroups holding `lds_bytes` of LDS each spin for ~`cycles` ticks on the current stream"""
+        _lib.check(self.lib.fn_occupy_cus(int(blocks), int(lds_bytes), int(cycles), self.stream()), "fn_occupy_cus")
+
     def axpy(self, alpha, x, y):
         _dense(x, name="x"), _dense(y, name="y")
         if x.numel() != y.numel():

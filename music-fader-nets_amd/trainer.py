@@ -87,12 +87,13 @@ class GMVAETrainer:
         self.sp = torch.zeros(8, device=dev)
         self._dev_step = 0                          # host mirror of counters[0]
         self.use_graph = dev.type == "cuda"          # replay the whole step as ONE hipGraph (no per-launch host cost)
-        if dist_ctx is not None and os.environ.get("FN_DP_GRAPH", "0") != "1":
-            # Data parallel: eager launches.  With the RCCL collectives inside the captured step, about 1 capture in 25 ended with
-            # hipErrorStreamCaptureUnjoined on this stack (torch 2.10 / RCCL 2.26), after which the process-group watchdog died on an event
-            # "last recorded in a capturing stream" - 150 single-rank runs of bench.py, see DESIGN.md.  The launches of a step cost
-            # less host time than the GPU needs to run them, so the eager step is GPU-bound as well.  FN_DP_GRAPH=1 captures anyway.
+        if dist_ctx is not None and (os.environ.get("FN_DP_GRAPH", "1") == "0" or not getattr(dist_ctx, "want_direct", False)):
+            # Data parallel: the collectives are RCCL calls on our own streams (parallel.DirectRccl, fn_comm_*) and part of the captured
+            # step.  (Through torch.distributed's process group they were not capturable reliably: about 1 capture in 25 ended with
+            # hipErrorStreamCaptureUnjoined on torch 2.10 / RCCL 2.26 and its watchdog thread then died on an event "last recorded in a
+            # capturing stream" - round 2, DESIGN.md.)  FN_DP_GRAPH=0 / DataParallelContext(direct=False): eager launches.
             self.use_graph = False
+        self._dens_all = None                        # data parallel: the batch's densities of ALL ranks (gathered once per batch)
         self._graphs = {}
         self._static = {}
         model.train()
@@ -130,6 +131,8 @@ class GMVAETrainer:
         beta0 = beta_schedule(step, self.beta)
         self._step_now = step
         fused = eng.fused_head
+        if want_grads:
+            eng.begin_step()                       # one fill for every zero-initialised accumulator of the step
         S = eng.forward(d, r, n, c, eps[0], eps[1], labels, head=not fused)
         dec, lat = S["dec"], S["lat"]
         st = self.stats
@@ -173,7 +176,8 @@ class GMVAETrainer:
             z0 = eng.buf("reg_z0_" + e, (B,))
             z0.copy_(lat[e]["z"][:, 0])
             if self.dist is not None:
-                z0_all, a_all, row0 = self.dist.gather_rows(z0, attr)
+                held = self._dens_all[0 if e == "r" else 1] if self._dens_all is not None else None
+                z0_all, a_all, row0 = self.dist.gather_rows(z0, attr, held)
             else:
                 z0_all, a_all, row0 = z0, attr, 0
             lrow = eng.buf("reg_rows_" + e, (B,))
@@ -223,10 +227,28 @@ class GMVAETrainer:
         supervised = batch[6] is not None
         Bg = batch[0].shape[0] if self.dist is None else self.dist.global_batch(batch[0].shape[0])
         eng.ops.step_params(self.counters, self.beta, self.lr, 0.9, 0.999, supervised, 1.0 / Bg, False, self.sp)
+        self._gather_densities(batch, None)
         fw = self._forward_losses(step, batch, eps, want_grads=True)
         self._run_backward(fw, None)
         eng.ops.sumsq(self.flat.grad, self.sumsq)
         return self._tuple8(fw[3], fw[4], supervised)
+
+    def _gather_densities(self, batch, static):
+        """data parallel: the pairwise regulariser needs the densities of the GLOBAL batch - constants of the batch, so they are
+        all-gathered once per batch (not once per step inside the step's graph); `static` holds the buffers a captured graph reads"""
+        if self.dist is None:
+            self._dens_all = None
+            return
+        outs = []
+        for i, t in enumerate((batch[4], batch[5])):
+            out = None
+            if static is not None:
+                key = "dens_all%d" % i
+                if key not in static:
+                    static[key] = torch.empty(t.numel() * self.dist.world, dtype=t.dtype, device=t.device)
+                out = static[key]
+            outs.append(self.dist.gather(t, out))
+        self._dens_all = tuple(outs)
 
     def _run_backward(self, fw, hook):
         """fw = what _forward_losses returned; fills flat.G"""
@@ -250,10 +272,10 @@ class GMVAETrainer:
         beta0, Bg = fw[3], fw[4]
         hook = None
         if self.dist is not None:
-            hook = lambda: self.dist.start_bucket(self.flat.grad[:self.flat.bucket_split])
+            hook = lambda: self.dist.start_bucket(self.flat.grad[:self.flat.bucket_split], "bucket1")
         self._run_backward(fw, hook)
         if self.dist is not None:
-            self.dist.start_bucket(self.flat.grad[self.flat.bucket_split:])
+            self.dist.start_bucket(self.flat.grad[self.flat.bucket_split:], "bucket2")
             self.dist.finish_buckets()
         ops.sumsq(self.flat.grad, self.sumsq)      # norm of the (all-reduced) gradient: identical on every rank
         ops.clip_adam(self.flat.param, self.flat.grad, self.flat.m, self.flat.v, self.sumsq, self.max_norm, self.sp[3:5], 0.9, 0.999, 1e-8)
@@ -275,6 +297,7 @@ class GMVAETrainer:
         self.flat.t += 1
         if not self.use_graph:
             m.engine()
+            self._gather_densities(batch, None)
             self._step_body(step, batch, eps)
             m._weights_version = m._version        # refresh_weights() already ran at the end of the step
             return beta0, Bg
@@ -288,6 +311,7 @@ class GMVAETrainer:
                 dst.copy_(src, non_blocking=True)
         sbatch, seps = tuple(st["batch"]), tuple(st["eps"])
         m.engine()                                  # (re)builds the engine / weight images outside of any capture
+        self._gather_densities(sbatch, st)          # per-batch constants: gathered eagerly into static buffers, outside of the graph
         if key in self._graphs:
             self._graphs[key].replay()
         elif st["runs"] == 0:
@@ -306,7 +330,7 @@ class GMVAETrainer:
                 warnings.warn("hipGraph capture of the training step failed (%s: %s); continuing with eager launches" % (type(e).__name__, e))
                 self.use_graph = False
                 if self.dist is not None:
-                    self.dist._pending = []           # work handles of the aborted capture
+                    self.dist.abort_capture()
                 torch.cuda.synchronize()
                 self._step_body(step, sbatch, seps)
             else:
@@ -334,6 +358,7 @@ class GMVAETrainer:
         if eps is None:
             eps = self.draw_eps(*batch[0].shape)
         self.model.engine()
+        self._gather_densities(batch, None)
         _, _, _, beta0, Bg = self._forward_losses(step, batch, eps, want_grads=False)
         return self._tuple8(beta0, Bg, is_supervised)
 

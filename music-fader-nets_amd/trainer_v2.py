@@ -55,6 +55,8 @@ class _SingleEncTrainer(GMVAETrainer):
         B, T = d.shape
         Bg = B if self.dist is None else self.dist.global_batch(B)
         fused = eng.fused_head
+        if want_grads:
+            eng.begin_step()                       # one fill for every zero-initialised accumulator of the step
         S = eng.forward(d, self._cond(batch), eps[0], self._enc_extra(batch), save=True, head=not fused)
         dec, lat = S["dec"], S["lat"]
         st = self.stats

@@ -41,6 +41,10 @@ class FakeOps:
         s = X.sum(dim=0)
         out.copy_((beta * out if beta != 0.0 else 0) + s.view_as(out))
 
+    def colsum_multi(self, jobs):
+        for j in jobs:
+            self.colsum(j[0], j[1], j[2] if len(j) > 2 else 0.0)
+
     def axpy(self, alpha, x, y):
         assert x.is_contiguous() and y.is_contiguous()
         y.add_(alpha * x)

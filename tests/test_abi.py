@@ -15,7 +15,7 @@ def test_header_symbols_exported():
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.fn_version() == 3
+    assert lib.fn_version() == 4
     assert lib.fn_strerror(-2) == b"unsupported or inconsistent sizes"
 
 
@@ -32,3 +32,14 @@ def test_argument_errors_without_gpu():
     # counters + sticky error word of the weight-stationary launches: whole 128-byte lines, error word in the last one
     nbytes = lib.fn_gru_sync_ws_bytes()
     assert nbytes % 128 == 0 and nbytes >= 64 * 128 + 128
+    # fn_comm_* / fn_colsum_multi validate before they touch RCCL or the device
+    assert lib.fn_comm_unique_id(None) == -1
+    assert lib.fn_comm_all_reduce_f32(None, None, 4, None) == -1
+    assert lib.fn_comm_destroy(None) == 0
+    import ctypes as C
+    h = C.c_void_p()
+    assert lib.fn_comm_init(C.byref(h), 2, 2, C.create_string_buffer(_lib.FN_COMM_ID_BYTES)) == -2      # rank outside the world
+    assert lib.fn_colsum_multi(None, 1, None) == -1
+    assert lib.fn_colsum_multi((_lib.FnColsumJob * 1)(), 65, None) == -5
+    assert lib.fn_occupy_cus(0, 1024, 10, None) == -2
+    assert lib.fn_strerror(-7).startswith(b"librccl")

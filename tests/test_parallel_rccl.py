@@ -1,9 +1,8 @@
-"""Data-parallel path through real RCCL on the GPU box (torch.distributed backend "nccl" = RCCL), the HIP kernels underneath.
+"""Data-parallel path through real RCCL on the GPU box (called directly through the C ABI, fn_comm_*), the HIP kernels underneath.
 
 * one rank (any GPU box): the step with the collectives in place - all-reduce buckets beside the weight-stationary scans, all-gather
-  of the regulariser inputs, all-reduce of the statistics - must be BIT-identical to the plain single-GPU step, with eager launches
-  (the data-parallel default) and captured into one hipGraph (FN_DP_GRAPH=1; about 1 capture in 25 fails on this torch / RCCL stack,
-  the trainer then continues eagerly - that outcome skips the graph assertion, it does not fail the test);
+  of the regulariser inputs, all-reduce of the statistics - must be BIT-identical to the plain single-GPU step, captured into ONE
+  hipGraph (the default) and with eager launches (FN_DP_GRAPH=0), with the control plane on gloo (default) or on torch's nccl backend;
 * two ranks (skipped below 2 visible GPUs): half the batch each == the single-process step on the full batch, as the gloo test
   checks on the CPU backend;
 * bench.py launches its own ranks when asked for --gpus N outside a launcher.
@@ -22,7 +21,7 @@ import torch.multiprocessing as mp
 from test_parallel_gloo import HERE, ROOT, _free_port
 
 
-def _rccl_worker(rank, world, port, out_dir, dp_graph="0"):
+def _rccl_worker(rank, world, port, out_dir, dp_graph="1", backend=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
@@ -31,7 +30,7 @@ def _rccl_worker(rank, world, port, out_dir, dp_graph="0"):
     from mfn_import import load_package
     pkg = load_package()
     from music_fader_nets_amd import parallel
-    ctx, local = parallel.init_from_env("nccl")
+    ctx, local = parallel.init_from_env(backend)
     assert ctx is not None and ctx.world == world
     dev = "cuda:%d" % local
     gold = load_golden("small")
@@ -47,8 +46,10 @@ def _rccl_worker(rank, world, port, out_dir, dp_graph="0"):
         step, tup = tr.train(step, None, None, None, b["d"][lo:hi], b["r"][lo:hi], b["n"][lo:hi], b["c"][lo:hi],
                              b["r_density"][lo:hi], b["n_density"][lo:hi], eps=(eps_r[lo:hi].contiguous().to(dev), eps_n[lo:hi].contiguous().to(dev)))
         tuples.append(tup)
-    torch.save(dict(tuples=tuples, flat=tr.flat.param.cpu(), gn=tr.grad_norm(), graphs=len(tr._graphs), use_graph=tr.use_graph),
-               os.path.join(out_dir, "r%d.pt" % rank))
+    torch.save(dict(tuples=tuples, flat=tr.flat.param.cpu(), gn=tr.grad_norm(), graphs=len(tr._graphs), use_graph=tr.use_graph,
+                    direct=ctx.rccl is not None), os.path.join(out_dir, "r%d.pt" % rank))
+    if ctx.rccl is not None:
+        ctx.rccl.close()
     assert not m.engine().ops.gru_sync_error()
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
@@ -72,23 +73,19 @@ def _single_process_run(steps, dev="cuda:0"):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dp_graph", ["0", "1"])
-def test_single_rank_rccl_step_is_bit_identical(tmp_path, dp_graph):
-    try:
-        mp.start_processes(_rccl_worker, args=(1, _free_port(), str(tmp_path), dp_graph), nprocs=1, join=True, start_method="spawn")
-    except Exception as e:
-        if dp_graph == "1":                       # opt-in mode: a failed capture can take the process-group watchdog down afterwards (see trainer.py)
-            pytest.skip("FN_DP_GRAPH=1 run died after a failed hipGraph capture (known on this torch / RCCL stack): %s" % str(e)[-200:])
-        raise
+@pytest.mark.parametrize("dp_graph,backend", [("1", None), ("0", None), ("1", "nccl")])
+def test_single_rank_rccl_step_is_bit_identical(tmp_path, dp_graph, backend):
+    mp.start_processes(_rccl_worker, args=(1, _free_port(), str(tmp_path), dp_graph, backend), nprocs=1, join=True, start_method="spawn")
     r0 = torch.load(os.path.join(tmp_path, "r0.pt"), weights_only=False)
     tuples, flat, gn, gold = _single_process_run(4)
     np.testing.assert_array_equal(np.asarray(r0["tuples"]), np.asarray(tuples))
     assert torch.equal(r0["flat"], flat)
     np.testing.assert_allclose(tuples[:3], gold["train_tuples"], rtol=5e-4)       # and both are the reference's train()
+    assert r0["direct"]                                                           # the collectives went through fn_comm_* (RCCL)
     if dp_graph == "0":
-        assert not r0["use_graph"] and r0["graphs"] == 0                          # data parallel default: eager launches
-    elif not (r0["use_graph"] and r0["graphs"] == 1):
-        pytest.skip("hipGraph capture of the step with RCCL collectives failed on this run (known, ~4 %); the eager continuation matched")
+        assert not r0["use_graph"] and r0["graphs"] == 0
+    else:
+        assert r0["use_graph"] and r0["graphs"] == 1                              # the data-parallel step IS one hipGraph
 
 
 @pytest.mark.gpu
