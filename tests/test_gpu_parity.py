@@ -1187,3 +1187,42 @@ def test_fader_sibling_at_hidden_512_batch_256_vs_reference():
     for k, v in m.state_dict().items():
         np.testing.assert_allclose([v.double().abs().sum().item()], g[pfx + "w1sum/" + k][1:2], rtol=1e-3, err_msg=k)
     assert not m.engine().ops.gru_sync_error()
+
+
+@pytest.mark.parametrize("blocks", [8, 32])
+def test_step_under_cu_contention_is_bit_identical(blocks):
+    """A foreign kernel that HOLDS compute units while a step runs (fn_occupy_cus: `blocks` workgroups with 64 KB of LDS each, relaunched
+    back to back on another stream - what an RCCL channel or another process' kernel looks like to the weight-stationary scans, whose
+    256 workgroups need every CU): the scan's missing workgroups become resident late, the resident ones spin at their counters.  The
+    step must come out bit-identical, the sync-error word must stay clear; the slow-down is printed (scratch/contention.py records it
+    at the benchmark shape)."""
+    import time
+    pkg = load_package()
+    from music_fader_nets_amd.synth import synth_batch
+    B, T, Tr = 256, 64, 16
+    m = make_model(512, 128, device=DEV)
+    tr = pkg.GMVAETrainer(m, lr=1e-3, beta=0.2)
+    b = synth_batch(np.random.RandomState(0), B, T, Tr)
+    batch = tr.prepare_batch(b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"])
+    torch.manual_seed(99)
+    eps = tr.draw_eps(B, T)
+    ops = m.engine().ops
+
+    def run(contend):
+        side = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if contend:
+            with torch.cuda.stream(side):
+                for _ in range(24):
+                    ops.occupy_cus(blocks, 64 * 1024, 1_000_000)        # ~0.5 ms each, back to back: the CUs stay taken for the whole step
+        t = tr.loss_and_grads(20000, batch, eps)
+        torch.cuda.synchronize()
+        return t, tr.flat.grad.clone(), time.perf_counter() - t0
+
+    run(False)
+    t_ref, g_ref, dt_ref = run(False)
+    t_c, g_c, dt_c = run(True)
+    assert not ops.gru_sync_error()
+    assert t_c == t_ref and torch.equal(g_c, g_ref)
+    print("contention: %d CUs held -> step %.2f ms vs %.2f ms alone" % (blocks, dt_c * 1e3, dt_ref * 1e3))
