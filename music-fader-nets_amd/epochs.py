@@ -46,8 +46,9 @@ def _run_half(trainer, step, train_dl, val_dl, supervised, log):
     return step
 
 
-def training_phase(trainer, step, n_epochs, vgm_train_dl, vgm_val_dl, train_dl, val_dl, save_path, name="model", log=print):
-    """Returns the step counter after n_epochs.  The loaders are any sized iterables of batches (lists, DataLoaders)."""
+def training_phase(trainer, step, n_epochs, vgm_train_dl, vgm_val_dl, train_dl, val_dl, save_path, name="model", log=print, save=True):
+    """Returns the step counter after n_epochs.  The loaders are any sized iterables of batches (lists, DataLoaders).
+    save=False: this process does not write checkpoints (data-parallel ranks other than 0)."""
     model = trainer.model
     log(HEADER)
     for i in range(1, n_epochs + 1):
@@ -55,8 +56,10 @@ def training_phase(trainer, step, n_epochs, vgm_train_dl, vgm_val_dl, train_dl, 
         step = _run_half(trainer, step, vgm_train_dl, vgm_val_dl, True, log)
         step = _run_half(trainer, step, train_dl, val_dl, False, log)
         log("Saving model...")
-        torch.save(cpu_state_dict(model), save_path)
-    stamped = os.path.join(os.path.dirname(save_path) or ".", "{}_{}.pt".format(name, datetime.now()))
-    torch.save(cpu_state_dict(model), stamped)
+        if save:
+            torch.save(cpu_state_dict(model), save_path)
+    if save:
+        stamped = os.path.join(os.path.dirname(save_path) or ".", "{}_{}.pt".format(name, datetime.now()))
+        torch.save(cpu_state_dict(model), stamped)
     log("Model saved as {}!".format(save_path))
     return step

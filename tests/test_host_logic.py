@@ -1,9 +1,13 @@
 """Host-side schedule (engine / trainer / decode) checked WITHOUT a GPU: the C-ABI ops are replaced by their documented
 semantics (tests/fake_ops.py) and results are compared with the golden fixtures / the oracle.  The same assertions
 run against the real HIP kernels in test_gpu_parity.py."""
+import os
+
 import numpy as np
 import pytest
 import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 from fake_ops import FakeOps
 from helpers import NOISE_PARAMS, batch_of, load_golden, make_model, relerr, sd_from
@@ -221,3 +225,29 @@ def test_glsr_trainer_host_logic():
     m = make_vae_model(H, Z, ops=FakeOps())
     m.load_state_dict(glsr_fixture_weights(g, H, Z))
     check_glsr(pkg, m, g, "cpu", tol_grad=5e-4, rtol_tuple=1e-4)
+
+
+def test_entry_driver_config_and_loaders():
+    """train.py: the reference's JSON config (tests/golden/gmm_model_config.json = its keys and values) is read verbatim; the synthetic
+    arrays go through the same dataset classes / DataLoader settings as the reference's caches; data-parallel ranks take disjoint rows."""
+    import argparse
+    load_package()
+    from music_fader_nets_amd import train as T
+    args = T.read_config(os.path.join(GOLDEN, "gmm_model_config.json"))
+    assert [args[k] for k in T.CONFIG_KEYS] == [128, 50, 1e-3, 0.9999, "music_attr_vae_reg_gmm_long_v", 512, 128, 0.2, 32, 2]
+    with pytest.raises(KeyError):
+        import json, tempfile
+        with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+            json.dump({"batch_size": 8}, f)
+        T.read_config(f.name)
+    opts = argparse.Namespace(data_root=None, synthetic_songs=200, seq_len=40)
+    dls, sizes = T.build_loaders(args, opts, 0, 1)
+    assert sizes == {"train": 160, "val": 20, "vgm_train": 57, "vgm_val": 3}           # 80/10/10 and 90/5/5 splits
+    x = next(iter(dls["train"]))
+    assert [tuple(t.shape) for t in x] == [(128, 40), (128, 10), (128, 10), (128, 24), (128,), (128,)] and x[0].dtype == torch.float32
+    v = next(iter(dls["vgm_train"]))
+    assert len(v) == 8 and v[0].shape[0] == 32 and set(v[4].tolist()) <= {0.0, 1.0}    # arousal binarised
+    assert bool((v[0] == 1).any(1).all())                                              # every song carries the inserted EOS token
+    a = next(iter(T.RankShard([x], 0, 2)))
+    b = next(iter(T.RankShard([x], 1, 2)))
+    assert torch.equal(torch.cat([a[0], b[0]]), x[0]) and a[3].shape == (64, 24)
