@@ -14,6 +14,8 @@
 // atomic on a monotonic counter; consumer: one lane polls, barrier, sc1 loads); every spin is bounded (timeout -> sticky error word,
 // all workgroups leave).  The ping-pong slabs cannot be overwritten early: a writer of step t+2 only starts after token t+1 exists,
 // which is after every reader of step t has arrived.  The 4 waves of a workgroup split K and add their partial tiles through LDS.
+#include <atomic>
+
 #include "gru_layout.h"
 
 namespace {
@@ -336,17 +338,17 @@ __global__ __launch_bounds__(NT) void decode_greedy_kernel(const DArgs a) {
 template <int MT>
 int launch_decode(const DArgs& a, int grid, hipStream_t st) {
     auto k = decode_greedy_kernel<MT>;
-    static int fits[32] = {0};                     // per device: 1 = at least one workgroup of this kernel fits a CU, -1 = it does not
+    static std::atomic<int> fits[32];              // write-once per device (zero-initialised): 1 = at least one workgroup of this kernel fits a CU, -1 = it does not
     const size_t lds = ((size_t)3 * a.H * 16 + (size_t)4 * MT * 3 * RT) * 4 + 16 + 64 * 4;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return FN_E_UNSUPPORTED;
-    if (fits[dev] == 0) {
+    if (fits[dev].load(std::memory_order_acquire) == 0) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
         if (e != hipSuccess) return (int)e;
         int nb = 0;                                // every role workgroup must be resident (one per CU): ask the occupancy calculator
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), NT, 160 * 1024 - 64);
         if (e != hipSuccess) return (int)e;
-        fits[dev] = nb > 0 ? 1 : -1;
+        fits[dev].store(nb > 0 ? 1 : -1, std::memory_order_release);   // idempotent: racing threads compute the same value
     }
     if (fits[dev] < 0) return FN_E_UNSUPPORTED;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, a);

@@ -1,6 +1,8 @@
 // gemm.hip - dense fp32 GEMM on the f32 MFMA + small dense helpers (transpose, column sums, axpy, sum).
 // Replaces nn.Linear forward / backward of the reference (gmm_model.py:86,91,108,113,123,137 and their
 // autograd), see include/fadernets.h.
+#include <atomic>
+
 #include "common.h"
 #include "mma_core.h"
 
@@ -546,14 +548,14 @@ int fn_out_head_f32(const float* h, int ldh, const float* W, int ldw, const floa
     if (dlogits && (((uintptr_t)dlogits) & 15)) return FN_E_ALIGN;
     const long R = (long)B * T;
     if (R > 0x7fffffff) return FN_E_SHAPE;
-    static bool attr_set[32] = {false};
+    static std::atomic<bool> attr_set[32];         // write-once per device; setting the attribute twice is harmless
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return FN_E_SHAPE;
     const size_t lds = out_head_lds_bytes();
-    if (!attr_set[dev]) {
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(out_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr_set[dev] = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(out_head_kernel, dim3((unsigned)((R + OH_BM - 1) / OH_BM)), dim3(NT), lds, (hipStream_t)stream, h, (long)ldh, W, (long)ldw,
                        bias, (int)R, V, H, B, T, target, grad_scale, nll_rows, dlogits, (long)ld);

@@ -23,6 +23,8 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <atomic>
+
 #include "gru_layout.h"
 
 #ifdef FN_TIMING
@@ -626,14 +628,14 @@ __global__ __launch_bounds__(NT, 2) void gru_cell_kernel(const CellArgs a) {
 template <int BM, int WM, int WN>
 int launch_cell(const CellArgs& a, hipStream_t st) {
     const size_t lds = (size_t)2 * (Stage<BM, GC_BK, true, NT>::WORDS + Stage<GC_BN, GC_BK, true, NT>::WORDS) * sizeof(float);
-    static bool attr_set[32] = {false};
+    static std::atomic<bool> attr_set[32];         // write-once per device; setting the attribute twice is harmless
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return FN_E_SHAPE;
     auto k = gru_cell_kernel<BM, WM, WN>;
-    if (!attr_set[dev]) {
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr_set[dev] = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     const int tiles = ((a.B + BM - 1) / BM) * (a.H / 32);
     hipLaunchKernelGGL(k, dim3(tiles), dim3(NT), lds, st, a);

@@ -17,6 +17,8 @@
 //     barrier, sc1 loads).  Block ids are dealt so that a row group sits on ONE XCD when there are 8 groups (speed only,
 //     correctness never depends on placement).
 //   * every spin is bounded: on timeout (or when another workgroup has timed out) the workgroup raises err and leaves.
+#include <atomic>
+
 #include "gru_layout.h"
 
 #ifdef FN_TIMING
@@ -566,15 +568,17 @@ __global__ __launch_bounds__(NT) void gru_bwd_persist_kernel(const QArgs args) {
 constexpr int FN_MAX_DEVICES = 32;
 
 int cu_count() {
-    static int n[FN_MAX_DEVICES] = {0};              // per device: a process may drive several GPUs
+    static std::atomic<int> n[FN_MAX_DEVICES];       // write-once per device (a process may drive several GPUs); zero-initialised
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= FN_MAX_DEVICES) return 0;
-    if (n[dev] == 0) {
+    int c = n[dev].load(std::memory_order_acquire);
+    if (c == 0) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-        n[dev] = prop.multiProcessorCount;
+        c = prop.multiProcessorCount;
+        n[dev].store(c, std::memory_order_release);
     }
-    return n[dev];
+    return c;
 }
 
 // The weight-stationary kernels spin on counters that OTHER workgroups of the same launch advance: every workgroup of the grid
@@ -585,20 +589,23 @@ int cu_count() {
 template <class Args, void (*K)(const Args)>
 int launch_k(const Args& a, int grid, size_t lds, int cus, hipStream_t st) {
     auto k = K;
-    static int blocks_per_cu[FN_MAX_DEVICES] = {0};  // 0 = not asked yet for this device
-    static size_t lds_asked[FN_MAX_DEVICES] = {0};
+    // per kernel instance and device: (blocks per CU << 32 | LDS bytes asked for), packed into ONE atomic word so that a reader never
+    // pairs the answer for one LDS size with another; recomputed (idempotently) when the LDS size differs
+    static std::atomic<unsigned long long> cache[FN_MAX_DEVICES];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= FN_MAX_DEVICES) return FN_PERSIST_NA;
-    if (blocks_per_cu[dev] == 0 || lds_asked[dev] != lds) {
+    unsigned long long w = cache[dev].load(std::memory_order_acquire);
+    if (w == 0 || (size_t)(w & 0xffffffffull) != lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
         if (e != hipSuccess) return (int)e;
         int nb = 0;
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), NT, lds);
         if (e != hipSuccess) return (int)e;
-        blocks_per_cu[dev] = nb > 0 ? nb : -1;
-        lds_asked[dev] = lds;
+        w = ((unsigned long long)(unsigned)(nb > 0 ? nb : 0x7fffffff) << 32) | (unsigned long long)lds;     // 0x7fffffff = does not fit
+        cache[dev].store(w, std::memory_order_release);
     }
-    if (blocks_per_cu[dev] < 0 || (long)grid > (long)cus * blocks_per_cu[dev]) return FN_PERSIST_NA;
+    const long blocks_per_cu = (w >> 32) == 0x7fffffffull ? -1 : (long)(w >> 32);
+    if (blocks_per_cu < 0 || (long)grid > (long)cus * blocks_per_cu) return FN_PERSIST_NA;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, a);
     FN_CHECK_LAUNCH();
     return FN_OK;
