@@ -379,6 +379,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn_under_launcher(args.gpus)
 
+    # stdout carries exactly ONE line (the JSON of rank 0): libraries that chat on stdout (gloo's "[Gloo] Rank 0 is connected ...", RCCL's
+    # version banner) are sent to stderr at the file-descriptor level, the result line is written to the saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     t_start = time.perf_counter()
     from mfn_import import load_package
     pkg = load_package()
@@ -399,7 +405,8 @@ def main():
 
     out = (bench_train if args.mode == "train" else bench_decode)(args, pkg, ctx, local, rank, world, log)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if ctx is not None:
         torch.distributed.barrier()
         if ctx.rccl is not None:
