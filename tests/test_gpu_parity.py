@@ -1239,7 +1239,7 @@ def test_entry_driver_runs_an_epoch_from_the_reference_config(tmp_path, capsys):
     argv = ["--config", cfg, "--synthetic", "--synthetic-songs", "320", "--seq-len", "48", "--epochs", "1", "--out", str(tmp_path), "--seed", "3"]
     step = main(argv)
     out = capsys.readouterr().out
-    assert step == 2 + 2                                       # 2 VGMIDI batches of 32 (72 songs) + 2 Yamaha batches of 128 (256 songs)
+    assert step == 3 + 2                                       # 3 VGMIDI batches (72 songs: 32 + 32 + 8) + 2 Yamaha batches of 128 (256 songs)
     for needle in ("Save path: ", "Epoch 1 / 1", "batch loss: ", "train loss by term - D: ", "test loss by term - D: ", "KLD-C: ", "Saving model...",
                    "Model saved as "):
         assert needle in out, (needle, out)
