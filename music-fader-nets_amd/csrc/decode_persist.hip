@@ -1,5 +1,5 @@
-// decode_persist.hip - greedy autoregressive decode of the global decoder (gmm_model.py:119-149 with model.eval()) for SMALL batches
-// (<= 64 sequences) as ONE launch: the per-token chain  layer-1 cell -> W_ih2 projection -> layer-2 cell -> 512->V output layer ->
+// decode_persist.hip - greedy autoregressive decode of the global decoder (gmm_model.py:119-149 with model.eval()) for up to 1024
+// sequences as ONE launch: the per-token chain  layer-1 cell -> W_ih2 projection -> layer-2 cell -> 512->V output layer ->
 // log-softmax + argmax -> next token  is latency-bound (five dependent kernels per token otherwise), so each link gets its own set
 // of workgroups that keep their weight slice in LDS for the whole decode and hand the activations to the next set through L2:
 //
@@ -14,6 +14,13 @@
 // atomic on a monotonic counter; consumer: one lane polls, barrier, sc1 loads); every spin is bounded (timeout -> sticky error word,
 // all workgroups leave).  The ping-pong slabs cannot be overwritten early: a writer of step t+2 only starts after token t+1 exists,
 // which is after every reader of step t has arrived.  The 4 waves of a workgroup split K and add their partial tiles through LDS.
+//
+// More than 32 sequences (the reference's evaluator decodes 8 fader values x 100 samples = 800 rows at once, test_class.py:84-85): the
+// batch is cut into BLOCKS of 32 rows that travel through the same role workgroups one after the other - a pipeline: while L1 works on
+// block b+1, P2 has block b, L2 block b-1 ... - with one set of counters and exchange slabs per block; the LDS-resident weight slices are
+// reused by every block, and a second replica of the whole role set (2 x 119 workgroups <= 256 CUs at H = 512) takes every other block.
+// Per-block state (a cell's own previous state slice, the per-row input constants) is re-read from the exchange slabs / L2 instead of
+// living in registers.  Per token: max(chain latency of one block, blocks per replica x busy time of the slowest role).
 #include <atomic>
 
 #include "gru_layout.h"
@@ -21,10 +28,14 @@
 namespace {
 
 constexpr int NT = 256;
-constexpr int C1 = 0, C2 = 32, C3 = 64, C4 = 96, C5 = 128, ERRW = 160;   // word offsets in sync (one 128-byte line each)
+constexpr int C1 = 0, C2 = 32, C3 = 64, C4 = 96, C5 = 128;               // word offsets inside a block's counters (one 128-byte line each)
+constexpr int BLKW = 160;                                                 // counter words per block
+constexpr int MAXBLK = 32;                                                // blocks of 32 rows: up to 1024 sequences
+constexpr int ERRW = MAXBLK * BLKW;                                       // sticky error word behind all counters
 
 struct DArgs {
     int B, steps, H, V, nvt;                         // nvt = ceil(V / 16) output slices
+    int nblk, nrep;                                  // row blocks (of MT x 16 rows) and replicas of the role set (replica r: blocks r, r + nrep, ...)
     int start_token, tok_ld;
     const float *w1, *bhh1, *bih1, *table1, *rowbias1, *h0;
     const float *wi2, *bih2, *w2, *bhh2;
@@ -42,7 +53,8 @@ FN_DEVINL f32x4 ldv4_sc1(const float* p) {
 }
 
 struct Sync {
-    u32* base;
+    u32* base;                                       // this block's counters
+    u32* errw;                                       // the launch's sticky error word
     volatile int* dead;
     // one lane waits until *counter >= target, then the whole workgroup continues; false = give up (bounded spin / error elsewhere)
     FN_DEVINL bool wait(int counter, u32 target) const {
@@ -50,8 +62,8 @@ struct Sync {
             u32 spins = 0;
             while (ld_cnt(base + counter) < target) {
                 __builtin_amdgcn_s_sleep(1);
-                if ((++spins & 63u) == 0 && (spins > SPIN_LIMIT || ld_cnt(base + ERRW) != 0)) {
-                    __hip_atomic_store(base + ERRW, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((++spins & 63u) == 0 && (spins > SPIN_LIMIT || ld_cnt(errw) != 0)) {
+                    __hip_atomic_store(errw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     *dead = 1;
                     break;
                 }
@@ -140,19 +152,23 @@ __global__ __launch_bounds__(NT) void decode_greedy_kernel(const DArgs a) {
     float* red = smem + 3 * H * 16;                   // [4][MT][3][RT]
     volatile int* dead = reinterpret_cast<volatile int*>(red + 4 * MT * 3 * RT);
     volatile int* tokl = dead + 4;                    // [64] tokens of the current step (layer-1 role)
-    const Sync sy = {a.sync, dead};
     if (tid == 0) *dead = 0;
-    const long FS = (long)MT * 16 * H;
+    const long FS = (long)MT * 16 * H;                // floats of one block's exchange slab
+    const long FSA = FS * a.nblk;                     // ... of one slot (all blocks)
+    constexpr int RB = MT * 16;                       // rows per block
 
     int role, slice;
+    const int per_rep = 3 * nsl + a.nvt + 1;
+    const int rep = blockIdx.x / per_rep;
     {
-        const int b = blockIdx.x;
+        const int b = blockIdx.x % per_rep;
         if (b < nsl) { role = 0; slice = b; }
         else if (b < 2 * nsl) { role = 1; slice = b - nsl; }
         else if (b < 3 * nsl) { role = 2; slice = b - 2 * nsl; }
         else if (b < 3 * nsl + a.nvt) { role = 3; slice = b - 3 * nsl; }
         else { role = 4; slice = 0; }
     }
+    const bool single = a.nblk <= a.nrep;             // one block per replica: a cell keeps its state slice in registers
     // one-time: weight slice -> LDS
     if (role < 3) {
         const float* w = role == 0 ? a.w1 : (role == 1 ? a.wi2 : a.w2);
@@ -169,47 +185,210 @@ __global__ __launch_bounds__(NT) void decode_greedy_kernel(const DArgs a) {
     }
     __syncthreads();
 
-    // epilogue item of this thread: row rl of the batch, units / columns 4 u4 .. of the slice
+    // epilogue item of this thread: row rl of the BLOCK, units / columns 4 u4 .. of the slice
     const int item = tid, rl = item >> 2, u4 = item & 3;
-    const bool act = item < MT * 64 && rl < B;
-    const int b = min(rl, B - 1);
     const int tile = min(rl >> 4, MT - 1);
     const int coff = ((rl & 15) >> 2) * 68 + u4 * 16 + (rl & 3);
     const int jj0 = slice * 16 + 4 * u4;              // hidden unit (roles 0-2) or vocabulary column (role 3)
     const u32 unsl = (u32)nsl;
+    const int vpad = a.nvt * 16;
+    u32* errw = a.sync + ERRW;
 
     if (role == 0) {                                  // ---------------- layer-1 cell ----------------
-        f32x4 bh[3], bi[3], rb[3], hp;
+        f32x4 bh[3], bi[3], hp_reg = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             bh[q] = ldv4(a.bhh1 + q * H + jj0);
             bi[q] = a.bih1 ? ldv4(a.bih1 + q * H + jj0) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            rb[q] = a.rowbias1 ? ldv4(a.rowbias1 + (long)b * 3 * H + q * H + jj0) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        hp = ldv4(a.h0 + (long)b * H + jj0);
         for (int t = 0; t < a.steps; ++t) {
-            // the recurrent product needs h1_{t-1} only, not the token: it runs while the previous token is still being produced
-            if (t > 0 && !sy.wait(C1, unsl * (u32)t)) return;
-            f32x4 acc[MT][3];
-            kquarter<MT, 3>(a.x1 + (long)((t + 1) & 1) * FS, wl, nk, lane, wave, acc);     // slot 1 holds h0 at t = 0
-            spill_partials<MT, 3>(red, lane, wave, acc);
-            f32x4 gh[3];
+            for (int blk = rep; blk < a.nblk; blk += a.nrep) {
+                const Sync sy = {a.sync + blk * BLKW, errw, dead};
+                const int r0 = blk * RB, nrow = min(RB, B - r0);          // rows of this block
+                const bool act = item < MT * 64 && rl < nrow;
+                const int b = r0 + min(rl, nrow - 1);
+                float* x1 = a.x1 + (long)blk * FS;
+                // the recurrent product needs h1_{t-1} only, not the token: it runs while the previous token is still being produced
+                if (t > 0 && !sy.wait(C1, unsl * (u32)t)) return;
+                const float* xin = x1 + (long)((t + 1) & 1) * FSA;        // slot 1 holds h0 at t = 0
+                // own previous state slice and the per-row input constants: registers when this workgroup serves ONE block, else re-read
+                // (requested together with the operand fragments: kquarter's single wait covers the asm load)
+                f32x4 hp = hp_reg, rb[3];
+                const bool reload = !(single && t > 0);
+                if (reload) gld4_sc1(hp, t == 0 ? a.h0 + (long)b * H + jj0 : xin + frag_off(min(rl, nrow - 1), jj0, nk));
 #pragma unroll
-            for (int q = 0; q < 3; ++q) gh[q] = gather_sum<MT, 3>(red, tile, q, coff) + bh[q];
-            // the token of step t-1: every layer-1 workgroup takes the argmax of the logits itself as soon as the output slices
-            // have arrived (the ARG workgroup, which writes tokens and log-probabilities out, is off the critical chain)
-            int tok = a.start_token;
-            if (t > 0) {
-                if (!sy.wait(C4, (u32)a.nvt * (u32)t)) return;
-                const int vpad = a.nvt * 16;
-                for (int row = wave; row < B; row += 4) {
+                for (int q = 0; q < 3; ++q) rb[q] = a.rowbias1 ? ldv4(a.rowbias1 + (long)b * 3 * H + q * H + jj0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                f32x4 acc[MT][3];
+                kquarter<MT, 3>(xin, wl, nk, lane, wave, acc);
+                fn_touch(hp);
+                spill_partials<MT, 3>(red, lane, wave, acc);
+                f32x4 gh[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) gh[q] = gather_sum<MT, 3>(red, tile, q, coff) + bh[q];
+                // the token of step t-1: every layer-1 workgroup takes the argmax of the logits itself as soon as the output slices
+                // have arrived (the ARG workgroup, which writes tokens and log-probabilities out, is off the critical chain)
+                int tok = a.start_token;
+                if (t > 0) {
+                    if (!sy.wait(C4, (u32)a.nvt * (u32)t)) return;
+                    // all rows of this wave are requested before the first is reduced: one L2 round trip instead of one per row
+                    constexpr int RPW = MT * 4;                              // rows per wave
+                    float xl[RPW][6];
+#pragma unroll
+                    for (int j = 0; j < RPW; ++j) {
+                        const int rowc = min(wave + 4 * j, nrow - 1);
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) {
+                            const int v = min(lane + 64 * k, vpad - 1);
+                            xl[j][k] = __hip_atomic_load(a.logits + (long)(r0 + rowc) * vpad + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < RPW; ++j) {
+                        const int row = wave + 4 * j;
+                        float mx = -3.0e38f;
+                        int am = 0x7fffffff;
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) {
+                            const int v = lane + 64 * k;
+                            const float x = v < a.V ? xl[j][k] : -3.0e38f;
+                            if (x > mx) { mx = x; am = v; }
+                        }
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) {
+                            const float om = __shfl_xor(mx, o, 64);
+                            const int oa = __shfl_xor(am, o, 64);
+                            if (om > mx || (om == mx && oa < am)) { mx = om; am = oa; }
+                        }
+                        if (lane == 0 && row < nrow) tokl[row] = am;
+                    }
+                    __syncthreads();
+                    tok = tokl[min(rl, nrow - 1)];
+                }
+                f32x4 ex[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) ex[q] = ldv4(a.table1 + (long)tok * 3 * H + q * H + jj0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float r = fn_sigmoid(((bi[0][c] + ex[0][c]) + rb[0][c]) + gh[0][c]);
+                    const float z = fn_sigmoid(((bi[1][c] + ex[1][c]) + rb[1][c]) + gh[1][c]);
+                    const float n = fn_tanh(((bi[2][c] + ex[2][c]) + rb[2][c]) + r * gh[2][c]);
+                    hp[c] = (1.0f - z) * n + z * hp[c];
+                }
+                hp_reg = hp;
+                if (act) stv4_sc1(x1 + (long)(t & 1) * FSA + frag_off(rl, jj0, nk), hp);
+                sy.arrive(C1);
+            }
+        }
+    } else if (role == 1) {                           // ---------------- W_ih2 projection ----------------
+        f32x4 bi[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) bi[q] = a.bih2 ? ldv4(a.bih2 + q * H + jj0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < a.steps; ++t) {
+            for (int blk = rep; blk < a.nblk; blk += a.nrep) {
+                const Sync sy = {a.sync + blk * BLKW, errw, dead};
+                const int r0 = blk * RB, nrow = min(RB, B - r0);
+                const bool act = item < MT * 64 && rl < nrow;
+                const int b = r0 + min(rl, nrow - 1);
+                // (g2 of step t-1 is free: h1_t exists only after token t-1, i.e. after layer 2 consumed it)
+                if (!sy.wait(C1, unsl * (u32)(t + 1))) return;
+                f32x4 acc[MT][3];
+                kquarter<MT, 3>(a.x1 + (long)blk * FS + (long)(t & 1) * FSA, wl, nk, lane, wave, acc);
+                spill_partials<MT, 3>(red, lane, wave, acc);
+                if (act) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) stv4_sc1(a.g2 + (long)b * 3 * H + q * H + jj0, gather_sum<MT, 3>(red, tile, q, coff) + bi[q]);
+                }
+                sy.arrive(C2);
+            }
+        }
+    } else if (role == 2) {                           // ---------------- layer-2 cell ----------------
+        f32x4 bh[3], hp_reg = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) bh[q] = ldv4(a.bhh2 + q * H + jj0);
+        for (int t = 0; t < a.steps; ++t) {
+            for (int blk = rep; blk < a.nblk; blk += a.nrep) {
+                const Sync sy = {a.sync + blk * BLKW, errw, dead};
+                const int r0 = blk * RB, nrow = min(RB, B - r0);
+                const bool act = item < MT * 64 && rl < nrow;
+                const int b = r0 + min(rl, nrow - 1);
+                // recurrent input: h2_{t-1}, or h1_0 at the first step (gmm_model.py:134-135: hx[1] = hx[0] at i == 0)
+                if (!(t == 0 ? sy.wait(C1, unsl) : sy.wait(C3, unsl * (u32)t))) return;
+                const float* xin = t == 0 ? a.x1 + (long)blk * FS : a.x2 + (long)blk * FS + (long)((t + 1) & 1) * FSA;
+                f32x4 hp = hp_reg;
+                if (!(single && t > 0)) gld4_sc1(hp, xin + frag_off(min(rl, nrow - 1), jj0, nk));
+                f32x4 acc[MT][3];
+                kquarter<MT, 3>(xin, wl, nk, lane, wave, acc);
+                fn_touch(hp);
+                spill_partials<MT, 3>(red, lane, wave, acc);
+                f32x4 gh[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) gh[q] = gather_sum<MT, 3>(red, tile, q, coff) + bh[q];
+                if (!sy.wait(C2, unsl * (u32)(t + 1))) return;
+                f32x4 gx[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) gx[q] = ldv4_sc1(a.g2 + (long)b * 3 * H + q * H + jj0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float r = fn_sigmoid(gx[0][c] + gh[0][c]);
+                    const float z = fn_sigmoid(gx[1][c] + gh[1][c]);
+                    const float n = fn_tanh(gx[2][c] + r * gh[2][c]);
+                    hp[c] = (1.0f - z) * n + z * hp[c];
+                }
+                hp_reg = hp;
+                if (act) stv4_sc1(a.x2 + (long)blk * FS + (long)(t & 1) * FSA + frag_off(rl, jj0, nk), hp);
+                sy.arrive(C3);
+            }
+        }
+    } else if (role == 3) {                           // ---------------- output layer slice ----------------
+        f32x4 bo = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (jj0 + c < a.V) bo[c] = a.bo[jj0 + c];
+        for (int t = 0; t < a.steps; ++t) {
+            for (int blk = rep; blk < a.nblk; blk += a.nrep) {
+                const Sync sy = {a.sync + blk * BLKW, errw, dead};
+                const int r0 = blk * RB, nrow = min(RB, B - r0);
+                const bool act = item < MT * 64 && rl < nrow;
+                const int b = r0 + min(rl, nrow - 1);
+                // the logits of step t-1 may only be overwritten once the ARG workgroup has read them (this wait is off the critical
+                // chain: the output slices are idle until layer 2 arrives anyway); every layer-1 workgroup has taken its own argmax of them
+                // before h1_t, hence h2_t, existed
+                if (t > 0 && !sy.wait(C5, (u32)t)) return;
+                if (!sy.wait(C3, unsl * (u32)(t + 1))) return;
+                f32x4 acc[MT][1];
+                kquarter<MT, 1>(a.x2 + (long)blk * FS + (long)(t & 1) * FSA, wl, nk, lane, wave, acc);
+                spill_partials<MT, 1>(red, lane, wave, acc);
+                if (act) stv4_sc1(a.logits + (long)b * vpad + jj0, gather_sum<MT, 1>(red, tile, 0, coff) + bo);
+                sy.arrive(C4);
+            }
+        }
+    } else {                                          // ---------------- log-softmax + first-index argmax ----------------
+        for (int t = 0; t < a.steps; ++t) {
+            for (int blk = rep; blk < a.nblk; blk += a.nrep) {
+                const Sync sy = {a.sync + blk * BLKW, errw, dead};
+                const int r0 = blk * RB, nrow = min(RB, B - r0);
+                if (!sy.wait(C4, (u32)a.nvt * (u32)(t + 1))) return;
+                constexpr int RPW = MT * 4;
+                float xl[RPW][6];
+#pragma unroll
+                for (int j = 0; j < RPW; ++j) {                               // every row of this wave requested up front
+                    const int rowc = r0 + min(wave + 4 * j, nrow - 1);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k)
+                        xl[j][k] = __hip_atomic_load(a.logits + (long)rowc * vpad + min(lane + 64 * k, vpad - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int j = 0; j < RPW; ++j) {
+                    if (wave + 4 * j >= nrow) continue;
+                    const int row = r0 + wave + 4 * j;
+                    float x[6];
                     float mx = -3.0e38f;
                     int am = 0x7fffffff;
 #pragma unroll
                     for (int k = 0; k < 6; ++k) {
                         const int v = lane + 64 * k;
-                        const float x = v < a.V ? __hip_atomic_load(a.logits + (long)row * vpad + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -3.0e38f;
-                        if (x > mx) { mx = x; am = v; }
+                        x[k] = v < a.V ? xl[j][k] : -3.0e38f;
+                        if (x[k] > mx) { mx = x[k]; am = v; }                 // ascending v: the first index wins inside a lane
                     }
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) {
@@ -217,120 +396,22 @@ __global__ __launch_bounds__(NT) void decode_greedy_kernel(const DArgs a) {
                         const int oa = __shfl_xor(am, o, 64);
                         if (om > mx || (om == mx && oa < am)) { mx = om; am = oa; }
                     }
-                    if (lane == 0) tokl[row] = am;
+                    if (a.logp) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 6; ++k)
+                            if (lane + 64 * k < a.V) s += expf(x[k] - mx);
+                        s = fn_wave_sum(s);
+                        const float lse = mx + logf(s);
+                        float* out = a.logp + ((long)row * a.steps + t) * a.V;
+#pragma unroll
+                        for (int k = 0; k < 6; ++k)
+                            if (lane + 64 * k < a.V) out[lane + 64 * k] = x[k] - lse;
+                    }
+                    if (lane == 0) __hip_atomic_store(a.tokens + (long)row * a.tok_ld + t, am, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                __syncthreads();
-                tok = tokl[b];
+                sy.arrive(C5);
             }
-            f32x4 ex[3];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) ex[q] = ldv4(a.table1 + (long)tok * 3 * H + q * H + jj0);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float r = fn_sigmoid(((bi[0][c] + ex[0][c]) + rb[0][c]) + gh[0][c]);
-                const float z = fn_sigmoid(((bi[1][c] + ex[1][c]) + rb[1][c]) + gh[1][c]);
-                const float n = fn_tanh(((bi[2][c] + ex[2][c]) + rb[2][c]) + r * gh[2][c]);
-                hp[c] = (1.0f - z) * n + z * hp[c];
-            }
-            if (act) stv4_sc1(a.x1 + (long)(t & 1) * FS + frag_off(b, jj0, nk), hp);
-            sy.arrive(C1);
-        }
-    } else if (role == 1) {                           // ---------------- W_ih2 projection ----------------
-        f32x4 bi[3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) bi[q] = a.bih2 ? ldv4(a.bih2 + q * H + jj0) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int t = 0; t < a.steps; ++t) {
-            if (!sy.wait(C1, unsl * (u32)(t + 1))) return;
-            f32x4 acc[MT][3];
-            kquarter<MT, 3>(a.x1 + (long)(t & 1) * FS, wl, nk, lane, wave, acc);
-            spill_partials<MT, 3>(red, lane, wave, acc);
-            if (act) {
-#pragma unroll
-                for (int q = 0; q < 3; ++q) stv4_sc1(a.g2 + (long)b * 3 * H + q * H + jj0, gather_sum<MT, 3>(red, tile, q, coff) + bi[q]);
-            }
-            sy.arrive(C2);
-        }
-    } else if (role == 2) {                           // ---------------- layer-2 cell ----------------
-        f32x4 bh[3], hp = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < 3; ++q) bh[q] = ldv4(a.bhh2 + q * H + jj0);
-        for (int t = 0; t < a.steps; ++t) {
-            // recurrent input: h2_{t-1}, or h1_0 at the first step (gmm_model.py:134-135: hx[1] = hx[0] at i == 0)
-            if (!(t == 0 ? sy.wait(C1, unsl) : sy.wait(C3, unsl * (u32)t))) return;
-            const float* xin = t == 0 ? a.x1 : a.x2 + (long)((t + 1) & 1) * FS;
-            if (t == 0) hp = ldv4_sc1(xin + frag_off(b, jj0, nk));
-            f32x4 acc[MT][3];
-            kquarter<MT, 3>(xin, wl, nk, lane, wave, acc);
-            spill_partials<MT, 3>(red, lane, wave, acc);
-            f32x4 gh[3];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) gh[q] = gather_sum<MT, 3>(red, tile, q, coff) + bh[q];
-            if (!sy.wait(C2, unsl * (u32)(t + 1))) return;
-            f32x4 gx[3];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) gx[q] = ldv4_sc1(a.g2 + (long)b * 3 * H + q * H + jj0);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float r = fn_sigmoid(gx[0][c] + gh[0][c]);
-                const float z = fn_sigmoid(gx[1][c] + gh[1][c]);
-                const float n = fn_tanh(gx[2][c] + r * gh[2][c]);
-                hp[c] = (1.0f - z) * n + z * hp[c];
-            }
-            if (act) stv4_sc1(a.x2 + (long)(t & 1) * FS + frag_off(b, jj0, nk), hp);
-            sy.arrive(C3);
-        }
-    } else if (role == 3) {                           // ---------------- output layer slice ----------------
-        const int vpad = a.nvt * 16;
-        f32x4 bo = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (jj0 + c < a.V) bo[c] = a.bo[jj0 + c];
-        for (int t = 0; t < a.steps; ++t) {
-            // the logits of step t-1 may only be overwritten once the ARG workgroup has read them (this wait is off the critical
-            // chain: the output slices are idle until layer 2 arrives anyway)
-            if (t > 0 && !sy.wait(C5, (u32)t)) return;
-            if (!sy.wait(C3, unsl * (u32)(t + 1))) return;
-            f32x4 acc[MT][1];
-            kquarter<MT, 1>(a.x2 + (long)(t & 1) * FS, wl, nk, lane, wave, acc);
-            spill_partials<MT, 1>(red, lane, wave, acc);
-            if (act) stv4_sc1(a.logits + (long)b * vpad + jj0, gather_sum<MT, 1>(red, tile, 0, coff) + bo);
-            sy.arrive(C4);
-        }
-    } else {                                          // ---------------- log-softmax + first-index argmax ----------------
-        const int vpad = a.nvt * 16;
-        for (int t = 0; t < a.steps; ++t) {
-            if (!sy.wait(C4, (u32)a.nvt * (u32)(t + 1))) return;
-            for (int row = wave; row < B; row += 4) {
-                float x[6];
-                float mx = -3.0e38f;
-                int am = 0x7fffffff;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    const int v = lane + 64 * k;
-                    x[k] = v < a.V ? __hip_atomic_load(a.logits + (long)row * vpad + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -3.0e38f;
-                    if (x[k] > mx) { mx = x[k]; am = v; }                 // ascending v: the first index wins inside a lane
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float om = __shfl_xor(mx, o, 64);
-                    const int oa = __shfl_xor(am, o, 64);
-                    if (om > mx || (om == mx && oa < am)) { mx = om; am = oa; }
-                }
-                if (a.logp) {
-                    float s = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 6; ++k)
-                        if (lane + 64 * k < a.V) s += expf(x[k] - mx);
-                    s = fn_wave_sum(s);
-                    const float lse = mx + logf(s);
-                    float* out = a.logp + ((long)row * a.steps + t) * a.V;
-#pragma unroll
-                    for (int k = 0; k < 6; ++k)
-                        if (lane + 64 * k < a.V) out[lane + 64 * k] = x[k] - lse;
-                }
-                if (lane == 0) __hip_atomic_store(a.tokens + (long)row * a.tok_ld + t, am, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            sy.arrive(C5);
         }
     }
 }
@@ -361,7 +442,7 @@ int launch_decode(const DArgs& a, int grid, hipStream_t st) {
 extern "C" {
 
 size_t fn_decode_ws_bytes(int B, int H, int V) {
-    const size_t bp = B <= 16 ? 16 : (B <= 32 ? 32 : 64), vp = (size_t)(V + 15) / 16 * 16;    // rows as the kernel tiles them
+    const size_t bp = B <= 16 ? 16 : (size_t)(B + 31) / 32 * 32, vp = (size_t)(V + 15) / 16 * 16;    // rows as the kernel tiles them
     return (4 * bp * H + bp * 3 * H + bp * vp) * sizeof(float);
 }
 
@@ -372,7 +453,7 @@ int fn_decode_greedy(const FnDecode* d, void* stream) {
     if (!d->w_hh1_frag || !d->b_hh1 || !d->table1 || !d->h0 || !d->w_ih2_frag || !d->w_hh2_frag || !d->b_hh2 || !d->w_out_frag || !d->b_out ||
         !d->tokens || !d->ws || !d->sync_ws)
         return FN_E_NULL;
-    if (d->B <= 0 || d->B > 64 || d->steps <= 0 || d->H <= 0 || (d->H % 32) != 0 || d->H > 512 || d->V <= 0 || d->V > 384 || d->tok_ld < d->steps)
+    if (d->B <= 0 || d->B > MAXBLK * 32 || d->steps <= 0 || d->H <= 0 || (d->H % 32) != 0 || d->H > 512 || d->V <= 0 || d->V > 384 || d->tok_ld < d->steps)
         return FN_E_SHAPE;
     const uintptr_t al = (uintptr_t)d->w_hh1_frag | (uintptr_t)d->w_ih2_frag | (uintptr_t)d->w_hh2_frag | (uintptr_t)d->w_out_frag |
                          (uintptr_t)d->b_hh1 | (uintptr_t)d->b_ih1 | (uintptr_t)d->table1 | (uintptr_t)d->rowbias1 | (uintptr_t)d->h0 |
@@ -382,13 +463,17 @@ int fn_decode_greedy(const FnDecode* d, void* stream) {
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FN_E_SHAPE;
     const int nsl = d->H / 16, nvt = (d->V + 15) / 16;
-    const int grid = 3 * nsl + nvt + 1;
-    if (grid > prop.multiProcessorCount) return FN_E_UNSUPPORTED;  // every workgroup must be resident: one per CU
+    const int per_rep = 3 * nsl + nvt + 1;
+    if (per_rep > prop.multiProcessorCount) return FN_E_UNSUPPORTED;  // every workgroup must be resident: one per CU
     hipStream_t st = (hipStream_t)stream;
-    const int mt = d->B <= 16 ? 1 : (d->B <= 32 ? 2 : 4);
-    const size_t bp = (size_t)mt * 16, vp = (size_t)nvt * 16;
+    const int mt = d->B <= 16 ? 1 : 2;                                 // row tiles per block (64-row blocks were measured slower per row: a block's time is latency, not MFMA)
+    const int nblk = (d->B + mt * 16 - 1) / (mt * 16);
+    int nrep = prop.multiProcessorCount / per_rep;                     // replicas of the role set that fit one workgroup per CU
+    nrep = nrep < nblk ? nrep : nblk;
+    const int grid = nrep * per_rep;
+    const size_t bp = (size_t)nblk * mt * 16, vp = (size_t)nvt * 16;
     DArgs a;
-    a.B = d->B; a.steps = d->steps; a.H = d->H; a.V = d->V; a.nvt = nvt;
+    a.B = d->B; a.steps = d->steps; a.H = d->H; a.V = d->V; a.nvt = nvt; a.nblk = nblk; a.nrep = nrep;
     a.start_token = d->start_token; a.tok_ld = d->tok_ld;
     a.w1 = d->w_hh1_frag; a.bhh1 = d->b_hh1; a.bih1 = d->b_ih1; a.table1 = d->table1; a.rowbias1 = d->rowbias1; a.h0 = d->h0;
     a.wi2 = d->w_ih2_frag; a.bih2 = d->b_ih2; a.w2 = d->w_hh2_frag; a.bhh2 = d->b_hh2;
@@ -402,11 +487,7 @@ int fn_decode_greedy(const FnDecode* d, void* stream) {
     if (rc != FN_OK) return rc;
     hipError_t me = hipMemsetAsync(a.sync, 0, (size_t)ERRW * 4, st);             // counters only: the error word is sticky
     if (me != hipSuccess) return (int)me;
-    switch (mt) {
-        case 1: return launch_decode<1>(a, grid, st);
-        case 2: return launch_decode<2>(a, grid, st);
-        default: return launch_decode<4>(a, grid, st);
-    }
+    return mt == 1 ? launch_decode<1>(a, grid, st) : launch_decode<2>(a, grid, st);
 }
 
 }  // extern "C"

@@ -28,6 +28,8 @@ FN_DEVINL void gld4_sc1(f32x4& dst, const float* p) { asm volatile("global_load_
 FN_DEVINL void stv4_sc1(float* p, const f32x4& v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
 FN_DEVINL f32x4 ldv4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 FN_DEVINL void stv4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+// orders every later use of v behind the preceding (volatile) wait: the value of an asm load must not be looked at before it
+FN_DEVINL void fn_touch(f32x4& v) { asm volatile("" : "+v"(v)); }
 FN_DEVINL u32 ld_cnt(u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // host-side entry points of gru_persist.hip: return FN_OK when the persistent kernel was launched,
 // FN_PERSIST_NA when the configuration is not eligible (the caller then uses the per-step kernels).

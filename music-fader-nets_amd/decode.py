@@ -15,7 +15,8 @@ from .engine import E_VOCAB, LOGIT_LD
 def greedy_decode(model, z, steps, want_logp=True, use_graph=None):
     """z (Bi, 2Z+24) -> (log-probs (Bi, steps, 342) or None, tokens (Bi, steps) int32).
 
-    Bi <= 32: ONE launch for the whole decode (fn_decode_greedy).  Larger batches: steps x {layer-1 cell, W_ih2 projection,
+    Bi <= Engine.single_launch_rows: ONE launch for the whole decode (fn_decode_greedy; above 32 rows a pipeline of 32-row blocks through
+    its role workgroups).  Larger batches: steps x {layer-1 cell, W_ih2 projection,
     layer-2 cell, output GEMM, log_softmax+argmax} (from Engine.cell_decode_rows sequences on: steps x {layer-1 cell, layer-2 cell incl.
     its projection - fn_gru_cell_f32 -, output GEMM, argmax}) captured once per (Bi, steps) into a hipGraph and replayed.  The captured
     kernels read the parameters and the engine's weight images IN PLACE (stable addresses, refreshed by Engine.refresh_weights
@@ -52,7 +53,7 @@ def greedy_decode(model, z, steps, want_logp=True, use_graph=None):
 
 def _single_launch_ok(eng, z):
     """small batches decode as ONE launch (fn_decode_greedy: weight slices resident in LDS, activations handed over through L2)"""
-    return hasattr(eng.ops, "decode_greedy") and z.is_cuda and z.shape[0] <= 32 and eng.H <= 512 and eng.single_launch_decode
+    return hasattr(eng.ops, "decode_greedy") and z.is_cuda and z.shape[0] <= eng.single_launch_rows and eng.H <= 512 and eng.single_launch_decode
 
 
 def _decode_single_launch(eng, z, steps, want_logp):

@@ -687,6 +687,35 @@ def test_single_launch_decode_matches_per_token_kernels(H, Bi, steps, monkeypatc
     close(lp1[:, :upto], lp0[:, :upto], 2e-5)
 
 
+@pytest.mark.parametrize("H,Bi,steps", [(64, 45, 20), (512, 64, 30), (512, 256, 25), (512, 800, 12), (64, 1024, 9)])
+def test_single_launch_decode_block_pipeline(H, Bi, steps):
+    """fn_decode_greedy above 32 sequences: 32-row blocks travel through the role workgroups as a pipeline (two replicas of the role set at
+    H = 512, one at H = 64 ... up to 16 blocks per replica, a ragged last block) - per row the tokens and log-probabilities of the per-token
+    kernels up to that row's first near-tie, bit-reproducible on warm buffers, sync-error word clear."""
+    pkg = load_package()
+    m = make_model(H, 32 if H == 64 else 128, device=DEV, seed=13)
+    m.eval()
+    torch.manual_seed(4)
+    z = torch.randn(Bi, 2 * m.latent_dim + 24, device=DEV)
+    eng = m.engine()
+    eng.single_launch_decode, eng.cell_decode_rows = False, 1 << 30
+    lp0, tk0 = pkg.greedy_decode(m, z, steps)
+    eng.single_launch_decode, eng.single_launch_rows = True, 1024       # force the one-launch pipeline (the default hands > 256 rows to the per-token kernels)
+    lp1, tk1 = pkg.greedy_decode(m, z, steps)
+    lp2, tk2 = pkg.greedy_decode(m, z, steps)
+    assert not eng.ops.gru_sync_error()
+    assert torch.equal(tk1, tk2) and torch.equal(lp1, lp2)
+    gap = lp0.topk(2, dim=-1).values
+    unclear = ((gap[..., 0] - gap[..., 1]) <= 1e-4)
+    first = torch.where(unclear.any(1), unclear.float().argmax(1), torch.full((Bi,), steps, device=DEV))
+    keep = torch.arange(steps, device=DEV).view(1, -1) < first.view(-1, 1)
+    assert bool(keep.float().mean() > 0.9)
+    assert torch.equal(tk0[keep], tk1[keep])
+    close(lp1[keep], lp0[keep], 2e-5)
+    _, tk3 = pkg.greedy_decode(m, z, steps, want_logp=False)          # the ARG role without the log-probability output
+    assert torch.equal(tk3, tk1)
+
+
 @pytest.mark.parametrize("H,Bi,steps", [(64, 1100, 14), (512, 1024, 10)])
 def test_large_batch_decode_cells_match_per_token_kernels(H, Bi, steps):
     """decode of >= Engine.cell_decode_rows sequences (fn_gru_cell_f32: every cell one staged-GEMM launch, layer 2's input projection in
@@ -698,6 +727,7 @@ def test_large_batch_decode_cells_match_per_token_kernels(H, Bi, steps):
     torch.manual_seed(5)
     z = torch.randn(Bi, 2 * m.latent_dim + 24, device=DEV)
     eng = m.engine()
+    eng.single_launch_decode = False                                          # (the one-launch pipeline takes <= 1024 rows otherwise)
     eng.cell_decode_rows = 1 << 30
     lp0, tk0 = pkg.greedy_decode(m, z, steps)
     eng.cell_decode_rows = 768
