@@ -192,13 +192,15 @@ def comm_times(trainer, ctx, batch, eps, step, reps=3):
             trainer.step_device(step + i, batch, eps)
         torch.cuda.synchronize()
         out = {}
-        for key, name in (("bucket1", "bucket1_ms"), ("bucket2", "bucket2_ms"), ("exposed", "exposed_ms")):
+        for key, name in (("bucket1", "bucket1_ms"), ("bucket2", "bucket2_ms"), ("bucket3", "bucket3_ms"), ("exposed", "exposed_ms")):
             evs = ctx.timing.get(key, [])
             out[name] = round(float(np.mean([a.elapsed_time(b) for a, b in evs])), 4) if evs else None
         out["bucket1_MB"] = round(trainer.flat.bucket_split * 4 / 1e6, 2)
-        out["bucket2_MB"] = round((trainer.flat.n - trainer.flat.bucket_split) * 4 / 1e6, 2)
+        out["bucket2_MB"] = round((trainer.flat.bucket_split2 - trainer.flat.bucket_split) * 4 / 1e6, 2)
+        out["bucket3_MB"] = round((trainer.flat.n - trainer.flat.bucket_split2) * 4 / 1e6, 2)
         out["note"] = ("bucket 1 (decoder-side gradients) is issued behind the decoder weight-gradient GEMMs and runs beside the latent block / encoder "
-                       "backward; bucket 2 follows the encoder weight gradients; exposed = wait of the step's stream in front of clip+Adam")
+                       "backward; bucket 2 (heads, component means, rhythm encoder) beside the note encoder's weight-gradient GEMMs; bucket 3 (note "
+                       "encoder) is the exposed one; exposed = wait of the step's stream in front of clip+Adam")
         return out
     finally:
         ctx.timing = None

@@ -531,7 +531,7 @@ class Engine:
         if flush:
             self.flush_colsums()
 
-    def backward(self, G, dlogits_sd, lat_up, w3=None, after_decoders=None):
+    def backward(self, G, dlogits_sd, lat_up, w3=None, after_decoders=None, after_encoder_r=None):
         """Backward of forward().
 
         G            name -> gradient tensor to FILL (views of the flat gradient buffer)
@@ -542,6 +542,8 @@ class Engine:
         w3           device tensor {w_lat, w_cls, w_clf}: fused loss weights of fn_latent_bwd (None = only the upstream gradients)
         after_decoders  optional callback fired once every decoder-side parameter gradient is enqueued
                      (data parallel: start reducing that bucket while the encoder scans run)
+        after_encoder_r optional callback fired once everything but the note encoder's gradients is enqueued (heads, component means,
+                     rhythm encoder: the second bucket, reduced beside the note encoder's weight-gradient GEMMs)
         """
         ops, P, H, Z, ZG, K = self.ops, self.p, self.H, self.Z, self.ZG, self.K
         S = self.saved
@@ -634,9 +636,12 @@ class Engine:
         # one-hot columns of the four W_ih: token-segment sums of the gate gradients (ONE launch pair, the batch's token sort is shared)
         ops.embed_grad_sorted(S["sort"]["d"], [dict(dgx=encb[key]["dgx"], out=G[pfx + "weight_ih" + sfx], transposed=True, reverse=rev)
                                                for e, pfx, key, sfx, rev in enc_keys])
-        for e, pfx, key, sfx, rev in enc_keys:
+        for i, (e, pfx, key, sfx, rev) in enumerate(enc_keys):
             self._gru_weight_grads(key, pfx, sfx, T, B, encb[key]["dgx"], encb[key]["dghn"], pre["h_all"][key], None, G, sk_T,
                                    encb[key]["rs"], encb[key]["rsn"])
             self.colsum(encb[key]["rs"], G[pfx + "bias_ih" + sfx])
+            if i == 1 and after_encoder_r is not None:           # both directions of gru_r done (enc_keys: r, r_reverse, n, n_reverse)
+                self.flush_colsums()
+                after_encoder_r()
         self.flush_colsums()
         self.main_wait_side()

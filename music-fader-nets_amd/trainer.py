@@ -41,22 +41,30 @@ class FlatParams:
 
     The module's parameters are re-pointed at views of the flat parameter buffer (``state_dict`` keeps
     working, one kernel updates everything) and the gradient buffer is what data-parallel all-reduces.
-    Decoder-side parameters come first so that their gradient bucket can be reduced while the encoder
-    backward scans still run."""
+    Order = the order in which the backward completes the gradients, so that data parallel can reduce them in three
+    contiguous buckets while later work still runs: [decoder side | heads, component means, rhythm encoder | note encoder]
+    (bucket 1 overlaps the encoder backward scans, bucket 2 the note encoder's weight-gradient GEMMs; only bucket 3 is exposed)."""
 
     def __init__(self, model):
         named = model.used_parameters()
-        named = [kp for kp in named if kp[0].startswith(DECODER_PREFIXES)] + \
-                [kp for kp in named if not kp[0].startswith(DECODER_PREFIXES)]
+        dec = [kp for kp in named if kp[0].startswith(DECODER_PREFIXES)]
+        last = [kp for kp in named if kp[0].startswith("gru_n.")]
+        mid = [kp for kp in named if not kp[0].startswith(DECODER_PREFIXES) and not kp[0].startswith("gru_n.")]
+        mid = [kp for kp in mid if not kp[0].startswith("gru_r.")] + [kp for kp in mid if kp[0].startswith("gru_r.")]
+        named = dec + mid + last
         dev = named[0][1].device
         self.offsets, off = {}, 0
-        self.bucket_split = 0
-        for k, p in named:
-            if not k.startswith(DECODER_PREFIXES) and self.bucket_split == 0:
+        self.bucket_split = self.bucket_split2 = None
+        for i, (k, p) in enumerate(named):
+            if i == len(dec):
                 self.bucket_split = off
+            if i == len(dec) + len(mid):
+                self.bucket_split2 = off
             self.offsets[k] = off
             off += (p.numel() + 3) // 4 * 4          # 16-byte aligned segment starts
         self.n = off
+        self.bucket_split = off if self.bucket_split is None else self.bucket_split
+        self.bucket_split2 = off if self.bucket_split2 is None else self.bucket_split2
         self.param = torch.zeros(off, device=dev)
         self.grad = torch.zeros(off, device=dev)
         self.m = torch.zeros(off, device=dev)
@@ -250,9 +258,9 @@ class GMVAETrainer:
             outs.append(self.dist.gather(t, out))
         self._dens_all = tuple(outs)
 
-    def _run_backward(self, fw, hook):
+    def _run_backward(self, fw, hook, hook2=None):
         """fw = what _forward_losses returned; fills flat.G"""
-        self.model.engine().backward(self.flat.G, fw[0], fw[1], fw[2], after_decoders=hook)
+        self.model.engine().backward(self.flat.G, fw[0], fw[1], fw[2], after_decoders=hook, after_encoder_r=hook2)
 
     def _sync_step_counter(self, step):
         """the caller owns `step` (trainer_gmm.py:60,252); the device counter follows it (one tiny copy only when they differ)"""
@@ -270,12 +278,18 @@ class GMVAETrainer:
         ops.step_params(self.counters, self.beta, self.lr, 0.9, 0.999, supervised, 1.0 / Bg, advance, self.sp)
         fw = self._forward_losses(step, batch, eps, want_grads=True)
         beta0, Bg = fw[3], fw[4]
-        hook = None
+        hook = hook2 = None
         if self.dist is not None:
-            hook = lambda: self.dist.start_bucket(self.flat.grad[:self.flat.bucket_split], "bucket1")
-        self._run_backward(fw, hook)
+            f = self.flat
+            hook = lambda: self.dist.start_bucket(f.grad[:f.bucket_split], "bucket1")
+            hook2 = lambda: self.dist.start_bucket(f.grad[f.bucket_split:f.bucket_split2], "bucket2")
+        if hook2 is not None and type(self)._run_backward is GMVAETrainer._run_backward:
+            self._run_backward(fw, hook, hook2)
+        else:                                      # trainers of other model families: two buckets
+            self._run_backward(fw, hook)
+            hook2 and hook2()
         if self.dist is not None:
-            self.dist.start_bucket(self.flat.grad[self.flat.bucket_split:], "bucket2")
+            self.dist.start_bucket(self.flat.grad[self.flat.bucket_split2:], "bucket3")
             self.dist.finish_buckets()
         ops.sumsq(self.flat.grad, self.sumsq)      # norm of the (all-reduced) gradient: identical on every rank
         ops.clip_adam(self.flat.param, self.flat.grad, self.flat.m, self.flat.v, self.sumsq, self.max_norm, self.sp[3:5], 0.9, 0.999, 1e-8)
