@@ -124,7 +124,7 @@ ROW_INFO = {   # row -> (bound, unit of work, kernel, peak share of the chip)
 # HBM bytes per launch from rocprofv3 PMC passes (2 x FETCH_SIZE with the gfx950 correction + WRITE_SIZE, separate passes): bench.py
 # itself cannot run the profiler, so these are the committed measurements of the same launches
 PMC_TRAFFIC = {"enc_fwd_scan": 4.33e9, "enc_bwd_scan": 7.91e9}
-PMC_SOURCE = "profiles/r02_pmc_training_step.txt (2 x FETCH_SIZE + WRITE_SIZE, separate passes; kernels unchanged since)"
+PMC_SOURCE = "profiles/r03_pmc_training_step.txt (2 x FETCH_SIZE + WRITE_SIZE, separate passes)"
 
 
 def roofline_rows(records):
