@@ -561,17 +561,7 @@ class Engine:
         pd = self.persist_dec
         # ---- sub-decoders: both attribute decoders, all Tr steps, ONE whole-chip launch ----------------------------------
         sd = dec["sd"]
-        dh_sd, sdb, sds = {}, {}, {}
-        for e, Ce in (("r", R_DIMS), ("n", N_DIMS)):
-            dl = dlogits_sd[e].view(Tr * B, Ce)
-            dh_sd[e] = self.buf("sd_dh_" + e, (Tr, B, H))
-            ops.gemm(dl, P["linear_out_%s.weight" % e], dh_sd[e].view(Tr * B, H), a_k=True, b_k=False)
-            sdb[e] = dict(dgx=self.buf("sd_dgx_" + e, (Tr, B, 3 * H)), dghn=self.buf("sd_dghn_" + e, (Tr, B, H)),
-                          drb=self.zbuf("sd_drb_" + e, (B, 3 * H)), rsn=self.zbuf("sd_rsn_" + e, (B, H)), dh0=self.buf("sd_dh0_" + e, (B, H)))
-            sds[e] = dict(B=B, T=Tr, H=H, w_hh_t_frag=self.whh_t["d_" + e], h0=sd[e]["h0"], h_all=sd[e]["h_all"], gates=sd[e]["gates"],
-                          dh_ext=dh_sd[e], dgx_all=sdb[e]["dgx"], dghn_all=sdb[e]["dghn"], scratch=self.buf("sd_scr_" + e, (B, H)),
-                          dgx_rowsum=sdb[e]["drb"], dghn_rowsum=sdb[e]["rsn"])
-        ops.gru_seq_bwd([self._bwd_chunk(sds[e], 0, Tr, None, sdb[e]["dh0"]) for e in ("r", "n")], persistent=pd)
+        sdb = self._bwd_sub_decoder_scans(sd, dlogits_sd, B, Tr)
         # ---- what the encoder side needs from the decoders (main stream, critical path): dz ---------------------
         Wz_g, Wig = P["grucell_g.weight_ih"], P["linear_init_global.weight"]
         jobs = []
@@ -584,24 +574,56 @@ class Engine:
         self.side_wait_main()
         with self.on_side():
             self._bwd_global_decoder_params(G, S, gd, flush=False)
-            for e, attr, Ce in (("r", r, R_DIMS), ("n", n, N_DIMS)):
-                pfx = "gru_d_%s." % e
-                z = lat[e]["z"]
-                dl = dlogits_sd[e].view(Tr * B, Ce)
-                ops.gemm(dl, sd[e]["h_all"].view(Tr * B, H), G["linear_out_%s.weight" % e], a_k=False, b_k=False, splitk=sk_Tr)
-                self.colsum(dl, G["linear_out_%s.bias" % e])
-                self._gru_weight_grads("d_" + e, pfx, "_l0", Tr, B, sdb[e]["dgx"], sdb[e]["dghn"], sd[e]["h_all"], sd[e]["h0"], G, sk_Tr,
-                                       sdb[e]["drb"], sdb[e]["rsn"], lean=self.lean_dw)
-                dW = G[pfx + "weight_ih_l0"]                        # [3H][Ce+Z]
-                ops.embed_grad_sorted(S["sort"][e], [dict(dgx=sdb[e]["dgx"], out=dW[:, :Ce], transposed=True)])
-                ops.gemm(sdb[e]["drb"], z, dW[:, Ce:], a_k=False, b_k=False)
-                self.colsum(sdb[e]["drb"], G[pfx + "bias_ih_l0"])
-                ops.gemm(sdb[e]["dh0"], z, G["linear_init_%s.weight" % e], a_k=False, b_k=False)
-                self.colsum(sdb[e]["dh0"], G["linear_init_%s.bias" % e])
+            self._bwd_sub_decoder_params(G, sd, sdb, dlogits_sd, S["sort"], {"r": lat["r"]["z"], "n": lat["n"]["z"]}, B, Tr)
             self.flush_colsums()
             if after_decoders is not None:
                 after_decoders()           # data parallel: this bucket's all-reduce is ordered behind the side stream
 
+        self.backward_encoder(G, S, lat_up, w3, after_encoder_r)
+        self.main_wait_side()
+
+    def _bwd_sub_decoder_scans(self, sd, dlogits_sd, B, Tr):
+        """output layers' input gradients + the reverse scans of both attribute decoders (ONE launch); -> per decoder dict(dgx, dghn,
+        drb = per-sequence sums of the gate gradients (= gradient wrt the z projection), rsn, dh0 = dL/d linear_init(z))"""
+        ops, P, H = self.ops, self.p, self.H
+        dh_sd, sdb, sds = {}, {}, {}
+        for e, Ce in (("r", R_DIMS), ("n", N_DIMS)):
+            dl = dlogits_sd[e].view(Tr * B, Ce)
+            dh_sd[e] = self.buf("sd_dh_" + e, (Tr, B, H))
+            ops.gemm(dl, P["linear_out_%s.weight" % e], dh_sd[e].view(Tr * B, H), a_k=True, b_k=False)
+            sdb[e] = dict(dgx=self.buf("sd_dgx_" + e, (Tr, B, 3 * H)), dghn=self.buf("sd_dghn_" + e, (Tr, B, H)),
+                          drb=self.zbuf("sd_drb_" + e, (B, 3 * H)), rsn=self.zbuf("sd_rsn_" + e, (B, H)), dh0=self.buf("sd_dh0_" + e, (B, H)))
+            sds[e] = dict(B=B, T=Tr, H=H, w_hh_t_frag=self.whh_t["d_" + e], h0=sd[e]["h0"], h_all=sd[e]["h_all"], gates=sd[e]["gates"],
+                          dh_ext=dh_sd[e], dgx_all=sdb[e]["dgx"], dghn_all=sdb[e]["dghn"], scratch=self.buf("sd_scr_" + e, (B, H)),
+                          dgx_rowsum=sdb[e]["drb"], dghn_rowsum=sdb[e]["rsn"])
+        ops.gru_seq_bwd([self._bwd_chunk(sds[e], 0, Tr, None, sdb[e]["dh0"]) for e in ("r", "n")], persistent=self.persist_dec)
+        return sdb
+
+    def _bwd_sub_decoder_params(self, G, sd, sdb, dlogits_sd, sorts, z, B, Tr):
+        """parameter gradients of both attribute decoders (gru_d_*, linear_out_*, linear_init_*) from the gate gradients"""
+        ops, H = self.ops, self.H
+        sk_Tr = self._splitk(Tr * B)
+        for e, Ce in (("r", R_DIMS), ("n", N_DIMS)):
+            pfx = "gru_d_%s." % e
+            dl = dlogits_sd[e].view(Tr * B, Ce)
+            ops.gemm(dl, sd[e]["h_all"].view(Tr * B, H), G["linear_out_%s.weight" % e], a_k=False, b_k=False, splitk=sk_Tr)
+            self.colsum(dl, G["linear_out_%s.bias" % e])
+            self._gru_weight_grads("d_" + e, pfx, "_l0", Tr, B, sdb[e]["dgx"], sdb[e]["dghn"], sd[e]["h_all"], sd[e]["h0"], G, sk_Tr,
+                                   sdb[e]["drb"], sdb[e]["rsn"], lean=self.lean_dw)
+            dW = G[pfx + "weight_ih_l0"]                        # [3H][Ce+Z]
+            ops.embed_grad_sorted(sorts[e], [dict(dgx=sdb[e]["dgx"], out=dW[:, :Ce], transposed=True)])
+            ops.gemm(sdb[e]["drb"], z[e], dW[:, Ce:], a_k=False, b_k=False)
+            self.colsum(sdb[e]["drb"], G[pfx + "bias_ih_l0"])
+            ops.gemm(sdb[e]["dh0"], z[e], G["linear_init_%s.weight" % e], a_k=False, b_k=False)
+            self.colsum(sdb[e]["dh0"], G["linear_init_%s.bias" % e])
+
+    def backward_encoder(self, G, S, lat_up, w3=None, after_encoder_r=None):
+        """latent block + heads + the four encoder scans and their parameter gradients (the last third of backward(); also the whole
+        backward of a direct ``model.encode(x)`` call: S then holds d, pre, lat, eps, labels, sort['d'] only)"""
+        ops, P, H, Z, K = self.ops, self.p, self.H, self.Z, self.K
+        pre, lat = S["pre"], S["lat"]
+        B, T = S["d"].shape
+        sk_T = self._splitk(T * B)
         # ---- latent block + heads -----------------------------------------------------------------
         scans = []
         encb = {}
@@ -644,4 +666,3 @@ class Engine:
                 self.flush_colsums()
                 after_encoder_r()
         self.flush_colsums()
-        self.main_wait_side()

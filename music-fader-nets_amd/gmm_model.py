@@ -145,9 +145,28 @@ class MusicAttrRegGMVAE(nn.Module):
         idx = self._indices(x, x.shape[-1]).long()
         return torch.zeros_like(x).scatter_(1, idx.view(-1, 1), 1.0)
 
-    @torch.no_grad()
+    # Direct calls of the sub-modules (the reference allows them anywhere, gmm_model.py:82-218): in train mode with autograd enabled each is ONE
+    # autograd node (classes _EncodeFunction ... below) whose backward runs the matching part of the HIP backward; in eval mode / under
+    # no_grad they are forward only.  The activations a node saves live in their own buffer namespace, so a direct call never disturbs
+    # the saved state of a full forward() that still waits for its backward().
+    def _autograd_on(self):
+        return self.training and torch.is_grad_enabled() and type(self) is MusicAttrRegGMVAE
+
+    def _named(self, prefixes):
+        kp = [(k, p) for k, p in self.used_parameters() if k.startswith(prefixes)]
+        return [k for k, _ in kp], [p for _, p in kp]
+
     def encode(self, x):
-        """gmm_model.py:82-98 -> (Normal(mu_r, sigma_r), Normal(mu_n, sigma_n)); no autograd (eval-side API)."""
+        """gmm_model.py:82-98 -> (Normal(mu_r, sigma_r), Normal(mu_n, sigma_n))."""
+        if self._autograd_on():
+            self.engine()
+            names, plist = self._named(_EncodeFunction.PREFIXES)
+            mu_r, sg_r, mu_n, sg_n = _EncodeFunction.apply(self, names, self._indices(x, self.roll_dims), *plist)
+            return Normal(mu_r, sg_r), Normal(mu_n, sg_n)
+        return self._encode_forward_only(x)
+
+    @torch.no_grad()
+    def _encode_forward_only(self, x):
         eng = self.engine()
         d = self._indices(x, self.roll_dims)
         pre = eng.encode(d, save=False)
@@ -157,9 +176,15 @@ class MusicAttrRegGMVAE(nn.Module):
         return (Normal(pre["r"][:, :Z].clone(), lat["r"]["sigma"].clone()),
                 Normal(pre["n"][:, :Z].clone(), lat["n"]["sigma"].clone()))
 
-    @torch.no_grad()
     def approx_qy_x(self, z, mu_lookup, logvar_lookup, n_component):
         """gmm_model.py:194-218 -> (logLogit_qy_x, qy_x); mu/logvar lookups are nn.Embedding modules."""
+        if self._autograd_on() and (z.requires_grad or mu_lookup.weight.requires_grad):
+            self.engine()
+            return _QyFunction.apply(self, n_component, z.float().contiguous(), mu_lookup.weight, logvar_lookup.weight)
+        return self._approx_qy_x_forward_only(z, mu_lookup, logvar_lookup, n_component)
+
+    @torch.no_grad()
+    def _approx_qy_x_forward_only(self, z, mu_lookup, logvar_lookup, n_component):
         eng = self.engine()
         B, Z = z.shape
         pre = torch.cat([z.float(), torch.zeros_like(z, dtype=torch.float32)], dim=1).contiguous()   # mu = z, sigma = 1
@@ -173,13 +198,27 @@ class MusicAttrRegGMVAE(nn.Module):
                            out[0], out[1], ll, qy, y, terms)
         return ll, qy
 
-    @torch.no_grad()
     def global_decoder(self, z, steps):
         """gmm_model.py:119-149 -> (B, steps, 342) log-probabilities.
 
         eval mode: greedy argmax feedback (:147-148), the call of test_class.py:253 / notebook cell 15.
         train mode: teacher forced with ``self.sample`` (the x of the last train-mode forward, :141-142), one ``torch.rand(1)`` draw
-        per step as the reference makes (:140).  No autograd through a direct call (training goes through forward())."""
+        per step as the reference makes (:140); with autograd enabled the result is connected to z and the decoder's parameters."""
+        if self._autograd_on():
+            if self.sample is None:
+                raise RuntimeError("global_decoder() in train mode reads self.sample (gmm_model.py:142): run forward() first or call model.eval()")
+            self.engine()
+            d = self._indices(self.sample, self.roll_dims, ids_ndim=2)
+            if d.shape[1] < steps or d.shape[0] != z.shape[0]:
+                raise IndexError("teacher forcing needs self.sample of shape (%d, >=%d, ...), got %s" % (z.shape[0], steps, tuple(self.sample.shape)))
+            for _ in range(steps):
+                torch.rand(1)
+            names, plist = self._named(_DecoderFunction.PREFIXES)
+            return _DecoderFunction.apply(self, names, d[:, :steps].contiguous(), z.float().contiguous(), *plist)
+        return self._global_decoder_forward_only(z, steps)
+
+    @torch.no_grad()
+    def _global_decoder_forward_only(self, z, steps):
         if not self.training:
             from .decode import greedy_decode
             logp, _ = greedy_decode(self, z, steps)
@@ -198,9 +237,18 @@ class MusicAttrRegGMVAE(nn.Module):
         eng.ops.vocab_logsoftmax(dec["logits"], z.shape[0], steps, E_VOCAB, logp_bt=out)
         return out
 
-    @torch.no_grad()
     def sub_decoders(self, rhythm, z_r, note, z_n):
-        """gmm_model.py:100-117 -> (rhythm_out, note_out, 0, 0), log_softmax over the TIME axis; no autograd."""
+        """gmm_model.py:100-117 -> (rhythm_out, note_out, 0, 0), log_softmax over the TIME axis."""
+        if self._autograd_on():
+            self.engine()
+            names, plist = self._named(_SubDecFunction.PREFIXES)
+            r_out, n_out = _SubDecFunction.apply(self, names, self._indices(rhythm, 3), self._indices(note, 16), z_r.float().contiguous(),
+                                                 z_n.float().contiguous(), *plist)
+            return r_out, n_out, 0, 0
+        return self._sub_decoders_forward_only(rhythm, z_r, note, z_n)
+
+    @torch.no_grad()
+    def _sub_decoders_forward_only(self, rhythm, z_r, note, z_n):
         eng = self.engine()
         r = self._indices(rhythm, 3)
         n = self._indices(note, 16)
@@ -337,3 +385,200 @@ class _GMVAEFunction(torch.autograd.Function):
         G = {k: torch.empty_like(p) for k, p in model.used_parameters()}
         eng.backward(G, dl_sd, lat_up, None)
         return (None,) * 8 + tuple(G[k] for k in ctx.names)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# autograd nodes of the DIRECT sub-module calls (encode / sub_decoders / global_decoder / approx_qy_x in train mode)
+# ------------------------------------------------------------------------------------------------------------------------------
+class _Namespace:
+    """run engine work inside a private buffer namespace"""
+
+    def __init__(self, eng, ns):
+        self.eng, self.ns = eng, ns
+
+    def __enter__(self):
+        self.prev = self.eng.buf_ns
+        self.eng.buf_ns = self.ns
+        gen = self.eng.__dict__.setdefault("_direct_gen", {})
+        return gen
+
+    def __exit__(self, *a):
+        self.eng.buf_ns = self.prev
+
+
+def _check_generation(eng, ns, mine, what):
+    if eng.__dict__.get("_direct_gen", {}).get(ns) != mine:
+        raise RuntimeError("backward() of a direct %s() call must run before the next %s() call (the engine keeps one set of saved "
+                           "activations per sub-module)" % (what, what))
+
+
+def _dense_or_zero(g, ref):
+    return torch.zeros_like(ref) if g is None else g.float().contiguous()
+
+
+class _EncodeFunction(torch.autograd.Function):
+    """model.encode(x) with a backward: encoder scans + mu / var heads (gmm_model.py:82-98)"""
+    PREFIXES = ("gru_r.", "gru_n.", "mu_r.", "var_r.", "mu_n.", "var_n.")
+    NS = "direct_enc/"
+
+    @staticmethod
+    def forward(ctx, model, names, d, *params):
+        from .engine import ops_sort
+        eng = model._engine
+        Z = eng.Z
+        with _Namespace(eng, _EncodeFunction.NS) as gen:
+            gen[_EncodeFunction.NS] = ctx.gen = gen.get(_EncodeFunction.NS, 0) + 1
+            sort = ops_sort(eng, "d", d, E_VOCAB)
+            pre = eng.encode(d, save=True)
+            zero = eng.buf("zero_eps", (d.shape[0], Z), zero_init=True)
+            lat = eng.latent(pre, {"r": zero, "n": zero})
+        ctx.S = dict(d=d, pre=pre, lat=lat, eps={"r": zero, "n": zero}, labels=None, sort={"d": sort})
+        ctx.model, ctx.names = model, names
+        return (pre["r"][:, :Z].clone(), lat["r"]["sigma"].clone(), pre["n"][:, :Z].clone(), lat["n"]["sigma"].clone())
+
+    @staticmethod
+    def backward(ctx, g_mu_r, g_sg_r, g_mu_n, g_sg_n):
+        model = ctx.model
+        eng = model._engine
+        _check_generation(eng, _EncodeFunction.NS, ctx.gen, "encode")
+        S = ctx.S
+        B, Z = S["d"].shape[0], eng.Z
+        G = {k: torch.zeros_like(p) for k, p in model.used_parameters() if k in ctx.names}
+        with _Namespace(eng, _EncodeFunction.NS):
+            lat_up = {}
+            for e, gm, gs in (("r", g_mu_r, g_sg_r), ("n", g_mu_n, g_sg_n)):
+                lat_up[e] = dict(g_z=eng.zbuf("g_z_" + e, (B, Z)), g_mu=None if gm is None else gm.float().contiguous(),
+                                 g_sigma=None if gs is None else gs.float().contiguous())
+            eng.backward_encoder(G, S, lat_up, None)
+        return (None, None, None) + tuple(G[k] for k in ctx.names)
+
+
+class _DecoderFunction(torch.autograd.Function):
+    """model.global_decoder(z, steps) in train mode (teacher forced, gmm_model.py:119-149) with a backward wrt z and the decoder"""
+    PREFIXES = ("linear_out_g.", "grucell_g_2.", "grucell_g.", "linear_init_global.")
+    NS = "direct_dec/"
+
+    @staticmethod
+    def forward(ctx, model, names, d, zc, *params):
+        from .engine import ops_sort
+        eng = model._engine
+        B, T = d.shape
+        with _Namespace(eng, _DecoderFunction.NS) as gen:
+            gen[_DecoderFunction.NS] = ctx.gen = gen.get(_DecoderFunction.NS, 0) + 1
+            sort = ops_sort(eng, "d", d, E_VOCAB)
+            zcs = eng.buf("zc_in", tuple(zc.shape))
+            zcs.copy_(zc)
+            dec = eng.global_decoder_tf(d, zcs, save=True)
+            out = torch.empty(B, T, E_VOCAB, device=d.device)
+            eng.ops.vocab_logsoftmax(dec["logits"], B, T, E_VOCAB, logp_bt=out)
+        ctx.S = dict(d=d, dec=dec, sort={"d": sort})
+        ctx.model, ctx.names = model, names
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        model = ctx.model
+        eng = model._engine
+        ops, P = eng.ops, eng.p
+        _check_generation(eng, _DecoderFunction.NS, ctx.gen, "global_decoder")
+        (out,) = ctx.saved_tensors
+        S = ctx.S
+        G = {k: torch.zeros_like(p) for k, p in model.used_parameters() if k in ctx.names}
+        with _Namespace(eng, _DecoderFunction.NS):
+            ops.vocab_logsoftmax_bwd(out, _dense_or_zero(g_out, out), S["dec"]["logits"])
+            gd = eng._bwd_global_decoder_scans(S)
+            eng._bwd_global_decoder_params(G, S, gd)
+            dzc = torch.empty_like(S["dec"]["zc"])
+            ops.gemm_multi([dict(C=dzc, segs=[(gd["drb_g"], P["grucell_g.weight_ih"][:, E_VOCAB:]), (gd["dh0_g"], P["linear_init_global.weight"])])],
+                           a_k=True, b_k=False)
+            eng.main_wait_side()
+        return (None, None, None, dzc) + tuple(G[k] for k in ctx.names)
+
+
+class _SubDecFunction(torch.autograd.Function):
+    """model.sub_decoders(rhythm, z_r, note, z_n) (gmm_model.py:100-117, TIME-axis log_softmax) with a backward wrt z_r, z_n and both decoders"""
+    PREFIXES = ("gru_d_r.", "gru_d_n.", "linear_out_r.", "linear_out_n.", "linear_init_r.", "linear_init_n.")
+    NS = "direct_sd/"
+
+    @staticmethod
+    def forward(ctx, model, names, r, n, z_r, z_n, *params):
+        from .engine import ops_sort
+        eng = model._engine
+        B, Tr = r.shape
+        with _Namespace(eng, _SubDecFunction.NS) as gen:
+            gen[_SubDecFunction.NS] = ctx.gen = gen.get(_SubDecFunction.NS, 0) + 1
+            sorts = {"r": ops_sort(eng, "r", r, 3), "n": ops_sort(eng, "n", n, 16)}
+            zs = {}
+            for e, z in (("r", z_r), ("n", z_n)):
+                zs[e] = eng.buf("z_in_" + e, tuple(z.shape))
+                zs[e].copy_(z)
+            sd = eng.sub_decoders_fwd(r, n, zs["r"], zs["n"], save=True)
+            outs = []
+            for e, Ce in (("r", 3), ("n", 16)):
+                lp = torch.empty(B, Tr, Ce, device=r.device)
+                eng.ops.time_logsoftmax(sd[e]["logits"], logp_bt=lp)
+                outs.append(lp)
+        ctx.S = dict(sd=sd, sorts=sorts, z=zs, B=B, Tr=Tr)
+        ctx.model, ctx.names = model, names
+        ctx.save_for_backward(*outs)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_r, g_n):
+        model = ctx.model
+        eng = model._engine
+        ops, P = eng.ops, eng.p
+        _check_generation(eng, _SubDecFunction.NS, ctx.gen, "sub_decoders")
+        r_out, n_out = ctx.saved_tensors
+        S = ctx.S
+        B, Tr = S["B"], S["Tr"]
+        G = {k: torch.zeros_like(p) for k, p in model.used_parameters() if k in ctx.names}
+        with _Namespace(eng, _SubDecFunction.NS):
+            dl_sd = {}
+            for e, lp, g in (("r", r_out, g_r), ("n", n_out, g_n)):
+                dl_sd[e] = eng.buf("sd_dlogits_" + e, S["sd"][e]["logits"].shape)
+                ops.time_logsoftmax_bwd(lp, _dense_or_zero(g, lp), dl_sd[e])
+            sdb = eng._bwd_sub_decoder_scans(S["sd"], dl_sd, B, Tr)
+            eng._bwd_sub_decoder_params(G, S["sd"], sdb, dl_sd, S["sorts"], S["z"], B, Tr)
+            eng.flush_colsums()
+            dz = {}
+            for e, Ce in (("r", 3), ("n", 16)):
+                dz[e] = torch.empty_like(S["z"][e])
+                ops.gemm_multi([dict(C=dz[e], segs=[(sdb[e]["drb"], P["gru_d_%s.weight_ih_l0" % e][:, Ce:]), (sdb[e]["dh0"], P["linear_init_%s.weight" % e])])],
+                               a_k=True, b_k=False)
+        return (None, None, None, None, dz["r"], dz["n"]) + tuple(G[k] for k in ctx.names)
+
+
+class _QyFunction(torch.autograd.Function):
+    """model.approx_qy_x(z, mu_lookup, logvar_lookup, K) (gmm_model.py:194-218) with a backward wrt z and the component means"""
+
+    @staticmethod
+    def forward(ctx, model, K, z, mu_w, lv_w):
+        eng = model._engine
+        B, Z = z.shape
+        pre = torch.cat([z, torch.zeros_like(z)], dim=1).contiguous()        # mu = z, sigma = exp(0) = 1, eps = 0  ->  the sample IS z
+        eps = torch.zeros(B, Z, device=z.device)
+        mu, lv = mu_w.data[:K].contiguous(), lv_w.data[:K].contiguous()
+        sig, zz = torch.empty(B, Z, device=z.device), torch.empty(B, Z, device=z.device)
+        ll, qy = torch.empty(B, K, device=z.device), torch.empty(B, K, device=z.device)
+        y, terms = torch.empty(B, dtype=torch.int32, device=z.device), torch.empty(B, 4, device=z.device)
+        eng.ops.latent_fwd(pre, eps, mu, lv, None, sig, zz, ll, qy, y, terms)
+        ctx.model, ctx.K = model, K
+        ctx.save_for_backward(pre, eps, mu, lv, zz, qy, mu_w)
+        return ll, qy
+
+    @staticmethod
+    def backward(ctx, g_ll, g_qy):
+        eng = ctx.model._engine
+        pre, eps, mu, lv, zz, qy, mu_w = ctx.saved_tensors
+        B, Z = eps.shape
+        K = ctx.K
+        dpre = torch.empty(B, 2 * Z, device=pre.device)
+        dmu_rows = torch.empty(B, K * Z, device=pre.device)
+        gz = torch.zeros(B, Z, device=pre.device)
+        eng.ops.latent_bwd(pre, eps, mu, lv, None, zz, qy, gz, None, None, None if g_ll is None else g_ll.float().contiguous(),
+                           None if g_qy is None else g_qy.float().contiguous(), None, dpre, dmu_rows)
+        dmu = torch.zeros_like(mu_w)
+        eng.ops.colsum(dmu_rows, dmu[:K].view(-1))
+        return None, None, dpre[:, :Z].contiguous(), dmu, None

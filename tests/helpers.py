@@ -405,3 +405,126 @@ def check_glsr(pkg, m, g, dev, tol_grad=1e-3, rtol_tuple=5e-4):
     torch.manual_seed(123)
     ev = tr.evaluate(step - 1, None, None, None, g["d"], g["r"], g["n"], g["c"], g["r_density"], g["n_density"])
     np.testing.assert_allclose(ev, g["eval_tuple"], rtol=2e-3)
+
+
+# ---- autograd through DIRECT sub-module calls (encode / sub_decoders / global_decoder / approx_qy_x, gmm_model.py:82-218) -----------------
+def check_direct_call_autograd(pkg, m, g, dev, tol=5e-4):
+    """each direct call in train mode is one autograd node: values and the gradients wrt inputs / parameters against torch autograd of the
+    oracle's restatement of the same reference lines, on the `small` fixture's weights and batch"""
+    from oracle import gmvae_oracle as orc
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    b = batch_of(g)
+    d, r, n = (torch.from_numpy(b[k]) for k in ("d", "r", "n"))
+    B, T = d.shape
+    Z = m.latent_dim
+    m.train()
+
+    def leaves(keys):
+        return {k: sd[k].clone().requires_grad_(True) for k in keys}
+
+    def cmp(got, ref, what):
+        got, ref = got.detach().cpu().double().numpy(), ref.detach().double().numpy()
+        scale = max(1e-6, float(np.abs(ref).max()))
+        assert float(np.abs(got - ref).max()) <= tol * scale, (what, float(np.abs(got - ref).max()), scale)
+
+    def zero_grads():
+        for p in m.parameters():
+            p.grad = None
+
+    # ---- encode ------------------------------------------------------------------------------------------------------
+    torch.manual_seed(1)
+    w = [torch.randn(B, Z) for _ in range(4)]
+    keys = [k for k in sd if k.startswith(("gru_r.", "gru_n.", "mu_r.", "var_r.", "mu_n.", "var_n."))]
+    L = leaves(keys)
+    p = dict(sd); p.update(L)
+    ref = orc.encode(p, orc.convert_to_one_hot(d, 342))
+    gref = torch.autograd.grad(sum((o * wi).sum() for o, wi in zip(ref, w)), [L[k] for k in keys])
+    zero_grads()
+    dis_r, dis_n = m.encode(pkg.convert_to_one_hot(d.to(dev), 342))
+    got = (dis_r.mean, dis_r.stddev, dis_n.mean, dis_n.stddev)
+    for o, ro, nm in zip(got, ref, ("mu_r", "sigma_r", "mu_n", "sigma_n")):
+        cmp(o, ro, "encode " + nm)
+    sum((o * wi.to(dev)).sum() for o, wi in zip(got, w)).backward()
+    params = dict(m.named_parameters())
+    for k, gr in zip(keys, gref):
+        cmp(params[k].grad, gr, "encode grad " + k)
+    assert params["linear_out_g.weight"].grad is None
+
+    # ---- sub_decoders ----------------------------------------------------------------------------------------------------
+    torch.manual_seed(2)
+    z_r, z_n = torch.randn(B, Z) * 0.5, torch.randn(B, Z) * 0.5
+    keys = [k for k in sd if k.startswith(("gru_d_r.", "gru_d_n.", "linear_out_r.", "linear_out_n.", "linear_init_r.", "linear_init_n."))]
+    L = leaves(keys)
+    p = dict(sd); p.update(L)
+    zr_l, zn_l = z_r.clone().requires_grad_(True), z_n.clone().requires_grad_(True)
+    ref_r = orc.sub_decoder(p, "r", orc.convert_to_one_hot(r, 3), zr_l)
+    ref_n = orc.sub_decoder(p, "n", orc.convert_to_one_hot(n, 16), zn_l)
+    wr, wn = torch.randn_like(ref_r), torch.randn_like(ref_n)
+    gref = torch.autograd.grad((ref_r * wr).sum() + (ref_n * wn).sum(), [zr_l, zn_l] + [L[k] for k in keys])
+    zero_grads()
+    zr_d, zn_d = z_r.to(dev).requires_grad_(True), z_n.to(dev).requires_grad_(True)
+    r_out, n_out, _, _ = m.sub_decoders(pkg.convert_to_one_hot(r.to(dev), 3), zr_d, pkg.convert_to_one_hot(n.to(dev), 16), zn_d)
+    cmp(r_out, ref_r, "sub_decoders r_out"), cmp(n_out, ref_n, "sub_decoders n_out")
+    ((r_out * wr.to(dev)).sum() + (n_out * wn.to(dev)).sum()).backward()
+    cmp(zr_d.grad, gref[0], "sub_decoders dz_r"), cmp(zn_d.grad, gref[1], "sub_decoders dz_n")
+    for k, gr in zip(keys, gref[2:]):
+        if k in ("linear_out_r.bias", "linear_out_n.bias"):       # mathematically zero (time-axis softmax): rounding noise on both sides
+            continue
+        cmp(params[k].grad, gr, "sub_decoders grad " + k)
+
+    # ---- global_decoder (train mode: teacher forced with self.sample) --------------------------------------------------
+    torch.manual_seed(3)
+    steps = T - 3
+    zc = torch.randn(B, 2 * Z + 24) * 0.5
+    keys = [k for k in sd if k.startswith(("linear_out_g.", "grucell_g_2.", "grucell_g.", "linear_init_global."))]
+    L = leaves(keys)
+    p = dict(sd); p.update(L)
+    zc_l = zc.clone().requires_grad_(True)
+    teacher = d.long()[:, :steps]
+    ref = orc.global_decoder(p, zc_l, steps, teacher=teacher)
+    wo = torch.randn_like(ref)
+    gref = torch.autograd.grad((ref * wo).sum(), [zc_l] + [L[k] for k in keys])
+    zero_grads()
+    m.sample = pkg.convert_to_one_hot(d.to(dev), 342)
+    zc_d = zc.to(dev).requires_grad_(True)
+    state = torch.get_rng_state()
+    out = m.global_decoder(zc_d, steps)
+    torch.set_rng_state(state)
+    for _ in range(steps):
+        torch.rand(1)
+    probe = torch.rand(1)
+    cmp(out, ref, "global_decoder out")
+    (out * wo.to(dev)).sum().backward()
+    cmp(zc_d.grad, gref[0], "global_decoder dz")
+    for k, gr in zip(keys, gref[1:]):
+        cmp(params[k].grad, gr, "global_decoder grad " + k)
+    assert probe.numel() == 1                                     # (the call drew `steps` x rand(1), as the reference does)
+
+    # ---- approx_qy_x -----------------------------------------------------------------------------------------------------
+    torch.manual_seed(4)
+    z = (torch.randn(B, Z) * 0.3)
+    z_l = z.clone().requires_grad_(True)
+    mu_l = sd["mu_r_lookup.weight"].clone().requires_grad_(True)
+    ll_ref, qy_ref = orc.approx_qy_x(z_l, mu_l, sd["logvar_r_lookup.weight"])
+    w1, w2 = torch.randn_like(ll_ref) * 1e-2, torch.randn_like(qy_ref)
+    gref = torch.autograd.grad((ll_ref * w1).sum() + (qy_ref * w2).sum(), [z_l, mu_l])
+    zero_grads()
+    z_d = z.to(dev).requires_grad_(True)
+    ll, qy = m.approx_qy_x(z_d, m.mu_r_lookup, m.logvar_r_lookup, m.n_component)
+    cmp(ll, ll_ref, "approx_qy_x ll")
+    ((ll * w1.to(dev)).sum() + (qy * w2.to(dev)).sum()).backward()
+    cmp(z_d.grad, gref[0], "approx_qy_x dz")
+    cmp(m.mu_r_lookup.weight.grad, gref[1], "approx_qy_x dmu_lookup")
+    # stale backward is refused; eval mode / no_grad stay forward only
+    o1 = m.encode(d.to(dev))[0].mean
+    m.encode(d.to(dev))
+    try:
+        o1.sum().backward()
+        raise AssertionError("stale backward accepted")
+    except RuntimeError as e:
+        assert "must run before the next" in str(e)
+    with torch.no_grad():
+        assert not m.encode(d.to(dev))[0].mean.requires_grad
+    m.eval()
+    assert not m.encode(d.to(dev))[0].mean.requires_grad
+    m.train()

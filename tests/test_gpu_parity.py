@@ -1279,3 +1279,13 @@ def test_entry_driver_runs_an_epoch_from_the_reference_config(tmp_path, capsys):
     assert os.path.isdir(os.path.join(str(tmp_path), "log"))
     main(argv)
     assert "Loading " + path in capsys.readouterr().out
+
+
+def test_direct_calls_have_autograd(small):
+    """encode / sub_decoders / global_decoder / approx_qy_x called directly in train mode: one autograd node each whose backward runs the
+    matching part of the HIP backward (the reference allows such calls anywhere, gmm_model.py:82-218)"""
+    from helpers import check_direct_call_autograd
+    pkg = load_package()
+    m = make_model(64, 32, sd_from(small, "w0/"), device=DEV)
+    check_direct_call_autograd(pkg, m, small, DEV, tol=5e-4)
+    assert not m.engine().ops.gru_sync_error()

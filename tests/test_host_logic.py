@@ -251,3 +251,12 @@ def test_entry_driver_config_and_loaders():
     a = next(iter(T.RankShard([x], 0, 2)))
     b = next(iter(T.RankShard([x], 1, 2)))
     assert torch.equal(torch.cat([a[0], b[0]]), x[0]) and a[3].shape == (64, 24)
+
+
+def test_direct_calls_have_autograd(small):
+    """encode / sub_decoders / global_decoder / approx_qy_x called directly in train mode (the reference allows it, gmm_model.py:82-218): one
+    autograd node each, values and gradients against torch autograd of the oracle (host schedule on the CPU test backend)"""
+    from helpers import check_direct_call_autograd
+    pkg = load_package()
+    m = make_model(64, 32, sd_from(small, "w0/"), ops=FakeOps())
+    check_direct_call_autograd(pkg, m, small, "cpu", tol=2e-4)
