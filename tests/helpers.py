@@ -263,7 +263,8 @@ def check_eval_side(pkg, m, g, dev, rtol=2e-5):
     (o_tf, _, _, _, _), _, z_out, _, _, _ = m(d, r, n, c)
     zc = torch.cat([z_out[0], z_out[1], c], dim=1).detach()
     o2 = m.global_decoder(zc, steps=T)
-    np.testing.assert_allclose(o2.cpu().numpy(), o_tf.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+    assert o2.requires_grad                                      # as in the reference: a train-mode call is part of the autograd graph
+    np.testing.assert_allclose(o2.detach().cpu().numpy(), o_tf.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
 # ---- single-encoder siblings (tests/golden/siblings.npz = the reference's model_v2 classes + their own trainers) ----------------------
