@@ -81,10 +81,12 @@ class SingleEncEngine(Engine):
         return S
 
     # ------------------------------------------------------------------------------------------
-    def backward(self, G, g_z, w3, after_decoders=None):
+    def backward(self, G, g_z, w3, after_decoders=None, g_mu=None, g_sigma=None):
         """Backward of forward(); dlogits of the decoder must already sit in saved['dec']['logits'].
         g_z   [B][ZL] upstream gradient wrt z (zero-filled, or holding the regulariser / adversarial parts); the decoder's is added
-        w3    device {w_lat, w_cls, w_clf}: w_lat * sum_b mean_Z KL(q || N(0,1)) is the fused KL term (fn_latent_bwd)"""
+        w3    device {w_lat, w_cls, w_clf}: w_lat * sum_b mean_Z KL(q || N(0,1)) is the fused KL term (fn_latent_bwd)
+        g_mu, g_sigma   optional upstream gradients wrt the heads' outputs (the drop-in forward's autograd node: a reference-style loss
+              computes its KL from Normal(mu, sigma) in torch)"""
         ops, P, H, Z = self.ops, self.p, self.H, self.Z
         S = self.saved
         d, enc, lat = S["d"], S["enc"], S["lat"]
@@ -101,7 +103,7 @@ class SingleEncEngine(Engine):
                 after_decoders()
         dpre = self.buf("dpre_e", (B, 2 * Z))
         dmu_rows = self.buf("dmulk_rows_e", (B, Z))
-        ops.latent_bwd(enc["pre"], S["eps"], self.mu_lk, self.lv_lk, None, lat["z"], lat["qy"], g_z, None, None, None, None, w3, dpre, dmu_rows)
+        ops.latent_bwd(enc["pre"], S["eps"], self.mu_lk, self.lv_lk, None, lat["z"], lat["qy"], g_z, g_mu, g_sigma, None, None, w3, dpre, dmu_rows)
         hf, hb = enc["h_all"]["e"][T - 1], enc["h_all"]["e_reverse"][T - 1]
         dhf, dhb = self.buf("enc_dhf", (B, H)), self.buf("enc_dhb", (B, H))
         for i, (head, c0) in enumerate((("mu", 0), ("var", Z))):

@@ -7,9 +7,11 @@ return nesting.
     MusicAttrCVAE       model_v2.py:288-423   encoder input = [one-hot | r_density | n_density], decoder conditioned on [z | densities]
     MusicAttrFaderNets  model_v2.py:438-586   CVAE-style decoder + two adversarial density regressors behind a gradient reversal
 
-The three single-encoder classes run on ``SingleEncEngine``.  Their ``forward`` is FORWARD ONLY (no autograd graph is attached to the
-outputs); training goes through the fused trainers of ``trainer_v2.py`` (``SingleVAETrainer``, ``CVAETrainer``, ``FaderTrainer``), which
-reproduce ``train`` / ``evaluate`` of the reference's ``trainer_singlevae.py`` / ``trainer_cvae.py`` / ``trainer_fader.py``.
+The three single-encoder classes run on ``SingleEncEngine``.  In train mode with autograd enabled their ``forward`` hangs on ONE autograd
+node (``_SingleEncFunction``; the Fader heads on ``_AdvHeadFunction`` behind the gradient reversal), so the reference's
+``loss.backward(); optimizer.step()`` loops work (call ``weights_changed()`` after the step); the fast path are the fused trainers of
+``trainer_v2.py`` (``SingleVAETrainer``, ``CVAETrainer``, ``FaderTrainer``), which reproduce ``train`` / ``evaluate`` of the reference's
+``trainer_singlevae.py`` / ``trainer_cvae.py`` / ``trainer_fader.py``.
 Random draws follow the reference's order on torch's global CPU generator: ``randn(B, ZL)`` for the reparameterisation, (Fader only:
 the two dropout masks of model_v2.py:574-575), then - in train mode - one ``torch.rand(1)`` per decoder step (:260, :400, :552).
 """
@@ -101,17 +103,21 @@ class _SingleEncModel(MusicAttrRegGMVAE):
         lat = eng.latent1(enc["pre"], torch.zeros(d.shape[0], Z, device=d.device))
         return Normal(enc["pre"][:, :Z].clone(), lat["sigma"].clone())
 
-    @torch.no_grad()
     def _forward_core(self, x, cond, extra, eps):
-        """encode -> z -> global decoder (teacher forced in train mode, greedy in eval mode) -> (out, dis, z_lat)"""
-        if self.training and not getattr(self, "_warned_no_autograd", False):
-            # forward-only drop-in: a reference-style `loss.backward(); optimizer.step()` on these outputs would fail with
-            # "does not require grad" - say so once, where the user can see why
-            import warnings
-            warnings.warn("%s.forward returns tensors without an autograd graph (forward-only drop-in); train through the fused "
-                          "%s classes of music_fader_nets_amd.trainer_v2, which reproduce the reference trainers' train()/evaluate()"
-                          % (type(self).__name__, "SingleVAETrainer / CVAETrainer / FaderTrainer"), stacklevel=3)
-            self._warned_no_autograd = True
+        """encode -> z -> global decoder (teacher forced in train mode, greedy in eval mode) -> (out, dis, z_lat).  Train mode with autograd
+        enabled: the outputs hang on ONE autograd node whose backward runs the HIP backward kernels (a reference-style
+        ``loss.backward(); optimizer.step()`` loop works; call ``model.weights_changed()`` after the optimiser step)."""
+        if self.training and torch.is_grad_enabled():
+            eng = self.engine()
+            d = self._indices(x, self.roll_dims)
+            names = [k for k, _ in self.used_parameters() if not k.startswith("discriminator_")]
+            plist = [p for k, p in self.used_parameters() if not k.startswith("discriminator_")]
+            out, mu, sigma, z = _SingleEncFunction.apply(self, names, d, cond, extra, eps, *plist)
+            return out, Normal(mu, sigma), z
+        return self._forward_core_no_grad(x, cond, extra, eps)
+
+    @torch.no_grad()
+    def _forward_core_no_grad(self, x, cond, extra, eps):
         eng = self.engine()
         d = self._indices(x, self.roll_dims)
         B, T = d.shape
@@ -247,9 +253,18 @@ class MusicAttrFaderNets(_SingleEncModel):
     def encoder(self, x):
         return self._encode_dis(x)
 
-    @torch.no_grad()
     def adversarial_heads(self, z, mask, dens=None):
-        """(r_out, n_out) = dropout(relu(discriminator(reverse(z)))) -> two (B, 1) tensors (model_v2.py:572-575)"""
+        """(r_out, n_out) = dropout(relu(discriminator(reverse(z)))) -> two (B, 1) tensors (model_v2.py:572-575); in train mode with
+        autograd enabled connected to the discriminators and - through the gradient reversal - to z"""
+        if self.training and torch.is_grad_enabled():
+            self.engine()
+            o = _AdvHeadFunction.apply(self, z, mask.float().contiguous().to(z.device), self.discriminator_r.weight, self.discriminator_r.bias,
+                                       self.discriminator_n.weight, self.discriminator_n.bias)
+            return o[:, 0:1], o[:, 1:2]
+        return self._adversarial_heads_no_grad(z, mask, dens)
+
+    @torch.no_grad()
+    def _adversarial_heads_no_grad(self, z, mask, dens=None):
         eng = self.engine()
         B = z.shape[0]
         o, lr_ = torch.empty(B, 2, device=z.device), torch.empty(B, 2, device=z.device)
@@ -273,3 +288,71 @@ class MusicAttrFaderNets(_SingleEncModel):
         out, dis, z = self._forward_core(x, dens, None, eps.float().contiguous().to(dev))
         r_out, n_out = self.adversarial_heads(z, mask, dens)
         return (out, r_out, n_out), dis, torch.cat([z, dens], dim=-1)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# autograd nodes of the drop-in forward of the single-encoder families
+# ------------------------------------------------------------------------------------------------------------------------------
+class _SingleEncFunction(torch.autograd.Function):
+    """forward = SingleEncEngine.forward + vocabulary log-softmax, backward = SingleEncEngine.backward (upstream gradients wrt out, mu,
+    sigma and z; the reference-style losses compute their KL from Normal(mu, sigma) in torch)"""
+
+    @staticmethod
+    def forward(ctx, model, names, d, cond, extra, eps, *params):
+        eng = model._engine
+        B, T = d.shape
+        Z = eng.Z
+        S = eng.forward(d, cond, eps, extra, save=True)
+        out = torch.empty(B, T, E_VOCAB, device=d.device)
+        eng.ops.vocab_logsoftmax(S["dec"]["logits"], B, T, E_VOCAB, logp_bt=out)
+        ctx.model, ctx.names, ctx.fw_id = model, names, id(S)
+        ctx.save_for_backward(out)
+        return out, S["enc"]["pre"][:, :Z].clone(), S["lat"]["sigma"].clone(), S["lat"]["z"].clone()
+
+    @staticmethod
+    def backward(ctx, g_out, g_mu, g_sigma, g_z):
+        model = ctx.model
+        eng = model._engine
+        S = eng.saved
+        if S is None or id(S) != ctx.fw_id:
+            raise RuntimeError("backward() must follow the forward() that produced these outputs (the engine keeps one set of saved activations)")
+        (out,) = ctx.saved_tensors
+        dense = lambda g, ref: torch.zeros_like(ref) if g is None else g.float().contiguous()
+        eng.ops.vocab_logsoftmax_bwd(out, dense(g_out, out), S["dec"]["logits"])
+        gz = dense(g_z, S["lat"]["z"]).clone()
+        G = {k: torch.zeros_like(p) for k, p in model.used_parameters() if k in ctx.names}
+        eng.backward(G, gz, None, g_mu=None if g_mu is None else g_mu.float().contiguous(),
+                     g_sigma=None if g_sigma is None else g_sigma.float().contiguous())
+        return (None,) * 6 + tuple(G[k] for k in ctx.names)
+
+
+class _AdvHeadFunction(torch.autograd.Function):
+    """o[b][a] = relu(w_a . z[b] + b_a) * mask[b][a] behind the gradient reversal of model_v2.py:426-435 (z receives MINUS the gradient)"""
+
+    @staticmethod
+    def forward(ctx, model, z, mask, w_r, b_r, w_n, b_n):
+        eng = model._engine
+        B = z.shape[0]
+        o, lrow = torch.empty(B, 2, device=z.device), torch.empty(B, 2, device=z.device)
+        zc = z.detach().float().contiguous()
+        eng.ops.adv_head(zc, w_r.data, w_n.data, b_r.data, b_n.data, mask, torch.zeros(B, 2, device=z.device), None, 1.0, o, lrow)
+        ctx.model = model
+        ctx.save_for_backward(zc, mask, o, w_r, w_n)
+        return o
+
+    @staticmethod
+    def backward(ctx, g_o):
+        eng = ctx.model._engine
+        ops = eng.ops
+        z, mask, o, w_r, w_n = ctx.saved_tensors
+        da = (g_o.float() * mask * (o > 0).float()).contiguous()          # d o / d pre: the keep-mask where the ReLU is open
+        Z = w_r.numel()
+        W = torch.cat([w_r.data.view(1, Z), w_n.data.view(1, Z)], 0).contiguous()       # [2][Z]
+        dz = torch.empty(z.shape[0], Z, device=z.device)
+        ops.gemm(da, W, dz, a_k=True, b_k=False, alpha=-1.0)                              # gradient reversal
+        dW = torch.empty(2, Z, device=z.device)
+        ops.gemm(da, z[:, :Z].contiguous() if z.shape[1] != Z else z, dW, a_k=False, b_k=False)
+        db = torch.empty(2, device=z.device)
+        ops.colsum(da, db)
+        dz_full = dz if z.shape[1] == Z else torch.cat([dz, torch.zeros(z.shape[0], z.shape[1] - Z, device=z.device)], 1)
+        return None, dz_full, None, dW[0:1].view_as(w_r), db[0:1].view(-1), dW[1:2].view_as(w_n), db[1:2].view(-1)

@@ -302,12 +302,13 @@ def check_sibling(pkg, kind, m, g, dev, rtol_fw=5e-5, tol_grad=5e-4, rtol_tuple=
     res = call()
     if kind == "fader":
         (o, r_out, n_out), dis, z = res
-        np.testing.assert_allclose(r_out.cpu().numpy(), g["fw_r_out"], rtol=1e-4, atol=1e-5)
-        np.testing.assert_allclose(n_out.cpu().numpy(), g["fw_n_out"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(r_out.detach().cpu().numpy(), g["fw_r_out"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(n_out.detach().cpu().numpy(), g["fw_n_out"], rtol=1e-4, atol=1e-5)
     else:
         o, dis, z = res
+    assert o.requires_grad                                        # a train-mode call is part of the autograd graph, as in the reference
     for k, v in (("out", o), ("mu", dis.mean), ("sigma", dis.stddev), ("z", z)):
-        np.testing.assert_allclose(v.cpu().numpy(), g["fw_" + k], rtol=rtol_fw, atol=rtol_fw, err_msg=k)
+        np.testing.assert_allclose(v.detach().cpu().numpy(), g["fw_" + k], rtol=rtol_fw, atol=rtol_fw, err_msg=k)
     # fused gradients
     tr = getattr(pkg, SIBLINGS[kind][1])(m, lr=1e-3, beta=0.2)
     batch = tr.prepare_batch(g["d"], g["r"], g["n"], g["c"], g["r_density"], g["n_density"])
@@ -529,3 +530,60 @@ def check_direct_call_autograd(pkg, m, g, dev, tol=5e-4):
     m.eval()
     assert not m.encode(d.to(dev))[0].mean.requires_grad
     m.train()
+
+
+def check_sibling_autograd(pkg, kind, m, g, dev, tol_grad=5e-4):
+    """the reference's own training pattern on the single-encoder drop-ins: forward in train mode, the trainer script's loss written with
+    torch ops on the returned tensors (trainer_singlevae.py:87-120, trainer_cvae.py:87-103, trainer_fader.py:87-110), loss.backward() - the
+    parameter gradients must be the reference's (siblings.npz grad_20000/*)"""
+    from torch.distributions import Normal, kl_divergence
+    H, Z, B, T, Tr = (int(x) for x in g["dims"])
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    d, r, n, c = t("d"), t("r"), t("n"), t("c")
+    rd32, nd32 = torch.from_numpy(g["r_density"]).float().unsqueeze(-1).to(dev), torch.from_numpy(g["n_density"]).float().unsqueeze(-1).to(dev)
+    m.train()
+    for p in m.parameters():
+        p.grad = None
+    torch.manual_seed(99)
+    if kind == "single":
+        out, dis, z = m(pkg.convert_to_one_hot(d, 342), c)
+    else:
+        res = m(pkg.convert_to_one_hot(d, 342), pkg.convert_to_one_hot(r, 3), pkg.convert_to_one_hot(n, 16), c, rd32, nd32)
+        (out, r_out, n_out), dis, z = res if kind == "fader" else ((res[0], None, None), res[1], res[2])
+    assert out.requires_grad and dis.mean.requires_grad and z.requires_grad
+    step, beta = 20000, 0.2
+    ce = torch.nn.functional.nll_loss(out.reshape(-1, out.shape[-1]), d.reshape(-1).long())
+    kld = kl_divergence(dis, Normal(torch.zeros_like(dis.mean), torch.ones_like(dis.stddev))).mean()
+    beta0 = 0.0 if step < 1000 else min((step - 10000) / 10000 * beta, beta)
+    if kind == "single":
+        regs = []
+        for col, a in ((0, g["r_density"]), (1, g["n_density"])):
+            da = torch.from_numpy(np.subtract.outer(np.asarray(a, np.float64), np.asarray(a, np.float64))).float().to(dev)
+            zc = z[:, col]
+            regs.append(((torch.tanh(zc.reshape(-1, 1) - zc) - torch.sign(da)) ** 2).mean())
+        loss = 5 * ce + beta * kld + regs[0] + regs[1]
+    elif kind == "cvae":
+        loss = ce + beta0 * kld
+    else:
+        lam = min(step / 2000 * 1e-4, 1e-4)
+        loss = ce + beta0 * kld + lam * torch.nn.functional.mse_loss(r_out, rd32) + lam * torch.nn.functional.mse_loss(n_out, nd32)
+    np.testing.assert_allclose(float(loss.detach()), g["loss_terms_20000"][0], rtol=5e-4)
+    loss.backward()
+    params = dict(m.named_parameters())
+    seen = 0
+    for k in [k[len("grad_20000/"):] for k in g if k.startswith("grad_20000/")]:
+        ref = g["grad_20000/" + k]
+        assert params[k].grad is not None, k
+        e = relerr(params[k].grad.cpu().numpy(), ref)
+        assert e < tol_grad or np.abs(ref).max() < 1e-7, (kind, k, e)
+        seen += 1
+    assert seen >= 10
+    # an optimiser step on these gradients, then the next forward sees the new weights
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    opt.step()
+    m.weights_changed()
+    torch.manual_seed(99)
+    out2 = (m(pkg.convert_to_one_hot(d, 342), c) if kind == "single" else
+            m(pkg.convert_to_one_hot(d, 342), pkg.convert_to_one_hot(r, 3), pkg.convert_to_one_hot(n, 16), c, rd32, nd32))[0]
+    out2 = out2[0] if kind == "fader" else out2
+    assert float((out2.detach() - out.detach()).abs().max()) > 1e-6

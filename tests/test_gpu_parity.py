@@ -1289,3 +1289,15 @@ def test_direct_calls_have_autograd(small):
     m = make_model(64, 32, sd_from(small, "w0/"), device=DEV)
     check_direct_call_autograd(pkg, m, small, DEV, tol=5e-4)
     assert not m.engine().ops.gru_sync_error()
+
+
+@pytest.mark.parametrize("kind", ["single", "cvae", "fader"])
+def test_sibling_forward_has_autograd(kind):
+    """single-encoder drop-ins in a reference-style loop (forward -> torch loss -> loss.backward() -> optimizer.step()) on the HIP kernels"""
+    from helpers import check_sibling_autograd, make_sibling, sibling_golden
+    pkg = load_package()
+    g = sibling_golden(kind)
+    H, Z = int(g["dims"][0]), int(g["dims"][1])
+    m = make_sibling(kind, H, Z, device=DEV)
+    check_sibling_autograd(pkg, kind, m, g, DEV, tol_grad=5e-4)
+    assert not m.engine().ops.gru_sync_error()

@@ -260,3 +260,15 @@ def test_direct_calls_have_autograd(small):
     pkg = load_package()
     m = make_model(64, 32, sd_from(small, "w0/"), ops=FakeOps())
     check_direct_call_autograd(pkg, m, small, "cpu", tol=2e-4)
+
+
+@pytest.mark.parametrize("kind", ["single", "cvae", "fader"])
+def test_sibling_forward_has_autograd(kind):
+    """single-encoder drop-ins in a reference-style loop (forward -> torch loss -> loss.backward() -> optimizer.step()): one autograd node
+    behind forward (+ one behind the Fader heads), gradients = the reference's own (host schedule on the CPU test backend)"""
+    from helpers import check_sibling_autograd, make_sibling, sibling_golden
+    pkg = load_package()
+    g = sibling_golden(kind)
+    H, Z = int(g["dims"][0]), int(g["dims"][1])
+    m = make_sibling(kind, H, Z, ops=FakeOps())
+    check_sibling_autograd(pkg, kind, m, g, "cpu", tol_grad=2e-4)
