@@ -2,13 +2,14 @@
 for an A/B of two library builds in one session: python scratch/bench_scan_ab.py scratch/lib_x.so"""
 import os, sys, shutil
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
-if len(sys.argv) > 1:
+if len(sys.argv) > 1 and sys.argv[1].endswith(".so"):
     shutil.copy(os.path.join(R, sys.argv[1]), os.path.join(R, "music-fader-nets_amd/libfadernets_hip.so"))
 import torch
 from mfn_import import load_package
 load_package()
 from music_fader_nets_amd.hipops import HipOps
 dev = torch.device("cuda:0"); ops = HipOps(dev)
+ops.variant = int(os.environ.get("FN_VARIANT", "0"))          # FnGruFwd.variant of every scan launch (tiling experiments)
 H, V = 512, 342
 def mk(n, B, T, dense):
     torch.manual_seed(0)
