@@ -25,6 +25,20 @@
 
 #include "gru_layout.h"
 
+#ifdef FN_TIMING
+// cycle stamps of the role workgroups at step 10 of the first block (slice 0 of each role): scratch/timing_decode.py
+__device__ unsigned long long fn_ddbg[5 * 16];
+#define FN_DSTAMP(role_, k)                                                                                              \
+    do {                                                                                                                 \
+        if (slice == 0 && rep == 0 && blk == 0 && threadIdx.x == 0 && t == 10) fn_ddbg[(role_) * 16 + (k)] = __builtin_readcyclecounter(); \
+    } while (0)
+extern "C" int fn_ddbg_read(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fn_ddbg), sizeof(unsigned long long) * 80);
+}
+#else
+#define FN_DSTAMP(role_, k)
+#endif
+
 namespace {
 
 constexpr int NT = 256;
@@ -45,6 +59,10 @@ struct DArgs {
     float* logp;                                     // [B][steps][V] or null
     u32* sync;
 };
+
+// L1-bypassing dword load WITHOUT a wait (pair with fn_wait_vm<0>()): an agent-scope atomic load is followed by its own s_waitcnt,
+// 48 of them per block were 48 dependent L2 round trips (13.8 k of the layer-1 role's 28 k cycles per block, scratch/timing_decode.py)
+FN_DEVINL void gld1_sc1(float& dst, const float* p) { asm volatile("global_load_dword %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory"); }
 
 FN_DEVINL f32x4 ldv4_sc1(const float* p) {
     f32x4 v;
@@ -208,8 +226,10 @@ __global__ __launch_bounds__(NT) void decode_greedy_kernel(const DArgs a) {
                 const bool act = item < MT * 64 && rl < nrow;
                 const int b = r0 + min(rl, nrow - 1);
                 float* x1 = a.x1 + (long)blk * FS;
+                FN_DSTAMP(0, 0);
                 // the recurrent product needs h1_{t-1} only, not the token: it runs while the previous token is still being produced
                 if (t > 0 && !sy.wait(C1, unsl * (u32)t)) return;
+                FN_DSTAMP(0, 1);
                 const float* xin = x1 + (long)((t + 1) & 1) * FSA;        // slot 1 holds h0 at t = 0
                 // own previous state slice and the per-row input constants: registers when this workgroup serves ONE block, else re-read
                 // (requested together with the operand fragments: kquarter's single wait covers the asm load)
@@ -221,15 +241,24 @@ __global__ __launch_bounds__(NT) void decode_greedy_kernel(const DArgs a) {
                 f32x4 acc[MT][3];
                 kquarter<MT, 3>(xin, wl, nk, lane, wave, acc);
                 fn_touch(hp);
+                FN_DSTAMP(0, 2);
                 spill_partials<MT, 3>(red, lane, wave, acc);
                 f32x4 gh[3];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) gh[q] = gather_sum<MT, 3>(red, tile, q, coff) + bh[q];
+                FN_DSTAMP(0, 3);
                 // the token of step t-1: every layer-1 workgroup takes the argmax of the logits itself as soon as the output slices
                 // have arrived (the ARG workgroup, which writes tokens and log-probabilities out, is off the critical chain)
                 int tok = a.start_token;
-                if (t > 0) {
+                if (t > 0 && !single) {
+                    // throughput regime (several blocks per replica): the token comes from the ARG workgroup - one more hand-over in a block's
+                    // chain, but the 32-fold redundant argmax (12 k of this role's 26 k cycles per block) no longer bounds the pipeline
+                    if (!sy.wait(C5, (u32)t)) return;
+                    tok = __hip_atomic_load(a.tokens + (long)b * a.tok_ld + (t - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    FN_DSTAMP(0, 5);
+                } else if (t > 0) {
                     if (!sy.wait(C4, (u32)a.nvt * (u32)t)) return;
+                    FN_DSTAMP(0, 4);
                     // all rows of this wave are requested before the first is reduced: one L2 round trip instead of one per row
                     constexpr int RPW = MT * 4;                              // rows per wave
                     float xl[RPW][6];
@@ -237,32 +266,44 @@ __global__ __launch_bounds__(NT) void decode_greedy_kernel(const DArgs a) {
                     for (int j = 0; j < RPW; ++j) {
                         const int rowc = min(wave + 4 * j, nrow - 1);
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) {
-                            const int v = min(lane + 64 * k, vpad - 1);
-                            xl[j][k] = __hip_atomic_load(a.logits + (long)(r0 + rowc) * vpad + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
+                        for (int k = 0; k < 6; ++k) gld1_sc1(xl[j][k], a.logits + (long)(r0 + rowc) * vpad + min(lane + 64 * k, vpad - 1));
                     }
+                    fn_wait_vm<0>();
+#pragma unroll
+                    for (int j = 0; j < RPW; ++j)
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) asm volatile("" : "+v"(xl[j][k]));
+                    // the cross-lane rounds of ALL rows side by side (round-major): 8 independent ds_bpermute chains in flight instead of 8
+                    // dependent chains one after the other (that order was 14 k of the role's 28 k cycles per block, scratch/timing_decode.py)
+                    float mxr[RPW];
+                    int amr[RPW];
 #pragma unroll
                     for (int j = 0; j < RPW; ++j) {
-                        const int row = wave + 4 * j;
-                        float mx = -3.0e38f;
-                        int am = 0x7fffffff;
+                        mxr[j] = -3.0e38f;
+                        amr[j] = 0x7fffffff;
 #pragma unroll
                         for (int k = 0; k < 6; ++k) {
                             const int v = lane + 64 * k;
                             const float x = v < a.V ? xl[j][k] : -3.0e38f;
-                            if (x > mx) { mx = x; am = v; }
+                            if (x > mxr[j]) { mxr[j] = x; amr[j] = v; }
                         }
-#pragma unroll
-                        for (int o = 32; o > 0; o >>= 1) {
-                            const float om = __shfl_xor(mx, o, 64);
-                            const int oa = __shfl_xor(am, o, 64);
-                            if (om > mx || (om == mx && oa < am)) { mx = om; am = oa; }
-                        }
-                        if (lane == 0 && row < nrow) tokl[row] = am;
                     }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        float om[RPW];
+                        int oa[RPW];
+#pragma unroll
+                        for (int j = 0; j < RPW; ++j) { om[j] = __shfl_xor(mxr[j], o, 64); oa[j] = __shfl_xor(amr[j], o, 64); }
+#pragma unroll
+                        for (int j = 0; j < RPW; ++j)
+                            if (om[j] > mxr[j] || (om[j] == mxr[j] && oa[j] < amr[j])) { mxr[j] = om[j]; amr[j] = oa[j]; }
+                    }
+#pragma unroll
+                    for (int j = 0; j < RPW; ++j)
+                        if (lane == 0 && wave + 4 * j < nrow) tokl[wave + 4 * j] = amr[j];
                     __syncthreads();
                     tok = tokl[min(rl, nrow - 1)];
+                    FN_DSTAMP(0, 5);
                 }
                 f32x4 ex[3];
 #pragma unroll
@@ -276,7 +317,9 @@ __global__ __launch_bounds__(NT) void decode_greedy_kernel(const DArgs a) {
                 }
                 hp_reg = hp;
                 if (act) stv4_sc1(x1 + (long)(t & 1) * FSA + frag_off(rl, jj0, nk), hp);
+                FN_DSTAMP(0, 6);
                 sy.arrive(C1);
+                FN_DSTAMP(0, 7);
             }
         }
     } else if (role == 1) {                           // ---------------- W_ih2 projection ----------------
@@ -290,7 +333,9 @@ __global__ __launch_bounds__(NT) void decode_greedy_kernel(const DArgs a) {
                 const bool act = item < MT * 64 && rl < nrow;
                 const int b = r0 + min(rl, nrow - 1);
                 // (g2 of step t-1 is free: h1_t exists only after token t-1, i.e. after layer 2 consumed it)
+                FN_DSTAMP(1, 0);
                 if (!sy.wait(C1, unsl * (u32)(t + 1))) return;
+                FN_DSTAMP(1, 1);
                 f32x4 acc[MT][3];
                 kquarter<MT, 3>(a.x1 + (long)blk * FS + (long)(t & 1) * FSA, wl, nk, lane, wave, acc);
                 spill_partials<MT, 3>(red, lane, wave, acc);
@@ -299,6 +344,7 @@ __global__ __launch_bounds__(NT) void decode_greedy_kernel(const DArgs a) {
                     for (int q = 0; q < 3; ++q) stv4_sc1(a.g2 + (long)b * 3 * H + q * H + jj0, gather_sum<MT, 3>(red, tile, q, coff) + bi[q]);
                 }
                 sy.arrive(C2);
+                FN_DSTAMP(1, 7);
             }
         }
     } else if (role == 2) {                           // ---------------- layer-2 cell ----------------
@@ -312,7 +358,9 @@ __global__ __launch_bounds__(NT) void decode_greedy_kernel(const DArgs a) {
                 const bool act = item < MT * 64 && rl < nrow;
                 const int b = r0 + min(rl, nrow - 1);
                 // recurrent input: h2_{t-1}, or h1_0 at the first step (gmm_model.py:134-135: hx[1] = hx[0] at i == 0)
+                FN_DSTAMP(2, 0);
                 if (!(t == 0 ? sy.wait(C1, unsl) : sy.wait(C3, unsl * (u32)t))) return;
+                FN_DSTAMP(2, 1);
                 const float* xin = t == 0 ? a.x1 + (long)blk * FS : a.x2 + (long)blk * FS + (long)((t + 1) & 1) * FSA;
                 f32x4 hp = hp_reg;
                 if (!(single && t > 0)) gld4_sc1(hp, xin + frag_off(min(rl, nrow - 1), jj0, nk));
@@ -323,7 +371,9 @@ __global__ __launch_bounds__(NT) void decode_greedy_kernel(const DArgs a) {
                 f32x4 gh[3];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) gh[q] = gather_sum<MT, 3>(red, tile, q, coff) + bh[q];
+                FN_DSTAMP(2, 3);
                 if (!sy.wait(C2, unsl * (u32)(t + 1))) return;
+                FN_DSTAMP(2, 4);
                 f32x4 gx[3];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) gx[q] = ldv4_sc1(a.g2 + (long)b * 3 * H + q * H + jj0);
@@ -337,6 +387,7 @@ __global__ __launch_bounds__(NT) void decode_greedy_kernel(const DArgs a) {
                 hp_reg = hp;
                 if (act) stv4_sc1(a.x2 + (long)blk * FS + (long)(t & 1) * FSA + frag_off(rl, jj0, nk), hp);
                 sy.arrive(C3);
+                FN_DSTAMP(2, 7);
             }
         }
     } else if (role == 3) {                           // ---------------- output layer slice ----------------
@@ -353,13 +404,16 @@ __global__ __launch_bounds__(NT) void decode_greedy_kernel(const DArgs a) {
                 // the logits of step t-1 may only be overwritten once the ARG workgroup has read them (this wait is off the critical
                 // chain: the output slices are idle until layer 2 arrives anyway); every layer-1 workgroup has taken its own argmax of them
                 // before h1_t, hence h2_t, existed
+                FN_DSTAMP(3, 0);
                 if (t > 0 && !sy.wait(C5, (u32)t)) return;
                 if (!sy.wait(C3, unsl * (u32)(t + 1))) return;
+                FN_DSTAMP(3, 1);
                 f32x4 acc[MT][1];
                 kquarter<MT, 1>(a.x2 + (long)blk * FS + (long)(t & 1) * FSA, wl, nk, lane, wave, acc);
                 spill_partials<MT, 1>(red, lane, wave, acc);
                 if (act) stv4_sc1(a.logits + (long)b * vpad + jj0, gather_sum<MT, 1>(red, tile, 0, coff) + bo);
                 sy.arrive(C4);
+                FN_DSTAMP(3, 7);
             }
         }
     } else {                                          // ---------------- log-softmax + first-index argmax ----------------
@@ -367,50 +421,78 @@ __global__ __launch_bounds__(NT) void decode_greedy_kernel(const DArgs a) {
             for (int blk = rep; blk < a.nblk; blk += a.nrep) {
                 const Sync sy = {a.sync + blk * BLKW, errw, dead};
                 const int r0 = blk * RB, nrow = min(RB, B - r0);
+                FN_DSTAMP(4, 0);
                 if (!sy.wait(C4, (u32)a.nvt * (u32)(t + 1))) return;
+                FN_DSTAMP(4, 1);
                 constexpr int RPW = MT * 4;
                 float xl[RPW][6];
 #pragma unroll
                 for (int j = 0; j < RPW; ++j) {                               // every row of this wave requested up front
                     const int rowc = r0 + min(wave + 4 * j, nrow - 1);
 #pragma unroll
-                    for (int k = 0; k < 6; ++k)
-                        xl[j][k] = __hip_atomic_load(a.logits + (long)rowc * vpad + min(lane + 64 * k, vpad - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int k = 0; k < 6; ++k) gld1_sc1(xl[j][k], a.logits + (long)rowc * vpad + min(lane + 64 * k, vpad - 1));
+                }
+                fn_wait_vm<0>();
+#pragma unroll
+                for (int j = 0; j < RPW; ++j)
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) asm volatile("" : "+v"(xl[j][k]));
+                float mxr[RPW];
+                int amr[RPW];
+#pragma unroll
+                for (int j = 0; j < RPW; ++j) {
+                    mxr[j] = -3.0e38f;
+                    amr[j] = 0x7fffffff;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const int v = lane + 64 * k;
+                        if (v >= a.V) xl[j][k] = -3.0e38f;
+                        if (xl[j][k] > mxr[j]) { mxr[j] = xl[j][k]; amr[j] = v; }     // ascending v: the first index wins inside a lane
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {                            // round-major: the rows' cross-lane chains side by side
+                    float om[RPW];
+                    int oa[RPW];
+#pragma unroll
+                    for (int j = 0; j < RPW; ++j) { om[j] = __shfl_xor(mxr[j], o, 64); oa[j] = __shfl_xor(amr[j], o, 64); }
+#pragma unroll
+                    for (int j = 0; j < RPW; ++j)
+                        if (om[j] > mxr[j] || (om[j] == mxr[j] && oa[j] < amr[j])) { mxr[j] = om[j]; amr[j] = oa[j]; }
+                }
+                float se[RPW];
+                if (a.logp) {                                                // sum of exponentials, also round-major
+#pragma unroll
+                    for (int j = 0; j < RPW; ++j) {
+                        se[j] = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 6; ++k)
+                            if (lane + 64 * k < a.V) se[j] += expf(xl[j][k] - mxr[j]);
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        float t2[RPW];
+#pragma unroll
+                        for (int j = 0; j < RPW; ++j) t2[j] = __shfl_xor(se[j], o, 64);
+#pragma unroll
+                        for (int j = 0; j < RPW; ++j) se[j] += t2[j];
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < RPW; ++j) {
                     if (wave + 4 * j >= nrow) continue;
                     const int row = r0 + wave + 4 * j;
-                    float x[6];
-                    float mx = -3.0e38f;
-                    int am = 0x7fffffff;
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        const int v = lane + 64 * k;
-                        x[k] = v < a.V ? xl[j][k] : -3.0e38f;
-                        if (x[k] > mx) { mx = x[k]; am = v; }                 // ascending v: the first index wins inside a lane
-                    }
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        const float om = __shfl_xor(mx, o, 64);
-                        const int oa = __shfl_xor(am, o, 64);
-                        if (om > mx || (om == mx && oa < am)) { mx = om; am = oa; }
-                    }
                     if (a.logp) {
-                        float s = 0.f;
-#pragma unroll
-                        for (int k = 0; k < 6; ++k)
-                            if (lane + 64 * k < a.V) s += expf(x[k] - mx);
-                        s = fn_wave_sum(s);
-                        const float lse = mx + logf(s);
+                        const float lse = mxr[j] + logf(se[j]);
                         float* out = a.logp + ((long)row * a.steps + t) * a.V;
 #pragma unroll
                         for (int k = 0; k < 6; ++k)
-                            if (lane + 64 * k < a.V) out[lane + 64 * k] = x[k] - lse;
+                            if (lane + 64 * k < a.V) out[lane + 64 * k] = xl[j][k] - lse;
                     }
-                    if (lane == 0) __hip_atomic_store(a.tokens + (long)row * a.tok_ld + t, am, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0) __hip_atomic_store(a.tokens + (long)row * a.tok_ld + t, amr[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 sy.arrive(C5);
+                FN_DSTAMP(4, 7);
             }
         }
     }

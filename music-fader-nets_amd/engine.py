@@ -44,7 +44,7 @@ class Engine:
         self.chunk = 32                 # time steps per pipeline chunk of the two decoder layers (layer 2 lags layer 1 by two chunks)
         self.persist_dec = True         # decoder scans as weight-stationary launches (False: per-step kernels; debug / tests)
         self.single_launch_decode = True   # decode.py: small / medium batches decode as ONE launch (False: per-token kernels; tests)
-        self.single_launch_rows = 256      # ... up to this many sequences (fn_decode_greedy takes <= 1024; measured: 27.7 vs 57.6 us per token at 128 rows, 49.6 vs 58.7 at 256, 75 vs 71 at 384); above: per-token kernels / staged-GEMM cells
+        self.single_launch_rows = 767      # ... up to this many sequences (fn_decode_greedy takes <= 1024; measured us per token, one launch vs the next best path: 128 rows 27.7 / 57.6, 256 rows 29.7 / 58.7, 512 rows 55.0 / 67.6, 704 rows 74.9 / 88.1, 800 rows 88.3 / 88.4); above: staged-GEMM cells
         self._lane_alias = {}           # lane -> lane it is folded into (debug)
         self.cell_decode_rows = 768     # decode.py: from this many sequences on, the per-token cells are staged-GEMM launches (fn_gru_cell_f32); measured crossover (scratch/bench_decode_rows.py): 512 rows 67 vs 87 us per token, 768 rows 97 vs 88
         self.fused_head = True          # trainers: output projection + log-softmax + NLL + gradient seed as ONE kernel (fn_out_head_f32); False: GEMM -> logits in HBM -> fn_vocab_logsoftmax

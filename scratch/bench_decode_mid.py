@@ -10,13 +10,14 @@ torch.manual_seed(0)
 m = pkg.MusicAttrRegGMVAE(roll_dims=342, rhythm_dims=3, note_dims=16, chroma_dims=24, hidden_dims=512, z_dims=128, n_step=256, n_component=2).to(dev)
 m.eval()
 eng = m.engine()
+eng.single_launch_rows = 1024          # measure the one-launch pipeline over its whole range, whatever the default threshold
 steps = 100
 def t(z):
     for _ in range(2): pkg.greedy_decode(m, z, steps, want_logp=False)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(3): pkg.greedy_decode(m, z, steps, want_logp=False)
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / 3 / steps * 1e6
-for Bi in (8, 32, 48, 64, 96, 128, 160, 192, 224, 256, 384, 512, 800, 1024):
+for Bi in (8, 32, 64, 128, 192, 256, 320, 384, 448, 512, 640, 704, 800, 1024):
     z = torch.randn(Bi, 280, device=dev)
     eng.single_launch_decode, eng.cell_decode_rows = True, 1 << 30
     a = t(z)
