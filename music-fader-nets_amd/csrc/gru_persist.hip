@@ -20,6 +20,7 @@
 #include <atomic>
 
 #include "gru_layout.h"
+#include "kloop_asm.h"
 
 #ifdef FN_TIMING
 __device__ unsigned long long fn_pdbg[8 * 8];
@@ -37,6 +38,9 @@ extern "C" int fn_pdbg_read(unsigned long long* host) {
 namespace {
 
 constexpr int NT = 256;
+
+// LDS byte address of a pointer into the workgroup's shared memory (what ds_read / ds_write take)
+FN_DEVINL unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p; }
 
 struct PScan {
     const float* w_frag;
@@ -59,6 +63,7 @@ struct PScan {
 struct PArgs {
     PScan s[FN_MAX_SCANS];
     int n, ngroups, H;
+    int no_hand;          // tuning / tests: the compiler-scheduled K loop instead of kloop_asm.h
     u32* sync;            // [ngroups * 32] arrival counters (one per 128-byte line), zero at launch
     u32* err;             // sticky error word
 };
@@ -138,6 +143,10 @@ __global__ __launch_bounds__(NT) void gru_fwd_persist_kernel(const PArgs args) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) aoff[m] = (long)min((m0 >> 4) + wm * MT + m, nrt - 1) * nk * 512 + lane * 4;
     constexpr int NLA = 2 * MT;                      // asm loads per chunk
+    // H = 512 with two row tiles per wave (the 128- and 64-row tilings of the training shapes): the hand-placed K loop of kloop_asm.h
+    const bool hand = MT == 2 && H == 512 && (nkw & 3) == 0 && nkw >= 4 && !args.no_hand;
+    const unsigned h_lp = lds_addr(wl) + c0 * 2048 + lane * 16;
+    const unsigned h_red = lds_addr(red) + (((wk * EM + wm * MT) * 3) * RT + lane * 4 + (lane >> 4) * 4) * 4;
 
 #pragma unroll 1
     for (int p = 0; p < T; ++p) {
@@ -188,7 +197,12 @@ __global__ __launch_bounds__(NT) void gru_fwd_persist_kernel(const PArgs args) {
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int n = 0; n < 3; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (has_k && nkw > 0) {
+        const bool hand_now = MT == 2 && hand && has_k;
+        if (MT == 2 && hand_now) {
+            const float* xin = (p == 0 && S.h0f) ? S.h0f : S.xf + (long)(p & 1) * FS;
+            // MFMAs, operand ring, weight-fragment reads and the accumulator hand-over (d) of this step
+            fn_kloop_fwd_h512(xin + (long)c0 * 512, (unsigned)aoff[0] * 4u, (unsigned)aoff[MT - 1] * 4u, h_lp, h_lp + 65536u, nkw >> 2, h_red);
+        } else if (has_k && nkw > 0) {
             const float* xin = (p == 0 && S.h0f) ? S.h0f : S.xf + (long)(p & 1) * FS;
             f32x4 fa[D][MT][2], fb[2][3][2];
             auto loadA = [&](int set, int it) {
@@ -244,11 +258,13 @@ __global__ __launch_bounds__(NT) void gru_fwd_persist_kernel(const PArgs args) {
         FN_PSTAMP(2);
         // (d) accumulators -> LDS in MFMA C layout (row = 4*(lane>>4) + reg, col = lane & 15), 4 floats of padding per
         //     16 lanes so that the epilogue's reads (4 row quads x 4 unit quads per wave) hit 64 different banks
+        if (!hand_now) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int n = 0; n < 3; ++n)
-                *reinterpret_cast<f32x4*>(red + ((long)((wk * EM + wm * MT + m) * 3 + n)) * RT + lane * 4 + (lane >> 4) * 4) = acc[m][n];
+                for (int n = 0; n < 3; ++n)
+                    *reinterpret_cast<f32x4*>(red + ((long)((wk * EM + wm * MT + m) * 3 + n)) * RT + lane * 4 + (lane >> 4) * 4) = acc[m][n];
+        }
         __syncthreads();
 
         FN_PSTAMP(3);
@@ -330,6 +346,7 @@ struct QScan {
 struct QArgs {
     QScan s[FN_MAX_SCANS];
     int n, ngroups, H;
+    int no_hand;
     u32* sync;
     u32* err;
 };
@@ -341,8 +358,8 @@ __global__ __launch_bounds__(NT) void gru_bwd_persist_kernel(const QArgs args) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = args.H, nk3 = (3 * H) >> 5;
     float* wl = smem;                                // [nk3][2][64][4]  W_hh^T slice, B-fragment order
-    float* red = smem + 3 * H * 16;                  // [WK][EM][RT]
-    volatile int& dead = *reinterpret_cast<volatile int*>(red + WK * EM * RT);
+    float* red = smem + 3 * H * 16;                  // [2][WK][EM][RT]  (second plane: the hand-placed K loop's odd-k accumulators)
+    volatile int& dead = *reinterpret_cast<volatile int*>(red + 2 * WK * EM * RT);
 
     const int g = blockIdx.x % args.ngroups, slice = blockIdx.x / args.ngroups;
     int si = 0;
@@ -394,10 +411,17 @@ __global__ __launch_bounds__(NT) void gru_bwd_persist_kernel(const QArgs args) {
     for (int m = 0; m < MT; ++m) aoff[m] = (long)min((m0 >> 4) + wm * MT + m, nrt - 1) * nk3 * 512 + lane * 4;
     constexpr int NLA = 2 * MT;
     const int iters = T + (S.dh0 ? 1 : 0);
+    const bool hand = MT == 2 && H == 512 && (nkw & 7) == 0 && nkw >= 8 && !args.no_hand;      // kloop_asm.h
+    const unsigned h_lp = lds_addr(wl) + c0 * 2048 + lane * 16;
+    const unsigned h_red = lds_addr(red) + ((wk * EM + wm * MT) * RT + lane * 4 + (lane >> 4) * 4) * 4;
+    static_assert(WK * EM == 8 || MT != 2, "kloop_asm.h: the second accumulator plane sits 8 tiles behind the first");
 
 #pragma unroll 1
     for (int it = 0; it < iters; ++it) {
         const int q = T - 1 - it;                     // step whose gate backward runs now (-1: only dh0 is left)
+        const int p = it;                             // FN_PSTAMP
+        (void)p;
+        FN_PSTAMP(0);
         // (a) operands that do not depend on the exchange
         f32x4 g_r[NI], g_z[NI], g_n[NI], g_hn[NI], hpv[NI], ext[NI];
 #pragma unroll
@@ -415,6 +439,7 @@ __global__ __launch_bounds__(NT) void gru_bwd_persist_kernel(const QArgs args) {
             }
         }
 
+        FN_PSTAMP(1);
         // (b) wait for every slice's gradient slab of the previous iteration
         if (it > 0) {
             if (tid == 0) {
@@ -433,11 +458,16 @@ __global__ __launch_bounds__(NT) void gru_bwd_persist_kernel(const QArgs args) {
             if (dead) return;
         }
 
+        FN_PSTAMP(2);
         // (c) dh partial = df_{q+1} W_hh (columns of this slice)
         f32x4 acc[MT][2];
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[m][0] = acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (it > 0 && nkw > 0) {
+        const bool hand_now = MT == 2 && hand && it > 0;
+        if (MT == 2 && hand_now) {
+            const float* xin = S.xf + (long)((it - 1) & 1) * FS3;
+            fn_kloop_bwd_h512(xin + (long)c0 * 512, (unsigned)aoff[0] * 4u, (unsigned)aoff[MT - 1] * 4u, h_lp, nkw >> 3, h_red);
+        } else if (it > 0 && nkw > 0) {
             const float* xin = S.xf + (long)((it - 1) & 1) * FS3;
             f32x4 fa[D][MT][2], fb[2][2];
             auto loadA = [&](int set, int k) {
@@ -485,12 +515,16 @@ __global__ __launch_bounds__(NT) void gru_bwd_persist_kernel(const QArgs args) {
                 for (int m = 0; m < MT; ++m) { fn_keep(fa[s][m][0]); fn_keep(fa[s][m][1]); }
         }
 
+        FN_PSTAMP(3);
         // (d) accumulators -> LDS (padded MFMA C layout)
+        if (!hand_now) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-            *reinterpret_cast<f32x4*>(red + (long)(wk * EM + wm * MT + m) * RT + lane * 4 + (lane >> 4) * 4) = acc[m][0] + acc[m][1];
+            for (int m = 0; m < MT; ++m)
+                *reinterpret_cast<f32x4*>(red + (long)(wk * EM + wm * MT + m) * RT + lane * 4 + (lane >> 4) * 4) = acc[m][0] + acc[m][1];
+        }
         __syncthreads();
 
+        FN_PSTAMP(4);
         // (e) gate backward, element-wise
         const bool publish = q > 0 || (q == 0 && S.dh0 != nullptr);
         float* xout = S.xf + (long)(it & 1) * FS3;
@@ -503,7 +537,11 @@ __global__ __launch_bounds__(NT) void gru_bwd_persist_kernel(const QArgs args) {
             for (int c = 0; c < 4; ++c) {
                 float a = 0.f;
 #pragma unroll
-                for (int w = 0; w < WK; ++w) a += red[(long)(w * EM) * RT + icoff[i] + c * 4];
+                for (int w = 0; w < WK; ++w) {
+                    float x = red[(long)(w * EM) * RT + icoff[i] + c * 4];
+                    if (hand_now) x += red[(long)((WK + w) * EM) * RT + icoff[i] + c * 4];      // even-k + odd-k accumulator, as acc[m][0] + acc[m][1]
+                    a += x;
+                }
                 dh[c] = (a + carry[i][c]) + ext[i][c];
             }
             if (q < 0) {
@@ -530,12 +568,14 @@ __global__ __launch_bounds__(NT) void gru_bwd_persist_kernel(const QArgs args) {
             }
         }
 
+        FN_PSTAMP(5);
         // (f) publish
         if (publish) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        FN_PSTAMP(6);
         // (g) outputs nobody in this launch waits for
         if (q >= 0) {
 #pragma unroll
@@ -549,6 +589,7 @@ __global__ __launch_bounds__(NT) void gru_bwd_persist_kernel(const QArgs args) {
                 stv4(S.dghn_all + (long)q * BH + (long)ib[i] * H + jj0, o_g[i]);
             }
         }
+        FN_PSTAMP(7);
     }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -651,6 +692,7 @@ int fn_gru_fwd_persist(const FnGruFwd* scans, int n_scans, hipStream_t st) {
     PArgs a;
     a.n = n_scans;
     a.H = H;
+    a.no_hand = (scans[0].variant & 0x400) ? 1 : 0;
     a.sync = reinterpret_cast<u32*>(scans[0].sync_ws);
     int groups = 0;
     for (int s = 0; s < n_scans; ++s) {
@@ -719,6 +761,7 @@ int fn_gru_bwd_persist(const FnGruBwd* scans, int n_scans, hipStream_t st) {
     QArgs a;
     a.n = n_scans;
     a.H = H;
+    a.no_hand = (scans[0].variant & 0x400) ? 1 : 0;
     a.sync = reinterpret_cast<u32*>(scans[0].sync_ws);
     int groups = 0;
     for (int s = 0; s < n_scans; ++s) {
@@ -740,7 +783,7 @@ int fn_gru_bwd_persist(const FnGruBwd* scans, int n_scans, hipStream_t st) {
     }
     const int grid = groups * nslices;
     const int wk = rpw == 16 ? 4 : rpw == 32 ? 2 : (rpw == 64 && !(scans[0].variant & 0x100)) ? 2 : 1;
-    const size_t lds = ((size_t)3 * H * 16 + (size_t)wk * (rpw / 16) * RT) * 4 + 16;
+    const size_t lds = ((size_t)3 * H * 16 + (size_t)2 * wk * (rpw / 16) * RT) * 4 + 16;
     switch (rpw) {
         case 128: return launch_k<QArgs, gru_bwd_persist_kernel<4, 1, 2, 8>>(a, grid, lds, cus, st);
         case 64:

@@ -1,3 +1,4 @@
+"""In-kernel cycle stamps of the shipped backward scan (FN_TIMING build, scratch/build_all.sh): iteration 10 of workgroups 0-7."""
 import os, sys, shutil, ctypes
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 shutil.copy(os.path.join(R, "scratch/lib_timing.so"), os.path.join(R, "music-fader-nets_amd/libfadernets_hip.so"))
@@ -8,10 +9,10 @@ from music_fader_nets_amd.hipops import HipOps
 from music_fader_nets_amd import _lib
 dev = torch.device("cuda:0"); ops = HipOps(dev)
 lib = _lib.load()
-B, T, H, V = 256, 24, 512, 342
+T, H, V = 24, 512, 342
 buf = (ctypes.c_ulonglong * 64)()
 lib.fn_pdbg_read.argtypes = [ctypes.c_void_p]
-for n, Bn in ((1, 256), (4, 256), (4, 128)):
+for n, Bn in ((4, 256), (2, 256)):
     fw, bw = [], []
     for s in range(n):
         w = (torch.randn(3*H, H, device=dev) / 22).contiguous()
@@ -24,11 +25,13 @@ for n, Bn in ((1, 256), (4, 256), (4, 128)):
         bw.append(dict(B=Bn, T=T, H=H, w_hh_t_frag=wtf, h0=None, h_all=d["h_all"], gates=d["gates"], dh_ext=torch.randn(T, Bn, H, device=dev) * 0.01,
                        dgx_all=torch.zeros(T, Bn, 3*H, device=dev), dghn_all=torch.zeros(T, Bn, H, device=dev), scratch=torch.zeros(Bn, H, device=dev),
                        dgx_rowsum=torch.zeros(Bn, 3*H, device=dev), dghn_rowsum=torch.zeros(Bn, H, device=dev)))
-    ops.gru_seq_fwd(fw)
-    for rep in range(3):
-        ops.gru_seq_bwd(bw); torch.cuda.synchronize()
-        lib.fn_pdbg_read(buf)
-        a = np.array(list(buf), dtype=np.int64).reshape(8, 8)[:, [0, 1, 7, 2, 3, 4, 5, 6]]
-        d = a - a[:, :1]
-    print("bwd scans=%d B=%d  iteration-10 stamps [ops issued, polled, first chunk landed, kloop, red, epi, drained, arrived]:" % (n, Bn))
-    for r in d[:3]: print("    ", r.tolist())
+    for which in ("fwd", "bwd"):
+        for rep in range(3):
+            (ops.gru_seq_fwd(fw) if which == "fwd" else ops.gru_seq_bwd(bw)); torch.cuda.synchronize()
+            lib.fn_pdbg_read(buf)
+            a = np.array(list(buf), dtype=np.int64).reshape(8, 8)
+        names = "[top | (a) issued, polled, kloop done, red barrier, epilogue, published, outputs issued]" if which == "bwd" else \
+                "[(a) issued | polled, kloop done, red barrier, epilogue, drained, arrived, -]"
+        print("%s scans=%d B=%d  step-10 stamps relative to the first, cycles %s" % (which, n, Bn, names))
+        for r in (a - a[:, :1])[:4]: print("    ", r.tolist())
+        print("     workgroup 0: previous-step-free deltas", np.diff(a[0]).tolist())
