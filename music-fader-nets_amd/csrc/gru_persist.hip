@@ -144,35 +144,52 @@ __global__ __launch_bounds__(NT) void gru_fwd_persist_kernel(const PArgs args) {
     for (int m = 0; m < MT; ++m) aoff[m] = (long)min((m0 >> 4) + wm * MT + m, nrt - 1) * nk * 512 + lane * 4;
     constexpr int NLA = 2 * MT;                      // asm loads per chunk
     // H = 512 with two row tiles per wave (the 128- and 64-row tilings of the training shapes): the hand-placed K loop of kloop_asm.h
-    const bool hand = MT == 2 && H == 512 && (nkw & 3) == 0 && nkw >= 4 && !args.no_hand;
+    const bool hand = MT == 2 && H == 512 && (nkw == 16 || nkw == 8) && !args.no_hand && ((S.gx_table != nullptr) != (S.gx_dense != nullptr));
     const unsigned h_lp = lds_addr(wl) + c0 * 2048 + lane * 16;
     const unsigned h_red = lds_addr(red) + (((wk * EM + wm * MT) * 3) * RT + lane * 4 + (lane >> 4) * 4) * 4;
 
+    // token of the step about to run (read one step ahead: the table-row address must not wait for it)
+    int tokn[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int tau0 = (S.reverse ? T - 1 : 0) + S.idx_shift;
+        tokn[i] = (S.gx_table && tau0 >= 0) ? S.idx[(long)ib[i] * S.idx_ld + tau0] : S.start_token;
+    }
+
 #pragma unroll 1
     for (int p = 0; p < T; ++p) {
-        // (a) h-independent epilogue operands of this step (their latency hides under the wait and the K loop)
-        const int tau = (S.reverse ? T - 1 - p : p) + S.idx_shift;
+        const bool has_k = p > 0 || S.h0 != nullptr;
+        const bool hand_now = MT == 2 && hand && has_k;
+        // (a) h-independent epilogue operands of this step: requested inside the hand-placed K loop (only their addresses here), else
+        //     up front (their latency then hides under the wait and the K loop)
         f32x4 e_x[NI][3];
+        const float* xa[2] = {nullptr, nullptr};
+        if (MT == 2 && hand_now) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) e_x[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (S.gx_table) {
-                const int tok = tau >= 0 ? S.idx[(long)ib[i] * S.idx_ld + tau] : S.start_token;
-                const float* row = S.gx_table + (long)tok * 3 * H + jj0;
-#pragma unroll
-                for (int q = 0; q < 3; ++q) e_x[i][q] = ldv4(row + q * H);
+            for (int i = 0; i < 2; ++i) {
+                const int ii = i < NI ? i : 0;
+                xa[i] = S.gx_table ? S.gx_table + (long)tokn[ii] * 3 * H + jj0 + H : S.gx_dense + ((long)p * B + ib[ii]) * 3 * H + jj0 + H;
             }
-            if (S.gx_dense) {
-                const float* row = S.gx_dense + ((long)p * B + ib[i]) * 3 * H + jj0;
+        } else {
 #pragma unroll
-                for (int q = 0; q < 3; ++q) e_x[i][q] += ldv4(row + q * H);
+            for (int i = 0; i < NI; ++i) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) e_x[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (S.gx_table) {
+                    const float* row = S.gx_table + (long)tokn[i] * 3 * H + jj0;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) e_x[i][q] = ldv4(row + q * H);
+                }
+                if (S.gx_dense) {
+                    const float* row = S.gx_dense + ((long)p * B + ib[i]) * 3 * H + jj0;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) e_x[i][q] += ldv4(row + q * H);
+                }
             }
         }
 
         FN_PSTAMP(0);
         // (b) wait until every slice of this row group has published h_{p-1}
-        const bool has_k = p > 0 || S.h0 != nullptr;
         if (p > 0) {
             if (tid == 0) {
                 const u32 target = (u32)nslices * (u32)p;
@@ -197,11 +214,16 @@ __global__ __launch_bounds__(NT) void gru_fwd_persist_kernel(const PArgs args) {
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int n = 0; n < 3; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const bool hand_now = MT == 2 && hand && has_k;
         if (MT == 2 && hand_now) {
             const float* xin = (p == 0 && S.h0f) ? S.h0f : S.xf + (long)(p & 1) * FS;
-            // MFMAs, operand ring, weight-fragment reads and the accumulator hand-over (d) of this step
-            fn_kloop_fwd_h512(xin + (long)c0 * 512, (unsigned)aoff[0] * 4u, (unsigned)aoff[MT - 1] * 4u, h_lp, h_lp + 65536u, nkw >> 2, h_red);
+            // MFMAs, operand ring, weight-fragment reads, the epilogue operands (a) and the accumulator hand-over (d) of this step
+            f32x4 ex[2][3];
+            if (WK == 1) fn_kloop_fwd_h512_k512(xin + (long)c0 * 512, (unsigned)aoff[0] * 4u, (unsigned)aoff[MT - 1] * 4u, h_lp, h_lp + 65536u, h_red, xa[0], xa[1], ex);
+            else fn_kloop_fwd_h512_k256(xin + (long)c0 * 512, (unsigned)aoff[0] * 4u, (unsigned)aoff[MT - 1] * 4u, h_lp, h_lp + 65536u, h_red, xa[0], xa[1], ex);
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) e_x[i][q] = ex[i < 2 ? i : 0][q];
         } else if (has_k && nkw > 0) {
             const float* xin = (p == 0 && S.h0f) ? S.h0f : S.xf + (long)(p & 1) * FS;
             f32x4 fa[D][MT][2], fb[2][3][2];
@@ -253,6 +275,13 @@ __global__ __launch_bounds__(NT) void gru_fwd_persist_kernel(const PArgs args) {
             for (int s = 0; s < D; ++s)
 #pragma unroll
                 for (int m = 0; m < MT; ++m) { fn_keep(fa[s][m][0]); fn_keep(fa[s][m][1]); }
+        }
+
+        // next step's token
+        if (S.gx_table && p + 1 < T) {
+            const int tau1 = (S.reverse ? T - 2 - p : p + 1) + S.idx_shift;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) tokn[i] = tau1 >= 0 ? S.idx[(long)ib[i] * S.idx_ld + tau1] : S.start_token;
         }
 
         FN_PSTAMP(2);
@@ -411,7 +440,7 @@ __global__ __launch_bounds__(NT) void gru_bwd_persist_kernel(const QArgs args) {
     for (int m = 0; m < MT; ++m) aoff[m] = (long)min((m0 >> 4) + wm * MT + m, nrt - 1) * nk3 * 512 + lane * 4;
     constexpr int NLA = 2 * MT;
     const int iters = T + (S.dh0 ? 1 : 0);
-    const bool hand = MT == 2 && H == 512 && (nkw & 7) == 0 && nkw >= 8 && !args.no_hand;      // kloop_asm.h
+    const bool hand = MT == 2 && H == 512 && (nkw == 48 || nkw == 24) && !args.no_hand;      // kloop_asm.h
     const unsigned h_lp = lds_addr(wl) + c0 * 2048 + lane * 16;
     const unsigned h_red = lds_addr(red) + ((wk * EM + wm * MT) * RT + lane * 4 + (lane >> 4) * 4) * 4;
     static_assert(WK * EM == 8 || MT != 2, "kloop_asm.h: the second accumulator plane sits 8 tiles behind the first");
@@ -422,12 +451,24 @@ __global__ __launch_bounds__(NT) void gru_bwd_persist_kernel(const QArgs args) {
         const int p = it;                             // FN_PSTAMP
         (void)p;
         FN_PSTAMP(0);
-        // (a) operands that do not depend on the exchange
+        // (a) operands that do not depend on the exchange: requested inside the hand-placed K loop (only their addresses here), else up front
+        const bool hand_now = MT == 2 && hand && it > 0;
         f32x4 g_r[NI], g_z[NI], g_n[NI], g_hn[NI], hpv[NI], ext[NI];
+        const float *ga[2], *ha[2], *xa[2];
+        const int qc = q > 0 ? q : 0;
+        const bool hzero = q < 0 || (q == 0 && !S.h0), xzero = q < 0 || !S.dh_ext;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ii = i < NI ? i : 0;
+            const long ro = (long)ib[ii] * H + jj0;
+            ga[i] = S.gates + (long)qc * GS + gate_off(ib[ii], 0, jj0, nrt);
+            ha[i] = qc > 0 ? S.h_all + (long)(qc - 1) * BH + ro : (S.h0 ? S.h0 + ro : S.h_all + ro);      // unused values still come from a legal address
+            xa[i] = S.dh_ext ? S.dh_ext + (long)qc * BH + ro : S.h_all + ro;
+        }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             g_r[i] = g_z[i] = g_n[i] = g_hn[i] = hpv[i] = ext[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (q >= 0) {
+            if (q >= 0 && !hand_now) {
                 const float* gq = S.gates + (long)q * GS;
                 g_r[i] = ldv4(gq + gate_off(ib[i], 0, jj0, nrt));
                 g_z[i] = ldv4(gq + gate_off(ib[i], 1, jj0, nrt));
@@ -463,10 +504,21 @@ __global__ __launch_bounds__(NT) void gru_bwd_persist_kernel(const QArgs args) {
         f32x4 acc[MT][2];
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[m][0] = acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const bool hand_now = MT == 2 && hand && it > 0;
         if (MT == 2 && hand_now) {
             const float* xin = S.xf + (long)((it - 1) & 1) * FS3;
-            fn_kloop_bwd_h512(xin + (long)c0 * 512, (unsigned)aoff[0] * 4u, (unsigned)aoff[MT - 1] * 4u, h_lp, nkw >> 3, h_red);
+            f32x4 gt[2][4], hp2[2], xt2[2];
+            if (WK == 1) fn_kloop_bwd_h512_k1536(xin + (long)c0 * 512, (unsigned)aoff[0] * 4u, (unsigned)aoff[MT - 1] * 4u, h_lp, h_red, ga[0], ga[1], ha[0], ha[1], xa[0], xa[1],
+                                                 gt, hp2, xt2);
+            else fn_kloop_bwd_h512_k768(xin + (long)c0 * 512, (unsigned)aoff[0] * 4u, (unsigned)aoff[MT - 1] * 4u, h_lp, h_red, ga[0], ga[1], ha[0], ha[1], xa[0], xa[1],
+                                        gt, hp2, xt2);
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int ii = i < 2 ? i : 0;
+                g_r[i] = gt[ii][0]; g_z[i] = gt[ii][1]; g_n[i] = gt[ii][2]; g_hn[i] = gt[ii][3];
+                hpv[i] = hzero ? zero4 : hp2[ii];
+                ext[i] = xzero ? zero4 : xt2[ii];
+            }
         } else if (it > 0 && nkw > 0) {
             const float* xin = S.xf + (long)((it - 1) & 1) * FS3;
             f32x4 fa[D][MT][2], fb[2][2];
