@@ -77,7 +77,7 @@ def _classify(name, a, k):
         kind = "fwd" if name == "gru_seq_fwd" else "bwd"
         if len(scans) == 4:
             return "enc_%s_scan" % kind, work
-        if all(str(s_.get("tag", "")).startswith("dec_l") for s_ in scans):
+        if all(str(s_.get("tag", "")).startswith(("dec_l", "sd_")) for s_ in scans):
             return ("dec_%s_scan_chunk" % kind, work) if len(scans) == 2 else None      # steady state: layer 1 + layer 2 in one launch
         if len(scans) == 2:
             return "subdec_%s_scan" % kind, work
@@ -107,8 +107,8 @@ def _classify(name, a, k):
 ROW_INFO = {   # row -> (bound, unit of work, kernel, peak share of the chip)
     "enc_fwd_scan": ("mfma", "flop", "gru_fwd_persist_kernel (4 encoder scans x 256 steps, one launch)", 1.0),
     "enc_bwd_scan": ("mfma", "flop", "gru_bwd_persist_kernel (4 encoder scans x 256 steps, one launch)", 1.0),
-    "dec_fwd_scan_chunk": ("mfma", "flop", "gru_fwd_persist_kernel (decoder layer 1 chunk k + layer 2 chunk k-2, one launch)", 1.0),
-    "dec_bwd_scan_chunk": ("mfma", "flop", "gru_bwd_persist_kernel (decoder layer 2 chunk k + layer 1 chunk k+2, one launch)", 1.0),
+    "dec_fwd_scan_chunk": ("mfma", "flop", "gru_fwd_persist_kernel (one launch of the decoder pipeline: 2 scans x 256 rows x 32 steps - layer 1 chunk k + layer 2 chunk k-2, attribute-decoder chunks at both ends)", 1.0),
+    "dec_bwd_scan_chunk": ("mfma", "flop", "gru_bwd_persist_kernel (one launch of the decoder pipeline: 2 scans x 256 rows x 32 steps - layer 2 chunk k + layer 1 chunk k+2, attribute-decoder chunks at both ends)", 1.0),
     "subdec_fwd_scan": ("mfma", "flop", "gru_fwd_persist_kernel (both sub-decoders, 64 steps)", 1.0),
     "subdec_bwd_scan": ("mfma", "flop", "gru_bwd_persist_kernel (both sub-decoders, 64 steps)", 1.0),
     "dwhh_gemm_tn": ("mfma", "flop", "gemm_tn_kernel via fn_gru_dwhh_f32 (dW_hh of the encoder scans, K = T*B rows)", 1.0),

@@ -43,6 +43,8 @@ class Engine:
         self.saved = None
         self.chunk = 32                 # time steps per pipeline chunk of the two decoder layers (layer 2 lags layer 1 by two chunks)
         self.persist_dec = True         # decoder scans as weight-stationary launches (False: per-step kernels; debug / tests)
+        self.fill_edges = True          # the attribute decoders' chunks ride in the half-empty head / tail launches of the global decoder's
+                                        # two-layer pipeline (same results; False: one launch of their own)
         self.single_launch_decode = True   # decode.py: small / medium batches decode as ONE launch (False: per-token kernels; tests)
         self.single_launch_rows = 767      # ... up to this many sequences (fn_decode_greedy takes <= 1024; measured us per token, one launch vs the next best path: 128 rows 27.7 / 57.6, 256 rows 29.7 / 58.7, 512 rows 55.0 / 67.6, 704 rows 74.9 / 88.1, 800 rows 88.3 / 88.4); above: staged-GEMM cells
         self._lane_alias = {}           # lane -> lane it is folded into (debug)
@@ -271,8 +273,10 @@ class Engine:
             out[e] = o
         return out
 
-    def sub_decoders_fwd(self, r, n, z_r, z_n, save=True):
-        """gmm_model.py:100-117 up to the pre-softmax logits: both attribute decoders as ONE weight-stationary launch (whole chip)."""
+    def sub_decoders_fwd(self, r, n, z_r, z_n, save=True, defer=False):
+        """gmm_model.py:100-117 up to the pre-softmax logits: both attribute decoders as ONE weight-stationary launch (whole chip).
+        defer=True: only the initial states / per-sequence input parts; the scan descriptors are left in sd[e]['scan'] for
+        global_decoder_tf(fill=...) and the logits for _sub_decoder_logits."""
         ops, P, H = self.ops, self.p, self.H
         B, Tr = r.shape
         scans, sd = [], {}
@@ -289,7 +293,16 @@ class Engine:
                               b_ih=P["gru_d_%s.bias_ih_l0" % e], h0=h0, gx_table=self.tab["d_" + e], idx=attr, gx_rowbias=rb,
                               h_all=sd[e]["h_all"], gates=sd[e]["gates"]))
         ops.gemm_multi(jobs)                                     # initial states + per-sequence input parts of both decoders: one launch
+        if defer:
+            for e, sc in zip(("r", "n"), scans):
+                sc["tag"] = "sd_" + e
+                sd[e]["scan"] = sc
+            return sd
         ops.gru_seq_fwd(scans)
+        return self._sub_decoder_logits(sd, Tr, B)
+
+    def _sub_decoder_logits(self, sd, Tr, B):
+        ops, P, H = self.ops, self.p, self.H
         for e, Ce in (("r", R_DIMS), ("n", N_DIMS)):
             sd[e]["logits"] = self.buf("sd_logits_" + e, (Tr, B, Ce))
             ops.gemm(sd[e]["h_all"].view(Tr * B, H), P["linear_out_%s.weight" % e], sd[e]["logits"].view(Tr * B, Ce),
@@ -305,7 +318,12 @@ class Engine:
         zc[:, 2 * Z:].copy_(c)
         return zc
 
-    def global_decoder_tf(self, d, zc, save=True, head=True):
+    def _fill_ok(self, T, Tr):
+        """the attribute decoders (Tr steps) fit the two head and two tail launches of the global decoder's pipeline"""
+        CH = self.chunk
+        return bool(self.fill_edges and self.persist_dec and Tr <= 2 * CH and T >= 2 * CH and Tr > 1)
+
+    def global_decoder_tf(self, d, zc, save=True, head=True, fill=None):
         """gmm_model.py:119-149 in train mode (teacher forced with d, start token 341, input shifted by one step) up to the
         pre-softmax logits [T*B][LOGIT_LD].  head=False: the output projection is left to the caller's fused head
         (ops.out_head on dec['hx1'], which writes the gradient seed into dec['logits']); the buffer is returned unwritten."""
@@ -336,20 +354,29 @@ class Engine:
         # a chunk leaves its final state ALSO in the fragment-major exchange layout; the next chunk of that layer starts from it
         # without a packing launch (FnGruFwd.h_last_frag -> h0_frag)
         nf = ops.frag_floats(B, H)
-        hand = {name: [self.buf("g_hand_%s_%d" % (name, i), (nf,)) for i in range(2)] for name in ("l1", "l2")}
+        hand = {name: [self.buf("g_hand_%s_%d" % (name, i), (nf,)) for i in range(2)] for name in ("l1", "l2", "sd_r", "sd_n")}
 
-        def chunk(name, sc, ci):
-            c = self._fwd_chunk(sc, starts[ci], starts[ci] + CH)
+        def chunk(name, sc, ci, n=None):
+            n = nch if n is None else n
+            c = self._fwd_chunk(sc, ci * CH, ci * CH + CH)
             if ci > 0:
                 c["h0_frag"] = hand[name][(ci - 1) & 1]
-            if ci + 1 < nch:
+            if ci + 1 < n:
                 c["h_last_frag"] = hand[name][ci & 1]
             return c
 
+        # launches 0, 1 (layer 1 alone) and nch, nch+1 (layer 2 alone) would leave half of the chip idle: the attribute decoders' chunks
+        # (independent scans of the same batch) ride there - 'r' in the head, 'n' in the tail
+        fill = fill or {}
+        nsd = {e: (sc["T"] + CH - 1) // CH for e, sc in fill.items()}
         for k in range(nch + 2):
             part = []
             if k < nch:
                 part.append(chunk("l1", l1, k))
+            if k < 2 and "r" in fill and k < nsd["r"]:
+                part.append(chunk("sd_r", fill["r"], k, nsd["r"]))
+            if k >= nch and "n" in fill and k - nch < nsd["n"]:
+                part.append(chunk("sd_n", fill["n"], k - nch, nsd["n"]))
             if k >= 2:
                 c2 = chunk("l2", l2, k - 2)
                 if k == 2:
@@ -371,8 +398,13 @@ class Engine:
 
     def decoders(self, d, r, n, c, z_r, z_n, save=True, head=True):
         """sub-decoders + teacher-forced global decoder up to the (pre-softmax) logits."""
-        sd = self.sub_decoders_fwd(r, n, z_r, z_n, save)
-        dec = self.global_decoder_tf(d, self.pack_zc(z_r, z_n, c), save, head)
+        if self._fill_ok(d.shape[1], r.shape[1]):
+            sd = self.sub_decoders_fwd(r, n, z_r, z_n, save, defer=True)
+            dec = self.global_decoder_tf(d, self.pack_zc(z_r, z_n, c), save, head, fill={e: sd[e].pop("scan") for e in ("r", "n")})
+            self._sub_decoder_logits(sd, r.shape[1], r.shape[0])
+        else:
+            sd = self.sub_decoders_fwd(r, n, z_r, z_n, save)
+            dec = self.global_decoder_tf(d, self.pack_zc(z_r, z_n, c), save, head)
         dec["sd"] = sd
         return dec
 
@@ -448,7 +480,7 @@ class Engine:
     def _splitk(rows):
         return 16 if rows >= 32768 else (8 if rows >= 4096 else (4 if rows >= 1024 else 1))
 
-    def _bwd_global_decoder_scans(self, S):
+    def _bwd_global_decoder_scans(self, S, fill=None):
         """Backward of global_decoder_tf up to the gate gradients (dlogits must already be in S['dec']['logits'], in place):
         output layer dX, then the two cells, chunk-pipelined.  Returns the gate-gradient buffers, the per-sequence row sums
         (drb_g = d(W_ih[:, V:] z) rows, i.e. the gradient wrt the conditioning projection) and dh0_g = dL/d(linear_init_global(z))."""
@@ -479,6 +511,15 @@ class Engine:
             slot = (t0 // CH) & 1
             return self._bwd_chunk(sc, t0, t1, None if t1 >= T else carry[name][slot ^ 1], carry[name][slot])
 
+        # the attribute decoders' reverse scans ride in the half-empty launches (see global_decoder_tf): 'n' beside layer 2's first two
+        # chunks, 'r' beside layer 1's last two; fill[e] = (descriptor, buffer for dL/dh0)
+        fill = fill or {}
+        fch = {}
+        for e, (sc, dh0) in fill.items():
+            ts = list(reversed(range(0, sc["T"], CH)))
+            cb = self.buf("carry_sd_" + e, (B, H))
+            fch[e] = [self._bwd_chunk(sc, t0, min(t0 + CH, sc["T"]), None if t0 + CH >= sc["T"] else cb, dh0 if t0 == 0 else cb) for t0 in ts]
+
         pd = self.persist_dec
         # launch k = [layer 2, chunk js[k]] + [layer 1, chunk js[k-2]] (time runs backwards: js = last chunk .. first), ONE weight-
         # stationary launch of two independent scans (8 row groups = one per XCD); beside launch k+1 the aux lane turns the layer-2
@@ -489,9 +530,13 @@ class Engine:
             part = []
             if k < nch:
                 part.append(chunk("l2", l2, js[k]))
+            if k < 2 and "n" in fch and k < len(fch["n"]):
+                part.append(fch["n"][k])
             if k >= 2:
                 self.lane_wait("main", "auxb%d" % (k & 1))
                 part.append(chunk("l1", l1, js[k - 2]))
+            if k >= nch and "r" in fch and k - nch < len(fch["r"]):
+                part.append(fch["r"][k - nch])
             if part:
                 ops.gru_seq_bwd(part, persistent=pd)
             if k < nch:
@@ -554,14 +599,20 @@ class Engine:
         sk_T, sk_Tr = self._splitk(T * B), self._splitk(Tr * B)
 
         # ---- global decoder: output layer + both cells, chunk-pipelined (see _bwd_global_decoder_scans) ----------------
-        gd = self._bwd_global_decoder_scans(S)
-        self.main_wait_side()            # the caller's loss terms / gradient seeds of the sub-decoders and of z (side lane)
+        sd = dec["sd"]
+        if self._fill_ok(T, Tr):
+            # ---- both attribute decoders ride in the half-empty launches of the global decoder's pipeline ------------------------
+            self.main_wait_side()        # the caller's loss terms / gradient seeds of the sub-decoders and of z (side lane)
+            sdb, sds = self._bwd_sub_decoder_scans(sd, dlogits_sd, B, Tr, defer=True)
+            gd = self._bwd_global_decoder_scans(S, fill={e: (sds[e], sdb[e]["dh0"]) for e in ("r", "n")})
+        else:
+            gd = self._bwd_global_decoder_scans(S)
+            self.main_wait_side()
+            # ---- sub-decoders: both attribute decoders, all Tr steps, ONE whole-chip launch ----------------------------------
+            sdb = self._bwd_sub_decoder_scans(sd, dlogits_sd, B, Tr)
         dgx1, dghn1, dgx2, dghn2, rs2, rsn2, drb_g, rsn_g, dh0_g = (gd[k] for k in ("dgx1", "dghn1", "dgx2", "dghn2", "rs2", "rsn2", "drb_g", "rsn_g", "dh0_g"))
         dlog = dec["logits"]
         pd = self.persist_dec
-        # ---- sub-decoders: both attribute decoders, all Tr steps, ONE whole-chip launch ----------------------------------
-        sd = dec["sd"]
-        sdb = self._bwd_sub_decoder_scans(sd, dlogits_sd, B, Tr)
         # ---- what the encoder side needs from the decoders (main stream, critical path): dz ---------------------
         Wz_g, Wig = P["grucell_g.weight_ih"], P["linear_init_global.weight"]
         jobs = []
@@ -582,7 +633,7 @@ class Engine:
         self.backward_encoder(G, S, lat_up, w3, after_encoder_r)
         self.main_wait_side()
 
-    def _bwd_sub_decoder_scans(self, sd, dlogits_sd, B, Tr):
+    def _bwd_sub_decoder_scans(self, sd, dlogits_sd, B, Tr, defer=False):
         """output layers' input gradients + the reverse scans of both attribute decoders (ONE launch); -> per decoder dict(dgx, dghn,
         drb = per-sequence sums of the gate gradients (= gradient wrt the z projection), rsn, dh0 = dL/d linear_init(z))"""
         ops, P, H = self.ops, self.p, self.H
@@ -595,7 +646,9 @@ class Engine:
                           drb=self.zbuf("sd_drb_" + e, (B, 3 * H)), rsn=self.zbuf("sd_rsn_" + e, (B, H)), dh0=self.buf("sd_dh0_" + e, (B, H)))
             sds[e] = dict(B=B, T=Tr, H=H, w_hh_t_frag=self.whh_t["d_" + e], h0=sd[e]["h0"], h_all=sd[e]["h_all"], gates=sd[e]["gates"],
                           dh_ext=dh_sd[e], dgx_all=sdb[e]["dgx"], dghn_all=sdb[e]["dghn"], scratch=self.buf("sd_scr_" + e, (B, H)),
-                          dgx_rowsum=sdb[e]["drb"], dghn_rowsum=sdb[e]["rsn"])
+                          dgx_rowsum=sdb[e]["drb"], dghn_rowsum=sdb[e]["rsn"], tag="sd_" + e)
+        if defer:                                                # the scans are left to _bwd_global_decoder_scans(fill=...)
+            return sdb, sds
         ops.gru_seq_bwd([self._bwd_chunk(sds[e], 0, Tr, None, sdb[e]["dh0"]) for e in ("r", "n")], persistent=self.persist_dec)
         return sdb
 
