@@ -50,7 +50,8 @@ class Engine:
         self._lane_alias = {}           # lane -> lane it is folded into (debug)
         self.cell_decode_rows = 768     # decode.py: from this many sequences on, the per-token cells are staged-GEMM launches (fn_gru_cell_f32); measured crossover (scratch/bench_decode_rows.py): 512 rows 67 vs 87 us per token, 768 rows 97 vs 88
         self.fused_head = True          # trainers: output projection + log-softmax + NLL + gradient seed as ONE kernel (fn_out_head_f32); False: GEMM -> logits in HBM -> fn_vocab_logsoftmax
-        self.lean_dw = True             # decoder-side weight-gradient GEMMs as the <= 128-register instance: one of its wavefronts fits on a SIMD beside an encoder-scan wavefront (374 of 512 registers), the 194-register instance waits for the scan to end
+        self.lean_dw = False            # decoder-side weight-gradient GEMMs as the <= 128-register instance.  Paid while an encoder-scan wavefront left 138 of a SIMD's 512 registers free (round 2: 9 % packing gain); the hand-placed K loops hold all of them, the side lane's GEMMs run once the scan has ended and the 194-register instance is the faster one (A/B in one session, scratch/ab_dw.py: 23.65 vs 24.29 ms per step)
+        self.dw_order = "side"          # decoder-side weight-gradient GEMMs: "side" = side stream, issued in front of the encoder backward; "before" / "after" = caller's stream, in front of / behind the encoder block
         self.losses_on_side = True      # trainer: the small loss-term launches run on the side lane beside the decoder backward's first launches
         self.buf_ns = ""                # namespace of buf(): a second decoder pass (GLSR) must not overwrite the saved activations of the first
         self.serialize_lanes = False    # True: every lane runs on the caller's stream (per-kernel measurements: each kernel alone)
@@ -615,23 +616,52 @@ class Engine:
         pd = self.persist_dec
         # ---- what the encoder side needs from the decoders (main stream, critical path): dz ---------------------
         Wz_g, Wig = P["grucell_g.weight_ih"], P["linear_init_global.weight"]
-        jobs = []
-        for e, c0, Ce in (("r", 0, R_DIMS), ("n", Z, N_DIMS)):      # four products into each g_z (it already holds the regulariser's part)
-            jobs.append(dict(C=lat_up[e]["g_z"], beta=1.0,
-                             segs=[(drb_g, Wz_g[:, E_VOCAB + c0:E_VOCAB + c0 + Z]), (dh0_g, Wig[:, c0:c0 + Z]),
-                                   (sdb[e]["drb"], P["gru_d_%s.weight_ih_l0" % e][:, Ce:]), (sdb[e]["dh0"], P["linear_init_%s.weight" % e])]))
+        # four products into each g_z (it already holds the regulariser's part).  As ONE job per latent that is 8 workgroups walking
+        # K = 4096 on the critical path (245 us); instead 6 partial products per latent with K <= 3H/2 (12 jobs, one launch) and one
+        # column-sum launch that adds the partials to g_z in a fixed order
+        NP = 6
+        part = self.buf("gz_part", (2, NP, B, Z))
+        jobs, sums = [], []
+        for ei, (e, c0, Ce) in enumerate((("r", 0, R_DIMS), ("n", Z, N_DIMS))):
+            prods = [(drb_g, Wz_g[:, E_VOCAB + c0:E_VOCAB + c0 + Z]), (dh0_g, Wig[:, c0:c0 + Z]),
+                     (sdb[e]["drb"], P["gru_d_%s.weight_ih_l0" % e][:, Ce:]), (sdb[e]["dh0"], P["linear_init_%s.weight" % e])]
+            pieces = []
+            for A, W in prods:
+                Kp = A.shape[1]
+                if Kp >= 2 * H and Kp % 2 == 0:
+                    pieces += [(A[:, :Kp // 2], W[:Kp // 2]), (A[:, Kp // 2:], W[Kp // 2:])]
+                else:
+                    pieces.append((A, W))
+            assert len(pieces) == NP
+            jobs += [dict(C=part[ei, i], beta=0.0, segs=[pc]) for i, pc in enumerate(pieces)]
+            sums.append((part[ei].view(NP, B * Z), lat_up[e]["g_z"].view(-1), 1.0))
         ops.gemm_multi(jobs, a_k=True, b_k=False)
-        # ---- decoder-side PARAMETER gradients: side stream, overlapping the latent block and the encoder scans ---
-        self.side_wait_main()
-        with self.on_side():
+        ops.colsum_multi(sums)
+        # ---- decoder-side PARAMETER gradients (dw_order: where they run relative to the latent block and the encoder scans) ---
+        def decoder_params():
             self._bwd_global_decoder_params(G, S, gd, flush=False)
             self._bwd_sub_decoder_params(G, sd, sdb, dlogits_sd, S["sort"], {"r": lat["r"]["z"], "n": lat["n"]["z"]}, B, Tr)
             self.flush_colsums()
             if after_decoders is not None:
-                after_decoders()           # data parallel: this bucket's all-reduce is ordered behind the side stream
+                after_decoders()           # data parallel: this bucket's all-reduce is ordered behind these launches
 
-        self.backward_encoder(G, S, lat_up, w3, after_encoder_r)
-        self.main_wait_side()
+        if self.dw_order in ("side", "side_late"):
+            def on_side_lane():
+                self.side_wait_main()
+                with self.on_side():
+                    decoder_params()
+            if self.dw_order == "side":
+                on_side_lane()
+            # "side_late": the side lane starts behind the latent block / heads, so its GEMMs do not sit beside those small
+            # launches of the critical path
+            self.backward_encoder(G, S, lat_up, w3, after_encoder_r, before_scans=on_side_lane if self.dw_order == "side_late" else None)
+            self.main_wait_side()
+        elif self.dw_order == "before":
+            decoder_params()
+            self.backward_encoder(G, S, lat_up, w3, after_encoder_r)
+        else:
+            self.backward_encoder(G, S, lat_up, w3, after_encoder_r)
+            decoder_params()
 
     def _bwd_sub_decoder_scans(self, sd, dlogits_sd, B, Tr, defer=False):
         """output layers' input gradients + the reverse scans of both attribute decoders (ONE launch); -> per decoder dict(dgx, dghn,
@@ -670,7 +700,7 @@ class Engine:
             ops.gemm(sdb[e]["dh0"], z[e], G["linear_init_%s.weight" % e], a_k=False, b_k=False)
             self.colsum(sdb[e]["dh0"], G["linear_init_%s.bias" % e])
 
-    def backward_encoder(self, G, S, lat_up, w3=None, after_encoder_r=None):
+    def backward_encoder(self, G, S, lat_up, w3=None, after_encoder_r=None, before_scans=None):
         """latent block + heads + the four encoder scans and their parameter gradients (the last third of backward(); also the whole
         backward of a direct ``model.encode(x)`` call: S then holds d, pre, lat, eps, labels, sort['d'] only)"""
         ops, P, H, Z, K = self.ops, self.p, self.H, self.Z, self.K
@@ -706,6 +736,8 @@ class Engine:
                 scans.append(dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t[key], h0=None, h_all=pre["h_all"][key],
                                   gates=pre["gates"][key], dh_last=dh, dgx_all=encb[key]["dgx"], dghn_all=encb[key]["dghn"],
                                   scratch=self.buf("enc_scr_" + key, (B, H)), dgx_rowsum=encb[key]["rs"], dghn_rowsum=encb[key]["rsn"]))
+        if before_scans is not None:
+            before_scans()
         ops.gru_seq_bwd(scans)        # 4 concurrent reverse scans, one weight-stationary launch
         enc_keys = [(e, "gru_%s." % e, key, sfx, rev) for e in ("r", "n") for key, sfx, rev in ((e, "_l0", 0), (e + "_reverse", "_l0_reverse", 1))]
         # one-hot columns of the four W_ih: token-segment sums of the gate gradients (ONE launch pair, the batch's token sort is shared)

@@ -95,14 +95,15 @@ def test_fused_step_gradients(small, sup, chunk):
     np.testing.assert_allclose(tr.grad_norm(), small["gradnorm_%s_20000" % tag][0], rtol=1e-4)
 
 
-@pytest.mark.parametrize("fused,lean", [(False, False), (True, True)])
-def test_fused_step_schedule_switches(small, fused, lean):
-    """Engine.fused_head (projection + log-softmax + NLL + gradient seed as one op, logits never written) and Engine.lean_dw (the
-    <= 128-register weight-gradient instance) change which ops run, never what comes out: the reference's gradients either way."""
+@pytest.mark.parametrize("fused,lean,order", [(False, False, "side"), (True, True, "before"), (True, False, "after")])
+def test_fused_step_schedule_switches(small, fused, lean, order):
+    """Engine.fused_head (projection + log-softmax + NLL + gradient seed as one op, logits never written), Engine.lean_dw (the
+    <= 128-register weight-gradient instance) and Engine.dw_order (where the decoder-side weight-gradient GEMMs are issued) change
+    which ops run and when, never what comes out: the reference's gradients either way."""
     pkg = load_package()
     m = make_model(64, 32, sd_from(small, "w0/"), ops=FakeOps())
     tr = pkg.GMVAETrainer(m, lr=1e-3, beta=0.2)
-    m.engine().fused_head, m.engine().lean_dw = fused, lean
+    m.engine().fused_head, m.engine().lean_dw, m.engine().dw_order = fused, lean, order
     b = batch_of(small)
     batch = tr.prepare_batch(b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"])
     eps = (torch.from_numpy(small["eps_r"]), torch.from_numpy(small["eps_n"]))
