@@ -282,12 +282,13 @@ int fn_embed_grad_f32(const float* dgx_all, int B, int T, int N3, const int32_t*
 /* out[m] = sum_t X[t*M + m]   (per-sequence sums over time of the gate gradients; M % 4 == 0, 16-byte aligned) */
 int fn_time_sum_f32(const float* X, int T, int64_t M, float* out, void* stream);
 
-/* Greedy autoregressive decode of the global decoder for B <= 1024 sequences (H <= 512) as ONE launch
+/* Greedy autoregressive decode of the global decoder for B <= 2048 sequences (H <= 512) as ONE launch
  * (gmm_model.py:119-149 with model.eval(): layer-1 cell, layer-2 cell (state initialised with the first layer-1 state, :134-135),
  * 512 -> V output layer, log_softmax, feedback = first-index argmax, :73-80,147-148).  Workgroup sets keep the four weight
  * matrices in LDS and hand activations over through L2 (bounded spins, sticky error word as in fn_gru_seq_fwd).  More than 32
  * sequences (the reference's evaluators decode 8 fader values x 100 samples at once, test_class.py:84-85,253) travel through the
- * role workgroups as a pipeline of 32-row blocks, two replicas of the role set side by side when the device has the CUs. */
+ * role workgroups as a pipeline of 32-row blocks (64-row blocks from 353 sequences on: a role's time per block is mostly latency), two
+ * replicas of the role set side by side when the device has the CUs. */
 typedef struct FnDecode {
     int32_t B, steps, H, V;
     int32_t start_token;      /* input token of step 0 (V - 1)                                       */

@@ -1,4 +1,4 @@
-// decode_persist.hip - greedy autoregressive decode of the global decoder (gmm_model.py:119-149 with model.eval()) for up to 1024
+// decode_persist.hip - greedy autoregressive decode of the global decoder (gmm_model.py:119-149 with model.eval()) for up to 2048
 // sequences as ONE launch: the per-token chain  layer-1 cell -> W_ih2 projection -> layer-2 cell -> 512->V output layer ->
 // log-softmax + argmax -> next token  is latency-bound (five dependent kernels per token otherwise), so each link gets its own set
 // of workgroups that keep their weight slice in LDS for the whole decode and hand the activations to the next set through L2:
@@ -16,7 +16,7 @@
 // which is after every reader of step t has arrived.  The 4 waves of a workgroup split K and add their partial tiles through LDS.
 //
 // More than 32 sequences (the reference's evaluator decodes 8 fader values x 100 samples = 800 rows at once, test_class.py:84-85): the
-// batch is cut into BLOCKS of 32 rows that travel through the same role workgroups one after the other - a pipeline: while L1 works on
+// batch is cut into BLOCKS of 32 rows (64 rows from FN_DECODE_MT4_ROWS sequences on) that travel through the same role workgroups one after the other - a pipeline: while L1 works on
 // block b+1, P2 has block b, L2 block b-1 ... - with one set of counters and exchange slabs per block; the LDS-resident weight slices are
 // reused by every block, and a second replica of the whole role set (2 x 119 workgroups <= 256 CUs at H = 512) takes every other block.
 // Per-block state (a cell's own previous state slice, the per-row input constants) is re-read from the exchange slabs / L2 instead of
@@ -44,7 +44,10 @@ namespace {
 constexpr int NT = 256;
 constexpr int C1 = 0, C2 = 32, C3 = 64, C4 = 96, C5 = 128;               // word offsets inside a block's counters (one 128-byte line each)
 constexpr int BLKW = 160;                                                 // counter words per block
-constexpr int MAXBLK = 32;                                                // blocks of 32 rows: up to 1024 sequences
+#ifndef FN_DECODE_MT4_ROWS
+#define FN_DECODE_MT4_ROWS 353                                            // from this many sequences on: 64-row blocks (measured crossover, profiles/r03_decode_block_pipeline.txt: 320 rows 34.5 vs 36.4 us per token, 384 rows 41.8 vs 35.9)
+#endif
+constexpr int MAXBLK = 32;                                                // blocks of 32 / 64 rows: up to 1024 / 2048 sequences
 constexpr int ERRW = MAXBLK * BLKW;                                       // sticky error word behind all counters
 
 struct DArgs {
@@ -117,10 +120,18 @@ FN_DEVINL void kquarter(const float* xin, const float* wl, int nk, int lane, int
                 gld4_sc1(fa[it][m][1], xin + ((long)m * nk + c0 + it) * 512 + 256 + lane * 4);
             }
         }
-    fn_wait_vm<0>();
+    // four chunks requested (H = 512): chunk `it` is multiplied as soon as it has landed, the younger ones stay in flight behind the MFMAs
+    const bool full = nkw == 4;
+    if (!full) fn_wait_vm<0>();
 #pragma unroll
     for (int it = 0; it < 4; ++it)
         if (it < nkw) {
+            if (full) {
+                if (it == 0) fn_wait_vm<3 * MT * 2>();
+                else if (it == 1) fn_wait_vm<2 * MT * 2>();
+                else if (it == 2) fn_wait_vm<1 * MT * 2>();
+                else fn_wait_vm<0>();
+            }
             const int c = c0 + it;
             f32x4 fb[NTN][2];
 #pragma unroll
@@ -374,9 +385,12 @@ __global__ __launch_bounds__(NT) void decode_greedy_kernel(const DArgs a) {
                 FN_DSTAMP(2, 3);
                 if (!sy.wait(C2, unsl * (u32)(t + 1))) return;
                 FN_DSTAMP(2, 4);
-                f32x4 gx[3];
+                f32x4 gx[3];                                              // three requests, ONE wait
 #pragma unroll
-                for (int q = 0; q < 3; ++q) gx[q] = ldv4_sc1(a.g2 + (long)b * 3 * H + q * H + jj0);
+                for (int q = 0; q < 3; ++q) gld4_sc1(gx[q], a.g2 + (long)b * 3 * H + q * H + jj0);
+                fn_wait_vm<0>();
+#pragma unroll
+                for (int q = 0; q < 3; ++q) fn_touch(gx[q]);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float r = fn_sigmoid(gx[0][c] + gh[0][c]);
@@ -524,7 +538,7 @@ int launch_decode(const DArgs& a, int grid, hipStream_t st) {
 extern "C" {
 
 size_t fn_decode_ws_bytes(int B, int H, int V) {
-    const size_t bp = B <= 16 ? 16 : (size_t)(B + 31) / 32 * 32, vp = (size_t)(V + 15) / 16 * 16;    // rows as the kernel tiles them
+    const size_t bp = B <= 16 ? 16 : (size_t)(B + 63) / 64 * 64, vp = (size_t)(V + 15) / 16 * 16;    // rows as the kernel tiles them (blocks of 16 / 32 / 64)
     return (4 * bp * H + bp * 3 * H + bp * vp) * sizeof(float);
 }
 
@@ -535,7 +549,7 @@ int fn_decode_greedy(const FnDecode* d, void* stream) {
     if (!d->w_hh1_frag || !d->b_hh1 || !d->table1 || !d->h0 || !d->w_ih2_frag || !d->w_hh2_frag || !d->b_hh2 || !d->w_out_frag || !d->b_out ||
         !d->tokens || !d->ws || !d->sync_ws)
         return FN_E_NULL;
-    if (d->B <= 0 || d->B > MAXBLK * 32 || d->steps <= 0 || d->H <= 0 || (d->H % 32) != 0 || d->H > 512 || d->V <= 0 || d->V > 384 || d->tok_ld < d->steps)
+    if (d->B <= 0 || d->B > MAXBLK * 64 || d->steps <= 0 || d->H <= 0 || (d->H % 32) != 0 || d->H > 512 || d->V <= 0 || d->V > 384 || d->tok_ld < d->steps)
         return FN_E_SHAPE;
     const uintptr_t al = (uintptr_t)d->w_hh1_frag | (uintptr_t)d->w_ih2_frag | (uintptr_t)d->w_hh2_frag | (uintptr_t)d->w_out_frag |
                          (uintptr_t)d->b_hh1 | (uintptr_t)d->b_ih1 | (uintptr_t)d->table1 | (uintptr_t)d->rowbias1 | (uintptr_t)d->h0 |
@@ -548,8 +562,12 @@ int fn_decode_greedy(const FnDecode* d, void* stream) {
     const int per_rep = 3 * nsl + nvt + 1;
     if (per_rep > prop.multiProcessorCount) return FN_E_UNSUPPORTED;  // every workgroup must be resident: one per CU
     hipStream_t st = (hipStream_t)stream;
-    const int mt = d->B <= 16 ? 1 : 2;                                 // row tiles per block (64-row blocks were measured slower per row: a block's time is latency, not MFMA)
+    // row tiles per block.  Latency regime (few blocks per replica): a block's time is its hand-over chain, 32-row blocks give the chain
+    // more blocks to overlap.  Throughput regime: a role's busy time per block is ~8.6 k cycles of latency + 6.1 k of MFMA per 32 rows, so
+    // 64-row blocks halve the latency share per row
+    const int mt = d->B <= 16 ? 1 : (d->B >= FN_DECODE_MT4_ROWS ? 4 : 2);
     const int nblk = (d->B + mt * 16 - 1) / (mt * 16);
+    if (nblk > MAXBLK) return FN_E_SHAPE;
     int nrep = prop.multiProcessorCount / per_rep;                     // replicas of the role set that fit one workgroup per CU
     nrep = nrep < nblk ? nrep : nblk;
     const int grid = nrep * per_rep;
@@ -569,7 +587,7 @@ int fn_decode_greedy(const FnDecode* d, void* stream) {
     if (rc != FN_OK) return rc;
     hipError_t me = hipMemsetAsync(a.sync, 0, (size_t)ERRW * 4, st);             // counters only: the error word is sticky
     if (me != hipSuccess) return (int)me;
-    return mt == 1 ? launch_decode<1>(a, grid, st) : launch_decode<2>(a, grid, st);
+    return mt == 1 ? launch_decode<1>(a, grid, st) : (mt == 2 ? launch_decode<2>(a, grid, st) : launch_decode<4>(a, grid, st));
 }
 
 }  // extern "C"

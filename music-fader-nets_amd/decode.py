@@ -15,7 +15,7 @@ from .engine import E_VOCAB, LOGIT_LD
 def greedy_decode(model, z, steps, want_logp=True, use_graph=None):
     """z (Bi, 2Z+24) -> (log-probs (Bi, steps, 342) or None, tokens (Bi, steps) int32).
 
-    Bi <= Engine.single_launch_rows: ONE launch for the whole decode (fn_decode_greedy; above 32 rows a pipeline of 32-row blocks through
+    Bi <= Engine.single_launch_rows: ONE launch for the whole decode (fn_decode_greedy; above 32 rows a pipeline of 32- / 64-row blocks through
     its role workgroups).  Larger batches: steps x {layer-1 cell, W_ih2 projection,
     layer-2 cell, output GEMM, log_softmax+argmax} (from Engine.cell_decode_rows sequences on: steps x {layer-1 cell, layer-2 cell incl.
     its projection - fn_gru_cell_f32 -, output GEMM, argmax}) captured once per (Bi, steps) into a hipGraph and replayed.  The captured

@@ -46,7 +46,7 @@ class Engine:
         self.fill_edges = True          # the attribute decoders' chunks ride in the half-empty head / tail launches of the global decoder's
                                         # two-layer pipeline (same results; False: one launch of their own)
         self.single_launch_decode = True   # decode.py: small / medium batches decode as ONE launch (False: per-token kernels; tests)
-        self.single_launch_rows = 767      # ... up to this many sequences (fn_decode_greedy takes <= 1024; measured us per token, one launch vs the next best path: 128 rows 27.7 / 57.6, 256 rows 29.7 / 58.7, 512 rows 55.0 / 67.6, 704 rows 74.9 / 88.1, 800 rows 88.3 / 88.4); above: staged-GEMM cells
+        self.single_launch_rows = 1536     # ... up to this many sequences (fn_decode_greedy takes <= 2048; 32-row blocks below 353 rows, 64-row blocks from there; measured us per token, one launch vs the next best path: 128 rows 27.1 / 57.5, 256 rows 28.0 / 58.8, 512 rows 41.2 / 67.9, 800 rows 68.9 / 88.2, 1024 rows 79.2 / 88.0, 1536 rows 117 / 126, 2048 rows 156 / 127); above: staged-GEMM cells
         self._lane_alias = {}           # lane -> lane it is folded into (debug)
         self.cell_decode_rows = 768     # decode.py: from this many sequences on, the per-token cells are staged-GEMM launches (fn_gru_cell_f32); measured crossover (scratch/bench_decode_rows.py): 512 rows 67 vs 87 us per token, 768 rows 97 vs 88
         self.fused_head = True          # trainers: output projection + log-softmax + NLL + gradient seed as ONE kernel (fn_out_head_f32); False: GEMM -> logits in HBM -> fn_vocab_logsoftmax

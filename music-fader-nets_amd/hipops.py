@@ -324,7 +324,7 @@ class HipOps:
 
     def decode_greedy(self, B, steps, H, V, start_token, w_hh1_frag, b_hh1, b_ih1, table1, rowbias1, h0, w_ih2_frag, b_ih2, w_hh2_frag, b_hh2,
                       w_out_frag, b_out, tokens, logp=None):
-        """single-launch greedy decode of <= 1024 sequences (fn_decode_greedy); tokens int32 [B][>=steps], logp [B][steps][V] or None"""
+        """single-launch greedy decode of <= 2048 sequences (fn_decode_greedy); tokens int32 [B][>=steps], logp [B][steps][V] or None"""
         d = _lib.FnDecode()
         for t, nm in ((w_hh1_frag, "w_hh1_frag"), (b_hh1, "b_hh1"), (b_ih1, "b_ih1"), (table1, "table1"), (rowbias1, "rowbias1"), (h0, "h0"),
                       (w_ih2_frag, "w_ih2_frag"), (b_ih2, "b_ih2"), (w_hh2_frag, "w_hh2_frag"), (b_hh2, "b_hh2"), (w_out_frag, "w_out_frag"),

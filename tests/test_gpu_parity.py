@@ -687,11 +687,12 @@ def test_single_launch_decode_matches_per_token_kernels(H, Bi, steps, monkeypatc
     close(lp1[:, :upto], lp0[:, :upto], 2e-5)
 
 
-@pytest.mark.parametrize("H,Bi,steps", [(64, 45, 20), (512, 64, 30), (512, 256, 25), (512, 800, 12), (64, 1024, 9)])
+@pytest.mark.parametrize("H,Bi,steps", [(64, 45, 20), (512, 64, 30), (512, 256, 25), (512, 400, 14), (512, 800, 12), (64, 1024, 9), (512, 1500, 6)])
 def test_single_launch_decode_block_pipeline(H, Bi, steps):
-    """fn_decode_greedy above 32 sequences: 32-row blocks travel through the role workgroups as a pipeline (two replicas of the role set at
-    H = 512, one at H = 64 ... up to 16 blocks per replica, a ragged last block) - per row the tokens and log-probabilities of the per-token
-    kernels up to that row's first near-tie, bit-reproducible on warm buffers, sync-error word clear."""
+    """fn_decode_greedy above 32 sequences: blocks of 32 rows (64 rows from 353 sequences on) travel through the role workgroups as a
+    pipeline (two replicas of the role set at H = 512, more at H = 64 ... up to 12 blocks per replica, ragged last blocks of 13 / 16 / 28
+    rows) - per row the tokens and log-probabilities of the per-token kernels up to that row's first near-tie, bit-reproducible on warm
+    buffers, sync-error word clear."""
     pkg = load_package()
     m = make_model(H, 32 if H == 64 else 128, device=DEV, seed=13)
     m.eval()
@@ -700,7 +701,7 @@ def test_single_launch_decode_block_pipeline(H, Bi, steps):
     eng = m.engine()
     eng.single_launch_decode, eng.cell_decode_rows = False, 1 << 30
     lp0, tk0 = pkg.greedy_decode(m, z, steps)
-    eng.single_launch_decode, eng.single_launch_rows = True, 1024       # force the one-launch pipeline (the default hands > 256 rows to the per-token kernels)
+    eng.single_launch_decode, eng.single_launch_rows = True, 2048       # force the one-launch pipeline whatever the default threshold
     lp1, tk1 = pkg.greedy_decode(m, z, steps)
     lp2, tk2 = pkg.greedy_decode(m, z, steps)
     assert not eng.ops.gru_sync_error()
@@ -727,7 +728,7 @@ def test_large_batch_decode_cells_match_per_token_kernels(H, Bi, steps):
     torch.manual_seed(5)
     z = torch.randn(Bi, 2 * m.latent_dim + 24, device=DEV)
     eng = m.engine()
-    eng.single_launch_decode = False                                          # (the one-launch pipeline takes <= 1024 rows otherwise)
+    eng.single_launch_decode = False                                          # (the one-launch pipeline takes these row counts otherwise)
     eng.cell_decode_rows = 1 << 30
     lp0, tk0 = pkg.greedy_decode(m, z, steps)
     eng.cell_decode_rows = 768
