@@ -85,7 +85,10 @@ def _classify(name, a, k):
     if name == "gru_dwhh":
         rows, Hh = a[2].shape
         # two kernel symbols: the <= 128-register instance (decoder side, beside the encoder backward scan) and the full one
-        return ("dwhh_gemm_tn_lean" if k.get("lean") else "dwhh_gemm_tn", 2.0 * rows * 3 * Hh * Hh) if rows >= 4096 else None
+        if rows < 4096:
+            return None
+        row = "dwhh_gemm_tn_lean" if k.get("lean") else ("dwhh_gemm_tn" if rows >= 32768 else "dwhh_gemm_tn_attr")
+        return row, 2.0 * rows * 3 * Hh * Hh
     if name == "embed_grad_sorted":                        # HBM-bound: every gate-gradient row of every job is read once
         nbytes = float(sum(j["dgx"].numel() for j in a[1]) * 4)
         return ("embed_grad", nbytes) if nbytes >= 1e8 else None
@@ -111,7 +114,8 @@ ROW_INFO = {   # row -> (bound, unit of work, kernel, peak share of the chip)
     "dec_bwd_scan_chunk": ("mfma", "flop", "gru_bwd_persist_kernel (one launch of the decoder pipeline: 2 scans x 256 rows x 32 steps - layer 2 chunk k + layer 1 chunk k+2, attribute-decoder chunks at both ends)", 1.0),
     "subdec_fwd_scan": ("mfma", "flop", "gru_fwd_persist_kernel (both sub-decoders, 64 steps)", 1.0),
     "subdec_bwd_scan": ("mfma", "flop", "gru_bwd_persist_kernel (both sub-decoders, 64 steps)", 1.0),
-    "dwhh_gemm_tn": ("mfma", "flop", "gemm_tn_kernel via fn_gru_dwhh_f32 (dW_hh of the encoder scans, K = T*B rows)", 1.0),
+    "dwhh_gemm_tn": ("mfma", "flop", "gemm_tn_kernel via fn_gru_dwhh_f32 (dW_hh of an encoder direction / a decoder layer: [3H x T*B] x [T*B x H], 48 tiles x 16 K ranges; 6 launches per step)", 1.0),
+    "dwhh_gemm_tn_attr": ("mfma", "flop", "gemm_tn_kernel via fn_gru_dwhh_f32 (dW_hh of the attribute decoders, K = Tr*B rows, 48 tiles x 8 K ranges)", 1.0),
     "dwhh_gemm_tn_lean": ("mfma", "flop", "gemm_tn_lean_kernel via fn_gru_dwhh_f32 (dW_hh of the decoder-side scans, <= 128 registers)", 1.0),
     "gemm_tn": ("mfma", "flop", "gemm_tn_kernel (dW of dense layers)", 1.0),
     "gemm_nt": ("mfma", "flop", "gemm_kernel (X W^T: W_ih2 projection, output layer)", 1.0),
@@ -123,7 +127,7 @@ ROW_INFO = {   # row -> (bound, unit of work, kernel, peak share of the chip)
 
 # HBM bytes per launch from rocprofv3 PMC passes (2 x FETCH_SIZE with the gfx950 correction + WRITE_SIZE, separate passes): bench.py
 # itself cannot run the profiler, so these are the committed measurements of the same launches
-PMC_TRAFFIC = {"enc_fwd_scan": 4.33e9, "enc_bwd_scan": 7.91e9}
+PMC_TRAFFIC = {"enc_fwd_scan": 4.34e9, "enc_bwd_scan": 7.94e9, "dwhh_gemm_tn": 0.711e9}
 PMC_SOURCE = "profiles/r03_pmc_training_step.txt (2 x FETCH_SIZE + WRITE_SIZE, separate passes)"
 
 
@@ -277,8 +281,10 @@ def bench_train(args, pkg, ctx, local, rank, world, log):
         dom_row = max(rows, key=lambda r: rows[r]["us_per_step"])          # the kernel (symbol) the step spends most of its time in
         dom = dict(rows[dom_row])
         dom.update(row=dom_row, traffic=PMC_TRAFFIC.get(dom_row), traffic_source=PMC_SOURCE if dom_row in PMC_TRAFFIC else None,
-                   flop_per_launch=dom.pop("work_per_launch"), steps_per_launch=T,
+                   flop_per_launch=dom.pop("work_per_launch"),
                    step_frac=round(tokens_per_s / world * F_ALG_PER_TOKEN / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
+        if dom_row.endswith("_scan"):
+            dom["steps_per_launch"] = T
         out["roofline"] = dom
         out["roofline_all"] = rows
         out["roofline_worst"] = min(rows, key=lambda r: rows[r]["frac"])

@@ -163,11 +163,23 @@ FN_DEVINL void gemm_tn_body(int M, int N, int K, float alpha, const float* __res
                             const float* __restrict__ bias, int ksplit_len, float* __restrict__ slabs,
                             const float* __restrict__ A2, long lda2, int msplit) {
     const int ntn = (N + 127) / 128, ntm = (M + 127) / 128;
-    const int tile = fn_xcd_remap(blockIdx.x, ntn * ntm);
+    // Split-K launches whose number of K ranges is a multiple of 8 come as a 1-D grid and give every XCD its own K ranges of ALL output
+    // tiles (workgroup id % 8 = XCD): the tiles of one K range walk the same rows of A and B at the same time, so each XCD's L2 fetches
+    // its share of the operands once.  With the tiles dealt to the XCDs instead (the 3-D grid below) every XCD streams all of B and a
+    // sixth of A for every K range: 1.67 GB per dW_hh product against 0.54 GB of operands (PMC, profiles/r03_pmc_training_step.txt).
+    int tile, zk;
+    if (gridDim.z == 1 && slabs != nullptr) {
+        const int S = (K + ksplit_len - 1) / ksplit_len, c = blockIdx.x & 7, q = blockIdx.x >> 3;
+        zk = c * (S >> 3) + q / (ntn * ntm);
+        tile = q % (ntn * ntm);
+    } else {
+        tile = fn_xcd_remap(blockIdx.x, ntn * ntm);
+        zk = blockIdx.z;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m0 = (tile / ntn) * 128 + (wave >> 1) * 64, n0 = (tile % ntn) * 128 + (wave & 1) * 64;
     const int li = lane & 15, lg = lane >> 4;
-    const int kbeg = blockIdx.z * ksplit_len, kend = min(K, kbeg + ksplit_len);
+    const int kbeg = zk * ksplit_len, kend = min(K, kbeg + ksplit_len);
     // column offsets clamped inside the padded row (results of out-of-range rows/cols are never stored)
     // optional second source for the output rows >= msplit (a multiple of the 128-row tile): A = [A | A2] along M
     if (A2 != nullptr && m0 >= msplit) { A = A2 - msplit; lda = lda2; }
@@ -247,7 +259,7 @@ FN_DEVINL void gemm_tn_body(int M, int N, int K, float alpha, const float* __res
                 if (col >= N) continue;
                 const float v = acc[a][b][r];
                 if (slabs) {
-                    slabs[((long)blockIdx.z * M + row) * N + col] = v;
+                    slabs[((long)zk * M + row) * N + col] = v;
                 } else {
                     float o = alpha * v;
                     if (bias) o += bias[col];
@@ -598,6 +610,11 @@ int fn_gemm_multi(int a_kmajor, int b_kmajor, const FnGemmJob* jobs, int n_jobs,
     return FN_OK;
 }
 
+// grid of a TN launch: 1-D (K ranges dealt to the XCDs, see gemm_tn_body) when the K ranges divide by 8, else tiles x 1 x K ranges
+static dim3 tn_grid(int tiles, int splitk) {
+    return splitk > 1 && (splitk & 7) == 0 ? dim3(tiles * splitk, 1, 1) : dim3(tiles, 1, splitk > 1 ? splitk : 1);
+}
+
 size_t fn_gemm_ws_bytes(int M, int N, int splitk) { return splitk > 1 ? (size_t)splitk * M * N * sizeof(float) : 0; }
 
 int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb,
@@ -617,7 +634,7 @@ int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha, co
         }
         const int ntm = (M + 127) / 128, ntn = (N + 127) / 128;
         float* slabs = splitk > 1 ? ws : nullptr;
-        hipLaunchKernelGGL(lean ? gemm_tn_lean_kernel : gemm_tn_kernel, dim3(ntm * ntn, 1, splitk > 1 ? splitk : 1), dim3(NT), 0, st, M, N, K, alpha, A, (long)lda, B,
+        hipLaunchKernelGGL(lean ? gemm_tn_lean_kernel : gemm_tn_kernel, tn_grid(ntm * ntn, splitk), dim3(NT), 0, st, M, N, K, alpha, A, (long)lda, B,
                            (long)ldb, beta, C, (long)ldc, bias, klen, slabs, (const float*)nullptr, 0L, 0);
         FN_CHECK_LAUNCH();
         if (splitk > 1) {
@@ -664,7 +681,7 @@ int fn_gru_dwhh_f32(const float* dgx, const float* dghn, const float* hprev, int
     }
     const int ntm = (M + 127) / 128, ntn = (N + 127) / 128;
     float* slabs = splitk > 1 ? ws : nullptr;
-    hipLaunchKernelGGL(lean ? gemm_tn_lean_kernel : gemm_tn_kernel, dim3(ntm * ntn, 1, splitk > 1 ? splitk : 1), dim3(NT), 0, st, M, N, K, 1.0f, dgx, (long)3 * H, hprev,
+    hipLaunchKernelGGL(lean ? gemm_tn_lean_kernel : gemm_tn_kernel, tn_grid(ntm * ntn, splitk), dim3(NT), 0, st, M, N, K, 1.0f, dgx, (long)3 * H, hprev,
                        (long)H, beta, dW, (long)H, (const float*)nullptr, klen, slabs, dghn, (long)H, 2 * H);
     FN_CHECK_LAUNCH();
     if (splitk > 1) {

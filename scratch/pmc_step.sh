@@ -13,6 +13,8 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_C
     for k in "gru_fwd_persist_kernel<4, 1, 2" "gru_bwd_persist_kernel<4, 1, 2" "gru_fwd_persist_kernel<2, 2, 2" "gru_bwd_persist_kernel<2, 2, 2" "gemm_tn_kernel" "gemm_tn_lean_kernel" "gemm_kernel<128" "eg_piece_kernel" "vocab_logsoftmax_kernel"; do
       echo "== $k"; python $R/scratch/pmc_avg.py $f "$k"
     done > $O/$tag.txt
+    # the weight-gradient GEMMs of the scans alone: 48 tiles x 16 K splits x 256 threads (M = 3H, N = H, K = T*B rows)
+    echo "== gemm_tn_kernel grid 196608 (dW_hh / dW_ih2, K = 65280-65536 rows)" >> $O/$tag.txt; python $R/scratch/pmc_avg.py $f "gemm_tn_kernel" 196608 >> $O/$tag.txt
     rm -rf $O/$tag
   else echo "no csv for $grp"; tail -3 $O/$tag.log; fi
 done
