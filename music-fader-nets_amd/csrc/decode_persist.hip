@@ -32,11 +32,17 @@ __device__ unsigned long long fn_ddbg[5 * 16];
     do {                                                                                                                 \
         if (slice == 0 && rep == 0 && blk == 0 && threadIdx.x == 0 && t == 10) fn_ddbg[(role_) * 16 + (k)] = __builtin_readcyclecounter(); \
     } while (0)
+// the same role's NEXT block of the same step (period of the role's block loop = its busy + idle time per block)
+#define FN_DSTAMP_NEXT(role_)                                                                                            \
+    do {                                                                                                                 \
+        if (slice == 0 && rep == 0 && blk == a.nrep && threadIdx.x == 0 && t == 10) fn_ddbg[(role_) * 16 + 8] = __builtin_readcyclecounter(); \
+    } while (0)
 extern "C" int fn_ddbg_read(unsigned long long* host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fn_ddbg), sizeof(unsigned long long) * 80);
 }
 #else
 #define FN_DSTAMP(role_, k)
+#define FN_DSTAMP_NEXT(role_)
 #endif
 
 namespace {
@@ -238,6 +244,7 @@ __global__ __launch_bounds__(NT) void decode_greedy_kernel(const DArgs a) {
                 const int b = r0 + min(rl, nrow - 1);
                 float* x1 = a.x1 + (long)blk * FS;
                 FN_DSTAMP(0, 0);
+                FN_DSTAMP_NEXT(0);
                 // the recurrent product needs h1_{t-1} only, not the token: it runs while the previous token is still being produced
                 if (t > 0 && !sy.wait(C1, unsl * (u32)t)) return;
                 FN_DSTAMP(0, 1);
@@ -345,6 +352,7 @@ __global__ __launch_bounds__(NT) void decode_greedy_kernel(const DArgs a) {
                 const int b = r0 + min(rl, nrow - 1);
                 // (g2 of step t-1 is free: h1_t exists only after token t-1, i.e. after layer 2 consumed it)
                 FN_DSTAMP(1, 0);
+                FN_DSTAMP_NEXT(1);
                 if (!sy.wait(C1, unsl * (u32)(t + 1))) return;
                 FN_DSTAMP(1, 1);
                 f32x4 acc[MT][3];
@@ -370,6 +378,7 @@ __global__ __launch_bounds__(NT) void decode_greedy_kernel(const DArgs a) {
                 const int b = r0 + min(rl, nrow - 1);
                 // recurrent input: h2_{t-1}, or h1_0 at the first step (gmm_model.py:134-135: hx[1] = hx[0] at i == 0)
                 FN_DSTAMP(2, 0);
+                FN_DSTAMP_NEXT(2);
                 if (!(t == 0 ? sy.wait(C1, unsl) : sy.wait(C3, unsl * (u32)t))) return;
                 FN_DSTAMP(2, 1);
                 const float* xin = t == 0 ? a.x1 + (long)blk * FS : a.x2 + (long)blk * FS + (long)((t + 1) & 1) * FSA;
@@ -419,6 +428,7 @@ __global__ __launch_bounds__(NT) void decode_greedy_kernel(const DArgs a) {
                 // chain: the output slices are idle until layer 2 arrives anyway); every layer-1 workgroup has taken its own argmax of them
                 // before h1_t, hence h2_t, existed
                 FN_DSTAMP(3, 0);
+                FN_DSTAMP_NEXT(3);
                 if (t > 0 && !sy.wait(C5, (u32)t)) return;
                 if (!sy.wait(C3, unsl * (u32)(t + 1))) return;
                 FN_DSTAMP(3, 1);
@@ -436,6 +446,7 @@ __global__ __launch_bounds__(NT) void decode_greedy_kernel(const DArgs a) {
                 const Sync sy = {a.sync + blk * BLKW, errw, dead};
                 const int r0 = blk * RB, nrow = min(RB, B - r0);
                 FN_DSTAMP(4, 0);
+                FN_DSTAMP_NEXT(4);
                 if (!sy.wait(C4, (u32)a.nvt * (u32)(t + 1))) return;
                 FN_DSTAMP(4, 1);
                 constexpr int RPW = MT * 4;
