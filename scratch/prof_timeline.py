@@ -21,3 +21,15 @@ for s, e, n, st, c, busy in runs:
     if (e - s) / 1e3 >= minus:
         print("%9.1f us  +%8.1f us  stream %d  x%-4d busy %8.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, st, c, busy / 1e3, n))
 print("step span %.1f us" % ((max(r[1] for r in rows) - t0) / 1e3))
+# idle analysis: time inside the step during which NO kernel runs (launch gaps of the graph), and the largest gaps
+iv = sorted((s, e, short(n)) for s, e, n, st in rows)
+cur_e, idle, gaps, last = iv[0][1], 0, [], iv[0][2]
+for s, e, n in iv[1:]:
+    if s > cur_e:
+        idle += s - cur_e
+        gaps.append((s - cur_e, (cur_e - t0) / 1e3, last, n))
+    if e > cur_e:
+        cur_e, last = e, n
+print("no kernel running for %.1f us of the step (%d gaps); largest:" % (idle / 1e3, len(gaps)))
+for g, at, a, b in sorted(gaps, reverse=True)[:14]:
+    print("   %6.1f us at %9.1f us   after %-40s before %s" % (g / 1e3, at, a, b))
