@@ -202,8 +202,8 @@ def comm_times(trainer, ctx, batch, eps, step, reps=3):
         out["bucket1_MB"] = round(trainer.flat.bucket_split * 4 / 1e6, 2)
         out["bucket2_MB"] = round((trainer.flat.bucket_split2 - trainer.flat.bucket_split) * 4 / 1e6, 2)
         out["bucket3_MB"] = round((trainer.flat.n - trainer.flat.bucket_split2) * 4 / 1e6, 2)
-        out["note"] = ("bucket 1 (decoder-side gradients) is issued behind the decoder weight-gradient GEMMs and runs beside the latent block / encoder "
-                       "backward; bucket 2 (heads, component means, rhythm encoder) beside the note encoder's weight-gradient GEMMs; bucket 3 (note "
+        out["note"] = ("bucket 1 (decoder-side gradients) is issued behind the decoder weight-gradient GEMMs of the side lane (they execute once the encoder "
+                       "backward scan has ended) and runs beside the encoder-side weight-gradient GEMMs; bucket 2 (heads, component means, rhythm encoder) beside the note encoder's weight-gradient GEMMs; bucket 3 (note "
                        "encoder) is the exposed one; exposed = wait of the step's stream in front of clip+Adam")
         return out
     finally:
