@@ -29,9 +29,10 @@ for i in range(20):
     lp, tok = pkg.greedy_decode(m, z, 300, want_logp=False)
 torch.cuda.synchronize()
 assert not m.engine().ops.gru_sync_error()
-zs = torch.randn(8, 280, device=dev)
-for i in range(50):
-    lp, tok = pkg.greedy_decode(m, zs, 300, want_logp=False)
-torch.cuda.synchronize()
-assert not m.engine().ops.gru_sync_error()
-print("soak ok: %d steps, 20 large-batch decodes, 50 single-launch decodes" % N)
+for rows in (8, 256, 800, 1536):          # one launch: one block | 32-row blocks | 64-row blocks (7 / 12 per replica)
+    zs = torch.randn(rows, 280, device=dev)
+    for i in range(50 if rows == 8 else 15):
+        lp, tok = pkg.greedy_decode(m, zs, 300, want_logp=False)
+    torch.cuda.synchronize()
+    assert not m.engine().ops.gru_sync_error(), rows
+print("soak ok: %d steps, 20 large-batch decodes (staged-GEMM cells), 50 + 3 x 15 single-launch decodes of 8 / 256 / 800 / 1536 rows x 300 steps" % N)
