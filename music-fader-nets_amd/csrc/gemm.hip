@@ -270,6 +270,110 @@ FN_DEVINL void gemm_tn_body(int M, int N, int K, float alpha, const float* __res
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// "NT" GEMM without LDS for the short-K products beside the decoder scans (layer-2 input projection gx2 = hx0 W_ih2^T and the input
+// gradient dhx0 = dgx2 W_ih2 through the transposed weight image): C[M][N] = alpha * sum_k A[m][k] B[n][k] (+ bias, + beta C), both
+// operands K-contiguous.  The LDS-staged kernel spends its 16 K tiles of a K = 512 product on prologue / barrier / epilogue (MFMA pipe
+// 54 % busy, 92 TFLOP/s); here a lane reads its MFMA operands straight from memory: lane (i = l & 15, g = l >> 4) loads the float4
+// A[row i of a 16-row tile][k0 + 4g .. 4g + 3]; MFMA j (j = 0..3) of the step takes element j of every lane, i.e. k slot g of MFMA j is
+// k0 + 4g + j - a permutation of the 16 k values of the step, the same for A and B, so the sum is the same set of products in a fixed
+// order.  One wave = 64 x 64 outputs (4 x 4 tiles), B tiles interleaved (tile b = columns n0 + 4i + b) so that a lane's four b values
+// are one float4 store; PF steps of 16 k (8 loads each) in flight, counted vmcnt; loads use a scalar base that advances 64 bytes per
+// step + a fixed 32-bit lane offset (no vector address arithmetic in the loop).  Requires M, N multiples of 128, K a multiple of 16,
+// 16-byte aligned operands with ld % 4 == 0 and < 4 GB spans (fn_gemm_f32 falls back to the staged kernel otherwise).
+// ---------------------------------------------------------------------------------------------------------
+FN_DEVINL void fn_gld4_s(f32x4& dst, unsigned voff, const float* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+
+template <int PF, int WGS>
+__global__ __launch_bounds__(NT, WGS) void gemm_nt_direct_kernel(int M, int N, int K, float alpha, const float* __restrict__ A, long lda,
+                                                            const float* __restrict__ B, long ldb, float beta, float* __restrict__ C, long ldc,
+                                                            const float* __restrict__ bias) {
+    const int ntn = N >> 7, ntm = M >> 7;
+    const int tile = fn_xcd_remap(blockIdx.x, ntn * ntm);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = (tile / ntn) * 128 + (wave >> 1) * 64, n0 = (tile % ntn) * 128 + (wave & 1) * 64;
+    const int li = lane & 15, lg = lane >> 4;
+    unsigned oa[4], ob[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        oa[a] = (unsigned)(((long)(m0 + 16 * a + li) * lda + 4 * lg) * 4);
+        ob[a] = (unsigned)(((long)(n0 + 4 * li + a) * ldb + 4 * lg) * 4);
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nks = K >> 4;                          // steps of 16 k
+    const int nmain = nks / PF * PF;
+    const float* pa = A;
+    const float* pb = B;
+    f32x4 fa[PF][4], fb[PF][4];
+    auto load = [&](int set) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) fn_gld4_s(fa[set][a], oa[a], pa);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) fn_gld4_s(fb[set][b], ob[b], pb);
+        pa += 16;
+        pb += 16;
+    };
+    auto mma = [&](int u) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(fa[u][a], j), f4c(fb[u][b], j), acc[a][b], 0, 0, 0);
+    };
+    if (nmain > 0) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) load(s);
+        for (int base = 0; base + PF < nmain; base += PF) {   // steady state: every step refills its own ring slot
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                fn_wait_vm<8 * (PF - 1)>();
+                mma(u);
+                load(u);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {                        // last PF steps: everything has been requested
+            if (u == 0) fn_wait_vm<8 * (PF - 1)>();
+            else if (u == 1 && PF > 1) fn_wait_vm<(PF > 1 ? 8 * (PF - 2) : 0)>();
+            else if (u == 2 && PF > 2) fn_wait_vm<(PF > 2 ? 8 * (PF - 3) : 0)>();
+            else fn_wait_vm<0>();
+            mma(u);
+        }
+#pragma unroll
+        for (int s = 0; s < PF; ++s)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { fn_keep(fa[s][a]); fn_keep(fb[s][a]); }
+    }
+    for (int ks = nmain; ks < nks; ++ks) {                    // < PF leftover steps, unpipelined
+        load(0);
+        fn_wait_vm<0>();
+        mma(0);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { fn_keep(fa[0][a]); fn_keep(fb[0][a]); }
+    }
+    f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + n0 + 4 * li);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long row = m0 + 16 * a + 4 * lg + r;
+            float* cp = C + row * ldc + n0 + 4 * li;
+            f32x4 o = (f32x4){acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]} * alpha + bv;
+            if (beta != 0.f) o += beta * *reinterpret_cast<const f32x4*>(cp);
+            *reinterpret_cast<f32x4*>(cp) = o;
+        }
+}
+
 __global__ __launch_bounds__(NT) void gemm_tn_kernel(int M, int N, int K, float alpha, const float* __restrict__ A, long lda,
                                                      const float* __restrict__ B, long ldb, float beta, float* __restrict__ C, long ldc,
                                                      const float* __restrict__ bias, int ksplit_len, float* __restrict__ slabs,
@@ -643,6 +747,15 @@ int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha, co
             hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, slabs, splitk, M, N, alpha, beta, C, (long)ldc, bias);
             FN_CHECK_LAUNCH();
         }
+        return FN_OK;
+    }
+    // K-contiguous operands, whole 128 x 128 tiles that fill the chip, short K, no split: the LDS-free kernel
+    if (a_kmajor && b_kmajor && splitk <= 1 && (M % 128) == 0 && (N % 128) == 0 && (K % 16) == 0 && K >= 64 && (lda % 4) == 0 && (ldb % 4) == 0 &&
+        (ldc % 4) == 0 && (((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C) | ((uintptr_t)bias)) & 15) == 0) &&
+        (long)M * lda < (1L << 30) && (long)N * ldb < (1L << 30) && (long)(M / 128) * (N / 128) >= 256) {
+        hipLaunchKernelGGL((gemm_nt_direct_kernel<4, 2>), dim3((M / 128) * (N / 128)), dim3(NT), 0, st, M, N, K, alpha, A, (long)lda, B, (long)ldb, beta, C,
+                           (long)ldc, bias);
+        FN_CHECK_LAUNCH();
         return FN_OK;
     }
     const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);

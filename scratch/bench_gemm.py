@@ -16,7 +16,7 @@ def t(fn, reps=8):
     return best
 cases = [("dW all sk16", False, False, 1536, 512, 65280, 16), ("dW out sk42", False, False, 342, 512, 65536, 42),
          ("fwd proj32", True, True, 8192, 1536, 512, 1), ("fwd proj64", True, True, 16384, 1536, 512, 1), ("logits", True, True, 65536, 342, 512, 1),
-         ("dX out", True, False, 65536, 512, 342, 1), ("dX proj32", True, False, 8192, 512, 1536, 1), ("dX proj64", True, False, 16384, 512, 1536, 1)]
+         ("dX out", True, False, 65536, 512, 342, 1), ("dX proj32", True, False, 8192, 512, 1536, 1), ("dX proj32 NT", True, True, 8192, 512, 1536, 1), ("dX out NT352", True, True, 65536, 512, 352, 1), ("dX proj64", True, False, 16384, 512, 1536, 1)]
 for name, ak, bk, M, N, K, sk in cases:
     lda = 344 if (not ak and M == 342) else (M if not ak else (344 if K == 342 else K))
     A = torch.randn((K, lda) if not ak else (M, lda), device=dev)
