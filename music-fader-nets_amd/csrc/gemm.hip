@@ -753,8 +753,12 @@ int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha, co
     if (a_kmajor && b_kmajor && splitk <= 1 && (M % 128) == 0 && (N % 128) == 0 && (K % 16) == 0 && K >= 64 && (lda % 4) == 0 && (ldb % 4) == 0 &&
         (ldc % 4) == 0 && (((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C) | ((uintptr_t)bias)) & 15) == 0) &&
         (long)M * lda < (1L << 30) && (long)N * ldb < (1L << 30) && (long)(M / 128) * (N / 128) >= 256) {
-        hipLaunchKernelGGL((gemm_nt_direct_kernel<4, 2>), dim3((M / 128) * (N / 128)), dim3(NT), 0, st, M, N, K, alpha, A, (long)lda, B, (long)ldb, beta, C,
-                           (long)ldc, bias);
+        if (lean)       // <= 128 registers, no LDS: one of its wavefronts fits a SIMD beside a wavefront of the decoder-shaped forward scans (377 registers)
+            hipLaunchKernelGGL((gemm_nt_direct_kernel<1, 4>), dim3((M / 128) * (N / 128)), dim3(NT), 0, st, M, N, K, alpha, A, (long)lda, B, (long)ldb, beta, C,
+                               (long)ldc, bias);
+        else
+            hipLaunchKernelGGL((gemm_nt_direct_kernel<4, 2>), dim3((M / 128) * (N / 128)), dim3(NT), 0, st, M, N, K, alpha, A, (long)lda, B, (long)ldb, beta, C,
+                               (long)ldc, bias);
         FN_CHECK_LAUNCH();
         return FN_OK;
     }

@@ -51,6 +51,7 @@ class Engine:
         self.cell_decode_rows = 768     # decode.py: from this many sequences on, the per-token cells are staged-GEMM launches (fn_gru_cell_f32); measured crossover (scratch/bench_decode_rows.py): 512 rows 67 vs 87 us per token, 768 rows 97 vs 88
         self.fused_head = True          # trainers: output projection + log-softmax + NLL + gradient seed as ONE kernel (fn_out_head_f32); False: GEMM -> logits in HBM -> fn_vocab_logsoftmax
         self.lean_dw = False            # decoder-side weight-gradient GEMMs as the <= 128-register instance.  Paid while an encoder-scan wavefront left 138 of a SIMD's 512 registers free (round 2: 9 % packing gain); the hand-placed K loops hold all of them, the side lane's GEMMs run once the scan has ended and the 194-register instance is the faster one (A/B in one session, scratch/ab_dw.py: 23.65 vs 24.29 ms per step)
+        self.lean_proj = True           # layer-2 input projection beside the decoder pipeline's forward launches as the <= 128-register instance of the LDS-free NT kernel: 4 workgroups per CU (768 tiles = one round) and one of its wavefronts fits a SIMD beside a forward-scan wavefront (377 registers): 107 us beside a 351 us launch (the 248-register instance: 125 us in front of the launch)
         self.dw_order = "side"          # decoder-side weight-gradient GEMMs: "side" = side stream, issued in front of the encoder backward; "before" / "after" = caller's stream, in front of / behind the encoder block
         self.losses_on_side = True      # trainer: the small loss-term launches run on the side lane beside the decoder backward's first launches
         self.buf_ns = ""                # namespace of buf(): a second decoder pass (GLSR) must not overwrite the saved activations of the first
@@ -397,7 +398,8 @@ class Engine:
                 lane = "aux%d" % (k & 1)
                 self.lane_wait(lane, "main")
                 with Engine._Lane(self, True, lane):
-                    ops.gemm(hx0[t0:t1].view(-1, H), P["grucell_g_2.weight_ih"], gx2[t0:t1].view(-1, 3 * H), bias=P["grucell_g_2.bias_ih"])
+                    ops.gemm(hx0[t0:t1].view(-1, H), P["grucell_g_2.weight_ih"], gx2[t0:t1].view(-1, 3 * H), bias=P["grucell_g_2.bias_ih"],
+                             lean=self.lean_proj)
         logits = self.buf("g_logits", (T * B, LOGIT_LD), zero_init=True)     # columns [342, 352) stay zero: every writer leaves them alone or writes zeros
         if head:
             ops.gemm(hx1.view(T * B, H), P["linear_out_g.weight"], logits[:, :E_VOCAB], bias=P["linear_out_g.bias"])

@@ -25,4 +25,8 @@ for name, ak, bk, M, N, K, sk in cases:
     ldc = 344 if N == 342 else N
     C = torch.zeros(M, ldc, device=dev)
     ms = t(lambda: ops.gemm(Av, Bm, C[:, :N], a_k=ak, b_k=bk, splitk=sk))
-    print("%-14s M=%6d N=%5d K=%6d splitk=%2d  %8.1f us  %6.1f TFLOP/s" % (name, M, N, K, sk, ms * 1e3, 2.0 * M * N * K / ms / 1e9), flush=True)
+    extra = ""
+    if ak and bk and sk == 1:          # the <= 128-register instance of the LDS-free NT kernel (4 workgroups per CU)
+        ml = t(lambda: ops.gemm(Av, Bm, C[:, :N], a_k=ak, b_k=bk, splitk=sk, lean=True))
+        extra = "   lean %8.1f us  %6.1f TFLOP/s" % (ml * 1e3, 2.0 * M * N * K / ml / 1e9)
+    print("%-14s M=%6d N=%5d K=%6d splitk=%2d  %8.1f us  %6.1f TFLOP/s%s" % (name, M, N, K, sk, ms * 1e3, 2.0 * M * N * K / ms / 1e9, extra), flush=True)
