@@ -10,7 +10,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_C
   timeout 300 rocprofv3 --kernel-trace --pmc $grp -d $O/$tag -o p --output-format csv -- python $R/scratch/pmc_step.py 2 > $O/$tag.log 2>&1
   f=$(find $O/$tag -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then
-    for k in "gru_fwd_persist_kernel<4, 1, 2" "gru_bwd_persist_kernel<4, 1, 2" "gru_fwd_persist_kernel<2, 2, 2" "gru_bwd_persist_kernel<2, 2, 2" "gemm_tn_kernel" "gemm_tn_lean_kernel" "gemm_kernel<128" "eg_piece_kernel" "vocab_logsoftmax_kernel"; do
+    for k in "gru_fwd_persist_kernel<4, 1, 2" "gru_bwd_persist_kernel<4, 1, 2" "gru_fwd_persist_kernel<2, 2, 2" "gru_bwd_persist_kernel<2, 2, 2" "gemm_tn_kernel" "gemm_tn_lean_kernel" "gemm_kernel<128" "gemm_nt_direct_kernel<1" "gemm_nt_direct_kernel<4" "out_head_kernel" "eg_piece_kernel" "vocab_logsoftmax_kernel"; do
       echo "== $k"; python $R/scratch/pmc_avg.py $f "$k"
     done > $O/$tag.txt
     # the weight-gradient GEMMs of the scans alone: 48 tiles x 16 K splits x 256 threads (M = 3H, N = H, K = T*B rows)
