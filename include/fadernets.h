@@ -333,7 +333,8 @@ int fn_vocab_logsoftmax(const float* logits, int B, int T, int E, int ld, float*
  *   nll_rows [T*B] or NULL       -log_softmax(logits)[target]
  *   dlogits  [T*B][ld] or NULL   grad_scale * (softmax - onehot(target)); ld a multiple of 4, V <= ld <= 384, 16-byte aligned;
  *                                columns [V, ld) are written as zeros
- * The logits are bit-identical to fn_gemm_f32's (same k order); the row sums run in a different order than fn_vocab_logsoftmax's. */
+ * With 16-byte aligned operands and H % 16 == 0 the projection runs as an LDS-free loop whose k order inside a 16-k step differs from
+ * fn_gemm_f32's (fixed, deterministic); the row sums run in a different order than fn_vocab_logsoftmax's. */
 int fn_out_head_f32(const float* h, int ldh, const float* W, int ldw, const float* bias, int B, int T, int V, int H,
                     const int32_t* target, float grad_scale, float* nll_rows, float* dlogits, int ld, void* stream);
 /* generic backward of the same log_softmax: dlogits[row] = g - softmax * sum(g), g = gout_bt[b][t][:] */

@@ -399,7 +399,7 @@ void gemm_tn_lean_kernel(int M, int N, int K, float alpha, const float* __restri
 // Workgroup = 64 rows x all vocabulary columns (384 = 24 column tiles of 16, columns >= V are padding), waves 2 x 2: wave (wm, wn) owns
 // rows [32 wm, 32 wm + 32) x columns [192 wn, 192 wn + 192) - 14 LDS fragment reads per 48 MFMAs (a 4 x 1 layout with complete rows per
 // wave needs 25 and was LDS-bound: 60 TFLOP/s); the row maximum / sum of the two column halves meet through LDS.  Same k order as
-// gemm_kernel -> the logits are bit-identical to the unfused product.  The gradient rows leave through LDS as aligned float4 rows.
+// gemm_kernel in the staged path; the LDS-free path (aligned operands, K % 16 == 0) permutes k inside a 16-k step.  The gradient rows leave through LDS as aligned float4 rows.
 constexpr int OH_BM = 64, OH_BN = 384, OH_BK = 16, OH_LDT = OH_BN + 4;
 size_t out_head_lds_bytes() {
     const size_t stage = (size_t)2 * (Stage<OH_BM, OH_BK, true, NT>::WORDS + Stage<OH_BN, OH_BK, true, NT>::WORDS) * sizeof(float);
@@ -425,7 +425,68 @@ __global__ __launch_bounds__(NT, 2) void out_head_kernel(const float* __restrict
 #pragma unroll
         for (int n = 0; n < TN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nk = (K + OH_BK - 1) / OH_BK;
-    if (SA::can_fast(h, ldh, ra, K) && SB::can_fast(W, ldw, rb, K)) {
+    if (fn_aligned16(h, ldh) && fn_aligned16(W, ldw) && (K % 16) == 0 && (long)R * ldh < (1L << 30) && (long)V * ldw < (1L << 30)) {
+        // LDS-free K loop (as gemm_nt_direct_kernel): lane (i, g) loads the float4 [row i][k0 + 4g ..] of its 2 row tiles and 12 weight-row
+        // tiles; MFMA j of a 16-k step takes element j of every lane.  14 loads per 96 MFMAs, two steps in flight, no barrier in the loop
+        // (MFMA pipe 54 % busy with the LDS-staged loop: 32 K tiles of staging and barriers per workgroup)
+        const int li = lane & 15, lg = lane >> 4;
+        unsigned oa[TM], ob[TN];
+#pragma unroll
+        for (int m = 0; m < TM; ++m) oa[m] = (unsigned)(((long)min(m0 + wm * 32 + 16 * m + li, R - 1) * ldh + 4 * lg) * 4);
+#pragma unroll
+        for (int n = 0; n < TN; ++n) ob[n] = (unsigned)(((long)min(wn * (OH_BN / 2) + 16 * n + li, V - 1) * ldw + 4 * lg) * 4);
+        constexpr int PFD = 2, NL = TM + TN;
+        f32x4 fa[PFD][TM], fb[PFD][TN];
+        const float* pa = h;
+        const float* pb = W;
+        auto load = [&](int set) {
+#pragma unroll
+            for (int m = 0; m < TM; ++m) fn_gld4_s(fa[set][m], oa[m], pa);
+#pragma unroll
+            for (int n = 0; n < TN; ++n) fn_gld4_s(fb[set][n], ob[n], pb);
+            pa += 16;
+            pb += 16;
+        };
+        auto mma = [&](int u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(fa[u][m], j), f4c(fb[u][n], j), acc[m][n], 0, 0, 0);
+        };
+        const int nks = K >> 4, nmain = nks / PFD * PFD;
+        if (nmain > 0) {
+            load(0);
+            load(1);
+            for (int base = 0; base + PFD < nmain; base += PFD) {
+#pragma unroll
+                for (int u = 0; u < PFD; ++u) {
+                    fn_wait_vm<NL*(PFD - 1)>();
+                    mma(u);
+                    load(u);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            fn_wait_vm<NL>();
+            mma(0);
+            fn_wait_vm<0>();
+            mma(1);
+        }
+        if (nmain < nks) {
+            load(0);
+            fn_wait_vm<0>();
+            mma(0);
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < PFD; ++s_) {
+#pragma unroll
+            for (int m = 0; m < TM; ++m) fn_keep(fa[s_][m]);
+#pragma unroll
+            for (int n = 0; n < TN; ++n) fn_keep(fb[s_][n]);
+        }
+    } else if (SA::can_fast(h, ldh, ra, K) && SB::can_fast(W, ldw, rb, K)) {
         auto loadA = [&](int k0, SA& st) { st.load_fast(h, ldh, ra, k0); };
         auto loadB = [&](int k0, SB& st) { st.load_fast(W, ldw, rb, k0); };
         fn_kloop<PF_DEPTH, TM, TN, OH_BK, SA, SB>(smem, nk, loadA, loadB, wm * 32, wn * (OH_BN / 2), lane, acc);

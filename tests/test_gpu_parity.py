@@ -100,8 +100,8 @@ def test_out_head_fused(ops, B, T, H, V, ld):
     ops.vocab_logsoftmax(logits, B, T, V, target=tgt, nll_rows=nll0, grad_scale=0.37, dlogits=dl0)
     dl1 = torch.full((T * B, ld), 7.0, device=DEV)
     ops.out_head(h, W, bias, B, T, tgt, nll_rows=nll1, grad_scale=0.37, dlogits=dl1)
-    close(nll1, nll0, 2e-6, "fused nll vs unfused")
-    close(dl1[:, :V], dl0[:, :V], 2e-6, "fused dlogits vs unfused")
+    close(nll1, nll0, 1e-5, "fused nll vs unfused")            # (the fused head sums k in the LDS-free loop's order, the GEMM in the staged loop's)
+    close(dl1[:, :V], dl0[:, :V], 1e-5, "fused dlogits vs unfused")
     assert float(dl1[:, V:].abs().max()) == 0.0 if ld > V else True
     ref = torch.log_softmax(h.double() @ W.double().t() + bias.double(), dim=-1).view(T, B, V)
     tg = tgt.long().t()
