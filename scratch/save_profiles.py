@@ -1,11 +1,11 @@
-"""copy the evidence of scratch/gpu_s4_call1.sh (gpurun_out/s4c1 + gpurun_out/pmc_step) into profiles/r03_* with their headers"""
+"""copy the evidence of scratch/make_evidence_r03.sh (gpurun_out/s4c1 + gpurun_out/pmc_step) into profiles/r03_* with their headers"""
 import os, json, subprocess, re
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); O = R + "/gpurun_out/s4c1"
 b = open(O + "/bench_train.json").read()
 open(R + "/profiles/r03_bench_train.json", "w").write(b)
 ms = json.loads(b)["ms_per_step"]
 hdr = """rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-decode   (MI355X, round 3, final state: hand-placed K loops of the scans,
-full-register weight-gradient GEMMs on the side lane with one K range set per XCD, dz partial products, LDS-free NT GEMMs beside the decoder pipeline; scratch/gpu_s4_call1.sh)
+full-register weight-gradient GEMMs on the side lane with one K range set per XCD, dz partial products, LDS-free NT GEMMs beside the decoder pipeline; scratch/make_evidence_r03.sh)
 + the 5 eager passes of bench.py's per-kernel roofline measurement; summary of the rocpd kernel table by scratch/prof_summary.py
 bench line of the un-profiled run in the same gpurun call: "ms_per_step": %s (profiles/r03_bench_train.json); the round's earlier collections (26.6 ms: column sums /
 zero arena only; 23.4 ms: before the LDS-free NT GEMMs) are in git history (697f01b, 5a0e4b1..)
