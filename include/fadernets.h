@@ -52,10 +52,14 @@ const char* fn_strerror(int code);    /* static string for FN_E_* / hipError_t *
  * Replaces nn.Linear forward (gmm_model.py:86,91,108,113,123,137: a_k=1,b_k=1), its input
  * gradient (a_k=1,b_k=0) and its weight gradient dW = dY^T X (a_k=0,b_k=0).
  * splitk>1 needs ws of fn_gemm_ws_bytes(M,N,splitk) bytes (deterministic slab reduction).
- * splitk | FN_GEMM_LEAN (weight-gradient form a_k=0,b_k=0 and fn_gru_dwhh_f32 only; ignored elsewhere): the instance whose
+ * splitk | FN_GEMM_LEAN (weight-gradient form a_k=0,b_k=0 and fn_gru_dwhh_f32): the instance whose
  * wavefronts need <= 128 vector registers, so that one of them fits on a SIMD BESIDE a wavefront of a weight-stationary scan
  * (fn_gru_seq_*: 336-376 registers of 512) and the product fills the scan's idle MFMA cycles instead of waiting for its CUs.
  * Same results bit for bit (same k order).
+ * The Linear-forward form (a_k=1,b_k=1) with whole 128 x 128 tiles (>= 256 of them), K % 16 == 0, 16-byte aligned operands and no
+ * split runs as an LDS-free kernel (MFMA operands straight from memory; k summed in a fixed order that differs from the staged
+ * kernel's inside every 16-k step); there FN_GEMM_LEAN selects its <= 128-register instance (four workgroups per CU; fits beside a
+ * wavefront of the decoder pipeline's forward scans) - same results as the full instance.
  * ------------------------------------------------------------------------------------------ */
 #define FN_GEMM_LEAN 0x10000
 size_t fn_gemm_ws_bytes(int M, int N, int splitk);
