@@ -1,0 +1,366 @@
+#!/usr/bin/env python3
+"""Generates kloop2_asm.h: the K loops of the PING-PONG weight-stationary GRU scans (gru_persist.hip, gru_*_pp_kernel) at H = 512.
+
+Round 4.  What the in-kernel stamps of the round-3 scans say (profiles/r04_scan_stamps.txt): per time step the MFMA pipe idles for
+  poll of the arrival counter 0.5-2 k cycles | first operand chunks from L2 ~2 k | gate epilogue 1.4-1.9 k | store drain 0.6-1.5 k | arrive 0.2 k
+and scratch/mfma_fill.hip says that a v_mfma_f32_16x16x4_f32 stream does NOT hide VALU work of its own wave (one v_add behind every MFMA:
+32.3 -> 45.5 cycles per MFMA) while LDS reads are free up to two per MFMA and vector-memory instructions cost their issue slot: the
+epilogue's arithmetic cannot disappear, the LATENCIES and the STORE ISSUE can.  So a workgroup owns two halves of its row group (every wave:
+one 16-row tile of each) and runs them alternately:
+
+    phase f = (half X, step p):   K loop of X  ->  accumulators to LDS  ->  gate epilogue of X (arithmetic only)
+
+  * the operand ring of phase f+1 (the other half: its inputs were published a whole K loop ago) is requested at the END of phase f's K loop,
+    BEFORE the epilogue of f: it lands while the epilogue computes, phase f+1 starts multiplying at once;
+  * the STORES of phase f's epilogue (exchange slab first, then the outputs nobody waits for) are issued INSIDE phase f+1's K loop, one per
+    K unit, each in the shadow of an MFMA (24 store instructions per CU and phase cost ~1 k cycles of issue when they follow each other);
+  * the arrival for those stores is made there as well (counted s_waitcnt behind the slab stores, s_barrier, one atomic by wave 0): nobody
+    waits for a store drain;
+  * the counter of the other half is read inside the K loop too (an ordinary load, ~2.5 k cycles before the end); only when it is short
+    does the wave fall back to a polling loop (and requests the ring itself, `*_pro`).
+
+One asm statement per phase (`*_main`; `*_first` = the variant with no stores to issue: first K phase of a launch).  State that crosses
+statements: the ring (RU - 1 units in flight) and the first weight fragments, in fixed AGPRs that the compiler never touches, and the vmcnt
+arithmetic: between two statements the compiler issues NO vector-memory instruction (scratch/check_pp_isa.py checks the ISA).
+
+Pipeline unit = 16 K values of ONE row tile: 1 operand load (1 KB), NB weight-fragment reads, 12 (forward: 3 gate tiles x 4 k-steps) or 4
+(backward) MFMAs.  The accumulation order of every accumulator equals the round-3 loops': bit-identical sums.
+
+Register maps (a = AGPR):  acc a[0..nacc), ring[slot] a[nacc + 4 slot ..], wfrag[bs][n] a[w0 + 4 (NB bs + n) ..].  Scalars s84..s87,
+temporaries v200, v201 (backward).
+"""
+import sys
+
+SB = 84          # s84:85 = running operand base, s86:87 = saved exec / scratch
+TV = 200         # v200, v201: address temporaries of the backward slab stores
+
+
+class Gen:
+    def __init__(self, name, fwd, units, RU, stores, masked):
+        self.name, self.fwd, self.units, self.RU, self.stores, self.masked = name, fwd, units, RU, stores, masked
+        assert units % RU == 0 and RU % 2 == 0
+        self.G = units // RU
+        self.NB = 3 if fwd else 1
+        self.nmf = 12 if fwd else 4
+        self.nacc = 12 if fwd else 8
+        self.ring0 = self.nacc
+        self.w0 = self.ring0 + RU * 4
+        self.nagpr = self.w0 + 2 * self.NB * 4
+        if fwd:      # 3 gate rows of the epilogue item off one base (middle gate: +-2048 bytes) + the token of the next step
+            self.extras = ["global_load_dwordx4 %%[ex%d], %%[xa], off offset:%d" % (q, (q - 1) * 2048) for q in range(3)]
+            self.extras.append("global_load_dword %[tokn], %[ta], off")
+            # stores of the previous epilogue: exchange slab (write-through), h_all, the four saved-gate vectors (1 KB apart)
+            self.st = [("slab", ["global_store_dwordx4 %[sa0], %[d0], off sc1"]), ("out", ["global_store_dwordx4 %[sa1], %[d0], off"])]
+            self.st += [("out", ["global_store_dwordx4 %%[sa2], %%[d%d], off offset:%d" % (q + 1, q * 1024)]) for q in range(4)]
+        else:        # saved gates r, z, n, hn (1 KB apart), previous state, external gradient
+            self.extras = ["global_load_dwordx4 %%[gt%d], %%[ga], off offset:%d" % (q, q * 1024) for q in range(4)]
+            self.extras += ["global_load_dwordx4 %[hp], %[ha], off", "global_load_dwordx4 %[xt], %[xa], off"]
+            # exchange slab: dr', dz', dn' r at column offsets 0, H, 2H of the [rows][3H] fragment image = 32 KB apart; dgx r / z / n (2 KB apart
+            # around the middle one), dghn
+            self.st = [("slab", ["global_store_dwordx4 %[so0], %[d0], %[sbase] sc1"]),
+                       ("slab", ["v_add_u32 v%d, 0x8000, %%[so0]" % TV, "global_store_dwordx4 v%d, %%[d1], %%[sbase] sc1" % TV]),
+                       ("slab", ["v_add_u32 v%d, 0x10000, %%[so0]" % (TV + 1), "global_store_dwordx4 v%d, %%[d3], %%[sbase] sc1" % (TV + 1)]),
+                       ("out", ["global_store_dwordx4 %[sg], %[d0], off offset:-2048"]), ("out", ["global_store_dwordx4 %[sg], %[d1], off"]),
+                       ("out", ["global_store_dwordx4 %[sg], %[d2], off offset:2048"]), ("out", ["global_store_dwordx4 %[sn], %[d3], off"])]
+
+    def ring(self, slot):
+        return self.ring0 + 4 * slot
+
+    def wf(self, bs, n):
+        return self.w0 + 4 * (self.NB * bs + n)
+
+    def mfmas(self, slot, bs):
+        out = []
+        for jj in range(4):
+            for x in (range(3) if self.fwd else [jj & 1]):
+                a = self.ring(slot) + jj
+                b = (self.wf(bs, x) if self.fwd else self.wf(bs, 0)) + jj
+                c = 4 * x
+                out.append("v_mfma_f32_16x16x4_f32 a[%d:%d], a%d, a%d, a[%d:%d]" % (c, c + 3, a, b, c, c + 3))
+        return out
+
+    # ---- ring request of a phase: units 0 .. RU-2 into slots 0 .. RU-2 off the scalar base in s[SB:SB+1] (clobbered), + weight fragments of unit 0
+    def request(self, xin, vo):
+        L = ["s_mov_b64 s[%d:%d], %s" % (SB, SB + 1, xin), "s_nop 4"]
+        rel = 0
+        for u in range(self.RU - 1):
+            while u * 1024 - rel > 4095:
+                L += ["s_add_u32 s%d, s%d, 0x1000" % (SB, SB), "s_addc_u32 s%d, s%d, 0" % (SB + 1, SB + 1), "s_nop 4"]
+                rel += 4096
+            r = self.ring(u)
+            L.append("global_load_dwordx4 a[%d:%d], %s, s[%d:%d] offset:%d sc1" % (r, r + 3, vo, SB, SB + 1, u * 1024 - rel))
+        for n in range(self.NB):
+            L.append(self.wread_at(0, n, 0))
+        return L
+
+    def wread_at(self, bs, n, unit):
+        """weight fragments of K unit `unit` (absolute inside this wave's K range); no pointer is ever advanced"""
+        r = self.wf(bs, n)
+        if self.fwd:      # wl[3][nk][2][64][4] floats, gate stride 32 KB at H = 512: gates 0, 1 off lp, gate 2 off lq = lp + 64 KB
+            ptr, off = ("%[lp]", n * 32768 + unit * 1024) if n < 2 else ("%[lq]", unit * 1024)
+        else:             # wl[nk3][2][64][4]: units 0-47 off lp, 48-95 off lq = lp + 48 KB
+            ptr, off = ("%[lp]", unit * 1024) if unit < 48 else ("%[lq]", (unit - 48) * 1024)
+        assert 0 <= off < 65536
+        return "ds_read_b128 a[%d:%d], %s offset:%d" % (r, r + 3, ptr, off)
+
+    def advance_to(self, need_rel):
+        out = []
+        while need_rel - self.s_rel > 3072:
+            out += ["s_add_u32 s%d, s%d, 0x1000" % (SB, SB), "s_addc_u32 s%d, s%d, 0" % (SB + 1, SB + 1)]
+            self.s_rel += 4096
+        assert 0 <= need_rel - self.s_rel <= 3072, (need_rel, self.s_rel)
+        return out
+
+    def wait_unit(self, unit_abs):
+        last = max(i for i, o in enumerate(self.vmops) if o == ("ring", unit_abs))
+        n = len(self.vmops) - 1 - last
+        assert n < 60, n
+        return "s_waitcnt vmcnt(%d)" % n
+
+    def arrive_block(self):
+        """the slab stores of the previous epilogue (or, without stores, everything older than this statement) have completed in every
+        wave -> one arrival (arr: 0 = none due, 1 = due, 2 = due and this wave issues it)"""
+        slab = [i for i, o in enumerate(self.vmops) if o == ("store", "slab")]
+        n = (len(self.vmops) - 1 - max(slab)) if slab else (len(self.vmops) - self.n0)
+        return ["s_cmp_eq_u32 %[arr], 0", "s_cbranch_scc1 .Lnoarr_%=", "s_waitcnt vmcnt(%d)" % n, "s_barrier",
+                "s_cmp_lt_u32 %[arr], 2", "s_cbranch_scc1 .Lnoarr_%=",
+                "s_mov_b64 s[%d:%d], exec" % (SB + 2, SB + 3), "s_mov_b64 exec, 1", "v_mov_b32 %[pv], 1",
+                "global_atomic_add %[acnt], %[pv], off", "s_mov_b64 exec, s[%d:%d]" % (SB + 2, SB + 3), ".Lnoarr_%=:"]
+
+    def store_ins(self, ins):
+        if not self.masked:
+            return ins
+        return ["s_mov_b64 s[%d:%d], exec" % (SB + 2, SB + 3), "s_mov_b64 exec, 0xffffffff"] + ins + ["s_mov_b64 exec, s[%d:%d]" % (SB + 2, SB + 3)]
+
+    def body(self):
+        RU, G = self.RU, self.G
+        assert G >= 2
+        self.vmops = [("ring", u) for u in range(RU - 1)]          # in flight when the statement starts: the ring request and nothing else
+        self.n0 = len(self.vmops)
+        self.s_rel = 0
+        L = ["s_mov_b64 s[%d:%d], %%[xin]" % (SB, SB + 1)]
+        start_rel = (RU - 1) * 1024 - 3072
+        while self.s_rel < start_rel:
+            L += ["s_add_u32 s%d, s%d, 0x1000" % (SB, SB), "s_addc_u32 s%d, s%d, 0" % (SB + 1, SB + 1)]
+            self.s_rel += 4096
+        assert self.s_rel == start_rel
+        for c in range(self.nacc):
+            L.append("v_accvgpr_write_b32 a%d, 0" % c)
+        pending = list(self.extras)
+        stores = list(self.st) if self.stores else []
+        nslab = sum(1 for k, _ in stores if k == "slab")
+        u_arr = (3 if self.fwd else 10) if self.stores else 0          # ~1.2 k cycles behind the (last) slab store; no stores: at once
+        assert u_arr >= nslab and u_arr < self.units - RU
+        u0 = (G - 1) * RU
+        # the epilogue operands of THIS phase (HBM reads): the last units of the second-to-last group - they retire (in order) long before the
+        # counter is looked at, and the ring loads issued behind them are not needed before 7 units later
+        ne = len(self.extras)
+        extra_units = {u0 - ne + j: j for j in range(ne)}
+        wslots = [2, 5, 8] if self.fwd else [1]
+        t_store = 6 if self.fwd else 3
+        t_extra = 10 if self.fwd else 2
+        KC = 2 if self.fwd else 7                                      # the counter is looked at behind unit u0 + KC (~1.1 k cycles after its load)
+
+        def unit(g, k, path):
+            """instructions of unit (g, k); path: None = common part, "R" = the next phase's ring is being requested, "N" = it is not"""
+            out = []
+            final = g == G - 1
+            u = g * RU + k
+            refill = (not final) or k == 0
+            wnext = (not final) or k < RU - 1
+            if path is None:
+                out.append(self.wait_unit(u))
+            out.append("s_waitcnt lgkmcnt(0)")
+            comp = [[] for _ in range(self.nmf)]
+            if refill:
+                imm = (k + RU - 1) * 1024 - self.s_rel
+                assert 0 <= imm <= 4095
+                r = self.ring((k - 1) % RU)
+                comp[0].append("global_load_dwordx4 a[%d:%d], %%[vo], s[%d:%d] offset:%d sc1" % (r, r + 3, SB, SB + 1, imm))
+                self.vmops.append(("ring", u + RU - 1))
+            if final and k == 0:
+                # the last refill is out: the counter of the NEXT phase's half, looked at KC units later
+                comp[1].append("global_load_dword %[pv], %[pcnt], off sc1")
+                self.vmops.append(("poll", 0))
+            if path == "R":
+                # ring of the next phase: slot s is free once unit u0 + s has been multiplied.  Unit KC + 1 requests slots 0 .. KC, every later one its predecessor's
+                slots = list(range(0, KC + 1)) if k == KC + 1 else [k - 1]
+                if self.RU == 16:                                      # backward: 15 slots over units KC+1 .. 15
+                    slots = {KC + 1: list(range(0, KC + 1))}.get(k, [k - 1])
+                ts = [0, 3, 6, 9, 1, 4, 7, 10] if self.fwd else [0, 2, 1, 3]
+                for n_, sl in enumerate(slots):
+                    if sl > RU - 2:
+                        continue
+                    r = self.ring(sl)
+                    assert sl * 1024 - self.y_rel <= 4095
+                    comp[ts[n_ % len(ts)]].append("global_load_dwordx4 a[%d:%d], %%[voy], s[%d:%d] offset:%d sc1" % (r, r + 3, SB, SB + 1, sl * 1024 - self.y_rel))
+            if stores and path is None and not final:                 # one store of the previous epilogue per unit, the exchange slab first
+                kind, ins = stores.pop(0)
+                comp[t_store] += self.store_ins(ins)
+                self.vmops.append(("store", kind))
+            if wnext:
+                for n, t in enumerate(wslots):
+                    comp[t].append(self.wread_at((k + 1) & 1, n, u + 1))
+            if u in extra_units:
+                comp[t_extra].append(pending.pop(0))
+                self.vmops.append(("extra", 0))
+            tail = []
+            if (not final) and k + 1 < RU:
+                tail += self.advance_to((k + 1 + RU - 1) * 1024)
+            if k == RU - 1 and not final:
+                tail += self.advance_to(RU * 1024 + start_rel + 3072)
+                assert self.s_rel == RU * 1024 + start_rel
+            t_tail = 9 if self.fwd else 2
+            for t, ins in enumerate(self.mfmas(k, k & 1)):
+                out.append(ins)
+                out += comp[t]
+                if t >= t_tail and tail and (not comp[t] or t == self.nmf - 1):
+                    out.append(tail.pop(0))
+                    if tail and tail[0].startswith("s_addc"):
+                        out.append(tail.pop(0))
+            out += tail
+            if u == u_arr:
+                out += self.arrive_block()
+            return out
+
+        for g in range(G - 1):
+            assert self.s_rel == start_rel
+            for k in range(RU):
+                L += unit(g, k, None)
+            self.s_rel -= RU * 1024
+        assert not pending and not stores
+        for k in range(KC + 1):
+            L += unit(G - 1, k, None)
+        # ---- the counter: everything requested so far has landed (own ring, epilogue operands, the counter value)
+        L += ["s_waitcnt vmcnt(0)", "v_readfirstlane_b32 s%d, %%[pv]" % (SB + 2), "s_cmp_ge_u32 s%d, %%[ptgt]" % (SB + 2), "s_cbranch_scc0 .Lnoreq_%="]
+        # path R: the remaining units with the next phase's ring request between their MFMAs
+        L += ["s_mov_b64 s[%d:%d], %%[xiny]" % (SB, SB + 1)]
+        self.y_rel = 0
+        for k in range(KC + 1, RU):
+            # scalar base of the next phase's operands: advance in 4 KB steps so that slot offsets stay below 4096
+            need = (k - 1) * 1024
+            if need - self.y_rel > 3072:
+                L += ["s_add_u32 s%d, s%d, 0x1000" % (SB, SB), "s_addc_u32 s%d, s%d, 0" % (SB + 1, SB + 1), "s_nop 4"]
+                self.y_rel += 4096
+                # slots requested by unit KC + 1 below the new base were issued before the advance (they are at offsets < 4096 of the old base)
+            L += unit(G - 1, k, "R")
+        L += ["s_branch .Ldone_%=", ".Lnoreq_%=:"]
+        for k in range(KC + 1, RU):
+            L += unit(G - 1, k, "N")
+        L += [".Ldone_%=:"]
+        for n in range(self.NB):          # weight fragments of the next phase's unit 0 (the same slice for both halves)
+            L.append(self.wread_at(0, n, 0))
+        L += ["s_nop 15"]
+        # accumulators -> LDS (padded MFMA C layout); an MFMA result needs 12 wait states before anything but an accumulating MFMA reads it
+        if self.fwd:
+            for n in range(3):
+                L.append("ds_write_b128 %%[red], a[%d:%d] offset:%d" % (4 * n, 4 * n + 3, n * 1088))
+        else:
+            for par in range(2):
+                L.append("ds_write_b128 %%[red], a[%d:%d] offset:%d" % (4 * par, 4 * par + 3, par * 8 * 1088))
+        L.append("s_waitcnt lgkmcnt(0)")
+        return L
+
+    def emit_main(self):
+        L = self.body()
+        body = "\n".join('        "%s\\n\\t"' % l for l in L)
+        clob = ", ".join(['"a%d"' % i for i in range(self.nagpr)] + ([] if self.fwd or not self.stores else ['"v%d"' % TV, '"v%d"' % (TV + 1)]))
+        sig = ("const float* xin_, unsigned vo, unsigned lp, unsigned lq, unsigned red,\n"
+               "        int arr, u32* acnt, const u32* pcnt, unsigned ptgt, const float* xiny_, unsigned voy,\n")
+        pre = ""
+        if self.fwd:
+            sig += "        const float* xa, const int* ta"
+            if self.stores:
+                sig += ",\n        float* sa0, float* sa1, float* sa2, const f32x4& d0, const f32x4& d1, const f32x4& d2, const f32x4& d3, const f32x4& d4"
+            sig += ",\n        f32x4 (&ex)[3], int& tokn, unsigned& pv"
+            outs = ", ".join(['[ex%d] "=&v"(ex[%d])' % (q, q) for q in range(3)] + ['[tokn] "=&v"(tokn)', '[pv] "=&v"(pv)'])
+            ins = '[xa] "v"(xa), [ta] "v"(ta)'
+            if self.stores:
+                ins += ', [sa0] "v"(sa0), [sa1] "v"(sa1), [sa2] "v"(sa2), [d0] "v"(d0), [d1] "v"(d1), [d2] "v"(d2), [d3] "v"(d3), [d4] "v"(d4)'
+        else:
+            sig += "        const float* ga, const float* ha, const float* xa"
+            if self.stores:
+                sig += ",\n        float* sbase_, unsigned so0, float* sg, float* sn, const f32x4& d0, const f32x4& d1, const f32x4& d2, const f32x4& d3"
+                pre = "    float* sbase = const_cast<float*>(fn_uniform_ptr(sbase_));\n"
+            sig += ",\n        f32x4 (&gt)[4], f32x4& hp, f32x4& xt, unsigned& pv"
+            outs = ", ".join(['[gt%d] "=&v"(gt[%d])' % (q, q) for q in range(4)] + ['[hp] "=&v"(hp)', '[xt] "=&v"(xt)', '[pv] "=&v"(pv)'])
+            ins = '[ga] "v"(ga), [ha] "v"(ha), [xa] "v"(xa)'
+            if self.stores:
+                ins += ', [sbase] "s"(sbase), [so0] "v"(so0), [sg] "v"(sg), [sn] "v"(sn), [d0] "v"(d0), [d1] "v"(d1), [d2] "v"(d2), [d3] "v"(d3)'
+        if self.fwd:
+            what = "sa0 / sa1 / sa2 + d0..d4: exchange-slab, h_all and saved-gates addresses and new state, r, z, n, W_hn h + b_hn" if self.stores else ""
+        else:
+            what = ("sbase + so0: exchange slab of the previous epilogue and this lane's byte offset in it, sg / sn: dgx (middle gate) and dghn addresses, "
+                    "d0..d3 = dr', dz', dn', dn' r") if self.stores else ""
+        return """
+// %s: K loop of one phase (%d units of 16 K values, ring of %d, %d MFMAs per unit, %d AGPRs; %s%s).
+// xin = this wave's first operand unit of THIS phase (uniform), vo = byte offset of its row tile (+ lane * 16); the first %d units are already
+// in flight.  arr / acnt: arrival for the previous phase's epilogue (0 none, 1 due, 2 due and this wave issues it / its counter).
+// pcnt / ptgt: counter and target of the next phase's half; xiny / voy: its operand base and tile offset - its ring is requested when
+// pv >= ptgt at the end of this loop (pv is returned: otherwise the caller polls and requests it with the *_pro statement).%s
+FN_DEVINL void %s(%s) {
+    const float* xin = fn_uniform_ptr(xin_);
+    const float* xiny = fn_uniform_ptr(xiny_);
+    // wave-uniform by construction; an "s" operand the compiler believes divergent would be handed over in a VGPR
+    arr = __builtin_amdgcn_readfirstlane(arr);
+    ptgt = (unsigned)__builtin_amdgcn_readfirstlane((int)ptgt);
+%s    asm volatile(
+%s
+        : %s
+        : [xin] "s"(xin), [xiny] "s"(xiny), [vo] "v"(vo), [voy] "v"(voy), [red] "v"(red), [lp] "v"(lp), [lq] "v"(lq), [arr] "s"(arr),
+          [acnt] "v"(acnt), [pcnt] "v"(pcnt), [ptgt] "s"(ptgt), %s
+        : "memory", "scc", "vcc", "s%d", "s%d", "s%d", "s%d", %s);
+}
+""" % (self.name, self.units, self.RU, self.nmf, self.nagpr, "issues the previous epilogue's stores" if self.stores else "no stores to issue",
+       ", lanes 0-31 store" if self.masked and self.stores else "", self.RU - 1, ("\n// " + what) if what else "", self.name, sig, pre, body, outs, ins,
+       SB, SB + 1, SB + 2, SB + 3, clob)
+
+    def emit_pro(self, name):
+        L = self.request("%[xin]", "%[vo]")
+        body = "\n".join('        "%s\\n\\t"' % l for l in L)
+        clob = ", ".join('"a%d"' % i for i in list(range(self.ring0, self.ring0 + (self.RU - 1) * 4)) + list(range(self.w0, self.w0 + self.NB * 4)))
+        return """
+// ring request of a phase (units 0 .. %d) + the weight fragments of unit 0: what the previous phase's statement does at its end when the
+// counter was already there
+FN_DEVINL void %s(const float* xin_, unsigned vo, unsigned lp, unsigned lq) {
+    const float* xin = fn_uniform_ptr(xin_);
+    asm volatile(
+%s
+        :
+        : [xin] "s"(xin), [vo] "v"(vo), [lp] "v"(lp), [lq] "v"(lq)
+        : "memory", "scc", "s%d", "s%d", %s);
+}
+""" % (self.RU - 2, name, body, SB, SB + 1, clob)
+
+
+HEAD = """// GENERATED by gen_kloop2.py - do not edit.  K loops of the ping-pong weight-stationary GRU scans (H = 512, one row tile per wave and phase).
+#pragma once
+#include "mma_core.h"
+typedef unsigned int u32;
+
+// wave-uniform by construction (depends on the wave id only); the compiler cannot see that
+FN_DEVINL const float* fn_uniform_ptr(const float* p) {
+    const unsigned long long q = (unsigned long long)(uintptr_t)p;
+    return reinterpret_cast<const float*>((uintptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(q >> 32)) << 32) |
+                                                      (unsigned)__builtin_amdgcn_readfirstlane((int)(q & 0xffffffffull))));
+}
+"""
+
+
+def main(path):
+    out = [HEAD]
+    # k512 / k1536: one wave over all of K (128-row groups, every lane has an epilogue item); k256 / k768: K split in two (64-row groups,
+    # lanes 0-31 of every wave have one)
+    for units, tag, masked, RUf in ((32, "k512", False, 8), (16, "k256", True, 8)):
+        for stores in (1, 0):
+            out.append(Gen("fn_pp_fwd_%s_%s" % (tag, "main" if stores else "first"), True, units, RUf, stores, masked).emit_main())
+        out.append(Gen("x", True, units, RUf, 0, masked).emit_pro("fn_pp_fwd_%s_pro" % tag))
+    for units, tag, masked in ((96, "k1536", False), (48, "k768", True)):
+        for stores in (1, 0):
+            out.append(Gen("fn_pp_bwd_%s_%s" % (tag, "main" if stores else "first"), False, units, 16, stores, masked).emit_main())
+        out.append(Gen("x", False, units, 16, 0, masked).emit_pro("fn_pp_bwd_%s_pro" % tag))
+    open(path, "w").write("\n".join(out))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "kloop2_asm.h")

@@ -17,6 +17,29 @@ FN_DEVINL long frag_off(int row, int k, int NC) {
 
 FN_DEVINL float f4at(const f32x4& v, int j) { return v[j]; }
 
+// Gate arithmetic of ONE element of a GRU step (gmm_model.py:131-136 / nn.GRU), contraction pinned: every weight-stationary kernel that
+// goes through here produces the same bits whatever the surrounding code looks like (the ping-pong kernels are tested bit for bit against
+// the single-group ones).  x* = input-side pre-activations (b_ih + W_ih x ...), gh* = W_hh h + b_hh.
+FN_DEVINL void fn_gru_gate(float xr, float xz, float xn, float ghr, float ghz, float ghn, float hprev, float& r, float& z, float& n, float& hnew) {
+#pragma clang fp contract(off)
+    r = fn_sigmoid(xr + ghr);
+    z = fn_sigmoid(xz + ghz);
+    n = fn_tanh(__builtin_fmaf(r, ghn, xn));
+    hnew = __builtin_fmaf(z, hprev, (1.0f - z) * n);
+}
+// ... and of the backward step: dh = gradient wrt the new state -> gradients wrt the pre-activations (dr', dz', dn'), dn' r and the part of dh
+// that flows straight into the previous state
+FN_DEVINL void fn_gru_gate_bwd(float dh, float r, float z, float n, float hn, float hprev, float& dr, float& dz, float& dnp, float& dnr, float& carry) {
+#pragma clang fp contract(off)
+    const float dn = dh * (1.0f - z);
+    const float dzz = dh * (hprev - n);
+    dnp = dn * (1.0f - n * n);
+    dz = dzz * z * (1.0f - z);
+    dr = dnp * hn * r * (1.0f - r);
+    dnr = dnp * r;
+    carry = dh * z;
+}
+
 // ---- in-launch hand-over helpers of the weight-stationary kernels (gru_persist.hip, decode_persist.hip) ----------------------
 // recipe R1 of cdna_hip_programming.md G16: 16-byte write-through (sc1) payload stores and L1-bypassing (sc1) loads; counters are
 // relaxed agent-scope atomics.  The asm loads are not counted by hipcc: pair them with fn_wait_vm<N>() / fn_keep() (mma_core.h).

@@ -18,9 +18,11 @@
 //     correctness never depends on placement).
 //   * every spin is bounded: on timeout (or when another workgroup has timed out) the workgroup raises err and leaves.
 #include <atomic>
+#include <type_traits>
 
 #include "gru_layout.h"
 #include "kloop_asm.h"
+#include "kloop2_asm.h"
 
 #ifdef FN_TIMING
 __device__ unsigned long long fn_pdbg[8 * 8];
@@ -28,11 +30,20 @@ __device__ unsigned long long fn_pdbg[8 * 8];
     do {                                                                                                     \
         if (blockIdx.x < 8 && threadIdx.x == 0 && p == 10) fn_pdbg[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); \
     } while (0)
+__device__ unsigned long long fn_pcnt[8];           // event counters of workgroup 0, thread 0 (ping-pong scans: [0] = counter polls that fell short)
+#define FN_PCOUNT(k)                                                      \
+    do {                                                                  \
+        if (blockIdx.x == 0 && threadIdx.x == 0) fn_pcnt[(k)] += 1;       \
+    } while (0)
 extern "C" int fn_pdbg_read(unsigned long long* host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fn_pdbg), sizeof(unsigned long long) * 64);
 }
+extern "C" int fn_pcnt_read(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fn_pcnt), sizeof(unsigned long long) * 8);
+}
 #else
 #define FN_PSTAMP(k)
+#define FN_PCOUNT(k)
 #endif
 
 namespace {
@@ -317,10 +328,10 @@ __global__ __launch_bounds__(NT) void gru_fwd_persist_kernel(const PArgs args) {
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float r = fn_sigmoid(((bi[0][c] + e_x[i][0][c]) + e_rb[i][0][c]) + gh[0][c]);
-                const float z = fn_sigmoid(((bi[1][c] + e_x[i][1][c]) + e_rb[i][1][c]) + gh[1][c]);
-                const float n = fn_tanh(((bi[2][c] + e_x[i][2][c]) + e_rb[i][2][c]) + r * gh[2][c]);
-                hp[i][c] = (1.0f - z) * n + z * hp[i][c];
+                float r, z, n, hn;
+                fn_gru_gate((bi[0][c] + e_x[i][0][c]) + e_rb[i][0][c], (bi[1][c] + e_x[i][1][c]) + e_rb[i][1][c], (bi[2][c] + e_x[i][2][c]) + e_rb[i][2][c],
+                            gh[0][c], gh[1][c], gh[2][c], hp[i][c], r, z, n, hn);
+                hp[i][c] = hn;
                 o_r[i][c] = r; o_z[i][c] = z; o_n[i][c] = n; o_g[i][c] = gh[2][c];
             }
             // the exchange slab first: it is all the other workgroups wait for
@@ -602,16 +613,9 @@ __global__ __launch_bounds__(NT) void gru_bwd_persist_kernel(const QArgs args) {
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float r = g_r[i][c], z = g_z[i][c], n = g_n[i][c], hn = g_hn[i][c];
-                const float dn = dh[c] * (1.0f - z);
-                const float dz = dh[c] * (hpv[i][c] - n);
-                const float dnp = dn * (1.0f - n * n);
-                const float dr = dnp * hn;
-                o_z[i][c] = dz * z * (1.0f - z);
-                o_r[i][c] = dr * r * (1.0f - r);
-                o_n[i][c] = dnp;
-                o_g[i][c] = dnp * r;
-                carry[i][c] = dh[c] * z;
+                float dr, dz, dnp, dnr, cy;
+                fn_gru_gate_bwd(dh[c], g_r[i][c], g_z[i][c], g_n[i][c], g_hn[i][c], hpv[i][c], dr, dz, dnp, dnr, cy);
+                o_r[i][c] = dr; o_z[i][c] = dz; o_n[i][c] = dnp; o_g[i][c] = dnr; carry[i][c] = cy;
             }
             if (publish && iact[i]) {
                 stv4_sc1(xout + frag_off(ib[i], jj0, nkc), o_r[i]);
@@ -654,6 +658,504 @@ __global__ __launch_bounds__(NT) void gru_bwd_persist_kernel(const QArgs args) {
         if (S.rowsum_n) {
             float* p = S.rowsum_n + (long)ib[i] * H + jj0;
             stv4(p, ldv4(p) + rsn[i]);
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Ping-pong forms of the two scans above (round 4; kloop2_asm.h has the why and the protocol): a workgroup owns TWO halves of its row
+// group - every wave one 16-row tile of each - and alternates between them.  Phase f = (half X = f & 1, step p = f >> 1): K loop of X
+// (the operand ring was requested a whole epilogue ago) -> accumulators to LDS -> gate epilogue of X.  The arrival for an epilogue's
+// stores is made inside the NEXT phase's K loop, the counter of the other half is read there as well, the other half's ring is requested
+// at its end.  H = 512, full row groups (every lane of every wave issues every store: the K loops count them), saved gates required.
+// Results are bit-identical to the kernels above (same accumulation order, same epilogue arithmetic).
+// ---------------------------------------------------------------------------------------------------------------
+FN_DEVINL void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// plain (write-back) 16-byte store as an asm statement: the ping-pong K loops count the stores of an epilogue
+FN_DEVINL void stv4_asm(float* p, const f32x4& v) { asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
+
+// waits (this wave) until *c >= target; false = gave up (sticky error word raised, `dead` set: every wave leaves behind the next barrier)
+FN_DEVINL int lds_ld(unsigned a) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
+FN_DEVINL void lds_st(unsigned a, int v) { asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+FN_DEVINL bool pp_wait_counter(u32* c, u32 target, u32* err, unsigned dead) {
+    u32 spins = 0;
+    while (ld_cnt(c) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 63u) == 0 && (spins > SPIN_LIMIT || ld_cnt(err) != 0)) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lds_st(dead, 1);
+            return false;
+        }
+    }
+    return true;
+}
+
+template <int WK>
+__global__ __launch_bounds__(NT) void gru_fwd_pp_kernel(const PArgs args) {
+    static_assert(WK == 1 || WK == 2, "128-row groups (one wave over all of K) or 64-row groups (K split in two)");
+    constexpr int WM = 4 / WK, EM = 2 * WM;          // wave rows; row tiles per workgroup (one per wave row and half)
+    constexpr int H = 512, nk = 16, nslices = 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wl = smem;                                // [3][nk][2][64][4]  W_hh slice, B-fragment order
+    float* red = smem + 3 * H * 16;                  // [WK][EM][3][RT]    accumulator exchange
+    // "a wave gave up" flag: an LDS word behind the accumulator tiles, accessed with ds_read / ds_write through its LDS address (as a C++
+    // object it is reached through FLAT instructions, which count on vmcnt: the compiler then drains the ring in flight)
+    const unsigned dead = lds_addr(red + WK * EM * 3 * RT);
+
+    const int g = blockIdx.x % args.ngroups, slice = blockIdx.x / args.ngroups;
+    int si = 0;
+#pragma unroll
+    for (int k = 1; k < FN_MAX_SCANS; ++k)
+        if (k < args.n && g >= args.s[k].group0) si = k;
+    const PScan& S = args.s[si];
+    const int B = S.B, T = S.T;
+    const int m0 = (g - S.group0) * (16 * EM), hh0 = slice * 16;
+    const int nrt = B >> 4;
+    const long FS = (long)nrt * 16 * H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wk = wave / WM;
+    u32* cnt[2] = {args.sync + (2 * g) * 32, args.sync + (2 * g + 1) * 32};      // one arrival counter per half
+    u32* err = args.err;
+
+    if (tid == 0) lds_st(dead, 0);
+#pragma unroll 1
+    for (int q = 0; q < 3; ++q) {
+        const float4* src = reinterpret_cast<const float4*>(S.w_frag + (long)(q * nslices + slice) * nk * 512);
+        float4* dst = reinterpret_cast<float4*>(wl + (long)q * nk * 512);
+        for (int i = tid; i < nk * 128; i += NT) dst[i] = src[i];
+    }
+
+    // epilogue item of this thread inside a half: (row, 4 consecutive units); 64-row groups have 128 items per half: lanes 0-31 of every
+    // wave (no wave without an item: every wave issues every store instruction)
+    const bool has_item = WK == 1 || lane < 32;
+    const int item = WK == 1 ? tid : wave * 32 + (lane & 31);
+    const int rl = item >> 2, th = rl >> 4;
+    const int jj0 = hh0 + 4 * (item & 3);
+    int ib[2], icoff[2];
+    f32x4 bh[3], bi[3], e_rb[2][3], hp[2];
+#pragma unroll
+    for (int hx = 0; hx < 2; ++hx) {
+        const int tile = 2 * th + hx;
+        ib[hx] = m0 + tile * 16 + (rl & 15);
+        icoff[hx] = (tile * 3) * RT + ((rl & 15) >> 2) * 68 + (item & 3) * 16 + (rl & 3);
+        hp[hx] = S.h0 ? ldv4(S.h0 + (long)ib[hx] * H + jj0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            e_rb[hx][q] = S.gx_rowbias ? ldv4(S.gx_rowbias + (long)ib[hx] * 3 * H + q * H + jj0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        bh[q] = ldv4(S.b_hh + q * H + jj0);
+        bi[q] = S.b_ih ? ldv4(S.b_ih + q * H + jj0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    int tokn[2];
+#pragma unroll
+    for (int hx = 0; hx < 2; ++hx) {
+        const int tau0 = (S.reverse ? T - 1 : 0) + S.idx_shift;
+        tokn[hx] = (S.gx_table && tau0 >= 0) ? S.idx[(long)ib[hx] * S.idx_ld + tau0] : S.start_token;
+    }
+    __syncthreads();
+
+    const int c0 = nk * wk / WK;                     // this wave's first K chunk
+    unsigned vo[2], h_red[2];
+#pragma unroll
+    for (int hx = 0; hx < 2; ++hx) {
+        const int tw = 2 * wm + hx;                  // this wave's row tile of half hx
+        vo[hx] = (unsigned)((((long)(m0 >> 4) + tw) * nk * 512 + lane * 4) * 4);
+        h_red[hx] = lds_addr(red) + ((((wk * EM + tw) * 3) * RT + lane * 4 + (lane >> 4) * 4) * 4);
+    }
+    const unsigned h_lp = lds_addr(wl) + c0 * 2048 + lane * 16;
+    const int* legal_i = S.idx ? S.idx : reinterpret_cast<const int*>(S.b_hh);
+
+    // stores of the last epilogue: issued by the NEXT phase's K loop statement (kloop2_asm.h), or by flush_stores() when none follows
+    float *st_a0 = nullptr, *st_a1 = nullptr, *st_a2 = nullptr;
+    f32x4 st_d[5];
+    auto flush_stores = [&]() __attribute__((always_inline)) {
+        if (has_item) {
+            stv4_sc1(st_a0, st_d[0]);
+            stv4(st_a1, st_d[0]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) stv4(st_a2 + q * 256, st_d[1 + q]);
+        }
+    };
+    // gate epilogue of half hx at step p: reads the accumulator tiles from LDS, leaves the new state (exchange slab + h_all) and the saved
+    // gates in st_*: arithmetic and LDS reads only, no vector-memory instruction
+    auto epilogue = [&](auto HX, const int p, const f32x4 (&e_x)[3]) __attribute__((always_inline)) {
+        constexpr int hx = decltype(HX)::value;
+        float* xout = (p + 1 < T || !S.hlf) ? S.xf + (long)((p + 1) & 1) * FS : S.hlf;      // last step: the next launch's hand-over slab (or a slab nobody reads)
+        f32x4 gh[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < WK; ++w) a += red[(long)(w * EM * 3 + q) * RT + icoff[hx] + c * 4];
+                gh[q][c] = a + bh[q][c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float r, z, n, hn;
+            fn_gru_gate((bi[0][c] + e_x[0][c]) + e_rb[hx][0][c], (bi[1][c] + e_x[1][c]) + e_rb[hx][1][c], (bi[2][c] + e_x[2][c]) + e_rb[hx][2][c],
+                        gh[0][c], gh[1][c], gh[2][c], hp[hx][c], r, z, n, hn);
+            hp[hx][c] = hn;
+            st_d[1][c] = r; st_d[2][c] = z; st_d[3][c] = n; st_d[4][c] = gh[2][c];
+        }
+        st_d[0] = hp[hx];
+        st_a0 = xout + frag_off(ib[hx], jj0, nk);
+        st_a1 = S.h_all + (long)p * B * H + (long)ib[hx] * H + jj0;
+        st_a2 = S.gates + (long)p * 4 * H * nrt * 16 + gate_off(ib[hx], 0, jj0, nrt);
+    };
+    auto next_token = [&](const int hx, const int p, const int loaded) {      // token of step p + 1 (loaded = idx value requested for it)
+        const int tau1 = (S.reverse ? T - 2 - p : p + 1) + S.idx_shift;
+        return tau1 >= 0 ? loaded : S.start_token;
+    };
+    auto token_addr = [&](const int hx, const int p) {                        // where the token of step p + 1 lives (a legal address otherwise)
+        const int tau1 = (S.reverse ? T - 2 - p : p + 1) + S.idx_shift;
+        return (S.gx_table && p + 1 < T && tau1 >= 0) ? S.idx + (long)ib[hx] * S.idx_ld + tau1 : legal_i;
+    };
+
+    int pend = -1;                                   // half whose epilogue stores still await their arrival (made inside the next K loop)
+    int p_first = 0;
+    if (!S.h0) {
+        // ---- step 0 from a zero state: no K loop (gh = b_hh); half A arrives at once, half B's arrival rides in the first K loop --------
+        p_first = 1;
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx)
+#pragma unroll
+            for (int n = 0; n < 3; ++n)
+                *reinterpret_cast<f32x4*>(red + (long)((wk * EM + 2 * wm + hx) * 3 + n) * RT + lane * 4 + (lane >> 4) * 4) = z4;
+        f32x4 e0[2][3];
+        int t1[2];
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                e0[hx][q] = z4;
+                if (S.gx_table) e0[hx][q] = ldv4(S.gx_table + (long)tokn[hx] * 3 * H + jj0 + q * H);
+                if (S.gx_dense) e0[hx][q] += ldv4(S.gx_dense + (long)ib[hx] * 3 * H + jj0 + q * H);
+            }
+            t1[hx] = *token_addr(hx, 0);
+        }
+        __syncthreads();
+        epilogue(std::integral_constant<int, 0>{}, 0, e0[0]);
+        flush_stores();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(cnt[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        epilogue(std::integral_constant<int, 1>{}, 0, e0[1]);
+        flush_stores();
+        pend = 1;
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx)
+            if (S.gx_table) tokn[hx] = next_token(hx, 0, t1[hx]);
+    }
+    // every load the compiler knows about has to be complete HERE: a value still pending at the loop entry would make it place an
+    // s_waitcnt vmcnt(0) at its first use inside the loop - executed by every iteration, draining the rings in flight
+#pragma unroll
+    for (int hx = 0; hx < 2; ++hx) {
+        asm volatile("" : "+v"(tokn[hx]));
+        fn_touch(hp[hx]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) fn_touch(e_rb[hx][q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { fn_touch(bh[q]); fn_touch(bi[q]); }
+
+    // ---- ring of the first K phase (half A of step p_first) ---------------------------------------------------------------------------
+    {
+        const float* xin = ((p_first == 0 && S.h0f) ? S.h0f : S.xf + (long)(p_first & 1) * FS) + (long)c0 * 512;
+        if (p_first > 0) pp_wait_counter(cnt[0], (u32)nslices * (u32)p_first, err, dead);
+        if (WK == 1) fn_pp_fwd_k512_pro(xin, vo[0], h_lp, h_lp + 65536u);
+        else fn_pp_fwd_k256_pro(xin, vo[0], h_lp, h_lp + 65536u);
+    }
+    bool first = true;                               // no epilogue stores are waiting to be issued (first K phase of the launch)
+
+    auto phase = [&](auto HX, const int p) __attribute__((always_inline)) -> bool {
+        constexpr int hx = decltype(HX)::value, hy = hx ^ 1;
+        const int f1 = 2 * p + hx + 1, p1 = f1 >> 1;
+        const bool next_k = f1 < 2 * T;
+        const float* xin = ((p == 0 && S.h0f) ? S.h0f : S.xf + (long)(p & 1) * FS) + (long)c0 * 512;
+        const float* xiny = S.xf + (long)(p1 & 1) * FS + (long)c0 * 512;      // p1 >= 1 whenever a next phase exists beyond (A, 0) -> (B, 0)
+        if (p1 == 0 && S.h0f) xiny = S.h0f + (long)c0 * 512;
+        const unsigned ptgt = next_k ? (u32)nslices * (u32)p1 : 0xffffffffu;
+        const float* xa = S.gx_table ? S.gx_table + (long)tokn[hx] * 3 * H + jj0 + H : S.gx_dense + ((long)p * B + ib[hx]) * 3 * H + jj0 + H;
+        const int* ta = token_addr(hx, p);
+        f32x4 e_x[3];
+        int tk;
+        unsigned pv;
+        const int arr = pend >= 0 ? (wave == 0 ? 2 : 1) : 0;
+        u32* acnt = cnt[pend > 0 ? 1 : 0];
+        FN_PSTAMP(hx * 4 + 0);
+        const unsigned h_lq = h_lp + 65536u;
+        if (WK == 1) {
+            if (first) fn_pp_fwd_k512_first(xin, vo[hx], h_lp, h_lq, h_red[hx], arr, acnt, cnt[hy], ptgt, xiny, vo[hy], xa, ta, e_x, tk, pv);
+            else fn_pp_fwd_k512_main(xin, vo[hx], h_lp, h_lq, h_red[hx], arr, acnt, cnt[hy], ptgt, xiny, vo[hy], xa, ta, st_a0, st_a1, st_a2, st_d[0], st_d[1], st_d[2],
+                                     st_d[3], st_d[4], e_x, tk, pv);
+        } else {
+            if (first) fn_pp_fwd_k256_first(xin, vo[hx], h_lp, h_lq, h_red[hx], arr, acnt, cnt[hy], ptgt, xiny, vo[hy], xa, ta, e_x, tk, pv);
+            else fn_pp_fwd_k256_main(xin, vo[hx], h_lp, h_lq, h_red[hx], arr, acnt, cnt[hy], ptgt, xiny, vo[hy], xa, ta, st_a0, st_a1, st_a2, st_d[0], st_d[1], st_d[2],
+                                     st_d[3], st_d[4], e_x, tk, pv);
+        }
+        first = false;
+        FN_PSTAMP(hx * 4 + 1);
+        if (S.gx_table) tokn[hx] = next_token(hx, p, tk);
+        if (next_k && pv < ptgt) {                   // rare: the other half's inputs were not all published yet - poll, then request its ring
+            FN_PCOUNT(0);
+            pp_wait_counter(cnt[hy], ptgt, err, dead);
+            if (WK == 1) fn_pp_fwd_k512_pro(xiny, vo[hy], h_lp, h_lp + 65536u);
+            else fn_pp_fwd_k256_pro(xiny, vo[hy], h_lp, h_lp + 65536u);
+        }
+        lds_barrier();
+        FN_PSTAMP(hx * 4 + 2);
+        if (lds_ld(dead)) return false;
+        epilogue(HX, p, e_x);
+        FN_PSTAMP(hx * 4 + 3);
+        pend = p + 1 < T ? hx : -1;                  // the arrival is made inside the next phase's K loop
+        return true;
+    };
+
+#pragma unroll 1
+    for (int p = p_first; p < T; ++p) {
+        if (!phase(std::integral_constant<int, 0>{}, p)) return;
+        if (!phase(std::integral_constant<int, 1>{}, p)) return;
+    }
+    flush_stores();                                  // the last epilogue's (no K loop follows)
+}
+
+// backward scan, ping-pong form (see gru_fwd_pp_kernel): iteration `it` handles step q = T - 1 - it; phase = (half, it)
+template <int WK>
+__global__ __launch_bounds__(NT) void gru_bwd_pp_kernel(const QArgs args) {
+    static_assert(WK == 1 || WK == 2, "128-row groups (one wave over all of K) or 64-row groups (K split in two)");
+    constexpr int WM = 4 / WK, EM = 2 * WM;
+    constexpr int H = 512, nk3 = 48, nslices = 32;
+    static_assert(WK * EM == 8, "kloop2_asm.h: the odd-k accumulator plane sits 8 tiles behind the even-k one");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wl = smem;                                // [nk3][2][64][4]  W_hh^T slice, B-fragment order
+    float* red = smem + 3 * H * 16;                  // [2][WK][EM][RT]
+    const unsigned dead = lds_addr(red + 2 * WK * EM * RT);
+
+    const int g = blockIdx.x % args.ngroups, slice = blockIdx.x / args.ngroups;
+    int si = 0;
+#pragma unroll
+    for (int k = 1; k < FN_MAX_SCANS; ++k)
+        if (k < args.n && g >= args.s[k].group0) si = k;
+    const QScan& S = args.s[si];
+    const int B = S.B, T = S.T;
+    const int m0 = (g - S.group0) * (16 * EM), hh0 = slice * 16;
+    const int nrt = B >> 4;
+    const long FS3 = (long)nrt * 16 * 3 * H;
+    const long BH = (long)B * H;
+    const long GS = (long)4 * H * nrt * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wk = wave / WM;
+    u32* cnt[2] = {args.sync + (2 * g) * 32, args.sync + (2 * g + 1) * 32};
+    u32* err = args.err;
+
+    if (tid == 0) lds_st(dead, 0);
+    {
+        const float4* src = reinterpret_cast<const float4*>(S.wt_frag + (long)slice * nk3 * 512);
+        float4* dst = reinterpret_cast<float4*>(wl);
+        for (int i = tid; i < nk3 * 128; i += NT) dst[i] = src[i];
+    }
+
+    const bool has_item = WK == 1 || lane < 32;
+    const int item = WK == 1 ? tid : wave * 32 + (lane & 31);
+    const int rl = item >> 2, th = rl >> 4;
+    const int jj0 = hh0 + 4 * (item & 3);
+    int ib[2], icoff[2];
+    f32x4 carry[2], rs[2][3], rsn[2];
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int hx = 0; hx < 2; ++hx) {
+        const int tile = 2 * th + hx;
+        ib[hx] = m0 + tile * 16 + (rl & 15);
+        icoff[hx] = tile * RT + ((rl & 15) >> 2) * 68 + (item & 3) * 16 + (rl & 3);
+        carry[hx] = S.dh_last ? ldv4(S.dh_last + (long)ib[hx] * H + jj0) : z4;
+        rsn[hx] = z4;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) rs[hx][q] = z4;
+    }
+    __syncthreads();
+
+    const int c0 = nk3 * wk / WK;
+    unsigned vo[2], h_red[2];
+#pragma unroll
+    for (int hx = 0; hx < 2; ++hx) {
+        const int tw = 2 * wm + hx;
+        vo[hx] = (unsigned)((((long)(m0 >> 4) + tw) * nk3 * 512 + lane * 4) * 4);
+        h_red[hx] = lds_addr(red) + (((wk * EM + tw) * RT + lane * 4 + (lane >> 4) * 4) * 4);
+    }
+    const unsigned h_lp = lds_addr(wl) + c0 * 2048 + lane * 16, h_lq = h_lp + 49152u;
+    const int iters = T + (S.dh0 ? 1 : 0);
+
+    // stores of the last epilogue: issued by the NEXT phase's K loop statement (kloop2_asm.h), or by flush_stores() when none follows
+    bool st_valid = false;
+    float *st_base = S.xf, *st_g = nullptr, *st_n = nullptr;
+    unsigned st_o = 0;
+    f32x4 st_d[4];
+    auto flush_stores = [&]() __attribute__((always_inline)) {
+        if (st_valid && has_item) {
+            char* sb = reinterpret_cast<char*>(st_base) + st_o;
+            stv4_sc1(reinterpret_cast<float*>(sb), st_d[0]);
+            stv4_sc1(reinterpret_cast<float*>(sb + 0x8000), st_d[1]);
+            stv4_sc1(reinterpret_cast<float*>(sb + 0x10000), st_d[3]);
+            stv4(st_g - H, st_d[0]);
+            stv4(st_g, st_d[1]);
+            stv4(st_g + H, st_d[2]);
+            stv4(st_n, st_d[3]);
+        }
+        st_valid = false;
+    };
+    // gate backward of half hx at iteration it (step q): arithmetic and LDS reads only; q < 0: only dL/dh0 is left (stored here)
+    auto epilogue = [&](auto HX, const int it, const f32x4 (&gt)[4], const f32x4& hpv, const f32x4& ext, const bool hand) __attribute__((always_inline)) {
+        constexpr int hx = decltype(HX)::value;
+        const int q = T - 1 - it;
+        f32x4 dh;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float a = 0.f;
+            if (hand) {
+#pragma unroll
+                for (int w = 0; w < WK; ++w) {
+                    float x = red[(long)(w * EM) * RT + icoff[hx] + c * 4];
+                    x += red[(long)((WK + w) * EM) * RT + icoff[hx] + c * 4];      // even-k + odd-k accumulator
+                    a += x;
+                }
+            }
+            dh[c] = (a + carry[hx][c]) + ext[c];
+        }
+        if (q < 0) {
+            if (has_item) stv4(S.dh0 + (long)ib[hx] * H + jj0, dh);
+            st_valid = false;
+            return;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float dr, dz, dnp, dnr, cy;
+            fn_gru_gate_bwd(dh[c], gt[0][c], gt[1][c], gt[2][c], gt[3][c], hpv[c], dr, dz, dnp, dnr, cy);
+            st_d[0][c] = dr; st_d[1][c] = dz; st_d[2][c] = dnp; st_d[3][c] = dnr; carry[hx][c] = cy;
+        }
+        rs[hx][0] += st_d[0]; rs[hx][1] += st_d[1]; rs[hx][2] += st_d[2]; rsn[hx] += st_d[3];
+        st_base = S.xf + (long)(it & 1) * FS3;
+        st_o = (unsigned)(frag_off(ib[hx], jj0, nk3) * 4);
+        st_g = S.dgx_all + (long)q * 3 * BH + (long)ib[hx] * 3 * H + jj0 + H;
+        st_n = S.dghn_all + (long)q * BH + (long)ib[hx] * H + jj0;
+        st_valid = true;
+    };
+
+    int pend = -1;
+    // ---- iteration 0: no K loop (dh = dh_last + dh_ext[T-1]); half A arrives at once, half B's arrival rides in the first K loop ----------
+    {
+        const int q = T - 1;
+        f32x4 g0[2][4], hp0[2], x0[2];
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) {
+            const float* gq = S.gates + (long)q * GS + gate_off(ib[hx], 0, jj0, nrt);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g0[hx][k] = ldv4(gq + k * 256);
+            hp0[hx] = q > 0 ? ldv4(S.h_all + (long)(q - 1) * BH + (long)ib[hx] * H + jj0) : (S.h0 ? ldv4(S.h0 + (long)ib[hx] * H + jj0) : z4);
+            x0[hx] = S.dh_ext ? ldv4(S.dh_ext + (long)q * BH + (long)ib[hx] * H + jj0) : z4;
+        }
+        const bool publish = iters > 1;
+        epilogue(std::integral_constant<int, 0>{}, 0, g0[0], hp0[0], x0[0], false);
+        flush_stores();
+        if (publish) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(cnt[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        epilogue(std::integral_constant<int, 1>{}, 0, g0[1], hp0[1], x0[1], false);
+        flush_stores();
+        pend = publish ? 1 : -1;
+    }
+    if (iters > 1) {
+        // every load the compiler knows about has to be complete before the loop (see gru_fwd_pp_kernel)
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) {
+            fn_touch(carry[hx]);
+            fn_touch(rsn[hx]);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) fn_touch(rs[hx][q]);
+        }
+        {
+            const float* xin = S.xf + (long)c0 * 512;          // slab 0: iteration 0's gate gradients
+            pp_wait_counter(cnt[0], (u32)nslices, err, dead);
+            if (WK == 1) fn_pp_bwd_k1536_pro(xin, vo[0], h_lp, h_lq);
+            else fn_pp_bwd_k768_pro(xin, vo[0], h_lp, h_lq);
+        }
+
+        auto phase = [&](auto HX, const int it) __attribute__((always_inline)) -> bool {
+            constexpr int hx = decltype(HX)::value, hy = hx ^ 1;
+            const int q = T - 1 - it, qc = q > 0 ? q : 0;
+            const int it1 = it + hx;
+            const int p = it;                             // FN_PSTAMP
+            (void)p;
+            const bool next_k = it1 < iters;
+            const float* xin = S.xf + (long)((it - 1) & 1) * FS3 + (long)c0 * 512;
+            const float* xiny = S.xf + (long)((it1 - 1) & 1) * FS3 + (long)c0 * 512;
+            const unsigned ptgt = next_k ? (u32)nslices * (u32)it1 : 0xffffffffu;
+            const long ro = (long)ib[hx] * H + jj0;
+            const float* ga = S.gates + (long)qc * GS + gate_off(ib[hx], 0, jj0, nrt);
+            const float* ha = qc > 0 ? S.h_all + (long)(qc - 1) * BH + ro : (S.h0 ? S.h0 + ro : S.h_all + ro);      // unused values still come from a legal address
+            const float* xa = S.dh_ext ? S.dh_ext + (long)qc * BH + ro : S.h_all + ro;
+            const bool hzero = q < 0 || (q == 0 && !S.h0), xzero = q < 0 || !S.dh_ext;
+            f32x4 gt[4], hp2, xt2;
+            unsigned pv;
+            const int arr = pend >= 0 ? (wave == 0 ? 2 : 1) : 0;
+            u32* acnt = cnt[pend > 0 ? 1 : 0];
+            FN_PSTAMP(hx * 4 + 0);
+            if (WK == 1) {
+                if (!st_valid) fn_pp_bwd_k1536_first(xin, vo[hx], h_lp, h_lq, h_red[hx], arr, acnt, cnt[hy], ptgt, xiny, vo[hy], ga, ha, xa, gt, hp2, xt2, pv);
+                else fn_pp_bwd_k1536_main(xin, vo[hx], h_lp, h_lq, h_red[hx], arr, acnt, cnt[hy], ptgt, xiny, vo[hy], ga, ha, xa, st_base, st_o, st_g, st_n, st_d[0], st_d[1],
+                                          st_d[2], st_d[3], gt, hp2, xt2, pv);
+            } else {
+                if (!st_valid) fn_pp_bwd_k768_first(xin, vo[hx], h_lp, h_lq, h_red[hx], arr, acnt, cnt[hy], ptgt, xiny, vo[hy], ga, ha, xa, gt, hp2, xt2, pv);
+                else fn_pp_bwd_k768_main(xin, vo[hx], h_lp, h_lq, h_red[hx], arr, acnt, cnt[hy], ptgt, xiny, vo[hy], ga, ha, xa, st_base, st_o, st_g, st_n, st_d[0], st_d[1],
+                                         st_d[2], st_d[3], gt, hp2, xt2, pv);
+            }
+            st_valid = false;
+            FN_PSTAMP(hx * 4 + 1);
+            if (next_k && pv < ptgt) {               // rare: the other half's inputs were not all published yet - poll, then request its ring
+                FN_PCOUNT(0);
+                pp_wait_counter(cnt[hy], ptgt, err, dead);
+                if (WK == 1) fn_pp_bwd_k1536_pro(xiny, vo[hy], h_lp, h_lq);
+                else fn_pp_bwd_k768_pro(xiny, vo[hy], h_lp, h_lq);
+            }
+            lds_barrier();
+            FN_PSTAMP(hx * 4 + 2);
+            if (lds_ld(dead)) return false;
+            epilogue(HX, it, gt, hzero ? z4 : hp2, xzero ? z4 : xt2, true);
+            FN_PSTAMP(hx * 4 + 3);
+            pend = (q > 0 || (q == 0 && S.dh0 != nullptr)) ? hx : -1;
+            return true;
+        };
+
+#pragma unroll 1
+        for (int it = 1; it < iters; ++it) {
+            if (!phase(std::integral_constant<int, 0>{}, it)) return;
+            if (!phase(std::integral_constant<int, 1>{}, it)) return;
+        }
+        flush_stores();
+    }
+#pragma unroll
+    for (int hx = 0; hx < 2; ++hx) {
+        if (!has_item) continue;
+        if (S.rowsum) {
+            float* p = S.rowsum + (long)ib[hx] * 3 * H + jj0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) stv4(p + q * H, ldv4(p + q * H) + rs[hx][q]);
+        }
+        if (S.rowsum_n) {
+            float* p = S.rowsum_n + (long)ib[hx] * H + jj0;
+            stv4(p, ldv4(p) + rsn[hx]);
         }
     }
 }
@@ -771,6 +1273,13 @@ int fn_gru_fwd_persist(const FnGruFwd* scans, int n_scans, hipStream_t st) {
     const int grid = groups * nslices;
     const int wk = rpw == 16 ? 4 : rpw == 32 ? 2 : (rpw == 64 && !(scans[0].variant & 0x100)) ? 2 : 1;     // K split of the chosen tiling
     const size_t lds = ((size_t)3 * H * 16 + (size_t)wk * (rpw / 16) * 3 * RT) * 4 + 16;
+    // ping-pong form (two halves per workgroup, kloop2_asm.h): H = 512, 128- or 64-row groups, full row groups, saved gates, one input source
+    bool pp = H == 512 && (rpw == 128 || (rpw == 64 && wk == 2)) && !(scans[0].variant & 0xC00) && 2 * groups <= FN_MAX_GROUPS;
+    for (int s = 0; s < n_scans && pp; ++s) {
+        const FnGruFwd& d = scans[s];
+        pp = d.B % rpw == 0 && d.gates && d.T >= 2 && ((d.gx_table != nullptr) != (d.gx_dense != nullptr));
+    }
+    if (pp) return rpw == 128 ? launch_k<PArgs, gru_fwd_pp_kernel<1>>(a, grid, lds, cus, st) : launch_k<PArgs, gru_fwd_pp_kernel<2>>(a, grid, lds, cus, st);
     switch (rpw) {
         case 128: return launch_k<PArgs, gru_fwd_persist_kernel<4, 1, 2, 4>>(a, grid, lds, cus, st);
         case 64:
@@ -836,6 +1345,12 @@ int fn_gru_bwd_persist(const FnGruBwd* scans, int n_scans, hipStream_t st) {
     const int grid = groups * nslices;
     const int wk = rpw == 16 ? 4 : rpw == 32 ? 2 : (rpw == 64 && !(scans[0].variant & 0x100)) ? 2 : 1;
     const size_t lds = ((size_t)3 * H * 16 + (size_t)2 * wk * (rpw / 16) * RT) * 4 + 16;
+    // ping-pong form (two halves per workgroup, kloop2_asm.h): H = 512, 128- or 64-row groups, full row groups
+    // (bit 12 selects it: measured no faster than the single-group loop - the backward K loop is bound by its operand stream, 768 KB per
+    // workgroup and step from L2, not by the hand-over latencies the ping-pong hides)
+    bool pp = H == 512 && (rpw == 128 || (rpw == 64 && wk == 2)) && !(scans[0].variant & 0xC00) && (scans[0].variant & 0x1000) && 2 * groups <= FN_MAX_GROUPS;
+    for (int s = 0; s < n_scans && pp; ++s) pp = scans[s].B % rpw == 0 && scans[s].T >= 2;
+    if (pp) return rpw == 128 ? launch_k<QArgs, gru_bwd_pp_kernel<1>>(a, grid, lds, cus, st) : launch_k<QArgs, gru_bwd_pp_kernel<2>>(a, grid, lds, cus, st);
     switch (rpw) {
         case 128: return launch_k<QArgs, gru_bwd_persist_kernel<4, 1, 2, 8>>(a, grid, lds, cus, st);
         case 64:

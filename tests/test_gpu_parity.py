@@ -1031,6 +1031,83 @@ def test_chunked_scan_with_fragment_handover_is_bit_identical(ops, B, H, rows):
     assert torch.equal(h_all, ref["h_all"]) and torch.equal(gates, ref["gates"])
 
 
+def _pp_forward_scans(ops, n, B, H, Ts, seed, kinds):
+    """n scan descriptors (device) for the ping-pong comparison; kinds[i] in {"table", "table_rev", "table_shift", "dense"}"""
+    torch.manual_seed(seed)
+    V = 50
+    scans = []
+    for i in range(n):
+        T = Ts[i % len(Ts)]
+        wf = torch.zeros(ops.frag_floats(3 * H, H), device=DEV)
+        ops.frag_pack((torch.randn(3 * H, H, device=DEV) / H ** 0.5).contiguous(), wf)
+        d = dict(B=B, T=T, H=H, reverse=0, w_hh_frag=wf, b_hh=torch.randn(3 * H, device=DEV) * 0.1,
+                 h_all=torch.zeros(T, B, H, device=DEV), gates=torch.zeros(T, ops.gates_floats(B, H), device=DEV))
+        kind = kinds[i % len(kinds)]
+        if kind.startswith("table"):
+            d["gx_table"] = torch.randn(V, 3 * H, device=DEV) * 0.3
+            d["idx"] = torch.randint(0, V, (B, T), dtype=torch.int32, device=DEV)
+            d["b_ih"] = torch.randn(3 * H, device=DEV) * 0.1
+            if kind == "table_rev":
+                d["reverse"] = 1
+            if kind == "table_shift":
+                d["idx_shift"], d["start_token"] = -1, V - 1
+                d["gx_rowbias"] = torch.randn(B, 3 * H, device=DEV) * 0.2
+                d["h0"] = torch.randn(B, H, device=DEV) * 0.3
+        else:
+            d["gx_dense"] = torch.randn(T, B, 3 * H, device=DEV) * 0.3
+            if i & 1:
+                d["h0"] = torch.randn(B, H, device=DEV) * 0.3
+        scans.append(d)
+    return scans
+
+
+@pytest.mark.parametrize("n,B,Ts,kinds", [(4, 256, (9,), ("table", "table_rev")), (4, 256, (2, 5, 3, 7), ("table_rev", "dense", "table_shift", "table")),
+                                          (2, 256, (8,), ("table_shift", "dense")), (2, 256, (3, 6), ("dense", "table")), (1, 512, (5,), ("table_shift",)),
+                                          (3, 128, (4,), ("table", "dense", "table_rev")), (8, 128, (6, 3), ("table", "table_shift"))])
+def test_ping_pong_scans_are_bit_identical_to_the_single_group_loops(ops, n, B, Ts, kinds):
+    """round 4: the forward / backward scans whose workgroups alternate between two halves of their row group (gru_*_pp_kernel: H = 512,
+    128- and 64-row groups) against the round-3 loops (variant bit 0x800), three launches in a row on the same buffers"""
+    H = 512
+    scans = _pp_forward_scans(ops, n, B, H, Ts, 7 * n + B, kinds)
+    ops.gru_seq_fwd(scans, variant=0x800)
+    ref = [(d["h_all"].clone(), d["gates"].clone()) for d in scans]
+    for rep in range(3):
+        for d in scans:
+            d["h_all"].fill_(float("nan"))
+            d["gates"].fill_(float("nan"))
+        ops.gru_seq_fwd(scans)
+        assert not ops.gru_sync_error()
+        for i, ((h, gt), d) in enumerate(zip(ref, scans)):
+            assert torch.equal(d["h_all"], h), "rep %d scan %d h_all: max diff %g" % (rep, i, float((d["h_all"] - h).abs().max()))
+            assert torch.equal(d["gates"], gt), "rep %d scan %d gates" % (rep, i)
+    # backward of the same scans: gradient from the last state, from every step, or both; dL/dh0 and the per-sequence row sums optional
+    torch.manual_seed(3 * n + B)
+    bw = []
+    for i, d in enumerate(scans):
+        T = d["T"]
+        wt = torch.zeros(ops.frag_floats(H, 3 * H), device=DEV)
+        ops.frag_pack((torch.randn(H, 3 * H, device=DEV) / H ** 0.5).contiguous(), wt)
+        bw.append(dict(B=B, T=T, H=H, w_hh_t_frag=wt, h0=d.get("h0"), h_all=d["h_all"], gates=d["gates"],
+                       dh_last=torch.randn(B, H, device=DEV) if i % 3 != 1 else None, dh_ext=torch.randn(T, B, H, device=DEV) * 0.1 if i % 3 != 0 else None,
+                       dgx_all=torch.zeros(T, B, 3 * H, device=DEV), dghn_all=torch.zeros(T, B, H, device=DEV),
+                       dh0=torch.zeros(B, H, device=DEV) if (d.get("h0") is not None or i == 0) else None,
+                       dgx_rowsum=torch.zeros(B, 3 * H, device=DEV) if i & 1 else None, dghn_rowsum=torch.zeros(B, H, device=DEV) if i != 2 else None,
+                       scratch=torch.zeros(B, H, device=DEV)))
+    outs = ("dgx_all", "dghn_all", "dh0", "dgx_rowsum", "dghn_rowsum")
+    ops.gru_seq_bwd(bw, variant=0x800)
+    refb = [{k: b[k].clone() for k in outs if b[k] is not None} for b in bw]
+    for rep in range(3):
+        for b in bw:
+            for k in outs:
+                if b[k] is not None:
+                    b[k].zero_() if "rowsum" in k else b[k].fill_(float("nan"))
+        ops.gru_seq_bwd(bw, variant=0x1000)
+        assert not ops.gru_sync_error()
+        for i, (r, b) in enumerate(zip(refb, bw)):
+            for k, v in r.items():
+                assert torch.equal(b[k], v), "backward rep %d scan %d %s: max diff %g" % (rep, i, k, float((b[k] - v).abs().max()))
+
+
 def test_masked_prob_kernel(ops):
     torch.manual_seed(31)
     rows, E, ld = 203, 342, 344
