@@ -46,6 +46,12 @@ class Gen:
         self.ring0 = self.nacc
         self.w0 = self.ring0 + RU * 4
         self.nagpr = self.w0 + 2 * self.NB * 4
+        self.wslots = [2, 5, 8] if fwd else [1]
+        self.t_store, self.t_extra, self.t_tail = (6, 10, 9) if fwd else (3, 2, 2)
+        self.KC = 2 if fwd else 7                  # the counter is looked at behind unit u0 + KC (~1.1 k cycles after its load)
+        self.u_arr = 3 if fwd else 10              # ~1.2 k cycles behind the (last) slab store
+        self.next_ts = [0, 3, 6, 9, 1, 4, 7, 10] if fwd else [0, 2, 1, 3]
+        self.extra_lead = 14 if fwd else 40        # units between the first epilogue-operand load and the counter check
         if fwd:      # 3 gate rows of the epilogue item off one base (middle gate: +-2048 bytes) + the token of the next step
             self.extras = ["global_load_dwordx4 %%[ex%d], %%[xa], off offset:%d" % (q, (q - 1) * 2048) for q in range(3)]
             self.extras.append("global_load_dword %[tokn], %[ta], off")
@@ -66,8 +72,20 @@ class Gen:
     def ring(self, slot):
         return self.ring0 + 4 * slot
 
+    def refill_ins(self, slot, imm):
+        """(MFMA gap, instruction) pairs that re-fill ring slot `slot` from byte offset imm off the running base"""
+        r = self.ring(slot)
+        return [(0, "global_load_dwordx4 a[%d:%d], %%[vo], s[%d:%d] offset:%d sc1" % (r, r + 3, SB, SB + 1, imm))]
+
+    def next_ring_ins(self, slot, off):
+        r = self.ring(slot)
+        return ["global_load_dwordx4 a[%d:%d], %%[voy], s[%d:%d] offset:%d sc1" % (r, r + 3, SB, SB + 1, off)]
+
     def wf(self, bs, n):
         return self.w0 + 4 * (self.NB * bs + n)
+
+    def mfmas_u(self, slot, bs, u):
+        return self.mfmas(slot, bs)
 
     def mfmas(self, slot, bs):
         out = []
@@ -135,7 +153,7 @@ class Gen:
     def body(self):
         RU, G = self.RU, self.G
         assert G >= 2
-        self.vmops = [("ring", u) for u in range(RU - 1)]          # in flight when the statement starts: the ring request and nothing else
+        self.vmops = [("ring", u) for u in range(RU - 1) for _ in range(getattr(self, "TH", 1))]      # in flight when the statement starts: the ring request and nothing else
         self.n0 = len(self.vmops)
         self.s_rel = 0
         L = ["s_mov_b64 s[%d:%d], %%[xin]" % (SB, SB + 1)]
@@ -149,17 +167,15 @@ class Gen:
         pending = list(self.extras)
         stores = list(self.st) if self.stores else []
         nslab = sum(1 for k, _ in stores if k == "slab")
-        u_arr = (3 if self.fwd else 10) if self.stores else 0          # ~1.2 k cycles behind the (last) slab store; no stores: at once
+        u_arr = self.u_arr if self.stores else 0                       # no stores: at once
         assert u_arr >= nslab and u_arr < self.units - RU
         u0 = (G - 1) * RU
-        # the epilogue operands of THIS phase (HBM reads): the last units of the second-to-last group - they retire (in order) long before the
-        # counter is looked at, and the ring loads issued behind them are not needed before 7 units later
+        # the epilogue operands of THIS phase (HBM reads): early enough to have retired (in order) when the counter is looked at (its check
+        # waits for vmcnt(0)); the ring loads issued behind them are not needed before RU - 1 units later
         ne = len(self.extras)
-        extra_units = {u0 - ne + j: j for j in range(ne)}
-        wslots = [2, 5, 8] if self.fwd else [1]
-        t_store = 6 if self.fwd else 3
-        t_extra = 10 if self.fwd else 2
-        KC = 2 if self.fwd else 7                                      # the counter is looked at behind unit u0 + KC (~1.1 k cycles after its load)
+        e0 = max(1, min(u0 - ne, u0 + self.KC - self.extra_lead))       # >= 2.3 k cycles (HBM latency under load) in front of the counter check
+        extra_units = {e0 + j: j for j in range(ne)}
+        wslots, t_store, t_extra, KC = self.wslots, self.t_store, self.t_extra, self.KC
 
         def unit(g, k, path):
             """instructions of unit (g, k); path: None = common part, "R" = the next phase's ring is being requested, "N" = it is not"""
@@ -175,9 +191,9 @@ class Gen:
             if refill:
                 imm = (k + RU - 1) * 1024 - self.s_rel
                 assert 0 <= imm <= 4095
-                r = self.ring((k - 1) % RU)
-                comp[0].append("global_load_dwordx4 a[%d:%d], %%[vo], s[%d:%d] offset:%d sc1" % (r, r + 3, SB, SB + 1, imm))
-                self.vmops.append(("ring", u + RU - 1))
+                for t_, ins_ in self.refill_ins((k - 1) % RU, imm):
+                    comp[t_].append(ins_)
+                    self.vmops.append(("ring", u + RU - 1))
             if final and k == 0:
                 # the last refill is out: the counter of the NEXT phase's half, looked at KC units later
                 comp[1].append("global_load_dword %[pv], %[pcnt], off sc1")
@@ -185,15 +201,15 @@ class Gen:
             if path == "R":
                 # ring of the next phase: slot s is free once unit u0 + s has been multiplied.  Unit KC + 1 requests slots 0 .. KC, every later one its predecessor's
                 slots = list(range(0, KC + 1)) if k == KC + 1 else [k - 1]
-                if self.RU == 16:                                      # backward: 15 slots over units KC+1 .. 15
-                    slots = {KC + 1: list(range(0, KC + 1))}.get(k, [k - 1])
-                ts = [0, 3, 6, 9, 1, 4, 7, 10] if self.fwd else [0, 2, 1, 3]
-                for n_, sl in enumerate(slots):
+                ts = self.next_ts
+                n_ = 0
+                for sl in slots:
                     if sl > RU - 2:
                         continue
-                    r = self.ring(sl)
-                    assert sl * 1024 - self.y_rel <= 4095
-                    comp[ts[n_ % len(ts)]].append("global_load_dwordx4 a[%d:%d], %%[voy], s[%d:%d] offset:%d sc1" % (r, r + 3, SB, SB + 1, sl * 1024 - self.y_rel))
+                    assert -4096 <= sl * 1024 - self.y_rel <= 4095
+                    for ins_ in self.next_ring_ins(sl, sl * 1024 - self.y_rel):
+                        comp[ts[n_ % len(ts)]].append(ins_)
+                        n_ += 1
             if stores and path is None and not final:                 # one store of the previous epilogue per unit, the exchange slab first
                 kind, ins = stores.pop(0)
                 comp[t_store] += self.store_ins(ins)
@@ -210,8 +226,8 @@ class Gen:
             if k == RU - 1 and not final:
                 tail += self.advance_to(RU * 1024 + start_rel + 3072)
                 assert self.s_rel == RU * 1024 + start_rel
-            t_tail = 9 if self.fwd else 2
-            for t, ins in enumerate(self.mfmas(k, k & 1)):
+            t_tail = self.t_tail
+            for t, ins in enumerate(self.mfmas_u(k, k & 1, u)):
                 out.append(ins)
                 out += comp[t]
                 if t >= t_tail and tail and (not comp[t] or t == self.nmf - 1):
@@ -252,14 +268,14 @@ class Gen:
             L.append(self.wread_at(0, n, 0))
         L += ["s_nop 15"]
         # accumulators -> LDS (padded MFMA C layout); an MFMA result needs 12 wait states before anything but an accumulating MFMA reads it
-        if self.fwd:
-            for n in range(3):
-                L.append("ds_write_b128 %%[red], a[%d:%d] offset:%d" % (4 * n, 4 * n + 3, n * 1088))
-        else:
-            for par in range(2):
-                L.append("ds_write_b128 %%[red], a[%d:%d] offset:%d" % (4 * par, 4 * par + 3, par * 8 * 1088))
+        L += self.acc_writes()
         L.append("s_waitcnt lgkmcnt(0)")
         return L
+
+    def acc_writes(self):
+        if self.fwd:
+            return ["ds_write_b128 %%[red], a[%d:%d] offset:%d" % (4 * n, 4 * n + 3, n * 1088) for n in range(3)]
+        return ["ds_write_b128 %%[red], a[%d:%d] offset:%d" % (4 * par, 4 * par + 3, par * 8 * 1088) for par in range(2)]
 
     def emit_main(self):
         L = self.body()
@@ -333,6 +349,167 @@ FN_DEVINL void %s(const float* xin_, unsigned vo, unsigned lp, unsigned lq) {
 """ % (self.RU - 2, name, body, SB, SB + 1, clob)
 
 
+class GenRS(Gen):
+    """backward K loop with HALF of the workgroup's W_hh^T slice REGISTER-stationary (round 4).
+
+    The backward product has one third of the forward's operand reuse (a workgroup of the kernels above owns 16 dh columns x all 3H gate-gradient
+    columns: every 1 KB operand load feeds 4 MFMAs, 768 KB per workgroup and step stream from L2 - the K loop is bound by that stream and by
+    the issue slots of its 192 loads).  Here a workgroup owns 32 dh columns of HALF as many rows: the slice of the first 16 columns lives in
+    AGPRs (each of the 4 waves holds its K quarter: 24 units x 4 registers = 96), the slice of the other 16 in LDS as before; every wave
+    multiplies ALL row tiles of the current half over its K quarter, the four partial sums meet in LDS (the epilogue adds them in wave order).
+    One operand load now feeds 8 MFMAs, the operand stream per workgroup halves (384 KB per step for 64 rows), weight-fragment LDS reads halve.
+    TH = row tiles per half (2: 64-row groups, 1: 32-row groups).
+
+    Register map (a = AGPR): acc[m][ct] a[4 (2 m + ct) ..], ring[slot][m] a[8 TH + 4 (TH slot + m) ..], wfrag[bs] (LDS half), W[u] a[wr0 + 4 u ..] (never
+    written after the preload).  v200-v203: address temporaries.
+    """
+
+    def __init__(self, name, TH, RU, stores):
+        Gen.__init__(self, name, False, 24, RU, stores, TH == 1)
+        self.TH = TH
+        self.NB = 1
+        self.nmf = 8 * TH
+        self.nacc = 8 * TH
+        self.ring0 = self.nacc
+        self.w0 = self.ring0 + RU * TH * 4
+        self.wr0 = self.w0 + 8
+        self.nagpr = self.wr0 + 96
+        self.wslots = [2]
+        self.t_store, self.t_extra, self.t_tail = (6, 10, 12) if TH == 2 else (5, 3, 6)
+        self.KC = 2 if TH == 2 else 4
+        self.u_arr = 4 if TH == 2 else 7
+        self.next_ts = [0, 2, 4, 6, 8, 10, 12, 14] if TH == 2 else [0, 1, 2, 3, 4, 5, 6, 7]
+        self.extra_lead = 12 if TH == 2 else 14
+
+    def ring(self, slot, m=0):
+        return self.ring0 + 4 * (self.TH * slot + m)
+
+    def vreg(self, m, y=False):
+        return ("%[voy]" if y else "%[vo]") if m == 0 else "v%d" % (TV + 3 if y else TV + 2)
+
+    def refill_ins(self, slot, imm):
+        out = []
+        for m in range(self.TH):
+            r = self.ring(slot, m)
+            out.append((4 * m, "global_load_dwordx4 a[%d:%d], %s, s[%d:%d] offset:%d sc1" % (r, r + 3, self.vreg(m), SB, SB + 1, imm)))
+        return out
+
+    def next_ring_ins(self, slot, off):
+        return ["global_load_dwordx4 a[%d:%d], %s, s[%d:%d] offset:%d sc1" % (self.ring(slot, m), self.ring(slot, m) + 3, self.vreg(m, True), SB, SB + 1, off)
+                for m in range(self.TH)]
+
+    def request(self, xin, vo):
+        y = vo == "%[voy]"
+        L = ["s_mov_b64 s[%d:%d], %s" % (SB, SB + 1, xin), "s_nop 4"]
+        rel = 0
+        for u in range(self.RU - 1):
+            while u * 1024 - rel > 4095:
+                L += ["s_add_u32 s%d, s%d, 0x1000" % (SB, SB), "s_addc_u32 s%d, s%d, 0" % (SB + 1, SB + 1), "s_nop 4"]
+                rel += 4096
+            for m in range(self.TH):
+                r = self.ring(u, m)
+                L.append("global_load_dwordx4 a[%d:%d], %s, s[%d:%d] offset:%d sc1" % (r, r + 3, self.vreg(m, y), SB, SB + 1, u * 1024 - rel))
+        L.append(self.wread_at(0, 0, 0))
+        return L
+
+    def mfmas_u(self, slot, bs, u):
+        out = []
+        for jj in range(4):
+            for m in range(self.TH):
+                a = self.ring(slot, m) + jj
+                for ct, b in ((0, self.wr0 + 4 * u + jj), (1, self.wf(bs, 0) + jj)):
+                    c = 4 * (2 * m + ct)
+                    out.append("v_mfma_f32_16x16x4_f32 a[%d:%d], a%d, a%d, a[%d:%d]" % (c, c + 3, a, b, c, c + 3))
+        return out
+
+    def acc_writes(self):
+        return ["ds_write_b128 %%[red], a[%d:%d] offset:%d" % (4 * t, 4 * t + 3, t * 1088) for t in range(2 * self.TH)]
+
+    def body(self):
+        # the second row tile's offsets (one row tile = nk3 * 2 KB further on) live in v202 / v203 for the whole statement
+        pre = ["v_add_u32 v%d, 0x18000, %%[vo]" % (TV + 2), "v_add_u32 v%d, 0x18000, %%[voy]" % (TV + 3)] if self.TH == 2 else []
+        # the ring holds TH loads per unit: the base class counts one vmop per ring load, which refill_ins / the initial state provide
+        L = Gen.body(self)
+        return pre + L
+
+    def emit_main(self):
+        # initial ring state: TH loads per unit (Gen.body starts from one per unit: patch the bookkeeping through a subclass hook)
+        L = self.body()
+        body = "\n".join('        "%s\\n\\t"' % l for l in L)
+        clob = ", ".join(['"a%d"' % i for i in range(self.wr0)] + ['"v%d"' % (TV + i) for i in range(4)])
+        sig = ("const float* xin_, unsigned vo, unsigned lp, unsigned red,\n"
+               "        int arr, u32* acnt, const u32* pcnt, unsigned ptgt, const float* xiny_, unsigned voy,\n"
+               "        const float* ga, const float* ha, const float* xa")
+        ins = '[ga] "v"(ga), [ha] "v"(ha), [xa] "v"(xa)'
+        pre = ""
+        if self.stores:
+            sig += ",\n        float* sbase_, unsigned so0, float* sg, float* sn, const f32x4& d0, const f32x4& d1, const f32x4& d2, const f32x4& d3"
+            pre = "    float* sbase = const_cast<float*>(fn_uniform_ptr(sbase_));\n"
+            ins += ', [sbase] "s"(sbase), [so0] "v"(so0), [sg] "v"(sg), [sn] "v"(sn), [d0] "v"(d0), [d1] "v"(d1), [d2] "v"(d2), [d3] "v"(d3)'
+        sig += ",\n        f32x4 (&gt)[4], f32x4& hp, f32x4& xt, unsigned& pv"
+        outs = ", ".join(['[gt%d] "=&v"(gt[%d])' % (q, q) for q in range(4)] + ['[hp] "=&v"(hp)', '[xt] "=&v"(xt)', '[pv] "=&v"(pv)'])
+        return """
+// %s: register-stationary backward K loop of one phase (%d row tile(s) x 2 column tiles, 24 units of 16 K values = this wave's K quarter, ring of %d,
+// %d MFMAs per unit; %s).  Operands as in the fn_pp_bwd_* statements; vo / voy = byte offset of the FIRST row tile of the half (the second one
+// follows nk3 * 2 KB further on); lp = LDS byte address of this wave's first weight-fragment unit of the LDS half of the slice.
+FN_DEVINL void %s(%s) {
+    const float* xin = fn_uniform_ptr(xin_);
+    const float* xiny = fn_uniform_ptr(xiny_);
+    arr = __builtin_amdgcn_readfirstlane(arr);
+    ptgt = (unsigned)__builtin_amdgcn_readfirstlane((int)ptgt);
+%s    asm volatile(
+%s
+        : %s
+        : [xin] "s"(xin), [xiny] "s"(xiny), [vo] "v"(vo), [voy] "v"(voy), [red] "v"(red), [lp] "v"(lp), [arr] "s"(arr),
+          [acnt] "v"(acnt), [pcnt] "v"(pcnt), [ptgt] "s"(ptgt), %s
+        : "memory", "scc", "vcc", "s%d", "s%d", "s%d", "s%d", %s);
+}
+""" % (self.name, self.TH, self.RU, self.nmf, "issues the previous epilogue's stores" if self.stores else "no stores to issue", self.name, sig, pre, body, outs, ins,
+       SB, SB + 1, SB + 2, SB + 3, clob)
+
+    def emit_pro(self, name):
+        L = (["v_add_u32 v%d, 0x18000, %%[vo]" % (TV + 2)] if self.TH == 2 else []) + self.request("%[xin]", "%[vo]")
+        body = "\n".join('        "%s\\n\\t"' % l for l in L)
+        regs = list(range(self.ring0, self.ring0 + (self.RU - 1) * self.TH * 4)) + list(range(self.w0, self.w0 + 4))
+        clob = ", ".join(['"a%d"' % i for i in regs] + ['"v%d"' % (TV + 2)])
+        return """
+// ring request of a phase (units 0 .. %d, %d row tile(s)) + the LDS-half weight fragments of unit 0
+FN_DEVINL void %s(const float* xin_, unsigned vo, unsigned lp) {
+    const float* xin = fn_uniform_ptr(xin_);
+    asm volatile(
+%s
+        :
+        : [xin] "s"(xin), [vo] "v"(vo), [lp] "v"(lp)
+        : "memory", "scc", "s%d", "s%d", %s);
+}
+""" % (self.RU - 2, self.TH, name, body, SB, SB + 1, clob)
+
+    def emit_wload(self, name):
+        """the register-stationary half of the slice: this wave's 24 units of column tile 0 -> a[wr0 .. wr0 + 96)"""
+        L = ["s_mov_b64 s[%d:%d], %%[src]" % (SB, SB + 1), "s_nop 4"]
+        rel = 0
+        for u in range(24):
+            while u * 1024 - rel > 4095:
+                L += ["s_add_u32 s%d, s%d, 0x1000" % (SB, SB), "s_addc_u32 s%d, s%d, 0" % (SB + 1, SB + 1), "s_nop 4"]
+                rel += 4096
+            L.append("global_load_dwordx4 a[%d:%d], %%[vo], s[%d:%d] offset:%d" % (self.wr0 + 4 * u, self.wr0 + 4 * u + 3, SB, SB + 1, u * 1024 - rel))
+        L.append("s_waitcnt vmcnt(0)")
+        body = "\n".join('        "%s\\n\\t"' % l for l in L)
+        clob = ", ".join('"a%d"' % i for i in range(self.wr0, self.wr0 + 96))
+        return """
+// one-time: the register-stationary half of the W_hh^T slice.  src = this wave's first unit of column tile 0 in the fragment image (uniform),
+// vo = lane * 16.  a[%d:%d] are read by every %s statement and never written again.
+FN_DEVINL void %s(const float* src_, unsigned vo) {
+    const float* src = fn_uniform_ptr(src_);
+    asm volatile(
+%s
+        :
+        : [src] "s"(src), [vo] "v"(vo)
+        : "memory", "scc", "s%d", "s%d", %s);
+}
+""" % (self.wr0, self.wr0 + 95, self.name, name, body, SB, SB + 1, clob)
+
+
 HEAD = """// GENERATED by gen_kloop2.py - do not edit.  K loops of the ping-pong weight-stationary GRU scans (H = 512, one row tile per wave and phase).
 #pragma once
 #include "mma_core.h"
@@ -359,6 +536,11 @@ def main(path):
         for stores in (1, 0):
             out.append(Gen("fn_pp_bwd_%s_%s" % (tag, "main" if stores else "first"), False, units, 16, stores, masked).emit_main())
         out.append(Gen("x", False, units, 16, 0, masked).emit_pro("fn_pp_bwd_%s_pro" % tag))
+    for TH, tag, RU in ((2, "t2", 8), (1, "t1", 12)):
+        for stores in (1, 0):
+            out.append(GenRS("fn_rs_bwd_%s_%s" % (tag, "main" if stores else "first"), TH, RU, stores).emit_main())
+        out.append(GenRS("fn_rs_bwd_%s" % tag, TH, RU, 0).emit_pro("fn_rs_bwd_%s_pro" % tag))
+        out.append(GenRS("fn_rs_bwd_%s" % tag, TH, RU, 0).emit_wload("fn_rs_bwd_%s_wload" % tag))
     open(path, "w").write("\n".join(out))
 
 

@@ -1160,6 +1160,236 @@ __global__ __launch_bounds__(NT) void gru_bwd_pp_kernel(const QArgs args) {
     }
 }
 
+// backward scan, ping-pong form with HALF of the W_hh^T slice register-stationary (kloop2_asm.h, GenRS): a workgroup owns 32 dh columns
+// (16 slices) of a 32 TH-row group; column tile 0 of its slice lives in AGPRs (every wave its K quarter), column tile 1 in LDS; every wave
+// multiplies all TH row tiles of the current half over its K quarter, the epilogue adds the four partial sums in wave order.  One operand
+// load feeds 8 MFMAs (4 in the kernels above), the operand stream per workgroup and the weight-fragment LDS reads halve.
+// NOT bit-identical to the kernels above (another summation order over K).
+template <int TH>
+__global__ __launch_bounds__(NT) void gru_bwd_rs_kernel(const QArgs args) {
+    static_assert(TH == 1 || TH == 2, "row tiles per half: 32-row or 64-row groups");
+    constexpr int TT = 2 * TH;                       // accumulator tiles per wave and half
+    constexpr int H = 512, nk3 = 48, nslices = 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wl = smem;                                // [nk3][2][64][4]  column tile 1 of the W_hh^T slice, B-fragment order
+    float* red = smem + 3 * H * 16;                  // [2 halves][4 waves][TT][RT]
+    const unsigned dead = lds_addr(red + 2 * 4 * TT * RT);
+
+    const int g = blockIdx.x % args.ngroups, slice = blockIdx.x / args.ngroups;
+    int si = 0;
+#pragma unroll
+    for (int k = 1; k < FN_MAX_SCANS; ++k)
+        if (k < args.n && g >= args.s[k].group0) si = k;
+    const QScan& S = args.s[si];
+    const int B = S.B, T = S.T;
+    const int m0 = (g - S.group0) * (32 * TH), hh0 = slice * 32;
+    const int nrt = B >> 4;
+    const long FS3 = (long)nrt * 16 * 3 * H;
+    const long BH = (long)B * H;
+    const long GS = (long)4 * H * nrt * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u32* cnt[2] = {args.sync + (2 * g) * 32, args.sync + (2 * g + 1) * 32};
+    u32* err = args.err;
+
+    if (tid == 0) lds_st(dead, 0);
+    {
+        const float4* src = reinterpret_cast<const float4*>(S.wt_frag + (long)(2 * slice + 1) * nk3 * 512);
+        float4* dst = reinterpret_cast<float4*>(wl);
+        for (int i = tid; i < nk3 * 128; i += NT) dst[i] = src[i];
+    }
+    // column tile 0: this wave's K quarter (chunks [12 wave, 12 wave + 12)) -> AGPRs, once
+    if (TH == 2) fn_rs_bwd_t2_wload(S.wt_frag + (long)(2 * slice) * nk3 * 512 + (long)wave * 12 * 512, (unsigned)lane * 16u);
+    else fn_rs_bwd_t1_wload(S.wt_frag + (long)(2 * slice) * nk3 * 512 + (long)wave * 12 * 512, (unsigned)lane * 16u);
+
+    // epilogue item inside a half: (row, 4 consecutive dh columns of the 32); 32-row groups have 128 items per half: lanes 0-31 of every wave
+    const bool has_item = TH == 2 || lane < 32;
+    const int item = TH == 2 ? tid : wave * 32 + (lane & 31);
+    const int rl = item >> 3, u4 = item & 7;
+    const int jj0 = hh0 + 4 * u4;
+    int ib[2], icoff[2];
+    f32x4 carry[2], rs[2][3], rsn[2];
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int hx = 0; hx < 2; ++hx) {
+        ib[hx] = m0 + (hx * TH + (rl >> 4)) * 16 + (rl & 15);
+        icoff[hx] = (hx * 4 * TT + (rl >> 4) * 2 + (u4 >> 2)) * RT + ((rl & 15) >> 2) * 68 + (u4 & 3) * 16 + (rl & 3);
+        carry[hx] = S.dh_last ? ldv4(S.dh_last + (long)ib[hx] * H + jj0) : z4;
+        rsn[hx] = z4;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) rs[hx][q] = z4;
+    }
+    __syncthreads();
+
+    const int c0 = 12 * wave;                         // this wave's first K chunk
+    unsigned vo[2], h_red[2];
+#pragma unroll
+    for (int hx = 0; hx < 2; ++hx) {
+        vo[hx] = (unsigned)((((long)(m0 >> 4) + hx * TH) * nk3 * 512 + lane * 4) * 4);      // first row tile of the half (the second follows nk3 * 2 KB on)
+        h_red[hx] = lds_addr(red) + ((((hx * 4 + wave) * TT) * RT + lane * 4 + (lane >> 4) * 4) * 4);
+    }
+    const unsigned h_lp = lds_addr(wl) + c0 * 2048 + lane * 16;
+    const int iters = T + (S.dh0 ? 1 : 0);
+
+    // stores of the last epilogue: issued by the NEXT phase's K loop statement (kloop2_asm.h), or by flush_stores() when none follows
+    bool st_valid = false;
+    float *st_base = S.xf, *st_g = nullptr, *st_n = nullptr;
+    unsigned st_o = 0;
+    f32x4 st_d[4];
+    auto flush_stores = [&]() __attribute__((always_inline)) {
+        if (st_valid && has_item) {
+            char* sb = reinterpret_cast<char*>(st_base) + st_o;
+            stv4_sc1(reinterpret_cast<float*>(sb), st_d[0]);
+            stv4_sc1(reinterpret_cast<float*>(sb + 0x8000), st_d[1]);
+            stv4_sc1(reinterpret_cast<float*>(sb + 0x10000), st_d[3]);
+            stv4(st_g - H, st_d[0]);
+            stv4(st_g, st_d[1]);
+            stv4(st_g + H, st_d[2]);
+            stv4(st_n, st_d[3]);
+        }
+        st_valid = false;
+    };
+    // gate backward of half hx at iteration it (step q): arithmetic and LDS reads only; q < 0: only dL/dh0 is left (stored here)
+    auto epilogue = [&](auto HX, const int it, const f32x4 (&gt)[4], const f32x4& hpv, const f32x4& ext, const bool hand) __attribute__((always_inline)) {
+        constexpr int hx = decltype(HX)::value;
+        const int q = T - 1 - it;
+        f32x4 dh;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float a = 0.f;
+            if (hand) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) a += red[(long)(w * TT) * RT + icoff[hx] + c * 4];      // the four K quarters, in wave order
+            }
+            dh[c] = (a + carry[hx][c]) + ext[c];
+        }
+        if (q < 0) {
+            if (has_item) stv4(S.dh0 + (long)ib[hx] * H + jj0, dh);
+            st_valid = false;
+            return;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float dr, dz, dnp, dnr, cy;
+            fn_gru_gate_bwd(dh[c], gt[0][c], gt[1][c], gt[2][c], gt[3][c], hpv[c], dr, dz, dnp, dnr, cy);
+            st_d[0][c] = dr; st_d[1][c] = dz; st_d[2][c] = dnp; st_d[3][c] = dnr; carry[hx][c] = cy;
+        }
+        rs[hx][0] += st_d[0]; rs[hx][1] += st_d[1]; rs[hx][2] += st_d[2]; rsn[hx] += st_d[3];
+        st_base = S.xf + (long)(it & 1) * FS3;
+        st_o = (unsigned)(frag_off(ib[hx], jj0, nk3) * 4);
+        st_g = S.dgx_all + (long)q * 3 * BH + (long)ib[hx] * 3 * H + jj0 + H;
+        st_n = S.dghn_all + (long)q * BH + (long)ib[hx] * H + jj0;
+        st_valid = true;
+    };
+
+    int pend = -1;
+    // ---- iteration 0: no K loop (dh = dh_last + dh_ext[T-1]); half A arrives at once, half B's arrival rides in the first K loop ----------
+    {
+        const int q = T - 1;
+        f32x4 g0[2][4], hp0[2], x0[2];
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) {
+            const float* gq = S.gates + (long)q * GS + gate_off(ib[hx], 0, jj0, nrt);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g0[hx][k] = ldv4(gq + k * 256);
+            hp0[hx] = q > 0 ? ldv4(S.h_all + (long)(q - 1) * BH + (long)ib[hx] * H + jj0) : (S.h0 ? ldv4(S.h0 + (long)ib[hx] * H + jj0) : z4);
+            x0[hx] = S.dh_ext ? ldv4(S.dh_ext + (long)q * BH + (long)ib[hx] * H + jj0) : z4;
+        }
+        const bool publish = iters > 1;
+        epilogue(std::integral_constant<int, 0>{}, 0, g0[0], hp0[0], x0[0], false);
+        flush_stores();
+        if (publish) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(cnt[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        epilogue(std::integral_constant<int, 1>{}, 0, g0[1], hp0[1], x0[1], false);
+        flush_stores();
+        pend = publish ? 1 : -1;
+    }
+    if (iters > 1) {
+        // every load the compiler knows about has to be complete before the loop (see gru_fwd_pp_kernel)
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) {
+            fn_touch(carry[hx]);
+            fn_touch(rsn[hx]);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) fn_touch(rs[hx][q]);
+        }
+        {
+            const float* xin = S.xf + (long)c0 * 512;          // slab 0: iteration 0's gate gradients
+            pp_wait_counter(cnt[0], (u32)nslices, err, dead);
+            if (TH == 2) fn_rs_bwd_t2_pro(xin, vo[0], h_lp);
+            else fn_rs_bwd_t1_pro(xin, vo[0], h_lp);
+        }
+
+        auto phase = [&](auto HX, const int it) __attribute__((always_inline)) -> bool {
+            constexpr int hx = decltype(HX)::value, hy = hx ^ 1;
+            const int q = T - 1 - it, qc = q > 0 ? q : 0;
+            const int it1 = it + hx;
+            const int p = it;                             // FN_PSTAMP
+            (void)p;
+            const bool next_k = it1 < iters;
+            const float* xin = S.xf + (long)((it - 1) & 1) * FS3 + (long)c0 * 512;
+            const float* xiny = S.xf + (long)((it1 - 1) & 1) * FS3 + (long)c0 * 512;
+            const unsigned ptgt = next_k ? (u32)nslices * (u32)it1 : 0xffffffffu;
+            const long ro = (long)ib[hx] * H + jj0;
+            const float* ga = S.gates + (long)qc * GS + gate_off(ib[hx], 0, jj0, nrt);
+            const float* ha = qc > 0 ? S.h_all + (long)(qc - 1) * BH + ro : (S.h0 ? S.h0 + ro : S.h_all + ro);      // unused values still come from a legal address
+            const float* xa = S.dh_ext ? S.dh_ext + (long)qc * BH + ro : S.h_all + ro;
+            const bool hzero = q < 0 || (q == 0 && !S.h0), xzero = q < 0 || !S.dh_ext;
+            f32x4 gt[4], hp2, xt2;
+            unsigned pv;
+            const int arr = pend >= 0 ? (wave == 0 ? 2 : 1) : 0;
+            u32* acnt = cnt[pend > 0 ? 1 : 0];
+            FN_PSTAMP(hx * 4 + 0);
+            if (TH == 2) {
+                if (!st_valid) fn_rs_bwd_t2_first(xin, vo[hx], h_lp, h_red[hx], arr, acnt, cnt[hy], ptgt, xiny, vo[hy], ga, ha, xa, gt, hp2, xt2, pv);
+                else fn_rs_bwd_t2_main(xin, vo[hx], h_lp, h_red[hx], arr, acnt, cnt[hy], ptgt, xiny, vo[hy], ga, ha, xa, st_base, st_o, st_g, st_n, st_d[0], st_d[1], st_d[2],
+                                       st_d[3], gt, hp2, xt2, pv);
+            } else {
+                if (!st_valid) fn_rs_bwd_t1_first(xin, vo[hx], h_lp, h_red[hx], arr, acnt, cnt[hy], ptgt, xiny, vo[hy], ga, ha, xa, gt, hp2, xt2, pv);
+                else fn_rs_bwd_t1_main(xin, vo[hx], h_lp, h_red[hx], arr, acnt, cnt[hy], ptgt, xiny, vo[hy], ga, ha, xa, st_base, st_o, st_g, st_n, st_d[0], st_d[1], st_d[2],
+                                       st_d[3], gt, hp2, xt2, pv);
+            }
+            st_valid = false;
+            FN_PSTAMP(hx * 4 + 1);
+            if (next_k && pv < ptgt) {               // rare: the other half's inputs were not all published yet - poll, then request its ring
+                FN_PCOUNT(0);
+                pp_wait_counter(cnt[hy], ptgt, err, dead);
+                if (TH == 2) fn_rs_bwd_t2_pro(xiny, vo[hy], h_lp);
+                else fn_rs_bwd_t1_pro(xiny, vo[hy], h_lp);
+            }
+            lds_barrier();
+            FN_PSTAMP(hx * 4 + 2);
+            if (lds_ld(dead)) return false;
+            epilogue(HX, it, gt, hzero ? z4 : hp2, xzero ? z4 : xt2, true);
+            FN_PSTAMP(hx * 4 + 3);
+            pend = (q > 0 || (q == 0 && S.dh0 != nullptr)) ? hx : -1;
+            return true;
+        };
+
+#pragma unroll 1
+        for (int it = 1; it < iters; ++it) {
+            if (!phase(std::integral_constant<int, 0>{}, it)) return;
+            if (!phase(std::integral_constant<int, 1>{}, it)) return;
+        }
+        flush_stores();
+    }
+#pragma unroll
+    for (int hx = 0; hx < 2; ++hx) {
+        if (!has_item) continue;
+        if (S.rowsum) {
+            float* p = S.rowsum + (long)ib[hx] * 3 * H + jj0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) stv4(p + q * H, ldv4(p + q * H) + rs[hx][q]);
+        }
+        if (S.rowsum_n) {
+            float* p = S.rowsum_n + (long)ib[hx] * H + jj0;
+            stv4(p, ldv4(p) + rsn[hx]);
+        }
+    }
+}
+
 constexpr int FN_MAX_DEVICES = 32;
 
 int cu_count() {
@@ -1307,10 +1537,49 @@ int fn_gru_bwd_persist(const FnGruBwd* scans, int n_scans, hipStream_t st) {
     if (scans[0].cu_budget > 0 && scans[0].cu_budget < cus) cus = scans[0].cu_budget;
     const int nslices = H / 16;
     if (cus <= 0 || nslices > cus) return FN_PERSIST_NA;
+    const int force_rows = scans[0].variant & 0xFF;         // tuning / tests: take this row block or none
+    // Register-stationary ping-pong form (gru_bwd_rs_kernel): H = 512, 16 slices of 32 columns x up to 16 groups of 64 (or 32) rows, every group
+    // full, more than half of the chip used (smaller problems keep the 32-slice kernels).  Variant bits 10 / 11 / 13 select the older loops.
+    if (H == 512 && !(scans[0].variant & 0x2C00) && !force_rows) {
+        long g64 = 0, g32 = 0;
+        bool d64 = true, d32 = true;
+        for (int s = 0; s < n_scans; ++s) {
+            const FnGruBwd& d = scans[s];
+            g64 += d.B / 64; g32 += d.B / 32;
+            d64 = d64 && d.B % 64 == 0 && d.T >= 2;
+            d32 = d32 && d.B % 32 == 0 && d.T >= 2;
+        }
+        const int th = (d64 && g64 > 8 && g64 <= 16 && g64 * 16 <= cus) ? 2 : (d32 && g32 > 8 && g32 <= 16 && g32 * 16 <= cus) ? 1 : 0;
+        if (th) {
+            QArgs a;
+            a.n = n_scans; a.H = H; a.no_hand = 0;
+            a.sync = reinterpret_cast<u32*>(scans[0].sync_ws);
+            int groups = 0;
+            for (int s = 0; s < n_scans; ++s) {
+                const FnGruBwd& d = scans[s];
+                QScan& f = a.s[s];
+                f.wt_frag = d.w_hh_t_frag; f.h0 = d.h0; f.h_all = d.h_all; f.gates = d.gates;
+                f.dh_last = d.dh_last; f.dh_ext = d.dh_ext;
+                f.dgx_all = d.dgx_all; f.dghn_all = d.dghn_all; f.dh0 = d.dh0;
+                f.rowsum = d.dgx_rowsum; f.rowsum_n = d.dghn_rowsum; f.xf = d.frag_ws;
+                f.B = d.B; f.T = d.T;
+                f.group0 = groups;
+                groups += d.B / (32 * th);
+            }
+            a.ngroups = groups;
+            a.err = scans[0].err_ws ? reinterpret_cast<u32*>(scans[0].err_ws) : a.sync + FN_MAX_GROUPS * 32;
+            if (!(scans[0].variant & 0x200)) {
+                hipError_t me = hipMemsetAsync(a.sync, 0, (size_t)FN_MAX_GROUPS * 32 * 4, st);
+                if (me != hipSuccess) return (int)me;
+            }
+            const size_t lds = ((size_t)3 * H * 16 + (size_t)2 * 4 * (2 * th) * RT) * 4 + 16;
+            const int rc = th == 2 ? launch_k<QArgs, gru_bwd_rs_kernel<2>>(a, groups * 16, lds, cus, st) : launch_k<QArgs, gru_bwd_rs_kernel<1>>(a, groups * 16, lds, cus, st);
+            if (rc != FN_PERSIST_NA) return rc;
+        }
+    }
     const int maxgroups = cus / nslices < FN_MAX_GROUPS ? cus / nslices : FN_MAX_GROUPS;
     int rpw = 0;
     const int cand[4] = {16, 32, 64, 128};
-    const int force_rows = scans[0].variant & 0xFF;         // tuning / tests: take this row block or none
     for (int c = 0; c < 4 && !rpw; ++c) {
         if (force_rows && force_rows != cand[c]) continue;
         long groups = 0;

@@ -1101,11 +1101,23 @@ def test_ping_pong_scans_are_bit_identical_to_the_single_group_loops(ops, n, B, 
             for k in outs:
                 if b[k] is not None:
                     b[k].zero_() if "rowsum" in k else b[k].fill_(float("nan"))
-        ops.gru_seq_bwd(bw, variant=0x1000)
+        ops.gru_seq_bwd(bw, variant=0x3000)            # bit 12: the ping-pong form of the 32-slice kernel, bit 13: not the register-stationary one
         assert not ops.gru_sync_error()
         for i, (r, b) in enumerate(zip(refb, bw)):
             for k, v in r.items():
                 assert torch.equal(b[k], v), "backward rep %d scan %d %s: max diff %g" % (rep, i, k, float((b[k] - v).abs().max()))
+    # the default backward of these shapes: 16 slices of 32 columns, half of each W_hh^T slice register-stationary (gru_bwd_rs_kernel) - another
+    # summation order over K, so equal within rounding
+    for rep in range(3):
+        for b in bw:
+            for k in outs:
+                if b[k] is not None:
+                    b[k].zero_() if "rowsum" in k else b[k].fill_(float("nan"))
+        ops.gru_seq_bwd(bw)
+        assert not ops.gru_sync_error()
+        for i, (r, b) in enumerate(zip(refb, bw)):
+            for k, v in r.items():
+                close(b[k], v, 2e-5, "register-stationary backward rep %d scan %d %s" % (rep, i, k))
 
 
 def test_masked_prob_kernel(ops):
