@@ -32,6 +32,32 @@ int fn_out_head_f32_host(const float* h, int ldh, const float* W, int ldw, const
 int fn_sumsq_f32_host(const float* g, int64_t n, float* out, float* ws, size_t ws_bytes, void* stream);  /* fn_sumsq_f32   */
 int fn_clip_adam_host(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, float max_norm,
                       const float* hyper, float beta1, float beta2, float eps, void* stream);            /* fn_clip_adam   */
+/* dense products */
+size_t fn_gemm_ws_bytes_host(int M, int N, int splitk);                                                  /* fn_gemm_ws_bytes */
+int fn_gemm_f32_host(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb,
+                     float beta, float* C, int ldc, const float* bias, int splitk, float* ws, size_t ws_bytes, void* stream);   /* fn_gemm_f32 */
+size_t fn_gru_dwhh_ws_bytes_host(int H, int splitk);                                                     /* fn_gru_dwhh_ws_bytes */
+int fn_gru_dwhh_f32_host(const float* dgx, const float* dghn, const float* hprev, int64_t rows, int H, float beta, float* dW,
+                         int splitk, float* ws, size_t ws_bytes, void* stream);                          /* fn_gru_dwhh_f32 */
+/* token sort + segment sums: the sort image has the device layout {seg [V+1], pstart [V+1], 2 pad, order [rows]}; the workspaces are the
+ * twins' own (ask the *_ws_bytes_host functions) */
+size_t fn_token_sort_ints_host(int64_t rows, int V);                                                     /* fn_token_sort_ints */
+size_t fn_token_sort_ws_bytes_host(int64_t rows, int V);                                                 /* fn_token_sort_ws_bytes */
+int fn_token_sort_host(const int32_t* idx, int B, int T, int idx_ld, int V, int32_t* img, void* ws, size_t ws_bytes, void* stream);   /* fn_token_sort */
+size_t fn_embed_grad_sorted_ws_bytes_host(int64_t rows, int B, int V, int N3, int n_jobs);               /* fn_embed_grad_sorted_ws_bytes */
+int fn_embed_grad_sorted_host(const FnEmbedGrad* jobs, int n_jobs, int B, int T, int N3, int V, const int32_t* img, float* ws,
+                              size_t ws_bytes, void* stream);                                            /* fn_embed_grad_sorted */
+/* sub-decoder heads, pairwise regulariser */
+int fn_time_logsoftmax_host(const float* logits, int B, int Tr, int Cc, float* logp_bt, const int32_t* target, float* nll_bc,
+                            float grad_scale, float* dlogits, void* stream);                             /* fn_time_logsoftmax */
+int fn_time_logsoftmax_bwd_host(const float* logp_bt, const float* gout_bt, int B, int Tr, int Cc, float* dlogits, void* stream);   /* fn_time_logsoftmax_bwd */
+int fn_pairwise_reg_host(const float* z0_all, const double* attr_all, int n_all, int row0, int nrows, float* loss_rows,
+                         float grad_scale, float* dz0, void* stream);                                    /* fn_pairwise_reg */
+/* eval-mode decode */
+int fn_gru_cell_f32_host(const FnGruCell* c, void* stream);                                              /* fn_gru_cell_f32 */
+size_t fn_decode_ws_bytes_host(int B, int H, int V);                                                     /* fn_decode_ws_bytes */
+size_t fn_decode_sync_ws_bytes_host(void);                                                               /* fn_decode_sync_ws_bytes */
+int fn_decode_greedy_host(const FnDecode* d, void* stream);                                              /* fn_decode_greedy */
 size_t fn_frag_floats_host(int rows, int K);                                                             /* fn_frag_floats */
 size_t fn_gru_gates_floats_host(int B, int H);                                                           /* fn_gru_gates_floats */
 

@@ -9,9 +9,9 @@ from .vae_model import MusicAttrRegVAE  # noqa: F401
 from .model_v2 import MusicAttrCVAE, MusicAttrFaderNets, MusicAttrSingleVAE  # noqa: F401
 from .trainer_v2 import CVAETrainer, FaderTrainer, GLSRTrainer, SingleVAETrainer  # noqa: F401
 from .decode import clean_output, fader_sweep, greedy_decode  # noqa: F401
-from .epochs import cpu_state_dict, training_phase  # noqa: F401
+from .epochs import cpu_state_dict, training_phase, training_phase_v2  # noqa: F401
 from .evaluators import GMMNoteEvaluator, GMMRhythmEvaluator, arousal_transfer, run_through_gmm  # noqa: F401
 
 __all__ = ["MusicAttrRegGMVAE", "MusicAttrRegVAE", "MusicAttrSingleVAE", "MusicAttrCVAE", "MusicAttrFaderNets", "SingleVAETrainer", "CVAETrainer",
            "FaderTrainer", "GLSRTrainer", "GMVAETrainer", "VAETrainer", "beta_schedule", "convert_to_one_hot", "clean_output", "fader_sweep",
-           "greedy_decode", "training_phase", "cpu_state_dict", "GMMRhythmEvaluator", "GMMNoteEvaluator", "arousal_transfer", "run_through_gmm"]
+           "greedy_decode", "training_phase", "training_phase_v2", "cpu_state_dict", "GMMRhythmEvaluator", "GMMNoteEvaluator", "arousal_transfer", "run_through_gmm"]

@@ -62,7 +62,7 @@ class MusicAttrRegGMVAE(nn.Module):
             setattr(self, name, emb)
         self._engine = None
         self._engine_key = None
-        self._weights_version = -1
+        self._weights_version = None
         self._version = 0
 
     # ------------------------------------------------------------------------------------------
@@ -73,23 +73,34 @@ class MusicAttrRegGMVAE(nn.Module):
         receive a gradient in the reference."""
         return [(k, p) for k, p in self.named_parameters() if not k.startswith(UNUSED_PREFIXES) and k not in FROZEN]
 
+    def _device(self):
+        return self.mu_r.weight.device
+
+    def _make_ops(self, dev):
+        """the kernel backend of this model: the HIP library on an MI355X, nothing else (there is deliberately no CPU fallback)"""
+        if dev.type != "cuda":
+            raise RuntimeError("%s runs on the MI355X HIP kernels only; call .cuda() first (there is deliberately no CPU fallback)" % type(self).__name__)
+        from .hipops import HipOps
+        return HipOps(dev)
+
+    def _param_versions(self):
+        """torch's in-place counters of the parameters: an ``optimizer.step()`` / ``copy_`` of an unmodified reference loop moves them, the
+        fused trainer (which writes through the flat buffer and refreshes the images itself) does not"""
+        return sum(p._version for p in self.parameters())
+
     def engine(self):
-        dev = self.mu_r.weight.device
-        # _ops_override is a TEST hook (tests/fake_ops.py checks the host-side schedule without a GPU);
-        # the product never sets it, and without it a CPU model raises here.
-        if dev.type != "cuda" and getattr(self, "_ops_override", None) is None:
-            raise RuntimeError("MusicAttrRegGMVAE runs on the MI355X HIP kernels only; call .cuda() first "
-                               "(there is deliberately no CPU fallback)")
+        dev = self._device()
         key = (dev, tuple(p.data_ptr() for _, p in self.named_parameters()))
         if self._engine is None or self._engine_key != key:
-            from .hipops import HipOps
-            ops = self._ops_override if getattr(self, "_ops_override", None) is not None else HipOps(dev)
-            self._engine = self._make_engine(ops, dev)
+            self._engine = self._make_engine(self._make_ops(dev), dev)
             self._engine_key = key
-            self._weights_version = -1
-        if self._weights_version != self._version:
+            self._weights_version = None
+        # the engine keeps transposed / fragment-order images of the recurrent weights: re-derive them when the values changed -
+        # announced (weights_changed(), load_state_dict) or detected (in-place updates by a torch optimiser)
+        ver = (self._version, self._param_versions())
+        if self._weights_version != ver:
             self._engine.refresh_weights()
-            self._weights_version = self._version
+            self._weights_version = ver
         return self._engine
 
     def _make_engine(self, ops, dev):

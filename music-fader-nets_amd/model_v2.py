@@ -44,7 +44,7 @@ class _SingleEncModel(MusicAttrRegGMVAE):
         self.n_component = 1
         self._engine = None
         self._engine_key = None
-        self._weights_version = -1
+        self._weights_version = None
         self._version = 0
 
     def _make_engine(self, ops, dev):
@@ -55,22 +55,6 @@ class _SingleEncModel(MusicAttrRegGMVAE):
 
     def _device(self):
         return self.mu.weight.device
-
-    def engine(self):
-        dev = self._device()
-        if dev.type != "cuda" and getattr(self, "_ops_override", None) is None:
-            raise RuntimeError("%s runs on the MI355X HIP kernels only; call .cuda() first (there is deliberately no CPU fallback)" % type(self).__name__)
-        key = (dev, tuple(p.data_ptr() for _, p in self.named_parameters()))
-        if self._engine is None or self._engine_key != key:
-            from .hipops import HipOps
-            ops = self._ops_override if getattr(self, "_ops_override", None) is not None else HipOps(dev)
-            self._engine = self._make_engine(ops, dev)
-            self._engine_key = key
-            self._weights_version = -1
-        if self._weights_version != self._version:
-            self._engine.refresh_weights()
-            self._weights_version = self._version
-        return self._engine
 
     def _draw(self, B, T):
         """the reference's draws for one forward: eps, (subclass extras), T x rand(1) in train mode"""

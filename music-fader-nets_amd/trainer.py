@@ -95,12 +95,16 @@ class GMVAETrainer:
         self.sp = torch.zeros(8, device=dev)
         self._dev_step = 0                          # host mirror of counters[0]
         self.use_graph = dev.type == "cuda"          # replay the whole step as ONE hipGraph (no per-launch host cost)
-        if dist_ctx is not None and (os.environ.get("FN_DP_GRAPH", "1") == "0" or not getattr(dist_ctx, "want_direct", False)):
-            # Data parallel: the collectives are RCCL calls on our own streams (parallel.DirectRccl, fn_comm_*) and part of the captured
+        if dist_ctx is not None:
+            # Data parallel: the collectives are RCCL calls on our own streams (parallel.DirectRccl, fn_comm_*) and CAN be part of the captured
             # step.  (Through torch.distributed's process group they were not capturable reliably: about 1 capture in 25 ended with
             # hipErrorStreamCaptureUnjoined on torch 2.10 / RCCL 2.26 and its watchdog thread then died on an event "last recorded in a
-            # capturing stream" - round 2, DESIGN.md.)  FN_DP_GRAPH=0 / DataParallelContext(direct=False): eager launches.
-            self.use_graph = False
+            # capturing stream" - round 2, DESIGN.md.)  The captured form has been run and soaked with ONE rank only (the pool hands out
+            # 1-GPU boxes), so with real peers (world > 1) the default is eager launches; FN_DP_GRAPH=1 opts in to the single-graph step,
+            # FN_DP_GRAPH=0 forces eager launches everywhere.  DataParallelContext(direct=False) (torch.distributed collectives): eager.
+            want = os.environ.get("FN_DP_GRAPH")
+            if not getattr(dist_ctx, "want_direct", False) or want == "0" or (want is None and dist_ctx.world > 1):
+                self.use_graph = False
         self._dens_all = None                        # data parallel: the batch's densities of ALL ranks (gathered once per batch)
         self._graphs = {}
         self._static = {}
@@ -124,8 +128,14 @@ class GMVAETrainer:
         return d, r, n, c, rd, nd, lab
 
     def draw_eps(self, B, T):
-        """eps in the reference's CPU-generator order (see MusicAttrRegGMVAE._draw_eps)."""
-        return self.model._draw_eps(B, T, self.flat.param.device)
+        """eps in the reference's CPU-generator order (see MusicAttrRegGMVAE._draw_eps).  Data parallel: the draw is made for the GLOBAL
+        batch and this rank keeps its rows - with lockstep generators (train.py seeds every rank alike) the concatenation over ranks is the
+        single-process draw, and no two shards share their noise."""
+        dev = self.flat.param.device
+        if self.dist is None or self.dist.world == 1:
+            return self.model._draw_eps(B, T, dev)
+        lo = self.dist.rank * B
+        return tuple(e[lo:lo + B].contiguous() for e in self.model._draw_eps(B * self.dist.world, T, dev))
 
     def _forward_losses(self, step, batch, eps, want_grads):
         m = self.model
@@ -313,7 +323,7 @@ class GMVAETrainer:
             m.engine()
             self._gather_densities(batch, None)
             self._step_body(step, batch, eps)
-            m._weights_version = m._version        # refresh_weights() already ran at the end of the step
+            m._weights_version = (m._version, m._param_versions())      # refresh_weights() already ran at the end of the step
             return beta0, Bg
         key = (tuple(batch[0].shape), tuple(batch[1].shape), batch[6] is not None)
         st = self._static.get(key)
@@ -351,7 +361,7 @@ class GMVAETrainer:
                 self._graphs[key] = g               # the capture itself does not execute: run the step now
                 g.replay()
         st["runs"] += 1
-        m._weights_version = m._version
+        m._weights_version = (m._version, m._param_versions())
         return beta0, Bg
 
     def train(self, step, d_oh, r_oh, n_oh, d, r, n, c, r_density, n_density, is_supervised=False, y_label=None, eps=None):

@@ -29,8 +29,13 @@ class _SingleEncTrainer(GMVAETrainer):
         return b
 
     def draw_eps(self, B, T):
-        eps, extra = self.model._draw(B, T)
         dev = self.flat.param.device
+        if self.dist is None or self.dist.world == 1:
+            eps, extra = self.model._draw(B, T)
+        else:                                      # data parallel: global draw, this rank's rows (GMVAETrainer.draw_eps)
+            eps, extra = self.model._draw(B * self.dist.world, T)
+            lo = self.dist.rank * B
+            eps, extra = eps[lo:lo + B].contiguous(), (None if extra is None else extra[lo:lo + B].contiguous())
         return (eps.to(dev), None if extra is None else extra.to(dev))
 
     # hooks --------------------------------------------------------------------------------------

@@ -52,7 +52,7 @@ class MusicAttrRegVAE(MusicAttrRegGMVAE):
         self.n_component = 1
         self._engine = None
         self._engine_key = None
-        self._weights_version = -1
+        self._weights_version = None
         self._version = 0
 
     def _engine_params(self):

@@ -32,7 +32,7 @@ def make_model(hidden, zdim, sd=None, device="cpu", ops=None, seed=1234):
         m.load_state_dict(sd)
     m = m.to(device)
     if ops is not None:
-        m._ops_override = ops
+        m._make_ops = lambda dev, _ops=ops: _ops          # test-side injection of the CPU stand-in for the kernel table
     m.train()
     return m
 
@@ -114,7 +114,7 @@ def make_vae_model(hidden, zdim, device="cpu", ops=None, seed=1234):
     torch.manual_seed(seed)
     m = pkg.MusicAttrRegVAE(roll_dims=342, rhythm_dims=3, note_dims=16, chroma_dims=24, hidden_dims=hidden, z_dims=zdim, n_step=20)
     if ops is not None:
-        m._ops_override = ops
+        m._make_ops = lambda dev, _ops=ops: _ops          # test-side injection of the CPU stand-in for the kernel table
     return m.to(device)
 
 
@@ -280,7 +280,7 @@ def make_sibling(kind, hidden, zdim, device="cpu", ops=None, seed=1234):
     torch.manual_seed(seed)
     m = getattr(pkg, SIBLINGS[kind][0])(roll_dims=342, rhythm_dims=3, note_dims=16, chroma_dims=24, hidden_dims=hidden, z_dims=zdim, n_step=20)
     if ops is not None:
-        m._ops_override = ops
+        m._make_ops = lambda dev, _ops=ops: _ops          # test-side injection of the CPU stand-in for the kernel table
     return m.to(device)
 
 
@@ -346,7 +346,7 @@ def check_sibling(pkg, kind, m, g, dev, rtol_fw=5e-5, tol_grad=5e-4, rtol_tuple=
         ev = tr.evaluate(step - 1, None, None, None, g["d"], g["r"], g["n"], g["c"], g["r_density"], g["n_density"])
     np.testing.assert_allclose(ev, g["eval_tuple"], rtol=rtol_tuple, atol=1e-9)
     # eval-mode forward on fresh weights: greedy decoder
-    m2 = make_sibling(kind, H, Z, device=dev, ops=getattr(m, "_ops_override", None))
+    m2 = make_sibling(kind, H, Z, device=dev, ops=m._make_ops(None) if "_make_ops" in m.__dict__ else None)
     m2.eval()
     d, r, n, c = (x.to(dev) for x in (d, r, n, c))
     torch.manual_seed(7)
@@ -587,3 +587,58 @@ def check_sibling_autograd(pkg, kind, m, g, dev, tol_grad=5e-4):
             m(pkg.convert_to_one_hot(d, 342), pkg.convert_to_one_hot(r, 3), pkg.convert_to_one_hot(n, 16), c, rd32, nd32))[0]
     out2 = out2[0] if kind == "fader" else out2
     assert float((out2.detach() - out.detach()).abs().max()) > 1e-6
+
+
+# ---- the five model_config_v2.json trainers: epoch drivers vs the reference's own training_phase (tests/golden/epoch_v2.npz) ---------------
+V2_FAMILIES = {"vae": ("MusicAttrRegVAE", "VAETrainer"), "singlevae": ("MusicAttrSingleVAE", "SingleVAETrainer"), "cvae": ("MusicAttrCVAE", "CVAETrainer"),
+               "fader": ("MusicAttrFaderNets", "FaderTrainer"), "glsr": ("MusicAttrRegVAE", "GLSRTrainer")}
+
+
+def make_v2_family(pkg, family, g, device="cpu", ops=None):
+    """the seeded model of make_golden_epoch_v2.py for `family` (GLSR: output layer rescaled like the fixture) + its trainer"""
+    P = family + "/"
+    H, Z, B, T, TR = (int(x) for x in g[P + "dims"])
+    torch.manual_seed(1234)
+    m = getattr(pkg, V2_FAMILIES[family][0])(roll_dims=342, rhythm_dims=3, note_dims=16, chroma_dims=24, hidden_dims=H, z_dims=Z, n_step=T)
+    if family == "glsr":
+        with torch.no_grad():
+            m.linear_out_g.weight.mul_(float(g[P + "out_scale"][0]))
+            m.linear_out_g.bias.add_(torch.from_numpy(g[P + "bias_shift"]))
+    if ops is not None:
+        m._make_ops = lambda dev, _ops=ops: _ops
+    m = m.to(device)
+    m.train()
+    return m, getattr(pkg, V2_FAMILIES[family][1])(m, lr=1e-3, beta=0.2)
+
+
+def check_epoch_v2_run(pkg, family, g, tmp_path, device="cpu", ops=None, rtol=5e-4, atol_w=1e-3, noise=()):
+    """pkg.training_phase_v2(family) on the golden loaders: same lines (text and numbers) as the reference's training_phase printed, same
+    checkpoint key set, weights within atol_w of the saved ones, one time-stamped copy"""
+    import re
+    P = family + "/"
+    m, tr = make_v2_family(pkg, family, g, device, ops)
+    dl = lambda name, n: [tuple(torch.from_numpy(np.asarray(g[P + "%s%d_%d" % (name, i, j)])) for j in range(6)) for i in range(n)]
+    lines = []
+    save_path = os.path.join(str(tmp_path), "golden_%s.pt" % family)
+    torch.manual_seed(4242)
+    start = int(g[P + "start_step"])
+    step = pkg.training_phase_v2(family, tr, start, 2, dl("tr", 2), dl("va", 1), save_path, name="golden_" + family, log=lines.append)
+    assert step == start + 4
+    ref = [str(l) for l in g[P + "lines"]]
+    assert len(lines) == len(ref), (lines, ref)
+    num = re.compile(r"-?\d+\.\d+")
+    for got, want in zip(lines[:-1], ref[:-1]):
+        assert num.sub("#", got) == num.sub("#", want), (got, want)
+        a, b = [float(x) for x in num.findall(got)], [float(x) for x in num.findall(want)]
+        np.testing.assert_allclose(a, b, rtol=rtol, atol=2e-4, err_msg=want)
+    assert lines[-1].startswith("Model saved as ") and ref[-1].startswith("Model saved as ")
+    saved = torch.load(save_path)
+    want_keys = [k[len(P + "wend/"):] for k in g.keys() if k.startswith(P + "wend/")]
+    assert sorted(saved.keys()) == sorted(want_keys)
+    assert all(v.device.type == "cpu" for v in saved.values())
+    for k, v in saved.items():
+        if k not in noise:
+            np.testing.assert_allclose(v.numpy(), g[P + "wend/" + k], rtol=0, atol=atol_w, err_msg=k)
+    stamped = [f for f in os.listdir(str(tmp_path)) if f.startswith("golden_%s_" % family) and f.endswith(".pt")]
+    assert len(stamped) == int(g[P + "stamped"]) == 1
+    return m

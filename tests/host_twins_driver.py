@@ -21,6 +21,11 @@ lib = C.CDLL(os.path.join(ROOT, "music-fader-nets_amd", "libfadernets_host.so"))
 lib.fn_frag_floats_host.restype = C.c_size_t
 lib.fn_gru_gates_floats_host.restype = C.c_size_t
 vp = C.c_void_p
+for _name, (_res, _args) in L.SIGNATURES.items():          # the twins carry the signatures of their device counterparts (include/fadernets_host.h)
+    if _name in ("fn_frag_floats", "fn_gru_gates_floats") or not hasattr(lib, _name + "_host"):
+        continue
+    _fn = getattr(lib, _name + "_host")
+    _fn.restype, _fn.argtypes = _res, _args
 
 
 def P(a):
@@ -194,10 +199,196 @@ def test_argument_errors():
     print("argument errors OK")
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[0] (tests/golden/c0.npz: hidden 512, z 128, B=8, T=64, Tr=16 - the reference's own forward / loss / greedy decode on seeded
+# weights) through the twins of the dense products, the sub-decoder head, the regulariser and the eval-mode decode
+# ---------------------------------------------------------------------------------------------------------------------------------
+def c0_model():
+    g = np.load(os.path.join(HERE, "golden", "c0.npz"))
+    H, Z, K, B, T, Tr = (int(x) for x in g["meta_dims"])
+    pkg = load_package()
+    torch.manual_seed(1234)                                                  # the seeded construction c0.npz was generated from
+    m = pkg.MusicAttrRegGMVAE(roll_dims=342, rhythm_dims=3, note_dims=16, chroma_dims=24, hidden_dims=H, z_dims=Z, n_step=32, n_component=K)
+    sd = {k: f32(v.detach().numpy()) for k, v in m.state_dict().items()}
+    for k in ("gru_r.weight_hh_l0", "linear_out_g.weight", "mu_r_lookup.weight"):
+        v = sd[k].astype(np.float64)
+        np.testing.assert_allclose([v.sum(), np.abs(v).sum()], g["w0sum/" + k][:2], rtol=1e-6)
+    return g, sd, (H, Z, K, B, T, Tr)
+
+
+def gemm(a_k, b_k, M, N, K, A, Bm, bias=None, beta=0.0, Cin=None, alpha=1.0):
+    out = np.zeros((M, N), np.float32) if Cin is None else f32(Cin).copy()
+    A, Bm = f32(A), f32(Bm)
+    bias = None if bias is None else f32(bias)
+    assert lib.fn_gemm_f32_host(a_k, b_k, M, N, K, alpha, P(A), A.shape[1], P(Bm), Bm.shape[1], beta, P(out), N, P(bias), 1, None, 0, None) == 0
+    return out
+
+
+def test_c0_subdecoder_and_regulariser(g, sd, dims):
+    """gmm_model.py:100-117 (rhythm sub-decoder incl. the TIME-axis log_softmax) and trainer_gmm.py:199-217 on the reference's z of c0"""
+    H, Z, K, B, T, Tr = dims
+    z = f32(g["fw_z_r"])
+    W = sd["gru_d_r.weight_ih_l0"]                                            # [3H][3 + Z]: attribute one-hot | z (tiled over time, :103-104)
+    rowbias = gemm(1, 1, B, 3 * H, Z, z, np.ascontiguousarray(W[:, 3:]))
+    h0 = gemm(1, 1, B, H, Z, z, sd["linear_init_r.weight"], bias=sd["linear_init_r.bias"])
+    d = L.FnGruFwd()
+    keep = dict(wf=frag(sd["gru_d_r.weight_hh_l0"]), b_hh=sd["gru_d_r.bias_hh_l0"], b_ih=sd["gru_d_r.bias_ih_l0"],
+                table=f32(np.ascontiguousarray(W[:, :3].T)), idx=np.ascontiguousarray(g["r"], np.int32), rb=rowbias, h0=h0,
+                h_all=np.zeros((Tr, B, H), np.float32), ws=np.zeros(2 * lib.fn_frag_floats_host(B, H), np.float32))
+    d.B, d.T, d.H, d.reverse = B, Tr, H, 0
+    d.w_hh_frag, d.b_hh, d.b_ih, d.gx_table, d.idx, d.idx_ld = P(keep["wf"]), P(keep["b_hh"]), P(keep["b_ih"]), P(keep["table"]), P(keep["idx"]), Tr
+    d.gx_rowbias, d.h0, d.h_all, d.frag_ws = P(keep["rb"]), P(keep["h0"]), P(keep["h_all"]), P(keep["ws"])
+    assert lib.fn_gru_seq_fwd_host(C.byref(d), 1, None) == 0
+    logits = gemm(1, 1, Tr * B, 3, H, keep["h_all"].reshape(Tr * B, H), sd["linear_out_r.weight"], bias=sd["linear_out_r.bias"])     # [Tr][B][3]
+    logp, nll, dl = np.zeros((B, Tr, 3), np.float32), np.zeros((B, 3), np.float32), np.zeros((Tr, B, 3), np.float32)
+    tgt = np.ascontiguousarray(g["r"], np.int32)
+    gs = 1.0 / (B * Tr)
+    assert lib.fn_time_logsoftmax_host(P(logits), B, Tr, 3, P(logp), P(tgt), P(nll), gs, P(dl), None) == 0
+    close(logp, g["fw_r_out"], 2e-5, "r_out (time-axis log_softmax)")
+    close(nll.sum() / (B * Tr), g["loss_unsup_20000"][2], 2e-5, "CE_R")
+    lt = torch.from_numpy(logits).view(Tr, B, 3).requires_grad_(True)        # autograd of the same NLL through torch's dim=time softmax
+    lp = torch.log_softmax(lt, 0)
+    ce = -lp.gather(2, torch.from_numpy(g["r"]).t().unsqueeze(-1)).sum() * gs
+    close(dl, torch.autograd.grad(ce, lt)[0].numpy(), 2e-5, "dlogits (time axis)")
+    gout = torch.randn(B, Tr, 3)
+    dl2 = np.zeros((Tr, B, 3), np.float32)
+    go = f32(gout)
+    assert lib.fn_time_logsoftmax_bwd_host(P(logp), P(go), B, Tr, 3, P(dl2), None) == 0
+    close(dl2, torch.autograd.grad((torch.log_softmax(lt, 0).permute(1, 0, 2) * gout).sum(), lt)[0].numpy(), 2e-5, "time_logsoftmax_bwd")
+    for e, dens, want in (("r", g["r_density"], g["loss_reg"][0]), ("n", g["n_density"], g["loss_reg"][1])):
+        z0, a = f32(g["fw_z_" + e][:, 0]), np.ascontiguousarray(dens, np.float64)
+        rows, dz = np.zeros(B, np.float32), np.zeros(B, np.float32)
+        assert lib.fn_pairwise_reg_host(P(z0), P(a), B, 0, B, P(rows), 1.0 / (B * B), P(dz), None) == 0
+        close(rows.sum() / (B * B), want, 2e-5, "l_" + e)
+        zt = torch.from_numpy(z0).requires_grad_(True)
+        D = zt[:, None] - zt[None, :]
+        S = torch.sign(torch.from_numpy(np.subtract.outer(a, a))).float()
+        close(dz, torch.autograd.grad(((torch.tanh(D) - S) ** 2).mean(), zt)[0].numpy(), 2e-5, "d l_%s / d z0" % e)
+        half = np.zeros(B // 2, np.float32)                                   # data-parallel form: rows [4, 8) of the global batch
+        assert lib.fn_pairwise_reg_host(P(z0), P(a), B, B // 2, B // 2, P(half), 1.0 / (B * B), None, None) == 0
+        close(half, rows[B // 2:], 1e-6, "row-offset form")
+    print("c0: sub-decoder (time-axis head) + regulariser through the host twins OK")
+
+
+def test_c0_global_decoder_cells_and_greedy_decode(g, sd, dims):
+    """gmm_model.py:119-149: teacher-forced steps through fn_gru_cell_f32_host + fn_gemm_f32_host vs the reference's `out`; eval-mode greedy
+    decode through fn_decode_greedy_host vs the reference's token indices (bit-exact up to its first near-tie)"""
+    H, Z, K, B, T, Tr = dims
+    zc = f32(np.concatenate([g["fw_z_r"], g["fw_z_n"], g["c"]], 1))          # [B][280]
+    Wih = sd["grucell_g.weight_ih"]                                           # [3H][342 + 280]
+    table = f32(np.ascontiguousarray(Wih[:, :342].T))
+    NS = 6                                                                    # teacher-forced steps checked (plain loops under ASAN)
+    rowbias = gemm(1, 1, B, 3 * H, 280, zc, np.ascontiguousarray(Wih[:, 342:]))
+    hx0 = gemm(1, 1, B, H, 280, zc, sd["linear_init_global.weight"], bias=sd["linear_init_global.bias"])
+    hx1 = None
+    toks = np.ascontiguousarray(np.concatenate([np.full((B, 1), 341), g["d"][:, :NS - 1]], 1), np.int32)      # input of step i = d[:, i-1] (:120-121,142)
+    for i in range(NS):
+        c = L.FnGruCell()
+        o1 = np.zeros((B, H), np.float32)
+        col = np.ascontiguousarray(toks[:, i])
+        c.B, c.H, c.gx_table, c.idx, c.idx_ld, c.start_token = B, H, P(table), P(col), 1, 341
+        c.gx_rowbias, c.h_prev, c.ldh, c.w_hh, c.ldw_hh = P(rowbias), P(hx0), H, P(sd["grucell_g.weight_hh"]), H
+        c.b_ih, c.b_hh, c.h_out, c.ldo = P(sd["grucell_g.bias_ih"]), P(sd["grucell_g.bias_hh"]), P(o1), H
+        assert lib.fn_gru_cell_f32_host(C.byref(c), None) == 0
+        hx0 = o1
+        if i == 0:
+            hx1 = hx0.copy()                                                  # :134-135
+        c2 = L.FnGruCell()
+        o2 = np.zeros((B, H), np.float32)
+        c2.B, c2.H, c2.x, c2.ldx, c2.K1, c2.w_ih, c2.ldw_ih = B, H, P(hx0), H, H, P(sd["grucell_g_2.weight_ih"]), H
+        c2.h_prev, c2.ldh, c2.w_hh, c2.ldw_hh = P(hx1), H, P(sd["grucell_g_2.weight_hh"]), H
+        c2.b_ih, c2.b_hh, c2.h_out, c2.ldo = P(sd["grucell_g_2.bias_ih"]), P(sd["grucell_g_2.bias_hh"]), P(o2), H
+        assert lib.fn_gru_cell_f32_host(C.byref(c2), None) == 0
+        hx1 = o2
+        logits = gemm(1, 1, B, 342, H, hx1, sd["linear_out_g.weight"], bias=sd["linear_out_g.bias"])
+        close(torch.log_softmax(torch.from_numpy(logits), -1).numpy(), g["fw_out"][:, i], 5e-5, "out[:, %d]" % i)
+    assert lib.fn_gru_cell_f32_host(None, None) == L.FN_E_NULL
+    # eval-mode greedy decode of the reference's dec_z
+    nb, steps = 3, 24
+    zd = f32(g["dec_z"][:nb])
+    d = L.FnDecode()
+    keep = dict(w1=frag(sd["grucell_g.weight_hh"]), w2i=frag(sd["grucell_g_2.weight_ih"]), w2h=frag(sd["grucell_g_2.weight_hh"]),
+                wo=frag(sd["linear_out_g.weight"]), rb=gemm(1, 1, nb, 3 * H, 280, zd, np.ascontiguousarray(Wih[:, 342:])),
+                h0=gemm(1, 1, nb, H, 280, zd, sd["linear_init_global.weight"], bias=sd["linear_init_global.bias"]),
+                tok=np.zeros((nb, steps), np.int32), logp=np.zeros((nb, steps, 342), np.float32),
+                ws=np.zeros(lib.fn_decode_ws_bytes_host(nb, H, 342) // 4 + 4, np.float32), sync=np.zeros(8, np.int32))
+    d.B, d.steps, d.H, d.V, d.start_token = nb, steps, H, 342, 341
+    d.w_hh1_frag, d.b_hh1, d.b_ih1, d.table1, d.rowbias1, d.h0 = P(keep["w1"]), P(sd["grucell_g.bias_hh"]), P(sd["grucell_g.bias_ih"]), P(table), P(keep["rb"]), P(keep["h0"])
+    d.w_ih2_frag, d.b_ih2, d.w_hh2_frag, d.b_hh2 = P(keep["w2i"]), P(sd["grucell_g_2.bias_ih"]), P(keep["w2h"]), P(sd["grucell_g_2.bias_hh"])
+    d.w_out_frag, d.b_out, d.tokens, d.tok_ld, d.logp, d.ws, d.sync_ws = P(keep["wo"]), P(sd["linear_out_g.bias"]), P(keep["tok"]), steps, P(keep["logp"]), P(keep["ws"]), P(keep["sync"])
+    assert lib.fn_decode_greedy_host(C.byref(d), None) == 0
+    close(keep["logp"][:, 0], g["dec_logp_first"][:nb], 1e-4, "log-probabilities of the first decode step")
+    checked = 0
+    for i in range(nb):
+        tight = np.nonzero(g["dec_gap"][i, :steps] < 1e-4)[0]
+        upto = int(tight[0]) if len(tight) else steps
+        assert np.array_equal(keep["tok"][i, :upto], g["dec_tokens"][i, :upto]), (i, upto, keep["tok"][i], g["dec_tokens"][i, :steps])
+        checked += upto
+    assert checked >= 0.9 * nb * steps
+    d.steps = 0
+    assert lib.fn_decode_greedy_host(C.byref(d), None) == L.FN_E_SHAPE
+    print("c0: teacher-forced decoder cells (%d steps) + greedy decode (%d x %d tokens, %d compared bit for bit) through the host twins OK" % (NS, nb, steps, checked))
+
+
+def test_c0_weight_gradient_products_and_segment_sums(g, sd, dims):
+    """dW = dY^T X forms (fn_gemm_f32 a_k = 0, b_k = 0; fn_gru_dwhh_f32) and the token-segment sums behind dW_ih[:, :V] on c0's token matrix"""
+    H, Z, K, B, T, Tr = dims
+    rng = np.random.RandomState(3)
+    M, N, Kk = 24, 20, 40
+    A, Bm, bias, C0 = rng.randn(M, Kk), rng.randn(N, Kk), rng.randn(N), rng.randn(M, N)
+    close(gemm(1, 1, M, N, Kk, A, Bm, bias=bias), A @ Bm.T + bias, 2e-6, "gemm NT + bias")
+    close(gemm(1, 0, M, N, Kk, A, Bm.T.copy(), beta=0.5, Cin=C0), A @ Bm.T + 0.5 * C0, 2e-6, "gemm NN + beta")
+    close(gemm(0, 0, M, N, Kk, A.T.copy(), Bm.T.copy(), alpha=2.0), 2.0 * (A @ Bm.T), 2e-6, "gemm TN (weight-gradient form)")
+    assert lib.fn_gemm_f32_host(1, 1, M, N, Kk, 1.0, None, Kk, None, Kk, 0.0, None, N, None, 1, None, 0, None) == L.FN_E_NULL
+    h = 32
+    rows = T * B
+    dgx, dghn, hp, dW0 = f32(rng.randn(rows, 3 * h)), f32(rng.randn(rows, h)), f32(rng.randn(rows, h)), f32(rng.randn(3 * h, h))
+    dW = dW0.copy()
+    assert lib.fn_gru_dwhh_f32_host(P(dgx), P(dghn), P(hp), rows, h, 1.0, P(dW), 1, None, 0, None) == 0
+    lhs = np.concatenate([dgx[:, :2 * h], dghn], 1).astype(np.float64)
+    close(dW, lhs.T @ hp.astype(np.float64) + dW0, 2e-6, "dW_hh = [dr' | dz' | dn' r]^T h_prev")
+    # token sort of c0's event tokens + the segment sums of three scans that read them: forward, reverse, input shifted by one (decoder layer 1)
+    V, N3 = 342, 48
+    idx = np.ascontiguousarray(g["d"], np.int32)
+    img = np.zeros(lib.fn_token_sort_ints_host(rows, V), np.int32)
+    ws = np.zeros(lib.fn_token_sort_ws_bytes_host(rows, V) // 4 + 4, np.int32)
+    assert lib.fn_token_sort_host(P(idx), B, T, T, V, P(img), P(ws), ws.nbytes, None) == 0
+    seg, order = img[:V + 1], img[2 * (V + 1) + 2:]
+    pos_tok = idx.T.reshape(-1)                                               # token of position r = tau * B + b
+    assert seg[0] == 0 and seg[V] == rows and np.array_equal(np.sort(order), np.arange(rows))
+    for v in (0, 1, 57, 341):
+        run = order[seg[v]:seg[v + 1]]
+        assert (pos_tok[run] == v).all() and (np.diff(run) > 0).all()         # grouped by token, stable
+    jobs = (L.FnEmbedGrad * 3)()
+    dg = [f32(rng.randn(T, B, N3)) for _ in range(3)]
+    outs = [np.zeros((V, N3), np.float32), np.zeros((V, N3), np.float32), np.zeros((N3, V + 2), np.float32)]
+    for j, (rev, sh, tr_) in enumerate(((0, 0, 0), (1, 0, 0), (0, -1, 1))):
+        jobs[j].dgx_all, jobs[j].out, jobs[j].out_ld, jobs[j].transposed = P(dg[j]), P(outs[j]), outs[j].shape[1], tr_
+        jobs[j].reverse, jobs[j].idx_shift, jobs[j].start_token = rev, sh, 341
+    ws2 = np.zeros(lib.fn_embed_grad_sorted_ws_bytes_host(rows, B, V, N3, 3) // 4 + 4, np.float32)
+    assert lib.fn_embed_grad_sorted_host(jobs, 3, B, T, N3, V, P(img), P(ws2), ws2.nbytes, None) == 0
+    for j, (rev, sh) in enumerate(((0, 0), (1, 0), (0, -1))):
+        want = np.zeros((V, N3), np.float64)
+        for p in range(T):
+            tau = (T - 1 - p if rev else p) + sh
+            tok = idx[:, tau] if tau >= 0 else np.full(B, 341)
+            np.add.at(want, tok, dg[j][p].astype(np.float64))
+        got = outs[j] if j < 2 else outs[j][:, :V].T
+        close(got, want, 2e-6, "segment sums of scan %d" % j)
+    assert not outs[2][:, V:].any()
+    jobs[0].idx_shift = 1
+    assert lib.fn_embed_grad_sorted_host(jobs, 3, B, T, N3, V, P(img), P(ws2), ws2.nbytes, None) == L.FN_E_SHAPE
+    print("c0: weight-gradient products + token sort / segment sums through the host twins OK")
+
+
 if __name__ == "__main__":
     test_argument_errors()
     test_small_golden_encoder_and_latent()
     test_gru_backward_vs_autograd()
     test_latent_backward_vs_autograd()
     test_out_head_and_adam()
+    c0 = c0_model()
+    test_c0_subdecoder_and_regulariser(*c0)
+    test_c0_global_decoder_cells_and_greedy_decode(*c0)
+    test_c0_weight_gradient_products_and_segment_sums(*c0)
     print("HOST TWINS OK")

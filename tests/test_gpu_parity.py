@@ -1372,6 +1372,44 @@ def test_entry_driver_runs_an_epoch_from_the_reference_config(tmp_path, capsys):
     assert "Loading " + path in capsys.readouterr().out
 
 
+@pytest.mark.parametrize("family", ["vae", "singlevae", "cvae", "fader", "glsr"])
+def test_epoch_driver_v2_vs_reference_training_phase(family, tmp_path):
+    """``training_phase`` of trainer.py / trainer_singlevae.py / trainer_cvae.py / trainer_fader.py / trainer_glsr.py (two epochs, executed
+    unmodified for tests/golden/epoch_v2.npz) on the HIP path: same log lines, same checkpoint"""
+    from helpers import check_epoch_v2_run
+    m = check_epoch_v2_run(load_package(), family, load_golden("epoch_v2"), tmp_path, device=DEV, noise=NOISE_PARAMS)
+    assert not m.engine().ops.gru_sync_error()
+
+
+@pytest.mark.parametrize("family", ["vae", "singlevae", "cvae", "fader", "glsr"])
+def test_entry_driver_v2_runs_an_epoch_from_model_config_v2(family, tmp_path, capsys):
+    """`python train_gmm.py --config <the reference's model_config_v2.json> --model <family> --synthetic --epochs 1`: the module bodies of the
+    five trainers that open model_config_v2.json (trainer.py:20-76 ...) - config (no ``num_clusters`` in it), model, resume, loaders,
+    training_phase - on the HIP path at the config's own size (hidden 512, batch 128)"""
+    import os
+    load_package()
+    from music_fader_nets_amd.train import main, read_config
+    cfg = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_config_v2.json")
+    assert "num_clusters" not in read_config(cfg, family)
+    with pytest.raises(KeyError):
+        read_config(cfg, "gmm")                                 # trainer_gmm.py indexes args['num_clusters']: that script needs the other file
+    T = "112" if family == "glsr" else "48"                     # the GLSR decodes are teacher forced for 100 steps
+    argv = ["--config", cfg, "--model", family, "--synthetic", "--synthetic-songs", "320", "--seq-len", T, "--epochs", "1", "--out", str(tmp_path), "--seed", "3"]
+    step = main(argv)
+    out = capsys.readouterr().out
+    assert step == 2                                            # 256 training songs in batches of 128
+    needles = ["Save path: ", "Train / Validation / Test", "256 32 32", "Epoch 1 / 1", "batch loss: ", "train loss by term - D: ", "test loss by term - D: ", "Model saved as "]
+    needles += ["RA: "] if family == "fader" else ["RD: "]
+    needles += ["Saving model..."] if family in ("vae", "singlevae", "glsr") else []
+    for needle in needles:
+        assert needle in out, (needle, out)
+    path = os.path.join(str(tmp_path), "params", "music_attr_vae_singlevae_8.pt.pt")       # the config's name already ends in .pt (reproduced)
+    sd = torch.load(path)
+    assert "linear_out_g.weight" in sd and all(not v.is_cuda for v in sd.values())
+    main(argv)
+    assert "Loading " + path in capsys.readouterr().out
+
+
 def test_direct_calls_have_autograd(small):
     """encode / sub_decoders / global_decoder / approx_qy_x called directly in train mode: one autograd node each whose backward runs the
     matching part of the HIP backward (the reference allows such calls anywhere, gmm_model.py:82-218)"""

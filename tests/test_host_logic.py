@@ -235,7 +235,15 @@ def test_entry_driver_config_and_loaders():
     load_package()
     from music_fader_nets_amd import train as T
     args = T.read_config(os.path.join(GOLDEN, "gmm_model_config.json"))
-    assert [args[k] for k in T.CONFIG_KEYS] == [128, 50, 1e-3, 0.9999, "music_attr_vae_reg_gmm_long_v", 512, 128, 0.2, 32, 2]
+    assert [args[k] for k in T.CONFIG_KEYS + T.GMM_KEYS] == [128, 50, 1e-3, 0.9999, "music_attr_vae_reg_gmm_long_v", 512, 128, 0.2, 32, 2]
+    # model_config_v2.json (the file trainer.py / trainer_singlevae.py / trainer_cvae.py / trainer_fader.py / trainer_glsr.py open) has no
+    # num_clusters: it loads unchanged for those five, and only trainer_gmm.py's script refuses it
+    v2 = os.path.join(GOLDEN, "model_config_v2.json")
+    for fam in ("vae", "singlevae", "cvae", "fader", "glsr"):
+        a2 = T.read_config(v2, fam)
+        assert [a2[k] for k in T.CONFIG_KEYS] == [128, 30, 1e-3, 0.9999, "music_attr_vae_singlevae_8.pt", 512, 128, 0.2, 32] and "num_clusters" not in a2
+    with pytest.raises(KeyError, match="num_clusters"):
+        T.read_config(v2, "gmm")
     with pytest.raises(KeyError):
         import json, tempfile
         with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
@@ -243,7 +251,15 @@ def test_entry_driver_config_and_loaders():
         T.read_config(f.name)
     opts = argparse.Namespace(data_root=None, synthetic_songs=200, seq_len=40)
     dls, sizes = T.build_loaders(args, opts, 0, 1)
-    assert sizes == {"train": 160, "val": 20, "vgm_train": 57, "vgm_val": 3}           # 80/10/10 and 90/5/5 splits
+    assert sizes == {"train": 160, "val": 20, "test": 20, "vgm_train": 57, "vgm_val": 3}           # 80/10/10 and 90/5/5 splits
+    dls2, sizes2 = T.build_loaders(args, opts, 0, 1, "fader")
+    assert sorted(dls2) == ["train", "val"] and sizes2 == {"train": 160, "val": 20, "test": 20}    # the v2 scripts read the Yamaha arrays only
+    # the shuffles come from an explicit generator: the same batches whatever happened to the global generator (data-parallel ranks rely on it)
+    torch.manual_seed(1)
+    first = next(iter(T.build_loaders(args, opts, 0, 1, "fader", seed=7)[0]["train"]))[0]
+    torch.manual_seed(2); torch.rand(5)
+    again = next(iter(T.build_loaders(args, opts, 0, 1, "fader", seed=7)[0]["train"]))[0]
+    assert torch.equal(first, again)
     x = next(iter(dls["train"]))
     assert [tuple(t.shape) for t in x] == [(128, 40), (128, 10), (128, 10), (128, 24), (128,), (128,)] and x[0].dtype == torch.float32
     v = next(iter(dls["vgm_train"]))
@@ -252,6 +268,50 @@ def test_entry_driver_config_and_loaders():
     a = next(iter(T.RankShard([x], 0, 2)))
     b = next(iter(T.RankShard([x], 1, 2)))
     assert torch.equal(torch.cat([a[0], b[0]]), x[0]) and a[3].shape == (64, 24)
+
+
+@pytest.mark.parametrize("family", ["vae", "singlevae", "cvae", "fader"])
+def test_epoch_driver_v2_vs_reference_training_phase(family, tmp_path):
+    """training_phase of the model_config_v2.json trainers (tests/golden/epoch_v2.npz: the reference's own loops, two epochs) on the CPU
+    semantics backend: same lines, same checkpoint.  (GLSR: gpu suite only - four 100-step decodes per step.)"""
+    from helpers import check_epoch_v2_run
+    check_epoch_v2_run(load_package(), family, load_golden("epoch_v2"), tmp_path, ops=FakeOps(), rtol=2e-4, atol_w=5e-4, noise=NOISE_PARAMS)
+
+
+def test_data_parallel_eps_is_the_global_draw_sliced(small):
+    """GMVAETrainer.draw_eps under data parallelism: rank k keeps rows [k B, (k+1) B) of the draw for the global batch (lockstep generators)"""
+    pkg = load_package()
+    class Ctx:                                                  # what draw_eps reads of a DataParallelContext
+        def __init__(self, rank, world): self.rank, self.world, self.want_direct = rank, world, False
+        def global_batch(self, b): return b * self.world
+    m = make_model(64, 32, sd_from(small, "w0/"), ops=FakeOps())
+    torch.manual_seed(11)
+    full = pkg.GMVAETrainer(m, dist_ctx=None).draw_eps(12, 5)
+    got = []
+    for rank in range(3):
+        torch.manual_seed(11)
+        got.append(pkg.GMVAETrainer(m, dist_ctx=Ctx(rank, 3)).draw_eps(4, 5))
+    for k in range(2):
+        assert torch.equal(torch.cat([g[k] for g in got]), full[k])
+    assert not torch.equal(got[0][0], got[1][0])
+
+
+def test_stale_weight_images_are_detected(small):
+    """an unmodified reference loop updates parameters in place (optimizer.step()) and never calls weights_changed(): engine() notices the
+    parameters' version counters and re-derives its transposed / fragment images"""
+    m = make_model(64, 32, sd_from(small, "w0/"), ops=FakeOps())
+    eng = m.engine()
+    calls = []
+    orig = eng.refresh_weights
+    eng.refresh_weights = lambda: (calls.append(1), orig())[1]
+    m.engine(); m.engine()
+    assert not calls
+    with torch.no_grad():
+        m.grucell_g.weight_hh.mul_(1.5)
+    m.engine()
+    assert len(calls) == 1
+    m.engine()
+    assert len(calls) == 1
 
 
 def test_direct_calls_have_autograd(small):
