@@ -12,9 +12,11 @@ mode train (default; BASELINE configs[1], configs[2-3] with N>1): a "step" = for
 mode decode (BASELINE configs[4]): a "step" = encode 256 sequences (T=256), 8 fader values each on z_r[:, 0], greedy decode of the
   2048 rows for 300 steps (test_class.py:233-254 batched; replicas only, no collective).
 
-Prints ONE JSON line on rank 0 with the contract fields plus `roofline` (the kernel with the largest time per step), `roofline_all`,
-(N=1) `cpu_baseline`, `decode` (the configs[4] measurement, so that the default run records it too) and, with collectives in place,
-`comm` (per-bucket all-reduce time and how long the step's stream stood still for them).
+Prints ONE JSON line on rank 0 with the contract fields plus `roofline` (the kernel SYMBOL - template instances merged, as rocprofv3 --stats
+lists them - with the largest time per step), `roofline_by_symbol`, `roofline_scans` (the four scan rows as one time-weighted figure),
+`roofline_all` (split by launch shape), `sustained_ms_per_step` (200 more steps behind the timed region), (N=1) `cpu_baseline`, `decode`
+(the configs[4] measurement, so that the default run records it too) and, with collectives in place, `comm` (per-bucket all-reduce time
+and how long the step's stream stood still for them).
 """
 import argparse
 import json
@@ -107,13 +109,46 @@ def _classify(name, a, k):
     return None
 
 
+def _symbol(name, a, k):
+    """op call -> (kernel symbol as rocprofv3 prints it without template arguments, bound, work of that launch) for EVERY launch of the heavy
+    symbols, whatever its shape (roofline_by_symbol merges what `_classify` splits by launch shape)"""
+    if name in ("gru_seq_fwd", "gru_seq_bwd"):
+        work = sum(s["B"] * s["T"] for s in a[0]) * FLOP_PER_SAMPLE_STEP
+        return ("gru_fwd_pp_kernel" if name == "gru_seq_fwd" else "gru_bwd_rs_kernel"), "mfma", work
+    if name == "gru_dwhh":
+        rows, Hh = a[2].shape
+        return "gemm_tn_kernel", "mfma", 2.0 * rows * 3 * Hh * Hh
+    if name == "gemm":
+        A, Cm = a[0], a[2]
+        M, N = Cm.shape
+        Kk = A.shape[1] if k.get("a_k", True) else A.shape[0]
+        if k.get("a_k", True) and k.get("b_k", True):
+            sym = "gemm_nt_direct_kernel / gemm_kernel"
+        else:
+            sym = "gemm_kernel" if k.get("a_k", True) else "gemm_tn_kernel"
+        return sym, "mfma", 2.0 * M * N * Kk
+    if name == "out_head":
+        h, W = a[0], a[1]
+        return "out_head_kernel", "mfma", 2.0 * h.shape[0] * W.shape[0] * h.shape[1]
+    if name == "embed_grad_sorted":
+        return "eg_piece_kernel + eg_final_kernel", "hbm", float(sum(j["dgx"].numel() for j in a[1]) * 4)
+    return None
+
+
+SYMBOL_NOTE = {
+    "gru_fwd_pp_kernel": "forward weight-stationary scans, ping-pong over two row halves (all launches: encoder 4 x 256 rows x 256 steps, decoder pipeline chunks, attribute decoders)",
+    "gru_bwd_rs_kernel": "backward weight-stationary scans, W_hh^T slice half register-stationary (all launches: encoder, decoder pipeline chunks, attribute decoders)",
+    "gemm_tn_kernel": "weight-gradient products dW = dY^T X (dW_hh of every scan via fn_gru_dwhh_f32, dW of the dense layers)",
+}
+
+
 ROW_INFO = {   # row -> (bound, unit of work, kernel, peak share of the chip)
-    "enc_fwd_scan": ("mfma", "flop", "gru_fwd_persist_kernel (4 encoder scans x 256 steps, one launch)", 1.0),
-    "enc_bwd_scan": ("mfma", "flop", "gru_bwd_persist_kernel (4 encoder scans x 256 steps, one launch)", 1.0),
-    "dec_fwd_scan_chunk": ("mfma", "flop", "gru_fwd_persist_kernel (one launch of the decoder pipeline: 2 scans x 256 rows x 32 steps - layer 1 chunk k + layer 2 chunk k-2, attribute-decoder chunks at both ends)", 1.0),
-    "dec_bwd_scan_chunk": ("mfma", "flop", "gru_bwd_persist_kernel (one launch of the decoder pipeline: 2 scans x 256 rows x 32 steps - layer 2 chunk k + layer 1 chunk k+2, attribute-decoder chunks at both ends)", 1.0),
-    "subdec_fwd_scan": ("mfma", "flop", "gru_fwd_persist_kernel (both sub-decoders, 64 steps)", 1.0),
-    "subdec_bwd_scan": ("mfma", "flop", "gru_bwd_persist_kernel (both sub-decoders, 64 steps)", 1.0),
+    "enc_fwd_scan": ("mfma", "flop", "gru_fwd_pp_kernel<1> (4 encoder scans x 256 steps, one launch)", 1.0),
+    "enc_bwd_scan": ("mfma", "flop", "gru_bwd_rs_kernel<2> (4 encoder scans x 256 steps, one launch)", 1.0),
+    "dec_fwd_scan_chunk": ("mfma", "flop", "gru_fwd_pp_kernel<2> (one launch of the decoder pipeline: 2 scans x 256 rows x 32 steps - layer 1 chunk k + layer 2 chunk k-2, attribute-decoder chunks at both ends)", 1.0),
+    "dec_bwd_scan_chunk": ("mfma", "flop", "gru_bwd_rs_kernel<1> (one launch of the decoder pipeline: 2 scans x 256 rows x 32 steps - layer 2 chunk k + layer 1 chunk k+2, attribute-decoder chunks at both ends)", 1.0),
+    "subdec_fwd_scan": ("mfma", "flop", "gru_fwd_pp_kernel (both sub-decoders, 64 steps)", 1.0),
+    "subdec_bwd_scan": ("mfma", "flop", "gru_bwd_rs_kernel (both sub-decoders, 64 steps)", 1.0),
     "dwhh_gemm_tn": ("mfma", "flop", "gemm_tn_kernel via fn_gru_dwhh_f32 (dW_hh of an encoder direction / a decoder layer: [3H x T*B] x [T*B x H], 48 tiles x 16 K ranges; 6 launches per step)", 1.0),
     "dwhh_gemm_tn_attr": ("mfma", "flop", "gemm_tn_kernel via fn_gru_dwhh_f32 (dW_hh of the attribute decoders, K = Tr*B rows, 48 tiles x 8 K ranges)", 1.0),
     "dwhh_gemm_tn_lean": ("mfma", "flop", "gemm_tn_lean_kernel via fn_gru_dwhh_f32 (dW_hh of the decoder-side scans, <= 128 registers)", 1.0),
@@ -128,6 +163,7 @@ ROW_INFO = {   # row -> (bound, unit of work, kernel, peak share of the chip)
 # HBM bytes per launch from rocprofv3 PMC passes (2 x FETCH_SIZE with the gfx950 correction + WRITE_SIZE, separate passes): bench.py
 # itself cannot run the profiler, so these are the committed measurements of the same launches
 PMC_TRAFFIC = {"enc_fwd_scan": 4.34e9, "enc_bwd_scan": 7.94e9, "dwhh_gemm_tn": 0.711e9}
+PMC_TRAFFIC_SYMBOL = {}        # symbol -> mean bytes per launch over all of its launches in one step (filled from the round's PMC pass)
 PMC_SOURCE = "profiles/r03_pmc_training_step.txt (2 x FETCH_SIZE + WRITE_SIZE, separate passes)"
 
 
@@ -154,6 +190,43 @@ def roofline_rows(records):
     return rows
 
 
+def symbol_rows(records, reps):
+    agg = {}
+    for name, a, k, e0, e1 in records:
+        c = _symbol(name, a, k)
+        if c is None:
+            continue
+        ent = agg.setdefault(c[0], [c[1], 0, 0.0, 0.0])
+        ent[1] += 1
+        ent[2] += e0.elapsed_time(e1)
+        ent[3] += c[2]
+    rows = {}
+    for sym, (bound, cnt, ms, work) in agg.items():
+        if bound == "mfma":
+            ach, peak, u = work / (ms * 1e-3) / 1e12, PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
+        else:
+            ach, peak, u = work / (ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
+        rows[sym] = dict(bound=bound, kernel=sym, note=SYMBOL_NOTE.get(sym), launches_per_step=round(cnt / reps, 1), avg_launch_us=round(ms / cnt * 1e3, 1),
+                         achieved=round(ach, 2), peak=peak, unit=u, frac=round(ach / peak, 4), work_per_launch=work / cnt,
+                         us_per_step=round(ms * 1e3 / reps, 1))
+    return rows
+
+
+SCAN_ROWS = ("enc_fwd_scan", "enc_bwd_scan", "dec_fwd_scan_chunk", "dec_bwd_scan_chunk")
+
+
+def scans_row(rows):
+    """the four scan rows of roofline_all as ONE time-weighted figure (0.633 then)"""
+    have = [rows[r] for r in SCAN_ROWS if r in rows]
+    if not have:
+        return None
+    us = sum(r["us_per_step"] for r in have)
+    work = sum(r["work_per_launch"] * r["launches"] for r in have) / max(1, have[0]["_reps"])
+    ach = work / (us * 1e-6) / 1e12
+    return dict(bound="mfma", rows=[r for r in SCAN_ROWS if r in rows], us_per_step=round(us, 1), achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS,
+                unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), flop_per_step=work)
+
+
 def per_kernel_rooflines(trainer, batch, eps, reps=5):
     """`reps` eager fwd+bwd passes (no optimiser update) under the TimedOps proxy, all lanes serialised on one stream -> per-kernel
     average launch durations with each kernel running alone (mean of all launches, not the best) and their roofline fractions."""
@@ -174,7 +247,8 @@ def per_kernel_rooflines(trainer, batch, eps, reps=5):
     rows = roofline_rows(proxy.records)
     for r in rows.values():
         r["us_per_step"] = round(r.pop("total_us") / reps, 1)        # kernel time of this row in ONE training step
-    return rows
+        r["_reps"] = reps
+    return rows, symbol_rows(proxy.records, reps)
 
 
 def _max_over_ranks(x, dev):
@@ -262,7 +336,24 @@ def bench_train(args, pkg, ctx, local, rank, world, log):
     assert all(np.isfinite(tup)), tup
     tokens_per_s = world * B * T * args.steps / dt
     log("timed region done: %.3f ms/step (host enqueue %.3f ms/step)" % (dt / args.steps * 1e3, t_host / args.steps * 1e3))
-    rows = per_kernel_rooflines(trainer, batch, eps)       # every rank: the pass contains the regulariser's all-gather
+    # sustained rate: >= 200 more replays right behind the timed region (clock / thermal settle: r03 soak 23.64 ms vs 22.78 in the 20-step bench)
+    sustained = None
+    if args.sustain > 0:
+        torch.cuda.synchronize()
+        if ctx is not None:
+            torch.distributed.barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.sustain):
+            trainer.step_device(step, batch, eps)
+            step += 1
+        torch.cuda.synchronize()
+        if ctx is not None:
+            torch.distributed.barrier()
+        sustained = (time.perf_counter() - t1) / args.sustain
+        if ctx is not None:
+            sustained = _max_over_ranks(sustained, dev)
+        log("sustained: %.3f ms/step over %d more steps" % (sustained * 1e3, args.sustain))
+    rows, by_symbol = per_kernel_rooflines(trainer, batch, eps)       # every rank: the pass contains the regulariser's all-gather
     log("per-kernel timing done")
     out = {
         "metric": "event-tokens/sec GM-VAE train, seq256 b256", "value": round(tokens_per_s, 1), "unit": "event-tokens/s",
@@ -273,19 +364,33 @@ def bench_train(args, pkg, ctx, local, rank, world, log):
                    "global_batch": B * world, "seq_len": T, "parallelism": "dp%d" % world},
         "last_loss": round(tup[0], 4),
     }
+    if sustained is not None:
+        out["sustained_ms_per_step"] = round(sustained * 1e3, 3)
+        out["sustained_value"] = round(world * B * T / sustained, 1)
+        out["sustained_steps"] = args.sustain
     if ctx is not None and getattr(ctx, "rccl", None) is not None:
         comm = comm_times(trainer, ctx, batch, eps, step)
         if rank == 0:
             out["comm"] = comm
     if rank == 0:
-        dom_row = max(rows, key=lambda r: rows[r]["us_per_step"])          # the kernel (symbol) the step spends most of its time in
-        dom = dict(rows[dom_row])
-        dom.update(row=dom_row, traffic=PMC_TRAFFIC.get(dom_row), traffic_source=PMC_SOURCE if dom_row in PMC_TRAFFIC else None,
+        # `roofline` = the kernel SYMBOL (template instances merged, as rocprofv3 --stats lists them) the step spends most of its time in;
+        # `roofline_all` keeps the split by launch shape, `roofline_scans` the four scan rows as one time-weighted figure
+        scans = scans_row(rows)
+        for r in rows.values():
+            r.pop("_reps", None)
+        dom_sym = max(by_symbol, key=lambda r: by_symbol[r]["us_per_step"])
+        dom = dict(by_symbol[dom_sym])
+        dom.update(symbol=dom_sym, traffic=PMC_TRAFFIC_SYMBOL.get(dom_sym), traffic_source=PMC_SOURCE if dom_sym in PMC_TRAFFIC_SYMBOL else None,
                    flop_per_launch=dom.pop("work_per_launch"),
                    step_frac=round(tokens_per_s / world * F_ALG_PER_TOKEN / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
-        if dom_row.endswith("_scan"):
-            dom["steps_per_launch"] = T
         out["roofline"] = dom
+        for r in by_symbol.values():
+            r.pop("work_per_launch", None)
+        out["roofline_by_symbol"] = by_symbol
+        out["roofline_scans"] = scans
+        for row, tr_ in PMC_TRAFFIC.items():
+            if row in rows:
+                rows[row]["traffic"], rows[row]["traffic_source"] = tr_, PMC_SOURCE
         out["roofline_all"] = rows
         out["roofline_worst"] = min(rows, key=lambda r: rows[r]["frac"])
         if first is not None and world == 1:                # same seeds as tests/golden/c1.npz (the reference's own train() at this size)
@@ -301,7 +406,7 @@ def bench_train(args, pkg, ctx, local, rank, world, log):
     if world == 1 and not args.no_decode:
         # BASELINE configs[4] rides along in the default line (about 0.3 s of GPU time): 1 warm-up + 3 timed passes
         del trainer
-        dargs = argparse.Namespace(steps=3, warmup=1, no_cpu_baseline=args.no_cpu_baseline)
+        dargs = argparse.Namespace(steps=3, warmup=1, no_cpu_baseline=args.no_cpu_baseline, sustain=0)
         d = bench_decode(dargs, pkg, None, local, rank, world, log)
         out["decode"] = dict(metric=d["metric"], value=d["value"], unit=d["unit"], ms_per_pass=d["ms_per_step"], workload=d["config"]["workload"],
                              roofline=d["roofline"], cpu_baseline=d.get("cpu_baseline"))
@@ -371,7 +476,7 @@ def bench_decode(args, pkg, ctx, local, rank, world, log):
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cpu_baseline
-        out["cpu_baseline"] = cpu_baseline.time_decode_baseline(H, Z, 256, 30)
+        out["cpu_baseline"] = cpu_baseline.time_decode_baseline(H, Z, rows, 30)      # the same 2048 rows as the GPU leg, 30 of its 300 steps
     return out
 
 
@@ -381,6 +486,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=("train", "decode"), default="train")
+    ap.add_argument("--sustain", type=int, default=200, help="train mode: more steps timed right behind the K timed ones -> sustained_ms_per_step (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="train mode: leave the configs[4] decode measurement out of the line")
     args = ap.parse_args()

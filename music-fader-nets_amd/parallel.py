@@ -130,6 +130,11 @@ class DataParallelContext:
         self._forked = True
 
     def finish_buckets(self):
+        """Join of the gradient buckets, called in front of clip + Adam.  For the direct RCCL path this is also the guarantee that a
+        collective's kernels have LEFT the compute units before the next weight-stationary launch asks for all 256 of them: an event
+        recorded on the communicator's stream behind the last all-reduce is waited on by the step's stream (``wait_stream``), and
+        everything the step enqueues afterwards - clip + Adam, the weight images, the NEXT step's encoder forward scan - is ordered
+        behind it; inside a captured step the same edge is a graph dependency."""
         for w in self._pending:
             w.wait()                              # current stream waits for the collective; the host does not block on NCCL
         self._pending = []

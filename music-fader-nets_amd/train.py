@@ -144,7 +144,8 @@ def sync_replicas(trainer, ctx):
         if ctx.rank != 0:
             flat.zero_()
         ctx.all_reduce_sum(flat)
-    torch.cuda.synchronize()
+    if flat.is_cuda:
+        torch.cuda.synchronize()
     trainer.model.weights_changed()
 
 

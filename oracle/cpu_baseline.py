@@ -102,18 +102,39 @@ def host_threads():
         return os.cpu_count() or 1
 
 
+MAX_THREADS = 64
+
+
+def pick_threads(probe=None, threads=None):
+    """SURVEY.md 8d asks for all host cores with the count printed.  On the pool's 256-core hosts torch's intra-op pool is pathological with
+    256 threads - measured in round 4: ONE 32-row x 256-step train step took 2814 s with 256 threads against 7.0 s with 64 - so the
+    baseline runs with min(usable cores, 64) threads (`cores`) and reports the host's core counts next to it (`host_cpus`, `usable_cpus`);
+    no all-core probe is made (it would cost the bench run most of an hour).  -> (threads, note)"""
+    if threads:
+        torch.set_num_threads(threads)
+        return threads, "threads fixed by the caller"
+    allc = host_threads()
+    n = min(allc, MAX_THREADS)
+    torch.set_num_threads(n)
+    if n == allc:
+        return n, "all %d usable cores" % allc
+    return n, ("%d of %d usable cores (torch's intra-op pool is pathological beyond that on this host class: 2814 s against 7.0 s for one "
+               "32-row step with 256 / 64 threads, measured round 4)" % (n, allc))
+
+
 def time_baseline(H, Z, B, T, Tr, seed=0, threads=None, max_step_s=120.0, fallback_B=32):
     """tokens/s of the CPU path: the benchmark shape itself, 1 warm-up step + 2 timed steps; only when the warm-up
     step takes longer than `max_step_s` the sample falls back to `fallback_B` rows of the same T-step sequences (again 1 + 2 steps)."""
+    import os
     from importlib import import_module
-    threads = threads or min(host_threads(), 64)
-    torch.set_num_threads(threads)
     sd = orc.init_state_dict(H, Z)
     model = build(sd, H, Z)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     synth = import_module("music_fader_nets_amd.synth")
     warm = synth.synth_batch(np.random.RandomState(1), 4, 16, 4)
     train_step(model, opt, warm, torch.randn(4, Z), torch.randn(4, Z), 20000)          # thread-pool / allocator warm-up
+
+    threads, tnote = pick_threads(None, threads)
 
     def run(b_rows, timed):
         b = synth.synth_batch(np.random.RandomState(seed), b_rows, T, Tr)
@@ -136,22 +157,25 @@ def time_baseline(H, Z, B, T, Tr, seed=0, threads=None, max_step_s=120.0, fallba
         note = " (B=%d warm-up step took %.0f s > %.0f s: fell back)" % (B, t_warm, max_step_s)
         b_used = fallback_B
         t_warm, dt = run(fallback_B, lambda tw: True)
-    return dict(value=b_used * T / dt, unit="event-tokens/s", cores=threads, kind="port",
+    return dict(value=b_used * T / dt, unit="event-tokens/s", cores=threads, host_cpus=os.cpu_count(), usable_cpus=host_threads(), kind="port",
                 sample="B=%d x T=%d (Tr=%d): 1 warm-up step (%.1f s) + 2 timed steps of the dense-one-hot torch.nn train step, "
-                       "%.1f s/step%s" % (b_used, T, Tr, t_warm, dt, note))
+                       "%.1f s/step%s; threads: %s" % (b_used, T, Tr, t_warm, dt, note, tnote))
 
 
 def time_decode_baseline(H, Z, rows, steps, seed=0, threads=None):
     """tokens/s of the reference's eval-mode ``global_decoder`` (gmm_model.py:119-149, argmax feedback) on the host cores:
-    `rows` sequences x `steps` greedy steps through the torch.nn restatement (dense one-hot inputs, as the reference executes)."""
-    threads = threads or min(host_threads(), 64)
-    torch.set_num_threads(threads)
+    `rows` sequences x `steps` greedy steps through the torch.nn restatement (dense one-hot inputs, as the reference executes).  Every
+    greedy step costs the same (no state grows with the step index), so tokens/s of `steps` steps is tokens/s of any longer decode."""
+    import os
     sd = orc.init_state_dict(H, Z)
     torch.manual_seed(seed)
     z = torch.randn(rows, 2 * Z + 24)
+
+    threads, tnote = pick_threads(None, threads)
     orc.greedy_decode(sd, z[:2], 2)                                                      # warm-up
     t0 = time.perf_counter()
     orc.greedy_decode(sd, z, steps)
     dt = time.perf_counter() - t0
-    return dict(value=rows * steps / dt, unit="event-tokens/s", cores=threads, kind="port",
-                sample="%d sequences x %d greedy steps of the eval-mode global_decoder restatement, %.1f s" % (rows, steps, dt))
+    return dict(value=rows * steps / dt, unit="event-tokens/s", cores=threads, host_cpus=os.cpu_count(), usable_cpus=host_threads(), kind="port",
+                sample="%d sequences x %d greedy steps of the eval-mode global_decoder restatement, %.1f s (the GPU leg decodes the same %d "
+                       "rows for 300 steps; every step costs the same, so the rate carries over); threads: %s" % (rows, steps, dt, rows, tnote))

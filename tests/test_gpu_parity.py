@@ -6,6 +6,7 @@ bit-exact wherever the reference's own top-2 log-prob gap exceeds 1e-4 (a flippe
 so rows are compared up to the first sub-threshold gap).
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -743,6 +744,97 @@ def test_large_batch_decode_cells_match_per_token_kernels(H, Bi, steps):
     assert bool(keep.float().mean() > 0.9)
     assert torch.equal(tk0[keep], tk1[keep])
     close(lp1[keep], lp0[keep], 2e-5)
+
+
+@pytest.mark.parametrize("path,Bi,steps", [("cells", 2048, 20), ("pipeline", 800, 16), ("pipeline", 1536, 12)])
+def test_large_decode_paths_vs_oracle(path, Bi, steps):
+    """The decode paths BASELINE configs[4] is timed on, checked DIRECTLY against the oracle's eval-mode global_decoder (gmm_model.py:119-149,
+    73-80; the oracle is pinned to the reference's greedy tokens by c0 / eval.npz) at hidden 512: the staged-GEMM cells (fn_gru_cell_f32,
+    2048 rows = 256 sequences x 8 fader values, test_class.py:84-85) and the one-launch block pipeline (fn_decode_greedy, 800 and 1536
+    rows).  Per row: the oracle's tokens up to the first step where the ORACLE's own top-2 gap is below 1e-4, log-probabilities to 1e-4."""
+    from oracle import gmvae_oracle as orc
+    pkg = load_package()
+    m = make_model(512, 128, device=DEV, seed=1234)
+    m.eval()
+    torch.manual_seed(21)
+    z = torch.randn(Bi, 2 * m.latent_dim + 24)
+    eng = m.engine()
+    if path == "cells":
+        eng.single_launch_decode, eng.cell_decode_rows = False, 768
+    else:
+        eng.single_launch_decode, eng.single_launch_rows = True, 2048
+    lp, tk = pkg.greedy_decode(m, z.to(DEV), steps)
+    assert not eng.ops.gru_sync_error()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    ref_lp, ref_tk = orc.greedy_decode(sd, z, steps)
+    top2 = ref_lp.topk(2, dim=-1).values
+    unclear = (top2[..., 0] - top2[..., 1]) < 1e-4                                          # [Bi][steps]
+    first = torch.where(unclear.any(1), unclear.float().argmax(1), torch.full((Bi,), steps))
+    keep = torch.arange(steps).view(1, -1) < first.view(-1, 1)
+    assert float(keep.float().mean()) > 0.95, float(keep.float().mean())
+    got_tk, got_lp = tk.cpu().long(), lp.cpu()
+    assert torch.equal(got_tk[keep], ref_tk[keep]), int((got_tk[keep] != ref_tk[keep]).sum())
+    np.testing.assert_allclose(got_lp[keep].numpy(), ref_lp[keep].numpy(), rtol=0, atol=1e-4)
+
+
+def test_configs4_sized_fader_sweep_properties():
+    """BASELINE configs[4] at its full size - 256 sequences (T = 256) encoded, 8 fader values each on z_r[:, 0] (test_class.py:84-85), 2048 rows
+    x 300 greedy steps - through the default dispatch of fader_sweep: token range, bit-reproducibility of a second pass, sync-error word
+    clear, and the first 24 steps of 64 of the rows against the oracle's decode of the same latent rows"""
+    from oracle import gmvae_oracle as orc
+    from music_fader_nets_amd.synth import synth_batch
+    pkg = load_package()
+    m = make_model(512, 128, device=DEV, seed=1234)
+    m.eval()
+    b = synth_batch(np.random.RandomState(0), 256, 256, 64)
+    d = torch.from_numpy(b["d"]).to(DEV).to(torch.int32)
+    c = torch.from_numpy(b["c"]).to(DEV)
+    torch.manual_seed(99)
+    eps = (torch.randn(256, 128).to(DEV), torch.randn(256, 128).to(DEV))
+    values = [-2.0 + 0.5 * k for k in range(8)]
+    tok, z0 = pkg.fader_sweep(m, d, c, values, steps=300, which="r", eps=eps)
+    tok2, _ = pkg.fader_sweep(m, d, c, values, steps=300, which="r", eps=eps)
+    assert not m.engine().ops.gru_sync_error()
+    assert tuple(tok.shape) == (256, 8, 300) and int(tok.min()) >= 0 and int(tok.max()) < 342
+    assert torch.equal(tok, tok2)
+    # the latent rows of 8 of the sequences, rebuilt as test_class.py:243-251 builds them, decoded by the oracle
+    dis_r, dis_n = m.encode(d)
+    np.testing.assert_allclose(z0.cpu().numpy(), (dis_r.mean + dis_r.stddev * eps[0])[:, 0].cpu().numpy(), rtol=1e-6, atol=1e-6)
+    seqs = torch.arange(0, 256, 32, device=DEV)
+    zr = (dis_r.mean + dis_r.stddev * eps[0])[seqs].unsqueeze(1).repeat(1, 8, 1)
+    zn = (dis_n.mean + dis_n.stddev * eps[1])[seqs].unsqueeze(1).repeat(1, 8, 1)
+    zr[:, :, 0] = torch.tensor(values, device=DEV)
+    zc = torch.cat([zr, zn, c[seqs].unsqueeze(1).repeat(1, 8, 1)], dim=2).view(64, -1)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    ref_lp, ref_tk = orc.greedy_decode(sd, zc.cpu(), 24)
+    top2 = ref_lp.topk(2, dim=-1).values
+    unclear = (top2[..., 0] - top2[..., 1]) < 1e-4
+    first = torch.where(unclear.any(1), unclear.float().argmax(1), torch.full((64,), 24))
+    keep = torch.arange(24).view(1, -1) < first.view(-1, 1)
+    assert float(keep.float().mean()) > 0.9
+    assert torch.equal(tok[seqs].reshape(64, 300)[:, :24].cpu().long()[keep], ref_tk[keep])
+
+
+@pytest.mark.parametrize("H,Bi,steps", [(512, 2048, 8), (512, 1100, 8), (64, 1700, 10)])
+def test_large_batch_decode_row_ranges_are_bit_identical(H, Bi, steps):
+    """the staged-GEMM decode with the batch cut into row ranges on their own streams (Engine.decode_lanes; cuts at multiples of 64 rows = the
+    kernels' row tiles, ragged last range) gives the tokens and log-probabilities of the one-range decode bit for bit"""
+    pkg = load_package()
+    m = make_model(H, 32 if H == 64 else 128, device=DEV, seed=17)
+    m.eval()
+    torch.manual_seed(6)
+    z = torch.randn(Bi, 2 * m.latent_dim + 24, device=DEV)
+    eng = m.engine()
+    eng.single_launch_decode, eng.cell_decode_rows = False, 512
+    out = {}
+    for lanes in (1, 2, 3):
+        eng.decode_lanes = lanes
+        out[lanes] = pkg.greedy_decode(m, z, steps)
+        again = pkg.greedy_decode(m, z, steps)
+        assert torch.equal(out[lanes][1], again[1])
+    for lanes in (2, 3):
+        assert torch.equal(out[lanes][1], out[1][1]) and torch.equal(out[lanes][0], out[1][0]), lanes
 
 
 def test_full_size_properties():

@@ -104,6 +104,95 @@ def test_two_rank_rccl_step_equals_single_process(tmp_path):
     assert float(diff.max()) <= 4.1e-3 and float((diff > 1e-5).float().mean()) < 2e-3    # Adam noise on ~zero gradients only
 
 
+def _burst_worker(rank, world, port, out_dir):
+    """one rank through real RCCL, eager launches; foreign kernels (fn_occupy_cus: 8 workgroups holding 64 KB of LDS each, ~0.3 ms per burst, 9
+    bursts) injected where a late collective would sit: behind the third gradient bucket.
+      "joined"  = on the communicator's stream (what a lingering RCCL channel kernel is): the join in front of clip + Adam must keep them
+                  away from the next step's encoder forward scan - the step just waits for them;
+      "foreign" = on a third stream that only waits for the bucket (another process' kernels in the same window): they collide with
+                  clip + Adam / the next step's first weight-stationary launch, whose workgroups then become resident late."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      FN_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", FN_DP_GRAPH="0")
+    import time
+    from helpers import make_model
+    from mfn_import import load_package
+    pkg = load_package()
+    from music_fader_nets_amd import parallel
+    from music_fader_nets_amd.synth import synth_batch
+    ctx, local = parallel.init_from_env()
+    dev = "cuda:%d" % local
+    B, T, Tr, NB, CYC = 256, 64, 16, 9, 600_000
+    b = synth_batch(np.random.RandomState(0), B, T, Tr)
+    res = {}
+    for mode in ("none", "joined", "foreign", "none2"):
+        m = make_model(512, 128, device=dev)
+        tr = pkg.GMVAETrainer(m, lr=1e-3, beta=0.2, dist_ctx=ctx)
+        assert not tr.use_graph
+        ops = m.engine().ops
+        side = torch.cuda.Stream(device=dev)
+        plain_finish = type(ctx).finish_buckets
+
+        def finish(self, mode=mode, ops=ops, side=side):
+            if mode == "joined":
+                with torch.cuda.stream(self.rccl.stream):
+                    for _ in range(NB):
+                        ops.occupy_cus(8, 64 * 1024, CYC)
+            elif mode == "foreign":
+                side.wait_stream(self.rccl.stream)
+                with torch.cuda.stream(side):
+                    for _ in range(NB):
+                        ops.occupy_cus(8, 64 * 1024, CYC)
+            plain_finish(self)
+        ctx.finish_buckets = finish.__get__(ctx)
+        batch = tr.prepare_batch(b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"])
+        torch.manual_seed(99)
+        eps = tr.draw_eps(B, T)
+        step = 20000
+        for _ in range(2):                                         # buffers, RCCL communicator
+            tr.step_device(step, batch, eps)
+            step += 1
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(6):
+            tr.step_device(step, batch, eps)
+            step += 1
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 6
+        assert not ops.gru_sync_error()
+        res[mode] = dict(ms=dt * 1e3, flat=tr.flat.param.cpu(), tup=tr._tuple8(0.2, B, False))
+        del ctx.finish_buckets
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(NB):
+        ops.occupy_cus(8, 64 * 1024, CYC)
+    e1.record()
+    torch.cuda.synchronize()
+    res["burst_ms"] = e0.elapsed_time(e1)
+    torch.save(res, os.path.join(out_dir, "bursts.pt"))
+    ctx.rccl.close()
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_bursts_behind_the_last_bucket_leave_the_step_bit_identical(tmp_path):
+    """VERDICT r3 #6b: the collision window of a late collective - between the third gradient bucket and the next step's encoder forward scan
+    (hidden 512, B = 256, T = 64; one rank through RCCL).  Bit-identical weights after 8 steps in every mode, sync-error word clear, and a
+    bounded slow-down: bursts on the communicator's stream cost their own duration (the join holds the step back, nothing collides with a
+    weight-stationary launch), bursts on a foreign stream at most twice their duration on top of that."""
+    mp.start_processes(_burst_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True, start_method="spawn")
+    r = torch.load(os.path.join(tmp_path, "bursts.pt"), weights_only=False)
+    base = min(r["none"]["ms"], r["none2"]["ms"])
+    for mode in ("joined", "foreign", "none2"):
+        assert torch.equal(r[mode]["flat"], r["none"]["flat"]), mode
+        assert r[mode]["tup"] == r["none"]["tup"], mode
+    print("bursts %.2f ms per step: step alone %.2f ms, joined %.2f ms, foreign %.2f ms" % (r["burst_ms"], base, r["joined"]["ms"], r["foreign"]["ms"]))
+    assert r["joined"]["ms"] <= base + 1.3 * r["burst_ms"] + 0.5
+    assert r["foreign"]["ms"] <= base + 2.0 * r["burst_ms"] + 0.5
+
+
 def _run_bench(extra, env_extra=None, timeout=900):
     env = dict(os.environ)
     env.update(env_extra or {})
@@ -121,7 +210,7 @@ def test_bench_launches_its_own_ranks(n):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     if n == 1:
         env["FN_FORCE_DIST"] = "1"
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "2", "--no-cpu-baseline"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "2", "--sustain", "20", "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -129,6 +218,8 @@ def test_bench_launches_its_own_ranks(n):
     out = json.loads(lines[0])
     assert out["n_gpus"] == n and out["config"]["global_batch"] == 256 * n and out["value"] > 0
     assert 0 < out["roofline"]["frac"] < 1 and out["roofline_all"]
+    assert out["roofline"]["symbol"] in out["roofline_by_symbol"] and 0 < out["roofline_scans"]["frac"] < 1
+    assert out["sustained_steps"] == 20 and out["sustained_ms_per_step"] > 0
 
 
 def test_bench_respawns_under_the_launcher_without_gpus():
