@@ -162,9 +162,11 @@ ROW_INFO = {   # row -> (bound, unit of work, kernel, peak share of the chip)
 
 # HBM bytes per launch from rocprofv3 PMC passes (2 x FETCH_SIZE with the gfx950 correction + WRITE_SIZE, separate passes): bench.py
 # itself cannot run the profiler, so these are the committed measurements of the same launches
-PMC_TRAFFIC = {"enc_fwd_scan": 4.34e9, "enc_bwd_scan": 7.94e9, "dwhh_gemm_tn": 0.711e9}
-PMC_TRAFFIC_SYMBOL = {}        # symbol -> mean bytes per launch over all of its launches in one step (filled from the round's PMC pass)
-PMC_SOURCE = "profiles/r03_pmc_training_step.txt (2 x FETCH_SIZE + WRITE_SIZE, separate passes)"
+PMC_TRAFFIC = {"enc_fwd_scan": 4.309e9, "enc_bwd_scan": 8.038e9, "dec_fwd_scan_chunk": 0.313e9, "dec_bwd_scan_chunk": 0.585e9, "dwhh_gemm_tn": 0.711e9,
+               "out_head": 0.287e9}
+# symbol -> mean bytes per launch over ALL of its launches in one step (1 encoder + 10 decoder-pipeline launches for the scans): per launch like `achieved`
+PMC_TRAFFIC_SYMBOL = {"gru_fwd_pp_kernel": 0.676e9, "gru_bwd_rs_kernel": 1.262e9, "gemm_tn_kernel": 0.291e9}
+PMC_SOURCE = "profiles/r04_pmc_training_step.txt (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes of the same launches)"
 
 
 def roofline_rows(records):

@@ -32,7 +32,7 @@ def greedy_decode(model, z, steps, want_logp=True, use_graph=None):
     if not use_graph:
         return _decode_body(eng, z, steps, want_logp, None, None)
     cache = eng.__dict__.setdefault("_decode_graphs", {})
-    key = (z.shape[0], steps, bool(want_logp), z.shape[0] >= eng.cell_decode_rows, int(getattr(eng, "decode_lanes", 2)))     # the captured launches depend on the path taken
+    key = (z.shape[0], steps, bool(want_logp), z.shape[0] >= eng.cell_decode_rows)     # the captured launches depend on the path taken
     ent = cache.get(key)
     if ent is None:
         zs = z.clone()
@@ -101,41 +101,15 @@ def _decode_body(eng, z, steps, want_logp, logp, tokens):
     hf1 = [eng.buf("dec_hf1_a", (nf,)), eng.buf("dec_hf1_b", (nf,))]
     if Bi >= eng.cell_decode_rows:
         # thousands of rows: every cell is ONE staged-GEMM launch with the gates in its epilogue (fn_gru_cell_f32); layer 2 takes its input
-        # projection in the same K loop - 3 launches + argmax per token instead of 4 + argmax, and no [B][3H] round trip.
-        # The four launches of a token depend on each other and each is about one round of workgroups, so the batch is cut into
-        # `decode_lanes` row ranges (multiples of 64 rows: the same tiles, bit-identical tokens) that run on their own streams: one range's
-        # launch boundaries and partial last rounds are filled by the other's kernels.
-        lanes = max(1, min(int(getattr(eng, "decode_lanes", 2)), Bi // 512))
-        per = (Bi + lanes - 1) // lanes
-        per = (per + 63) // 64 * 64
-        cuts = [(lo, min(Bi, lo + per)) for lo in range(0, Bi, per)]
-        main = torch.cuda.current_stream(dev) if z.is_cuda else None
-        side = eng.__dict__.setdefault("_decode_lane_streams", [])
-        while z.is_cuda and len(side) < len(cuts) - 1:
-            side.append(torch.cuda.Stream(device=dev))
-
-        def lane(lo, hi):
-            for i in range(steps):
-                cur, prv = i & 1, (i & 1) ^ 1
-                ops.gru_cell(h0g[lo:hi] if i == 0 else hx0[prv][0][lo:hi], P["grucell_g.weight_hh"], P["grucell_g.bias_hh"], hx0[cur][0][lo:hi],
-                             b_ih=P["grucell_g.bias_ih"], gx_table=eng.tab["g"], idx=tokens[lo:hi, i - 1] if i > 0 else None, start_token=E_VOCAB - 1,
-                             gx_rowbias=rbg[lo:hi])
-                ops.gru_cell(hx0[cur][0][lo:hi] if i == 0 else hx1[prv][0][lo:hi], P["grucell_g_2.weight_hh"], P["grucell_g_2.bias_hh"], hx1[cur][0][lo:hi],
-                             x=hx0[cur][0][lo:hi], w_ih=P["grucell_g_2.weight_ih"], b_ih=P["grucell_g_2.bias_ih"])
-                ops.gemm(hx1[cur][0][lo:hi], P["linear_out_g.weight"], logits[lo:hi, :E_VOCAB], bias=P["linear_out_g.bias"])
-                ops.vocab_argmax(logits[lo:hi], E_VOCAB, logp[lo:hi, i, :] if want_logp else None, tokens[lo:hi, i])
-
-        if len(cuts) == 1 or main is None:
-            for lo, hi in cuts:
-                lane(lo, hi)
-            return logp, tokens
-        for st_, (lo, hi) in zip(side, cuts[1:]):
-            st_.wait_stream(main)
-            with torch.cuda.stream(st_):
-                lane(lo, hi)
-        lane(*cuts[0])
-        for st_ in side[:len(cuts) - 1]:
-            main.wait_stream(st_)
+        # projection in the same K loop - 3 launches + argmax per token instead of 4 + argmax, and no [B][3H] round trip
+        for i in range(steps):
+            cur, prv = i & 1, (i & 1) ^ 1
+            ops.gru_cell(h0g if i == 0 else hx0[prv][0], P["grucell_g.weight_hh"], P["grucell_g.bias_hh"], hx0[cur][0], b_ih=P["grucell_g.bias_ih"],
+                         gx_table=eng.tab["g"], idx=tokens[:, i - 1] if i > 0 else None, start_token=E_VOCAB - 1, gx_rowbias=rbg)
+            ops.gru_cell(hx0[cur][0] if i == 0 else hx1[prv][0], P["grucell_g_2.weight_hh"], P["grucell_g_2.bias_hh"], hx1[cur][0],
+                         x=hx0[cur][0], w_ih=P["grucell_g_2.weight_ih"], b_ih=P["grucell_g_2.bias_ih"])
+            ops.gemm(hx1[cur][0], P["linear_out_g.weight"], logits[:, :E_VOCAB], bias=P["linear_out_g.bias"])
+            ops.vocab_argmax(logits, E_VOCAB, logp[:, i, :] if want_logp else None, tokens[:, i])
         return logp, tokens
     for i in range(steps):
         cur, prv = i & 1, (i & 1) ^ 1

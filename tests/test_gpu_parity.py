@@ -816,27 +816,6 @@ def test_configs4_sized_fader_sweep_properties():
     assert torch.equal(tok[seqs].reshape(64, 300)[:, :24].cpu().long()[keep], ref_tk[keep])
 
 
-@pytest.mark.parametrize("H,Bi,steps", [(512, 2048, 8), (512, 1100, 8), (64, 1700, 10)])
-def test_large_batch_decode_row_ranges_are_bit_identical(H, Bi, steps):
-    """the staged-GEMM decode with the batch cut into row ranges on their own streams (Engine.decode_lanes; cuts at multiples of 64 rows = the
-    kernels' row tiles, ragged last range) gives the tokens and log-probabilities of the one-range decode bit for bit"""
-    pkg = load_package()
-    m = make_model(H, 32 if H == 64 else 128, device=DEV, seed=17)
-    m.eval()
-    torch.manual_seed(6)
-    z = torch.randn(Bi, 2 * m.latent_dim + 24, device=DEV)
-    eng = m.engine()
-    eng.single_launch_decode, eng.cell_decode_rows = False, 512
-    out = {}
-    for lanes in (1, 2, 3):
-        eng.decode_lanes = lanes
-        out[lanes] = pkg.greedy_decode(m, z, steps)
-        again = pkg.greedy_decode(m, z, steps)
-        assert torch.equal(out[lanes][1], again[1])
-    for lanes in (2, 3):
-        assert torch.equal(out[lanes][1], out[1][1]) and torch.equal(out[lanes][0], out[1][0]), lanes
-
-
 def test_full_size_properties():
     pkg = load_package()
     from music_fader_nets_amd.synth import synth_batch
