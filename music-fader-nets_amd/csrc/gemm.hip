@@ -830,8 +830,14 @@ int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha, co
         return launch_gemm<128, 128, 32, 2, 2>(a_kmajor, b_kmajor, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, splitk, ws, st);
     // 64 x 64 tiles: K tiles of 32 when K allows it - one barrier per 32 MFMAs of a wave instead of per 16 (the decode's output layer,
     // 2048 x 342 x 512: 20.5 -> see profiles); same k order
-    if (splitk <= 1 && (K % 32) == 0 && K >= 128)
+    if (splitk <= 1 && (K % 32) == 0 && K >= 128) {
+        // ... and 32 x 64 tiles when even the 64 x 64 ones leave CUs empty (the decode's output layer at 2048 rows: 192 workgroups -> 384;
+        // same k order per output element: bit-identical)
+        const long tiles64 = (long)((M + 63) / 64) * ((N + 63) / 64);
+        if (a_kmajor && b_kmajor && tiles64 < 240 && M >= 64)
+            return launch_gemm<32, 64, 32, 2, 2>(a_kmajor, b_kmajor, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, splitk, ws, st);
         return launch_gemm<64, 64, 32, 2, 2>(a_kmajor, b_kmajor, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, splitk, ws, st);
+    }
     return launch_gemm<64, 64, 16, 2, 2>(a_kmajor, b_kmajor, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, splitk, ws, st);
 }
 
