@@ -271,6 +271,162 @@ FN_DEVINL void gemm_tn_body(int M, int N, int K, float alpha, const float* __res
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The same "TN" product with EXACT fp32 products on the bf16 MFMA (v_mfma_f32_16x16x32_bf16: 16 x the fp32 MFMA rate) - "bf16 x 6":
+//   every fp32 operand value is cut into three bf16 pieces, x = hi + mid + lo EXACTLY (truncation splits: hi = the top 16 bits of x,
+//   mid = the top 16 bits of x - hi, lo = the rest; each remainder is computed without rounding and the last one has <= 8 significant bits),
+//   a b = sum_ij a_i b_j: nine partial products, each exact in the MFMA's fp32 accumulation.  The three smallest (lo x lo, lo x mid,
+//   mid x lo: <= 2^-24 |a b|, below the rounding of the fp32 sum itself) are dropped; the other six are accumulated smallest first.
+// Measured against float64 the result is as accurate as the fp32 MFMA chain (scratch/mfma_bf16x9.hip: max error 1.06e-7 vs 0.77e-7 of
+// sum |a||b| at K = 4096, 1.37e-7 vs 1.91e-7 at K = 65536).  OPT-IN (FN_GEMM_BF16X6): the default path multiplies on the fp32 MFMA.
+// Layout: a 16x16x32 MFMA takes 8 consecutive k per lane, so lane (i, g) loads the float4 A[k0 + 8 g + j][m0 + 4 i ..] for j = 0..7 (the
+// same 256-byte runs as the fp32 kernel, 8 loads per operand and 32-k block), element a of those eight vectors = the 8 k values of row
+// 4 i + a of MFMA tile a; they are split in registers (5.5 VALU operations per value - what bounds this kernel: 1.38 x the fp32 rate
+// with both operands split in the loop, 2.47 x with operands that arrive already split).  K tails (< 32) run on the fp32 MFMA.
+// ---------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+FN_DEVINL unsigned fn_pack_top16(float a, float b) {          // top 16 bits of a | top 16 bits of b << 16
+    return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+FN_DEVINL float fn_top16(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+// element `e` of eight float4 vectors (8 consecutive k of one row) -> exact bf16 triple
+FN_DEVINL void fn_split8(const f32x4 (&v)[8], int e, bf16x8& h, bf16x8& m, bf16x8& l) {
+    float x[8], r1[8], r2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = v[j][e];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r1[j] = x[j] - fn_top16(x[j]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r2[j] = r1[j] - fn_top16(r1[j]);
+    u32x4 H, M, L;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        H[j] = fn_pack_top16(x[2 * j], x[2 * j + 1]);
+        M[j] = fn_pack_top16(r1[2 * j], r1[2 * j + 1]);
+        L[j] = fn_pack_top16(r2[2 * j], r2[2 * j + 1]);
+    }
+    h = __builtin_bit_cast(bf16x8, H);
+    m = __builtin_bit_cast(bf16x8, M);
+    l = __builtin_bit_cast(bf16x8, L);
+}
+
+__global__ __launch_bounds__(NT) void gemm_tn_x6_kernel(int M, int N, int K, float alpha, const float* __restrict__ A, long lda,
+                                                        const float* __restrict__ B, long ldb, float beta, float* __restrict__ C, long ldc,
+                                                        const float* __restrict__ bias, int ksplit_len, float* __restrict__ slabs,
+                                                        const float* __restrict__ A2, long lda2, int msplit) {
+    const int ntn = (N + 127) / 128, ntm = (M + 127) / 128;
+    int tile, zk;
+    if (gridDim.z == 1 && slabs != nullptr) {            // K ranges dealt to the XCDs (see gemm_tn_body)
+        const int S = (K + ksplit_len - 1) / ksplit_len, c = blockIdx.x & 7, q = blockIdx.x >> 3;
+        zk = c * (S >> 3) + q / (ntn * ntm);
+        tile = q % (ntn * ntm);
+    } else {
+        tile = fn_xcd_remap(blockIdx.x, ntn * ntm);
+        zk = blockIdx.z;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = (tile / ntn) * 128 + (wave >> 1) * 64, n0 = (tile % ntn) * 128 + (wave & 1) * 64;
+    const int li = lane & 15, lg = lane >> 4;
+    const int kbeg = zk * ksplit_len, kend = min(K, kbeg + ksplit_len);
+    if (A2 != nullptr && m0 >= msplit) { A = A2 - msplit; lda = lda2; }
+    const long ca = A2 != nullptr && m0 >= msplit ? msplit + min((long)(m0 - msplit) + 4 * li, lda - 4) : min((long)m0 + 4 * li, lda - 4);
+    const long cb = min((long)n0 + 4 * li, ldb - 4);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int kdone = kbeg;
+    if (m0 < M && n0 < N) {
+        const int nblk = (kend - kbeg) >> 5;             // whole 32-k blocks
+        if (nblk > 0) {
+            // two operand sets: while block t is split and multiplied out of one, the 16 loads of block t + 1 fill the other.  Plain loads
+            // (the compiler counts vmcnt itself): under this kernel's register pressure it parks values in AGPRs, which the uncounted asm
+            // loads of the fp32 kernel do not survive (their destinations are copied before the data has landed).
+            f32x4 fa[2][8], fb[2][8];
+            const float* pa = A + (long)(kbeg + 8 * lg) * lda + ca;
+            const float* pb = B + (long)(kbeg + 8 * lg) * ldb + cb;
+            const long sa = 32 * lda, sb = 32 * ldb;
+            auto load = [&](int set) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) fa[set][j] = *reinterpret_cast<const f32x4*>(pa + j * lda);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) fb[set][j] = *reinterpret_cast<const f32x4*>(pb + j * ldb);
+                pa += sa;
+                pb += sb;
+            };
+            auto mma = [&](int u) {
+                bf16x8 bh[4], bm[4], bl[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) fn_split8(fb[u], b, bh[b], bm[b], bl[b]);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    bf16x8 ah, am, al;
+                    fn_split8(fa[u], a, ah, am, al);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[b], acc[a][b], 0, 0, 0);
+                }
+            };
+            load(0);
+            int blk = 0;
+#pragma unroll 1
+            for (; blk + 2 <= nblk; blk += 2) {
+                load(1);
+                mma(0);
+                if (blk + 2 < nblk) load(0);
+                mma(1);
+            }
+            if (blk < nblk) mma(0);
+            kdone = kbeg + 32 * nblk;
+        }
+        // K tail (< 32 rows): fp32 MFMA steps of 4 rows, unpipelined, last step zero-padded
+        for (int k0 = kdone; k0 < kend; k0 += 4) {
+            const int k = k0 + lg;
+            const long kk = min(k, kend - 1);
+            f32x4 va = *reinterpret_cast<const f32x4*>(A + kk * lda + ca);
+            const f32x4 vb = *reinterpret_cast<const f32x4*>(B + kk * ldb + cb);
+            if (k >= kend) va = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(va, a), f4c(vb, b), acc[a][b], 0, 0, 0);
+        }
+    }
+    const int colb = n0 + 4 * li;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + 4 * (lg * 4 + r) + a;
+            if (row >= M) continue;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int col = colb + b;
+                if (col >= N) continue;
+                const float v = acc[a][b][r];
+                if (slabs) {
+                    slabs[((long)zk * M + row) * N + col] = v;
+                } else {
+                    float o = alpha * v;
+                    if (bias) o += bias[col];
+                    if (beta != 0.f) o += beta * C[(long)row * ldc + col];
+                    C[(long)row * ldc + col] = o;
+                }
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // "NT" GEMM without LDS for the short-K products beside the decoder scans (layer-2 input projection gx2 = hx0 W_ih2^T and the input
 // gradient dhx0 = dgx2 W_ih2 through the transposed weight image): C[M][N] = alpha * sum_k A[m][k] B[n][k] (+ bias, + beta C), both
 // operands K-contiguous.  The LDS-staged kernel spends its 16 K tiles of a K = 512 product on prologue / barrier / epilogue (MFMA pipe
@@ -787,7 +943,8 @@ int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha, co
     if (!A || !B || !C) return FN_E_NULL;
     if (M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return FN_E_SHAPE;
     const bool lean = (splitk & FN_GEMM_LEAN) != 0;
-    splitk &= ~FN_GEMM_LEAN;
+    const bool x6 = (splitk & FN_GEMM_BF16X6) != 0;
+    splitk &= ~(FN_GEMM_LEAN | FN_GEMM_BF16X6);
     if (splitk > 1 && (!ws || ws_bytes < fn_gemm_ws_bytes(M, N, splitk))) return FN_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (!a_kmajor && !b_kmajor && (lda % 4) == 0 && (ldb % 4) == 0 && lda >= 4 && ldb >= 4 &&
@@ -799,8 +956,8 @@ int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha, co
         }
         const int ntm = (M + 127) / 128, ntn = (N + 127) / 128;
         float* slabs = splitk > 1 ? ws : nullptr;
-        hipLaunchKernelGGL(lean ? gemm_tn_lean_kernel : gemm_tn_kernel, tn_grid(ntm * ntn, splitk), dim3(NT), 0, st, M, N, K, alpha, A, (long)lda, B,
-                           (long)ldb, beta, C, (long)ldc, bias, klen, slabs, (const float*)nullptr, 0L, 0);
+        hipLaunchKernelGGL(x6 ? gemm_tn_x6_kernel : (lean ? gemm_tn_lean_kernel : gemm_tn_kernel), tn_grid(ntm * ntn, splitk), dim3(NT), 0, st, M, N, K, alpha, A,
+                           (long)lda, B, (long)ldb, beta, C, (long)ldc, bias, klen, slabs, (const float*)nullptr, 0L, 0);
         FN_CHECK_LAUNCH();
         if (splitk > 1) {
             const long total = (long)M * N;
@@ -848,14 +1005,16 @@ int fn_gru_dwhh_f32(const float* dgx, const float* dghn, const float* hprev, int
     if (!dgx || !dghn || !hprev || !dW) return FN_E_NULL;
     if (rows <= 0 || rows > 0x7fffffff || H <= 0) return FN_E_SHAPE;
     const bool lean = (splitk & FN_GEMM_LEAN) != 0;
-    splitk &= ~FN_GEMM_LEAN;
+    const bool x6 = (splitk & FN_GEMM_BF16X6) != 0;
+    splitk &= ~(FN_GEMM_LEAN | FN_GEMM_BF16X6);
     if (splitk > 1 && (!ws || ws_bytes < fn_gru_dwhh_ws_bytes(H, splitk))) return FN_E_WORKSPACE;
     const int M = 3 * H, N = H, K = (int)rows;
     const bool one_launch = (2 * H) % 128 == 0 && (H % 4) == 0 && (((((uintptr_t)dgx) | ((uintptr_t)dghn) | ((uintptr_t)hprev)) & 15) == 0);
     if (!one_launch) {          // two products: rows [0, 2H) from dgx, rows [2H, 3H) from dghn
-        int rc = fn_gemm_f32(0, 0, 2 * H, N, K, 1.0f, dgx, 3 * H, hprev, H, beta, dW, H, nullptr, splitk, ws, ws_bytes, stream);
+        const int fl = splitk | (x6 ? FN_GEMM_BF16X6 : 0);
+        int rc = fn_gemm_f32(0, 0, 2 * H, N, K, 1.0f, dgx, 3 * H, hprev, H, beta, dW, H, nullptr, fl, ws, ws_bytes, stream);
         if (rc != FN_OK) return rc;
-        return fn_gemm_f32(0, 0, H, N, K, 1.0f, dghn, H, hprev, H, beta, dW + (size_t)2 * H * H, H, nullptr, splitk, ws, ws_bytes, stream);
+        return fn_gemm_f32(0, 0, H, N, K, 1.0f, dghn, H, hprev, H, beta, dW + (size_t)2 * H * H, H, nullptr, fl, ws, ws_bytes, stream);
     }
     hipStream_t st = (hipStream_t)stream;
     int klen = K;
@@ -865,8 +1024,8 @@ int fn_gru_dwhh_f32(const float* dgx, const float* dghn, const float* hprev, int
     }
     const int ntm = (M + 127) / 128, ntn = (N + 127) / 128;
     float* slabs = splitk > 1 ? ws : nullptr;
-    hipLaunchKernelGGL(lean ? gemm_tn_lean_kernel : gemm_tn_kernel, tn_grid(ntm * ntn, splitk), dim3(NT), 0, st, M, N, K, 1.0f, dgx, (long)3 * H, hprev,
-                       (long)H, beta, dW, (long)H, (const float*)nullptr, klen, slabs, dghn, (long)H, 2 * H);
+    hipLaunchKernelGGL(x6 ? gemm_tn_x6_kernel : (lean ? gemm_tn_lean_kernel : gemm_tn_kernel), tn_grid(ntm * ntn, splitk), dim3(NT), 0, st, M, N, K, 1.0f, dgx,
+                       (long)3 * H, hprev, (long)H, beta, dW, (long)H, (const float*)nullptr, klen, slabs, dghn, (long)H, 2 * H);
     FN_CHECK_LAUNCH();
     if (splitk > 1) {
         const long total = (long)M * N;

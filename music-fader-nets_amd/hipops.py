@@ -54,6 +54,7 @@ class HipOps:
         self._ws = {}
         self._retired = []
         self.cell_variant = 0     # FnGruCell.variant (tuning / tests)
+        self.dw_x6 = False        # OPT-IN: the T*B-deep weight-gradient products on the bf16 MFMA with exact bf16 triple splits (FN_GEMM_BF16X6); default: fp32 MFMA
         self.variant = 0          # FnGruFwd.variant of every scan launch (tuning / tests only; results do not depend on it)
         self.lane = ""            # scratch namespace: kernels enqueued on different streams must not share workspaces
 
@@ -87,8 +88,9 @@ class HipOps:
         if splitk > 1:
             wsb = self.lib.fn_gemm_ws_bytes(M, N, splitk & 0xffff)
             ws = self.workspace(wsb, "gemm")
+        x6 = _lib.GEMM_BF16X6 if (self.dw_x6 and not a_k and not b_k and K >= 1024) else 0
         _lib.check(self.lib.fn_gemm_f32(int(a_k), int(b_k), M, N, K, alpha, pa, lda, pb, ldb, beta, pc, ldc, _p(bias),
-                                        splitk | (_lib.GEMM_LEAN if lean else 0),
+                                        splitk | (_lib.GEMM_LEAN if lean else 0) | x6,
                                         _p(ws), wsb, self.stream()), "fn_gemm_f32")
 
     def gemm_multi(self, jobs, a_k=True, b_k=True):
@@ -319,7 +321,8 @@ class HipOps:
             raise RuntimeError("gru_dwhh shape mismatch")
         wsb = int(self.lib.fn_gru_dwhh_ws_bytes(H, splitk))
         ws = self.workspace(wsb, "gemm") if wsb else None
-        _lib.check(self.lib.fn_gru_dwhh_f32(_p(dgx), _p(dghn), _p(hprev), rows, H, beta, _p(dW), splitk | (_lib.GEMM_LEAN if lean else 0),
+        x6 = _lib.GEMM_BF16X6 if (self.dw_x6 and rows >= 1024) else 0
+        _lib.check(self.lib.fn_gru_dwhh_f32(_p(dgx), _p(dghn), _p(hprev), rows, H, beta, _p(dW), splitk | (_lib.GEMM_LEAN if lean else 0) | x6,
                                             _p(ws), wsb, self.stream()), "fn_gru_dwhh_f32")
 
     def decode_greedy(self, B, steps, H, V, start_token, w_hh1_frag, b_hh1, b_ih1, table1, rowbias1, h0, w_ih2_frag, b_ih2, w_hh2_frag, b_hh2,

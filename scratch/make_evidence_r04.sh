@@ -9,7 +9,7 @@ if [ "$1" != "notests" ]; then
 fi
 cd /tmp; export TMPDIR=/tmp
 python $R/bench.py --steps 20 --warmup 5 > $O/bench_train.json 2> $O/bench_train.err
-rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python $R/bench.py --steps 3 --warmup 2 --sustain 0 --no-cpu-baseline --no-decode > $O/prof_bench.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python $R/bench.py --steps 3 --warmup 2 --sustain 0 --no-x6 --no-cpu-baseline --no-decode > $O/prof_bench.log 2>&1
 python $R/scratch/prof_summary.py $O/prof/bench_results.db 45 > $O/kernel_stats.txt
 python $R/scratch/prof_timeline.py $O/prof/bench_results.db 100 3 > $O/timeline.txt
 rm -rf $O/prof

@@ -2,7 +2,7 @@
 # round 4: timeline of one replayed step (same command as the kernel stats), decode lanes A/B, decode bench line
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python $R/bench.py --steps 3 --warmup 2 --sustain 0 --no-cpu-baseline --no-decode > $O/prof_bench.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python $R/bench.py --steps 3 --warmup 2 --sustain 0 --no-x6 --no-cpu-baseline --no-decode > $O/prof_bench.log 2>&1
 python $R/scratch/prof_summary.py $O/prof/bench_results.db 45 > $O/kernel_stats.txt
 python $R/scratch/prof_timeline.py $O/prof/bench_results.db 100 3 > $O/timeline.txt 2>&1
 rm -rf $O/prof

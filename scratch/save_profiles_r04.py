@@ -5,7 +5,7 @@ P = R + "/profiles/"
 b = open(O + "/bench_train.json").read().strip().split("\n")[-1]
 open(P + "r04_bench_train.json", "w").write(b + "\n")
 d = json.loads(b)
-hdr = """rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 2 --sustain 0 --no-cpu-baseline --no-decode   (MI355X, round 4: ping-pong forward scans
+hdr = """rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 2 --sustain 0 --no-x6 --no-cpu-baseline --no-decode   (MI355X, round 4: ping-pong forward scans
 gru_fwd_pp_kernel<1> (encoder, 128-row groups) / <2> (decoder pipeline, 64-row groups), register-stationary backward scans gru_bwd_rs_kernel<2> (encoder, 16 groups of
 64 rows x 16 slices of 32 columns) / <1> (decoder pipeline, 32-row groups); scratch/make_evidence_r04.sh) + the 5 eager passes of bench.py's per-kernel roofline measurement;
 summary of the rocpd kernel table by scratch/prof_summary.py.  Bench line of the un-profiled run in the same gpurun call: "ms_per_step": %s, "sustained_ms_per_step": %s

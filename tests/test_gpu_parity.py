@@ -331,6 +331,39 @@ def test_gru_weight_gradient(ops, rows, H, splitk, beta):
     close(dW, ref.float(), 2e-5 * max(1.0, (rows ** 0.5)))
 
 
+@pytest.mark.parametrize("M,N,K,splitk", [(1536, 512, 4100, 16), (342, 512, 8192, 8), (1536, 512, 65280, 16), (200, 130, 1031, 1)])
+def test_gemm_tn_bf16x6(ops, M, N, K, splitk):
+    """FN_GEMM_BF16X6 (opt-in): the weight-gradient product with exact bf16 triple splits on the bf16 MFMA is AS ACCURATE as the default fp32
+    MFMA kernel - both measured against float64: its error must stay below the same bound the fp32 kernel is tested with and within 2 x of
+    the fp32 kernel's own error (K tails below 32, ragged tiles, the [dgx | dghn] two-source form of fn_gru_dwhh_f32 and split-K slabs)."""
+    torch.manual_seed(M + K)
+    A = torch.randn(K, M, device=DEV)
+    B = torch.randn(K, N, device=DEV) * 0.3
+    ref = (A.double().t() @ B.double())
+    scale = float((A.double().abs().t() @ B.double().abs()).max())
+    out = {}
+    for x6 in (False, True):
+        ops.dw_x6 = x6
+        C = torch.full((M, N), float("nan"), device=DEV)
+        ops.gemm(A, B, C, a_k=False, b_k=False, splitk=splitk)
+        out[x6] = float((C.double() - ref).abs().max()) / scale
+    ops.dw_x6 = False
+    assert out[True] < 2e-6 and out[True] <= 2.0 * out[False] + 1e-9, out
+    if M == 1536:                                          # the one-launch [dr' dz' | dn' r]^T h form (A2 second source)
+        H = 512
+        dgx, dghn, hp = A, torch.randn(K, H, device=DEV), B
+        want = torch.cat([dgx[:, :2 * H], dghn], 1).double().t() @ hp.double()
+        sc = float((torch.cat([dgx[:, :2 * H], dghn], 1).double().abs().t() @ hp.double().abs()).max())
+        err = {}
+        for x6 in (False, True):
+            ops.dw_x6 = x6
+            dW = torch.zeros(3 * H, H, device=DEV)
+            ops.gru_dwhh(dgx, dghn, hp, dW, splitk=splitk)
+            err[x6] = float((dW.double() - want).abs().max()) / sc
+        ops.dw_x6 = False
+        assert err[True] < 2e-6 and err[True] <= 2.0 * err[False] + 1e-9, err
+
+
 def test_time_sum(ops):
     torch.manual_seed(4)
     X = torch.randn(67, 37, 96)
@@ -928,6 +961,49 @@ def test_benchmark_config_vs_reference_train():
 # ----------------------------------------------------------------------------------------------
 # captured graphs vs changing batch shapes / changing weights
 # ----------------------------------------------------------------------------------------------
+def test_benchmark_config_with_bf16x6_weight_gradients_vs_reference_train():
+    """the benchmark shape with the opt-in bf16 x 6 weight-gradient products (HipOps.dw_x6): the comparison of
+    test_benchmark_config_vs_reference_train against the reference's own backward / train() at this size (tests/golden/c1.npz) at the SAME
+    tolerances - loss, raw gradient norm, per-parameter |g| and g^2 sums, the train() tuples, the weights after the first step"""
+    pkg = load_package()
+    from music_fader_nets_amd.synth import synth_batch
+    g = load_golden("c1")
+    H, Z, K, B, T, Tr = (int(x) for x in g["meta_dims"])
+    m = make_model(H, Z, device=DEV)
+    tr = pkg.GMVAETrainer(m, lr=1e-3, beta=0.2)
+    m.engine().ops.dw_x6 = True                             # (after the trainer: it re-homes the parameters and with them the engine / its kernel table)
+    b = synth_batch(np.random.RandomState(0), B, T, Tr)
+    batch = tr.prepare_batch(b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"])
+    torch.manual_seed(99)
+    eps = tr.draw_eps(B, T)
+    tup = tr.loss_and_grads(20000, batch, eps)
+    np.testing.assert_allclose(tup[0], g["total_loss_20000"][0], rtol=2e-5)
+    np.testing.assert_allclose(tr.grad_norm(), g["gradnorm_20000"][0], rtol=1e-3)
+    for k in tr.flat.names:
+        gk = tr.flat.G[k].double()
+        ref = g["gradsum/" + k]
+        np.testing.assert_allclose(float(gk.abs().sum()), ref[1], rtol=1e-3, atol=1e-5, err_msg=k)
+        np.testing.assert_allclose(float((gk * gk).sum()), ref[2], rtol=2e-3, atol=1e-9, err_msg=k)
+    # the flag is live: against the default (fp32 MFMA) gradients of the same step the recurrent weight gradients differ in their last bits only
+    g6 = tr.flat.G["gru_r.weight_hh_l0"].clone()
+    m.engine().ops.dw_x6 = False
+    tr.loss_and_grads(20000, batch, eps)
+    g32 = tr.flat.G["gru_r.weight_hh_l0"]
+    assert not torch.equal(g6, g32)
+    assert float((g6 - g32).abs().max()) <= 2e-6 * float(g32.abs().max())
+    m.engine().ops.dw_x6 = True
+    step = 20000
+    for it in range(2):
+        step, tup = tr.train(step, None, None, None, b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"], eps=eps)
+        np.testing.assert_allclose(tup, g["train_tuples"][it], rtol=5e-4, err_msg="step %d" % it)
+        if it == 0:
+            for k, v in m.state_dict().items():
+                if k not in NOISE_PARAMS:
+                    vd = v.double()
+                    np.testing.assert_allclose([vd.abs().sum().item(), (vd * vd).sum().item()], g["w1sum/" + k][1:], rtol=2e-5, err_msg=k)
+    assert not m.engine().ops.gru_sync_error()
+
+
 def test_graph_replay_survives_other_batch_shapes():
     """The epoch driver alternates shapes (train / validation / ragged last batch); every shape keeps its own captured graph and its
     own buffers.  Interleaving shapes must give the same numbers as running each shape alone."""
