@@ -1,6 +1,6 @@
 """Single-rank data-parallel soak: N fresh processes, each builds the communicator (RCCL through fn_comm_*), captures the benchmark
 training step WITH its collectives into one hipGraph and replays it; every run must capture (no fallback to eager launches), stay finite and
-leave the sync-error word clear.  usage: python scratch/soak_dp.py [runs] -> profiles/r03_dp_graph_soak.txt
+leave the sync-error word clear.  usage: python scratch/soak_dp.py [runs] -> profiles/r04_dp_graph_soak.txt
 (round 2: the same through torch.distributed's process group failed 6 of 150 captures and took the watchdog thread down)"""
 import json, os, subprocess, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
