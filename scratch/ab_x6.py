@@ -32,6 +32,7 @@ for rep in range(3):
         m = pkg.MusicAttrRegGMVAE(342, 3, 16, 24, 512, 128, 32, n_component=2).to(dev)
         tr = pkg.GMVAETrainer(m, lr=1e-3, beta=0.2)
         m.engine().ops.dw_x6 = x6
+        m.weights_changed()
         b = synth_batch(np.random.RandomState(0), 256, 256, 64)
         batch = tr.prepare_batch(b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"])
         torch.manual_seed(99); eps = tr.draw_eps(256, 256)
