@@ -1542,6 +1542,8 @@ def test_entry_driver_v2_runs_an_epoch_from_model_config_v2(family, tmp_path, ca
         read_config(cfg, "gmm")                                 # trainer_gmm.py indexes args['num_clusters']: that script needs the other file
     T = "112" if family == "glsr" else "48"                     # the GLSR decodes are teacher forced for 100 steps
     argv = ["--config", cfg, "--model", family, "--synthetic", "--synthetic-songs", "320", "--seq-len", T, "--epochs", "1", "--out", str(tmp_path), "--seed", "3"]
+    if family == "fader":
+        argv.append("--bf16x6")                                 # the opt-in weight-gradient arithmetic is reachable from the entry driver
     step = main(argv)
     out = capsys.readouterr().out
     assert step == 2                                            # 256 training songs in batches of 128
