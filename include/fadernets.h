@@ -170,6 +170,13 @@ typedef struct FnGruFwd {
 
 /* fragment-major operand image: floats needed for a [rows][K] matrix, and the packing kernel
  * (src row-major with leading dimension ld, K % 32 == 0; rows are zero-padded to a multiple of 16) */
+/* OPT-IN (FnGruFwd.variant bit 14 = 0x4000): the forward scan with exact split products on the bf16 MFMA ("bf16 x 6", see FN_GEMM_BF16X6):
+ * w_hh_frag must then be the fn_frag3_pack image of W_hh [3H][H] (bf16 triples hi | mid | lo, hi + mid + lo == W exactly; 3/2 of
+ * fn_frag_floats(3H, H) floats) and frag_ws 3 * fn_frag_floats(B, H) floats (the state is exchanged as triples too).  H = 512, every
+ * scan in full row groups of 64 (or 128) rows, saved gates, T >= 2 (h0_frag / h_last_frag are then triple images of 3/2 * fn_frag_floats(B, H)
+ * floats); anything else returns FN_E_UNSUPPORTED (the caller repeats the call without the bit).  Same gate arithmetic; against the default kernels the states differ by fp32 rounding only
+ * (tests/test_gpu_parity.py::test_forward_scan_bf16x6). */
+int fn_frag3_pack(const float* src, int rows, int K, int ld, void* dst, void* stream);
 size_t fn_frag_floats(int rows, int K);
 int fn_frag_pack(const float* src, int rows, int K, int ld, float* dst, void* stream);
 

@@ -76,6 +76,7 @@ class FnDecode(C.Structure):
 SIGNATURES = {
     "fn_version": (C.c_int, []),
     "fn_strerror": (C.c_char_p, [C.c_int]),
+    "fn_frag3_pack": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "fn_gemm_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "fn_gemm_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, C.c_int, vp, C.c_int,
                               C.c_float, vp, C.c_int, vp, C.c_int, vp, C.c_size_t, vp]),

@@ -428,6 +428,37 @@ __global__ void frag_pack_kernel(const float* __restrict__ src, int rows, int K,
     }
 }
 
+// row-major [rows][K] -> bf16 TRIPLE image for the bf16 x 6 kernels (gru_persist.hip: gru_fwd_x6_kernel): [row tile 16][k block 32][piece 3][64 lanes][8 bf16],
+// lane (i, g) = row 16 t + i, k values 32 b + 8 g .. + 7; piece 0 / 1 / 2 = hi / mid / lo with hi + mid + lo == src exactly (truncation splits);
+// rows padded to a multiple of 16 with zeros.  One thread per (row, 8 k).
+__global__ void frag3_pack_kernel(const float* __restrict__ src, int rows, int K, long ld, unsigned* __restrict__ dst) {
+    const int rows16 = (rows + 15) & ~15, nb = K >> 5;
+    const long total = (long)rows16 * (K >> 3);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / (K >> 3)), k8 = (int)(i % (K >> 3));
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = row < rows ? src[(long)row * ld + 8 * k8 + j] : 0.f;
+        unsigned* o = dst + ((((long)(row >> 4) * nb + (k8 >> 2)) * 3) * 64 + (row & 15) + 16 * (k8 & 3)) * 4;
+        unsigned h[4], m[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float r1[2], r2[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float v = x[2 * j + e];
+                r1[e] = v - __uint_as_float(__float_as_uint(v) & 0xffff0000u);
+                r2[e] = r1[e] - __uint_as_float(__float_as_uint(r1[e]) & 0xffff0000u);
+            }
+            h[j] = (__float_as_uint(x[2 * j]) >> 16) | (__float_as_uint(x[2 * j + 1]) & 0xffff0000u);
+            m[j] = (__float_as_uint(r1[0]) >> 16) | (__float_as_uint(r1[1]) & 0xffff0000u);
+            l[j] = (__float_as_uint(r2[0]) >> 16) | (__float_as_uint(r2[1]) & 0xffff0000u);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[j] = h[j]; o[256 + j] = m[j]; o[512 + j] = l[j]; }
+    }
+}
+
 // ---- all weight images of one optimiser step in ONE launch (fn_weight_images) -------------------------------------------------------
 // job kinds: 0 = dst [C][R] = src^T (src [R][C], leading dimension ld): the one-hot column table W_ih[:, :V]^T
 //            1 = fragment-major image of src [rows = R][K = C]                           (forward scans: W_hh, W_ih2, W_out)
@@ -657,6 +688,17 @@ extern "C" int fn_weight_images(const FnWeightImage* jobs, int n_jobs, void* str
         a.job[j] = WiJob{d.src, d.dst, d.rows, d.cols, d.ld, d.kind};
     }
     hipLaunchKernelGGL(weight_images_kernel, dim3(128, n_jobs), dim3(256), 0, (hipStream_t)stream, a);
+    FN_CHECK_LAUNCH();
+    return FN_OK;
+}
+
+extern "C" int fn_frag3_pack(const float* src, int rows, int K, int ld, void* dst, void* stream) {
+    if (!src || !dst) return FN_E_NULL;
+    if (rows <= 0 || K <= 0 || (K % 32) != 0 || ld < K) return FN_E_SHAPE;
+    if (((uintptr_t)dst) & 15) return FN_E_ALIGN;
+    const long total = (long)((rows + 15) & ~15) * (K >> 3);
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(frag3_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, rows, K, (long)ld, reinterpret_cast<unsigned*>(dst));
     FN_CHECK_LAUNCH();
     return FN_OK;
 }

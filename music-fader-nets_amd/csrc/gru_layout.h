@@ -60,3 +60,4 @@ FN_DEVINL u32 ld_cnt(u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __H
 int fn_gru_fwd_persist(const FnGruFwd* scans, int n_scans, hipStream_t st);
 int fn_gru_bwd_persist(const FnGruBwd* scans, int n_scans, hipStream_t st);
 int launch_pack(const float* src, int rows, int K, long ld, float* dst, hipStream_t st);
+extern "C" int fn_frag3_pack(const float* src, int rows, int K, int ld, void* dst, void* stream);

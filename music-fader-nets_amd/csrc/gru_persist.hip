@@ -363,6 +363,241 @@ __global__ __launch_bounds__(NT) void gru_fwd_persist_kernel(const PArgs args) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Forward scan with EXACT split products on the bf16 MFMA ("bf16 x 6", gemm.hip / DESIGN.md; OPT-IN: FnGruFwd.variant bit 14).  Weights and
+// recurrent operand are bf16 TRIPLES (x = hi + mid + lo exactly; fn_frag3_pack image = [row tile 16][k block 32][piece 3][64 lanes][8 bf16]:
+// lane (i, g) of a v_mfma_f32_16x16x32_bf16 operand = row i, k values 8 g .. 8 g + 7 of the block): the W_hh slice is split ONCE per optimiser
+// step (144 KB of LDS per workgroup at H = 512), the new state is split by the gate epilogue that publishes it (6 instead of 4 bytes per
+// value on the exchange slab), so the K loop runs at the pre-split rate - 6 bf16 MFMAs of 16 cycles per (row tile, gate, 32 k) instead
+// of 8 fp32 ones of 32 (scratch/scan_x6_kloop.hip: 6.1 against 12.0 us per encoder-shaped step for the loop alone).  Six of the nine exact
+// partial products, smallest first; gate arithmetic = fn_gru_gate as everywhere.  Structure of gru_fwd_persist_kernel (one row group per
+// workgroup, counter hand-over, no ping-pong): 4 waves x MT row tiles, every wave all of K (no K split, no accumulator reduction); the
+// accumulators reach the (row, 4 units) epilogue items through LDS one tile per wave at a time (MT rounds: 144 KB + 13 KB of LDS).
+// H = 512, full row groups of 64 MT rows, saved gates; initial state / chunk hand-over as in gru_fwd_persist_kernel (h0f / hlf are triple images).
+// ---------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+FN_DEVINL float fn_top16(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+FN_DEVINL unsigned fn_pack_top16(float a, float b) { return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u); }
+FN_DEVINL void gld4u_sc1(u32x4& dst, const u32x4* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory"); }
+FN_DEVINL void stv2_sc1(void* p, const u32x2& v) { asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
+
+template <int MT>
+__global__ __launch_bounds__(NT) void gru_fwd_x6_kernel(const PArgs args) {
+    constexpr int H = 512, NB = 16, nslices = 32, EM = 4 * MT, D = 4;        // D k-blocks of operands in flight
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    u32x4* wl = reinterpret_cast<u32x4*>(smem);                              // [3][NB][3][64] weight triples, B-operand order
+    float* red = smem + 3 * NB * 3 * 64 * 4;                                 // [4 waves][3][RT] one accumulator tile per wave
+    volatile int& dead = *reinterpret_cast<volatile int*>(red + 4 * 3 * RT);
+
+    const int g = blockIdx.x % args.ngroups, slice = blockIdx.x / args.ngroups;
+    int si = 0;
+#pragma unroll
+    for (int k = 1; k < FN_MAX_SCANS; ++k)
+        if (k < args.n && g >= args.s[k].group0) si = k;
+    const PScan& S = args.s[si];
+    const int B = S.B, T = S.T;
+    const int m0 = (g - S.group0) * (16 * EM), hh0 = slice * 16;
+    const int nrt = B >> 4;
+    const long FS = (long)nrt * NB * 3 * 64;                                 // u32x4 elements of one exchange slab
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u32* counter = args.sync + g * 32;
+    u32* err = args.err;
+    u32x4* xs = reinterpret_cast<u32x4*>(S.xf);
+
+    if (tid == 0) dead = 0;
+#pragma unroll 1
+    for (int q = 0; q < 3; ++q) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(S.w_frag) + (long)(q * nslices + slice) * NB * 3 * 64;
+        u32x4* dst = wl + q * NB * 3 * 64;
+        for (int i = tid; i < NB * 3 * 64; i += NT) dst[i] = src[i];
+    }
+    // epilogue item of this thread in round m: row rl16 of this wave's m-th tile, units jj0 .. jj0 + 3
+    const int rl16 = lane >> 2, u4 = lane & 3;
+    const int jj0 = hh0 + 4 * u4;
+    const int icoff = (wave * 3) * RT + (rl16 >> 2) * 68 + u4 * 16 + (rl16 & 3);
+    int ib[MT];
+    f32x4 bh[3], bi[3], e_rb[MT][3], hp[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        ib[m] = m0 + (wave * MT + m) * 16 + rl16;
+        hp[m] = S.h0 ? ldv4(S.h0 + (long)ib[m] * H + jj0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            e_rb[m][q] = S.gx_rowbias ? ldv4(S.gx_rowbias + (long)ib[m] * 3 * H + q * H + jj0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        bh[q] = ldv4(S.b_hh + q * H + jj0);
+        bi[q] = S.b_ih ? ldv4(S.b_ih + q * H + jj0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    int tokn[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int tau0 = (S.reverse ? T - 1 : 0) + S.idx_shift;
+        tokn[m] = (S.gx_table && tau0 >= 0) ? S.idx[(long)ib[m] * S.idx_ld + tau0] : S.start_token;
+    }
+    // where this thread's four new state values go on the exchange slab: row tile, k block = slice / 2, k group 2 (slice & 1) + u4 / 2, half u4 & 1
+    long soff[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+        soff[m] = ((((long)(ib[m] >> 4) * NB + (slice >> 1)) * 3) * 64 + (ib[m] & 15) + 16 * (2 * (slice & 1) + (u4 >> 1))) * 16 + (u4 & 1) * 8;
+    long aoff[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) aoff[m] = ((long)((m0 >> 4) + wave * MT + m) * NB * 3) * 64 + lane;
+    __syncthreads();
+
+#pragma unroll 1
+    for (int p = 0; p < T; ++p) {
+        // (a) input-side pre-activations of this step
+        f32x4 e_x[MT][3];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) e_x[m][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (S.gx_table) {
+                const float* row = S.gx_table + (long)tokn[m] * 3 * H + jj0;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) e_x[m][q] = ldv4(row + q * H);
+            }
+            if (S.gx_dense) {
+                const float* row = S.gx_dense + ((long)p * B + ib[m]) * 3 * H + jj0;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) e_x[m][q] += ldv4(row + q * H);
+            }
+        }
+        // (b) every slice of this row group has published h_{p-1}
+        if (p > 0) {
+            if (tid == 0) {
+                const u32 target = (u32)nslices * (u32)p;
+                u32 spins = 0;
+                while (ld_cnt(counter) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 63u) == 0 && (spins > SPIN_LIMIT || ld_cnt(err) != 0)) {
+                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        dead = 1;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            if (dead) return;
+        }
+        // (c) gh = h_{p-1} W_hh^T slice: six bf16 MFMAs per (row tile, gate, k block)
+        f32x4 acc[MT][3];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) acc[m][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (p > 0 || S.h0) {
+            // step 0 of a launch with an initial state: its triples come from the previous chunk's hand-over image or were packed into slab 0
+            const u32x4* xin = (p == 0 && S.h0f) ? reinterpret_cast<const u32x4*>(S.h0f) : xs + (long)(p & 1) * FS;
+            u32x4 a[D][MT][3];
+            auto load = [&](int set, int blk) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) gld4u_sc1(a[set][m][pc], xin + aoff[m] + (blk * 3 + pc) * 64);
+            };
+            auto mma = [&](int set, int blk) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const bf16x8 bhh = __builtin_bit_cast(bf16x8, wl[((q * NB + blk) * 3 + 0) * 64 + lane]);
+                    const bf16x8 bmm = __builtin_bit_cast(bf16x8, wl[((q * NB + blk) * 3 + 1) * 64 + lane]);
+                    const bf16x8 bll = __builtin_bit_cast(bf16x8, wl[((q * NB + blk) * 3 + 2) * 64 + lane]);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, a[set][m][0]), am = __builtin_bit_cast(bf16x8, a[set][m][1]),
+                                     al = __builtin_bit_cast(bf16x8, a[set][m][2]);
+                        f32x4& c = acc[m][q];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhh, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bll, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bmm, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bhh, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bmm, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhh, c, 0, 0, 0);
+                    }
+                }
+            };
+#pragma unroll
+            for (int b = 0; b < D - 1; ++b) load(b, b);
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                if (blk + D - 1 < NB) load((blk + D - 1) % D, blk + D - 1);
+                const int behind = (blk + D - 1 < NB ? D - 1 : NB - 1 - blk);       // blocks requested behind blk: 3 MT loads each
+                if (behind >= 3) fn_wait_vm<9 * MT>();
+                else if (behind == 2) fn_wait_vm<6 * MT>();
+                else if (behind == 1) fn_wait_vm<3 * MT>();
+                else fn_wait_vm<0>();
+                mma(blk % D, blk);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int b = 0; b < D; ++b)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) asm volatile("" ::"v"(a[b][m][pc]));
+        }
+        if (S.gx_table && p + 1 < T) {
+            const int tau1 = (S.reverse ? T - 2 - p : p + 1) + S.idx_shift;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) tokn[m] = tau1 >= 0 ? S.idx[(long)ib[m] * S.idx_ld + tau1] : S.start_token;
+        }
+        // (d) + (e): MT rounds - this wave's m-th accumulator tile to LDS, then the gates of its rows as (row, 4 units) items
+        float* h_out = S.h_all + (long)p * B * H;
+        float* gt = S.gates + (long)p * 4 * H * nrt * 16;
+        char* xout = (p + 1 < T) ? reinterpret_cast<char*>(xs + (long)((p + 1) & 1) * FS) : reinterpret_cast<char*>(S.hlf);    // last step: the next chunk's hand-over image (or none)
+        f32x4 o_r[MT], o_z[MT], o_n[MT], o_g[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            // the tile region is private to this wave (its 64 lanes write the tile and read it back as 64 items): no workgroup barrier - LDS
+            // operations of one wave complete in order; the asm statements keep the compiler from moving accesses across them
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < 3; ++q) *reinterpret_cast<f32x4*>(red + (long)(wave * 3 + q) * RT + lane * 4 + (lane >> 4) * 4) = acc[m][q];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            f32x4 gh[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) gh[q][c] = red[(long)q * RT + icoff + c * 4] + bh[q][c];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float r, z, n, hn;
+                fn_gru_gate((bi[0][c] + e_x[m][0][c]) + e_rb[m][0][c], (bi[1][c] + e_x[m][1][c]) + e_rb[m][1][c], (bi[2][c] + e_x[m][2][c]) + e_rb[m][2][c],
+                            gh[0][c], gh[1][c], gh[2][c], hp[m][c], r, z, n, hn);
+                hp[m][c] = hn;
+                o_r[m][c] = r; o_z[m][c] = z; o_n[m][c] = n; o_g[m][c] = gh[2][c];
+            }
+            if (xout) {                                  // the new state as bf16 triples, straight into the next step's operand layout
+                float r1[4], r2[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { r1[c] = hp[m][c] - fn_top16(hp[m][c]); r2[c] = r1[c] - fn_top16(r1[c]); }
+                stv2_sc1(xout + soff[m], (u32x2){fn_pack_top16(hp[m][0], hp[m][1]), fn_pack_top16(hp[m][2], hp[m][3])});
+                stv2_sc1(xout + soff[m] + 1024, (u32x2){fn_pack_top16(r1[0], r1[1]), fn_pack_top16(r1[2], r1[3])});
+                stv2_sc1(xout + soff[m] + 2048, (u32x2){fn_pack_top16(r2[0], r2[1]), fn_pack_top16(r2[2], r2[3])});
+            }
+        }
+        // (f) publish: every wave drains its stores, then ONE lane arrives at the group counter
+        if (p + 1 < T) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // (g) outputs nobody in this launch waits for
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            stv4(h_out + (long)ib[m] * H + jj0, hp[m]);
+            stv4(gt + gate_off(ib[m], 0, jj0, nrt), o_r[m]);
+            stv4(gt + gate_off(ib[m], 1, jj0, nrt), o_z[m]);
+            stv4(gt + gate_off(ib[m], 2, jj0, nrt), o_n[m]);
+            stv4(gt + gate_off(ib[m], 3, jj0, nrt), o_g[m]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // backward: dh_q = [dr' | dz' | dn' r]_{q+1} W_hh + dh_q z_{q+1} (carried in registers) + dh_ext[q]; gate backward of step q.
 // Workgroup (g, j) owns dh columns [16j, 16j+16): its W_hh^T slice (16 rows x 3H, 96 KB at H = 512) stays in LDS; the
 // operand exchanged between the slices is the [rows][3H] pre-activation gradient (3x the forward's volume).
@@ -1461,6 +1696,52 @@ int fn_gru_fwd_persist(const FnGruFwd* scans, int n_scans, hipStream_t st) {
     const int nslices = H / 16;
     if (cus <= 0 || nslices > cus) return FN_PERSIST_NA;
     const int maxgroups = cus / nslices < FN_MAX_GROUPS ? cus / nslices : FN_MAX_GROUPS;
+    if (scans[0].variant & 0x4000) {
+        // OPT-IN: exact split products on the bf16 MFMA (gru_fwd_x6_kernel).  The caller hands over w_hh_frag = fn_frag3_pack image and
+        // frag_ws of 3 * fn_frag_floats(B, H) floats.  H = 512, full 64- / 128-row groups, saved gates, no initial state, T >= 2.
+        if (H != 512) return FN_E_UNSUPPORTED;
+        long g64 = 0, g128 = 0;
+        bool d64 = true, d128 = true;
+        for (int s = 0; s < n_scans; ++s) {
+            const FnGruFwd& d = scans[s];
+            if (!d.gates || d.T < 2) return FN_E_UNSUPPORTED;
+            if (d.h0_frag && !d.h0) return FN_E_NULL;
+            if ((((uintptr_t)d.h0_frag) | ((uintptr_t)d.h_last_frag) | (uintptr_t)d.h0) & 15) return FN_E_ALIGN;
+            d64 = d64 && d.B % 64 == 0; d128 = d128 && d.B % 128 == 0;
+            g64 += d.B / 64; g128 += d.B / 128;
+        }
+        const int mt = (d64 && g64 <= maxgroups) ? 1 : ((d128 && g128 <= maxgroups) ? 2 : 0);
+        if (!mt) return FN_E_UNSUPPORTED;
+        PArgs a;
+        a.n = n_scans; a.H = H; a.no_hand = 0;
+        a.sync = reinterpret_cast<u32*>(scans[0].sync_ws);
+        int groups = 0;
+        for (int s = 0; s < n_scans; ++s) {
+            const FnGruFwd& d = scans[s];
+            PScan& f = a.s[s];
+            f.w_frag = d.w_hh_frag; f.b_hh = d.b_hh; f.b_ih = d.b_ih; f.h0 = d.h0;
+            f.gx_dense = d.gx_dense; f.gx_table = d.gx_table; f.idx = d.idx; f.gx_rowbias = d.gx_rowbias;
+            f.h_all = d.h_all; f.gates = d.gates; f.xf = d.frag_ws; f.h0f = d.h0_frag; f.hlf = d.h_last_frag;
+            if (d.h0 && !d.h0_frag) {                   // the initial state as triples into slab 0 (what step 0 reads)
+                const int rc = fn_frag3_pack(d.h0, d.B, d.H, d.H, d.frag_ws, st);
+                if (rc != FN_OK) return rc;
+            }
+            f.idx_ld = d.idx_ld; f.idx_shift = d.idx_shift; f.start_token = d.start_token; f.reverse = d.reverse;
+            f.B = d.B; f.T = d.T;
+            f.group0 = groups;
+            groups += d.B / (64 * mt);
+        }
+        a.ngroups = groups;
+        a.err = scans[0].err_ws ? reinterpret_cast<u32*>(scans[0].err_ws) : a.sync + FN_MAX_GROUPS * 32;
+        if (!(scans[0].variant & 0x200)) {
+            hipError_t me = hipMemsetAsync(a.sync, 0, (size_t)FN_MAX_GROUPS * 32 * 4, st);
+            if (me != hipSuccess) return (int)me;
+        }
+        const size_t lds = (size_t)3 * 16 * 3 * 1024 + (size_t)4 * 3 * RT * 4 + 16;
+        const int rc = mt == 1 ? launch_k<PArgs, gru_fwd_x6_kernel<1>>(a, groups * nslices, lds, cus, st)
+                               : launch_k<PArgs, gru_fwd_x6_kernel<2>>(a, groups * nslices, lds, cus, st);
+        return rc == FN_PERSIST_NA ? FN_E_UNSUPPORTED : rc;
+    }
     // smallest row block whose group count fits on the chip with one workgroup per CU
     int rpw = 0;
     const int cand[4] = {16, 32, 64, 128};

@@ -38,6 +38,7 @@ class Engine:
         self._bufs = {}
         self.tab = {}                   # transposed one-hot columns of W_ih:  key -> [V][3H]
         self.whh_f = {}                 # W_hh in the kernels' fragment-major operand layout (forward scans)
+        self.whh_f3 = {}                # ... as bf16 triple images (opt-in bf16 x 6 forward scans, HipOps.dw_x6)
         self.whh_t = {}                 # W_hh^T, fragment-major (backward scans)
         self.packs = {}                 # fragment-major W_ih2 / W_out (single-launch greedy decode)
         self.saved = None
@@ -241,6 +242,13 @@ class Engine:
         self.ops.weight_images(jobs)
         if need_backward:
             self.ops.transpose(self.p["linear_out_g.weight"], self.wout_t[:, :E_VOCAB])
+        if getattr(self.ops, "dw_x6", False) and hasattr(self.ops, "frag3_pack") and H == 512:
+            # OPT-IN arithmetic (HipOps.dw_x6): bf16 triple images of the recurrent matrices for the forward scans on the bf16 MFMA
+            for key, (pfx, sfx, V) in self._gru_sets().items():
+                self.whh_f3[key] = self.buf("whhf3_" + key, (self.ops.frag_floats(3 * H, H) * 3 // 2,))
+                self.ops.frag3_pack(self.p[pfx + "weight_hh" + sfx], self.whh_f3[key])
+        else:
+            self.whh_f3.clear()
 
     # ------------------------------------------------------------------------------------------
     # forward
@@ -254,7 +262,7 @@ class Engine:
             for key, sfx, rev in ((e, "_l0", 0), (e + "_reverse", "_l0_reverse", 1)):
                 pfx = "gru_%s." % e
                 hall[key] = self.buf("enc_h_" + key, (T, B, H))
-                scans.append(dict(B=B, T=T, H=H, reverse=rev, w_hh_frag=self.whh_f[key], b_hh=P[pfx + "bias_hh" + sfx],
+                scans.append(dict(B=B, T=T, H=H, reverse=rev, w_hh_frag=self.whh_f[key], w_hh_frag3=self.whh_f3.get(key), b_hh=P[pfx + "bias_hh" + sfx],
                                   b_ih=P[pfx + "bias_ih" + sfx], gx_table=self.tab[key], idx=d, idx_shift=0,
                                   h_all=hall[key], gates=self.buf("enc_g_" + key, (T, ops.gates_floats(B, H))) if save else None))
         ops.gru_seq_fwd(scans)
@@ -297,7 +305,7 @@ class Engine:
             jobs.append(dict(C=rb, segs=[(z, w_ih[:, Ce:])]))
             sd[e] = dict(h0=h0, rb=rb, h_all=self.buf("sd_h_" + e, (Tr, B, H)),
                          gates=self.buf("sd_g_" + e, (Tr, ops.gates_floats(B, H))) if save else None)
-            scans.append(dict(B=B, T=Tr, H=H, w_hh_frag=self.whh_f["d_" + e], b_hh=P["gru_d_%s.bias_hh_l0" % e],
+            scans.append(dict(B=B, T=Tr, H=H, w_hh_frag=self.whh_f["d_" + e], w_hh_frag3=self.whh_f3.get("d_" + e), b_hh=P["gru_d_%s.bias_hh_l0" % e],
                               b_ih=P["gru_d_%s.bias_ih_l0" % e], h0=h0, gx_table=self.tab["d_" + e], idx=attr, gx_rowbias=rb,
                               h_all=sd[e]["h_all"], gates=sd[e]["gates"]))
         ops.gemm_multi(jobs)                                     # initial states + per-sequence input parts of both decoders: one launch
@@ -343,12 +351,12 @@ class Engine:
                         dict(C=rbg, segs=[(zc, P["grucell_g.weight_ih"][:, E_VOCAB:])])])
         hx0 = self.buf("g_hx0", (T, B, H))
         g1 = self.buf("g_gates1", (T, ops.gates_floats(B, H))) if save else None
-        l1 = dict(B=B, T=T, H=H, w_hh_frag=self.whh_f["g"], b_hh=P["grucell_g.bias_hh"], b_ih=P["grucell_g.bias_ih"],
+        l1 = dict(B=B, T=T, H=H, w_hh_frag=self.whh_f["g"], w_hh_frag3=self.whh_f3.get("g"), b_hh=P["grucell_g.bias_hh"], b_ih=P["grucell_g.bias_ih"],
                   h0=h0g, gx_table=self.tab["g"], idx=d, idx_shift=-1, start_token=E_VOCAB - 1, gx_rowbias=rbg, h_all=hx0, gates=g1)
         gx2 = self.buf("g_gx2", (T, B, 3 * H))
         hx1 = self.buf("g_hx1", (T, B, H))
         g2 = self.buf("g_gates2", (T, ops.gates_floats(B, H))) if save else None
-        l2 = dict(B=B, T=T, H=H, w_hh_frag=self.whh_f["g2"], b_hh=P["grucell_g_2.bias_hh"], h0=None, gx_dense=gx2, h_all=hx1, gates=g2)
+        l2 = dict(B=B, T=T, H=H, w_hh_frag=self.whh_f["g2"], w_hh_frag3=self.whh_f3.get("g2"), b_hh=P["grucell_g_2.bias_hh"], h0=None, gx_dense=gx2, h_all=hx1, gates=g2)
         # Time is cut into chunks and the two layers run as ONE weight-stationary launch per chunk step k:
         #     launch k = [layer 1, chunk k] + [layer 2, chunk k-2]      (two independent scans: 8 row groups of 64 = one per XCD, so a
         #                                                                row group's state exchange stays inside one XCD's L2)
@@ -361,7 +369,7 @@ class Engine:
         nch = len(starts)
         # a chunk leaves its final state ALSO in the fragment-major exchange layout; the next chunk of that layer starts from it
         # without a packing launch (FnGruFwd.h_last_frag -> h0_frag)
-        nf = ops.frag_floats(B, H)
+        nf = ops.frag_floats(B, H) * 3 // 2          # fp32 fragments, or bf16 triples (the opt-in bf16 x 6 scans)
         hand = {name: [self.buf("g_hand_%s_%d" % (name, i), (nf,)) for i in range(2)] for name in ("l1", "l2", "sd_r", "sd_n")}
 
         def chunk(name, sc, ci, n=None):

@@ -256,7 +256,7 @@ class HipOps:
             for k in ("h0_frag", "h_last_frag"):
                 if s.get(k) is not None and s[k].numel() < self.frag_floats(s["B"], s["H"]):
                     raise RuntimeError("%s needs frag_floats(B, H) floats" % k)
-            d.frag_ws = _p(self._frag_ws("fragf", i, 2 * self.frag_floats(s["B"], s["H"])))
+            d.frag_ws = _p(self._frag_ws("fragf", i, 3 * self.frag_floats(s["B"], s["H"])))      # 2 slabs of fp32 fragments, or 2 of bf16 triples (x6)
             d.sync_ws, d.err_ws, d.variant = (_p(sync[0]), _p(sync[1]), int(variant) | sync[2]) if persistent else (None, None, int(variant))
             d.cu_budget = int(cu_budget)
             _dense(s.get("idx"), torch.int32, "idx")
@@ -267,7 +267,25 @@ class HipOps:
             d.idx_shift, d.start_token = int(s.get("idx_shift", 0)), int(s.get("start_token", 0))
             d.gx_rowbias, d.h_all, d.gates = _p(s.get("gx_rowbias")), _p(s["h_all"]), _p(s.get("gates"))
             d.h0_frag, d.h_last_frag = _p(s.get("h0_frag")), _p(s.get("h_last_frag"))
+        if persistent and self.dw_x6 and all(s.get("w_hh_frag3") is not None for s in scans):
+            # OPT-IN arithmetic: the bf16 x 6 forward scan where the configuration is eligible (variant bit 14), else the default kernels
+            for d, s in zip(arr, scans):
+                d.w_hh_frag, d.variant = _p(s["w_hh_frag3"]), d.variant | 0x4000
+            rc = self.lib.fn_gru_seq_fwd(arr, len(scans), self.stream())
+            if rc != _lib.FN_E_UNSUPPORTED:
+                _lib.check(rc, "fn_gru_seq_fwd (bf16 x 6)")
+                return
+            for d, s in zip(arr, scans):
+                d.w_hh_frag, d.variant = _p(s["w_hh_frag"]), d.variant & ~0x4000
         _lib.check(self.lib.fn_gru_seq_fwd(arr, len(scans), self.stream()), "fn_gru_seq_fwd")
+
+    def frag3_pack(self, src, dst):
+        """bf16 triple image of src [rows][K] (fn_frag3_pack); dst: 3/2 * frag_floats(rows, K) floats"""
+        ps, R, K, ld = _mat(src, "src")
+        _dense(dst, name="dst")
+        if dst.numel() * dst.element_size() < self.frag_floats(R, K) * 6:
+            raise RuntimeError("frag3_pack: dst too small")
+        _lib.check(self.lib.fn_frag3_pack(ps, R, K, ld, _p(dst), self.stream()), "fn_frag3_pack")
 
     def gru_cell(self, h_prev, w_hh, b_hh, h_out, x=None, w_ih=None, b_ih=None, gx_table=None, idx=None, start_token=0, gx_rowbias=None, variant=None):
         """one GRUCell step of a large batch (fn_gru_cell_f32): h_out [B][H] from h_prev [B][H], optional dense input x [B][K1] with the

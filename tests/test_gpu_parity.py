@@ -364,6 +364,104 @@ def test_gemm_tn_bf16x6(ops, M, N, K, splitk):
         assert err[True] < 2e-6 and err[True] <= 2.0 * err[False] + 1e-9, err
 
 
+@pytest.mark.parametrize("n,B,T", [(4, 256, 14), (2, 256, 9), (1, 128, 6), (3, 64, 5)])
+def test_forward_scan_bf16x6(ops, n, B, T):
+    """the opt-in forward scan with exact split products on the bf16 MFMA (FnGruFwd.variant bit 14: weights and exchanged state as bf16 triples,
+    fn_frag3_pack) against the default weight-stationary kernels at H = 512: states and saved gates agree to fp32 rounding (the products are
+    exact, the sums run in another order); 128-row groups (4 x 256 rows), 64-row groups, table / dense inputs, reverse scans, row biases,
+    shifted tokens, initial states, two chunks with the state handed over as a triple image (bit-identical to one launch); repeated launches on warm
+    slabs are bit-identical; a scan without saved gates makes the call fall back to the default kernels"""
+    H, V = 512, 57
+    rng = np.random.RandomState(n * 100 + B + T)
+    torch.manual_seed(n + B)
+    scans = []
+    for s_ in range(n):
+        w = (torch.randn(3 * H, H, device=DEV) / (H ** 0.5)).contiguous()
+        wf = torch.zeros(ops.frag_floats(3 * H, H), device=DEV)
+        ops.frag_pack(w, wf)
+        wf3 = torch.zeros(ops.frag_floats(3 * H, H) * 3 // 2, device=DEV)
+        ops.frag3_pack(w, wf3)
+        d = dict(B=B, T=T, H=H, reverse=int(rng.randint(2)), w_hh_frag=wf, w_hh_frag3=wf3, b_hh=torch.randn(3 * H, device=DEV) * 0.1,
+                 b_ih=torch.randn(3 * H, device=DEV) * 0.1, h_all=torch.zeros(T, B, H, device=DEV), gates=torch.zeros(T, ops.gates_floats(B, H), device=DEV))
+        if s_ % 2 == 0:
+            d["gx_table"] = torch.randn(V, 3 * H, device=DEV) * 0.3
+            d["idx"] = torch.randint(0, V, (B, T + 3), dtype=torch.int32, device=DEV)
+            if not d["reverse"] and s_ == 0:
+                d["idx_shift"], d["start_token"] = -1, V - 1
+        else:
+            d["gx_dense"] = torch.randn(T, B, 3 * H, device=DEV) * 0.3
+        if s_ != 1:
+            d["gx_rowbias"] = torch.randn(B, 3 * H, device=DEV) * 0.2
+        scans.append(d)
+
+    def run(x6):
+        ops.dw_x6 = x6
+        for d in scans:
+            d["h_all"].fill_(float("nan")); d["gates"].fill_(float("nan"))
+        ops.gru_seq_fwd(scans)
+        torch.cuda.synchronize()
+        return [d["h_all"].clone() for d in scans] + [d["gates"].clone() for d in scans]
+    try:
+        ref = run(False)
+        got = run(True)
+        again = run(True)
+        assert not ops.gru_sync_error()
+        differs = False
+        for a, b, c in zip(ref, got, again):
+            assert torch.equal(b, c)
+            assert not torch.isnan(b).any()
+            differs |= not torch.equal(a, b)
+            assert float((a - b).abs().max()) <= 5e-5 * float(a.abs().max()), float((a - b).abs().max())
+        assert differs                                     # the x6 kernel really ran (another summation order)
+        # initial state + two chunks with the state handed over as a triple image (what the decoder pipeline does)
+        for d in scans:
+            d["h0"] = torch.randn(B, H, device=DEV) * 0.1
+        ref = run(False)
+        got = run(True)
+        for a, b in zip(ref, got):
+            assert float((a - b).abs().max()) <= 5e-5 * float(a.abs().max())
+        T1 = T // 2
+        hand = [torch.zeros(ops.frag_floats(B, H) * 3 // 2, device=DEV) for _ in scans]
+
+        def chunk(d, t0, t1, first):
+            c = dict(d)
+            c.update(T=t1 - t0, h_all=d["h_all"][t0:t1], gates=d["gates"][t0:t1])
+            if d.get("gx_dense") is not None:
+                c["gx_dense"] = d["gx_dense"][t0:t1]
+            if d.get("idx") is not None:
+                c["idx_shift"] = d.get("idx_shift", 0) + t0
+            if not first:
+                c["h0"] = d["h_all"][t0 - 1]
+            return c
+        if all(not d["reverse"] for d in scans) or True:
+            fw = [d for d in scans if not d["reverse"]]
+            if fw:
+                ops.dw_x6 = True
+                for d in fw:
+                    d["h_all"].fill_(float("nan")); d["gates"].fill_(float("nan"))
+                part = [chunk(d, 0, T1, True) for d in fw]
+                for c, hb in zip(part, hand):
+                    c["h_last_frag"] = hb
+                ops.gru_seq_fwd(part)
+                part = [chunk(d, T1, T, False) for d in fw]
+                for c, hb in zip(part, hand):
+                    c["h0_frag"] = hb
+                ops.gru_seq_fwd(part)
+                torch.cuda.synchronize()
+                for d in fw:
+                    i = scans.index(d)
+                    assert torch.equal(d["h_all"], got[i]) and torch.equal(d["gates"], got[len(scans) + i])      # chunked == one launch, bit for bit
+        scans[0]["gates"] = None                               # not eligible (no saved gates): falls back to the default kernels, bit for bit
+        ops.dw_x6 = False
+        ops.gru_seq_fwd(scans); torch.cuda.synchronize()
+        ref = [d["h_all"].clone() for d in scans]
+        ops.dw_x6 = True
+        ops.gru_seq_fwd(scans); torch.cuda.synchronize()
+        assert all(torch.equal(a, d["h_all"]) for a, d in zip(ref, scans))
+    finally:
+        ops.dw_x6 = False
+
+
 def test_time_sum(ops):
     torch.manual_seed(4)
     X = torch.randn(67, 37, 96)
