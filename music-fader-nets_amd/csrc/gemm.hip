@@ -183,8 +183,16 @@ FN_DEVINL void gemm_tn_body(int M, int N, int K, float alpha, const float* __res
     // column offsets clamped inside the padded row (results of out-of-range rows/cols are never stored)
     // optional second source for the output rows >= msplit (a multiple of the 128-row tile): A = [A | A2] along M
     if (A2 != nullptr && m0 >= msplit) { A = A2 - msplit; lda = lda2; }
-    const long ca = A2 != nullptr && m0 >= msplit ? msplit + min((long)(m0 - msplit) + 4 * li, lda - 4) : min((long)m0 + 4 * li, lda - 4);
-    const long cb = min((long)n0 + 4 * li, ldb - 4);
+    // Column offsets of the 16-byte operand loads, kept inside the columns the operand REALLY has (M resp. N of them; results of
+    // out-of-range rows / columns are never stored).  Clamping to the leading dimension instead is wrong for a column-offset view
+    // (dpre[:, Z:2Z] of the latent block): its last row ends lda - offset floats behind the view's first column, and a load at lda - 4 ran
+    // 128 bytes past the allocation - a memory fault once that allocation sat at the end of a mapped segment (found in round 4).
+    const long mcols = A2 != nullptr ? (m0 >= msplit ? (long)M - msplit : (long)msplit) : (long)M;
+    const long mrel = A2 != nullptr && m0 >= msplit ? (long)(m0 - msplit) : (long)m0;
+    // (a lane's window of 4 columns is tied to its output columns: windows that still hold a valid column are read where they are - up to 3
+    // floats of row padding, which ld % 4 == 0 guarantees - and only windows entirely beyond the last column move, to the last valid one)
+    const long ca = (A2 != nullptr && m0 >= msplit ? msplit : 0) + min(mrel + 4 * li, ((mcols - 1) >> 2) << 2);
+    const long cb = min((long)n0 + 4 * li, (((long)N - 1) >> 2) << 2);
     f32x4 acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -329,8 +337,16 @@ __global__ __launch_bounds__(NT) void gemm_tn_x6_kernel(int M, int N, int K, flo
     const int li = lane & 15, lg = lane >> 4;
     const int kbeg = zk * ksplit_len, kend = min(K, kbeg + ksplit_len);
     if (A2 != nullptr && m0 >= msplit) { A = A2 - msplit; lda = lda2; }
-    const long ca = A2 != nullptr && m0 >= msplit ? msplit + min((long)(m0 - msplit) + 4 * li, lda - 4) : min((long)m0 + 4 * li, lda - 4);
-    const long cb = min((long)n0 + 4 * li, ldb - 4);
+    // Column offsets of the 16-byte operand loads, kept inside the columns the operand REALLY has (M resp. N of them; results of
+    // out-of-range rows / columns are never stored).  Clamping to the leading dimension instead is wrong for a column-offset view
+    // (dpre[:, Z:2Z] of the latent block): its last row ends lda - offset floats behind the view's first column, and a load at lda - 4 ran
+    // 128 bytes past the allocation - a memory fault once that allocation sat at the end of a mapped segment (found in round 4).
+    const long mcols = A2 != nullptr ? (m0 >= msplit ? (long)M - msplit : (long)msplit) : (long)M;
+    const long mrel = A2 != nullptr && m0 >= msplit ? (long)(m0 - msplit) : (long)m0;
+    // (a lane's window of 4 columns is tied to its output columns: windows that still hold a valid column are read where they are - up to 3
+    // floats of row padding, which ld % 4 == 0 guarantees - and only windows entirely beyond the last column move, to the last valid one)
+    const long ca = (A2 != nullptr && m0 >= msplit ? msplit : 0) + min(mrel + 4 * li, ((mcols - 1) >> 2) << 2);
+    const long cb = min((long)n0 + 4 * li, (((long)N - 1) >> 2) << 2);
     f32x4 acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)

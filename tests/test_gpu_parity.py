@@ -136,6 +136,27 @@ def test_gru_cell_dense(ops, B, H, K1, mode):
     close(out, ref, 2e-5, "gru_cell")
 
 
+def test_gemm_tn_column_view_at_the_end_of_its_allocation(ops):
+    """weight-gradient form on a COLUMN-OFFSET view whose last row ends with the allocation (dpre[:, Z:2Z] of the latent block, K = batch rows):
+    the operand loads must stay inside the view's columns - clamped to the leading dimension they ran 128 bytes past the buffer (a memory fault
+    whenever that buffer closed a mapped segment; found in round 4).  Results against float64; a canary buffer allocated right behind stays intact."""
+    torch.manual_seed(3)
+    K, Z, H = 6, 32, 64
+    for x6 in (False, True):
+        ops.dw_x6 = x6
+        parent = torch.randn(K, 2 * Z, device=DEV)
+        canary = torch.full((64,), 7.0, device=DEV)
+        hf = torch.randn(K, H, device=DEV)
+        dW = torch.zeros(Z, 2 * H, device=DEV)
+        ops.gemm(parent[:, Z:], hf, dW[:, :H], a_k=False, b_k=False)
+        ops.gemm(parent[:, Z:], hf, dW[:, H:], a_k=False, b_k=False)
+        want = parent[:, Z:].double().t() @ hf.double()
+        close(dW[:, :H], want.float(), 2e-5)
+        close(dW[:, H:], want.float(), 2e-5)
+        assert bool((canary == 7.0).all())
+    ops.dw_x6 = False
+
+
 def test_gemm_is_transpose_detecting(ops):
     """identity A with an ASYMMETRIC B: catches a swapped C-write (cdna guide rule 16)."""
     n = 96
@@ -1060,7 +1081,7 @@ def test_benchmark_config_vs_reference_train():
 # captured graphs vs changing batch shapes / changing weights
 # ----------------------------------------------------------------------------------------------
 def test_benchmark_config_with_bf16x6_weight_gradients_vs_reference_train():
-    """the benchmark shape with the opt-in bf16 x 6 weight-gradient products (HipOps.dw_x6): the comparison of
+    """the benchmark shape with the opt-in bf16 x 6 arithmetic (HipOps.dw_x6: weight-gradient products AND forward scans): the comparison of
     test_benchmark_config_vs_reference_train against the reference's own backward / train() at this size (tests/golden/c1.npz) at the SAME
     tolerances - loss, raw gradient norm, per-parameter |g| and g^2 sums, the train() tuples, the weights after the first step"""
     pkg = load_package()
@@ -1088,7 +1109,7 @@ def test_benchmark_config_with_bf16x6_weight_gradients_vs_reference_train():
     tr.loss_and_grads(20000, batch, eps)
     g32 = tr.flat.G["gru_r.weight_hh_l0"]
     assert not torch.equal(g6, g32)
-    assert float((g6 - g32).abs().max()) <= 2e-6 * float(g32.abs().max())
+    assert float((g6 - g32).abs().max()) <= 1e-5 * float(g32.abs().max())      # fp32 rounding through 256 recurrent steps (forward scans + products differ in their last bits)
     m.engine().ops.dw_x6 = True
     step = 20000
     for it in range(2):
@@ -1444,6 +1465,7 @@ def test_glsr_full_size_keeps_the_scans_apart():
     stationary launches; queued on a side stream they would be in flight together with the main decoder backward and starve each other
     into the bounded-spin error.  Two steps must finish with finite numbers and a clear sync-error word."""
     from helpers import make_vae_model
+    load_package()
     from music_fader_nets_amd.synth import synth_batch
     pkg = load_package()
     m = make_vae_model(512, 128, device=DEV)
