@@ -403,9 +403,10 @@ def bench_train(args, pkg, ctx, local, rank, world, log):
                 out["first_step_loss_reference"] = round(ref, 4)
                 assert abs(first[0] - ref) <= 5e-4 * abs(ref), "first optimisation step deviates from the reference: %r vs %r" % (first[0], ref)
     if world == 1 and not args.no_x6:
-        # OPT-IN arithmetic, reported BESIDE the headline (never inside it): the T*B-deep weight-gradient products on the bf16 MFMA with every
-        # fp32 operand value cut exactly into three bf16 pieces (FN_GEMM_BF16X6, HipOps.dw_x6) - same seeds, same steps, its own trainer
-        out["bf16x6_weight_gradients"] = _aux(lambda: bench_x6_leg(args, pkg, batch, eps, dev, first, log), log, "bf16x6 leg")
+        # OPT-IN arithmetic, reported BESIDE the headline (never inside it): the T*B-deep weight-gradient products and the forward scans on the
+        # bf16 MFMA with every fp32 operand value cut exactly into three bf16 pieces (FN_GEMM_BF16X6, FnGruFwd.variant bit 14; HipOps.dw_x6) -
+        # same seeds, same steps, its own trainer
+        out["bf16x6_opt_in"] = _aux(lambda: bench_x6_leg(args, pkg, batch, eps, dev, first, log), log, "bf16x6 leg")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cpu_baseline
         out["cpu_baseline"] = _aux(lambda: cpu_baseline.time_baseline(H, Z, B, T, TR), log, "cpu baseline")
@@ -429,11 +430,13 @@ def _aux(fn, log, what):
 
 
 def bench_x6_leg(args, pkg, batch, eps, dev, first, log):
-    """the same timed region with HipOps.dw_x6 = True (weight-gradient GEMMs: exact bf16 triple splits, 6 of 9 partial products, fp32 accumulation)"""
+    """the same timed region with HipOps.dw_x6 = True (weight-gradient GEMMs and forward scans: exact bf16 triple splits, 6 of 9 partial products,
+    fp32 accumulation)"""
     torch.manual_seed(1234)
     model = pkg.MusicAttrRegGMVAE(342, 3, 16, 24, H, Z, 32, n_component=K).to(dev)
     trainer = pkg.GMVAETrainer(model, lr=1e-3, beta=0.2)
     model.engine().ops.dw_x6 = True                         # (after the trainer: it re-homes the parameters and with them the engine / its kernel table)
+    model.weights_changed()                                 # the engine re-derives its weight images, now incl. the bf16 triple images of W_hh
     step, first6 = 20000, None
     for i in range(args.warmup):
         beta0, Bg = trainer.step_device(step, batch, eps)
@@ -449,14 +452,16 @@ def bench_x6_leg(args, pkg, batch, eps, dev, first, log):
     dt = (time.perf_counter() - t0) / args.steps
     tup = trainer._tuple8(0.2, B, False)
     assert all(np.isfinite(tup)), tup
-    log("bf16x6 weight gradients: %.3f ms/step" % (dt * 1e3))
+    log("bf16x6 (weight gradients + forward scans): %.3f ms/step" % (dt * 1e3))
     out = dict(ms_per_step=round(dt * 1e3, 3), value=round(B * T / dt, 1), unit="event-tokens/s", steps=args.steps, last_loss=round(tup[0], 4),
                first_step_loss=None if first6 is None else round(first6[0], 4),
                first_step_loss_fp32_path=None if first is None else round(first[0], 4),
-               note="NOT the headline and not the default: fn_gru_dwhh_f32 / fn_gemm_f32(a_k=0, b_k=0) with FN_GEMM_BF16X6 - fp32 operands cut EXACTLY into three bf16 "
-                    "pieces, six of the nine exact partial products accumulated in fp32 on v_mfma_f32_16x16x32_bf16 (dropped terms <= 2^-24 |a b|); against float64 "
-                    "as accurate as the fp32 MFMA kernel (tests/test_gpu_parity.py::test_gemm_tn_bf16x6, scratch/mfma_bf16x9.hip), the benchmark shape passes the "
-                    "reference comparison at the same tolerances (test_benchmark_config_with_bf16x6_weight_gradients_vs_reference_train); every other kernel unchanged")
+               note="NOT the headline and not the default: fn_gru_dwhh_f32 / fn_gemm_f32(a_k=0, b_k=0) with FN_GEMM_BF16X6 and the forward weight-stationary scans "
+                    "with FnGruFwd.variant bit 14 (gru_fwd_x6_kernel: weights and exchanged state as bf16 triples) - fp32 values cut EXACTLY into three bf16 pieces, "
+                    "six of the nine exact partial products accumulated in fp32 on v_mfma_f32_16x16x32_bf16 (dropped terms <= 2^-24 |a b|); against float64 as "
+                    "accurate as the fp32 MFMA kernels (tests/test_gpu_parity.py::test_gemm_tn_bf16x6, test_forward_scan_bf16x6, scratch/mfma_bf16x9.hip), the "
+                    "benchmark shape passes the reference comparison at the same tolerances (test_benchmark_config_with_bf16x6_vs_reference_train) and the "
+                    "whole gpu suite passes with the flag forced on (pytest -m gpu --x6); backward scans and every other kernel unchanged")
     del trainer, model
     return out
 

@@ -1080,7 +1080,7 @@ def test_benchmark_config_vs_reference_train():
 # ----------------------------------------------------------------------------------------------
 # captured graphs vs changing batch shapes / changing weights
 # ----------------------------------------------------------------------------------------------
-def test_benchmark_config_with_bf16x6_weight_gradients_vs_reference_train():
+def test_benchmark_config_with_bf16x6_vs_reference_train():
     """the benchmark shape with the opt-in bf16 x 6 arithmetic (HipOps.dw_x6: weight-gradient products AND forward scans): the comparison of
     test_benchmark_config_vs_reference_train against the reference's own backward / train() at this size (tests/golden/c1.npz) at the SAME
     tolerances - loss, raw gradient norm, per-parameter |g| and g^2 sums, the train() tuples, the weights after the first step"""

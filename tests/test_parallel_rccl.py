@@ -220,7 +220,7 @@ def test_bench_launches_its_own_ranks(n):
     assert 0 < out["roofline"]["frac"] < 1 and out["roofline_all"]
     assert out["roofline"]["symbol"] in out["roofline_by_symbol"] and 0 < out["roofline_scans"]["frac"] < 1
     assert out["sustained_steps"] == 20 and out["sustained_ms_per_step"] > 0
-    x6 = out["bf16x6_weight_gradients"]                                           # the opt-in arithmetic rides beside the headline, never inside it
+    x6 = out["bf16x6_opt_in"]                                           # the opt-in arithmetic rides beside the headline, never inside it
     assert x6["ms_per_step"] > 0 and abs(x6["first_step_loss"] - x6["first_step_loss_fp32_path"]) <= 1e-4 * abs(x6["first_step_loss_fp32_path"])
 
 
