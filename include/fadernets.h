@@ -205,9 +205,11 @@ int fn_gru_seq_fwd(const FnGruFwd* scans, int n_scans, void* stream);
 /* ONE GRU cell step for a large batch (nn.GRUCell, gmm_model.py:131-136 in the eval-mode decode loop of thousands of rows):
  *    gi = x W_ih^T + b_ih + gx_table[tok] + gx_rowbias[b]      (every term optional)       gh = h_prev W_hh^T + b_hh
  *    r = sigmoid(gi_r + gh_r), z = sigmoid(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h_out = (1 - z) n + z h_prev
- * as a staged MFMA GEMM (128 rows x 32 hidden units per workgroup, both products in one K loop) with the gates in its epilogue:
- * layer 2 of the decoder needs no separate W_ih projection launch and no [B][3H] round trip.  Weights are the torch matrices
- * themselves ([3H][K] row-major), states row-major; h_out must not alias h_prev.  H % 32 == 0.
+ * as ONE MFMA launch with the gates in its epilogue (both products in its K loops: layer 2 of the decoder needs no separate W_ih
+ * projection launch and no [B][3H] round trip).  Two kernels: an LDS-free loop whose lanes read their MFMA operands straight from the
+ * K-contiguous rows (above 512 rows, 16-byte aligned operands, K1 % 16 == 0, row strides % 4 == 0) and an LDS-staged GEMM (everything
+ * else); they sum k in different orders (fp32 rounding apart).  Weights are the torch matrices themselves ([3H][K] row-major),
+ * states row-major; h_out must not alias h_prev.  H % 32 == 0.
  * tok = idx ? idx[b * idx_ld] : start_token (point idx at the column of the previous step's tokens). */
 typedef struct FnGruCell {
     int32_t B, H;
@@ -227,7 +229,8 @@ typedef struct FnGruCell {
     const float* b_hh;        /* [3H]                                                         */
     float* h_out;             /* [B][ldo]                                                     */
     int32_t ldo;
-    int32_t variant;          /* 0 = default tiling (64 rows x 32 units, waves 2 x 2); 1-3: other tilings (measurements) */
+    int32_t variant;          /* 0 = automatic.  Tuning / tests: 1-3, 8 force a staged tiling (8 = its default: 64 rows x 32 units), 4-7 the LDS-free
+                                 loop (4, 6: 128 rows x 32 units per workgroup, 4 / 2 k steps in flight; 5, 7: 64 rows, 4 / 6) where eligible */
 } FnGruCell;
 int fn_gru_cell_f32(const FnGruCell* c, void* stream);
 

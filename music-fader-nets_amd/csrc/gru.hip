@@ -656,6 +656,200 @@ __global__ __launch_bounds__(NT, 2) void gru_cell_kernel(const CellArgs a) {
         }
 }
 
+// The same cell WITHOUT LDS (the loop of gemm_nt_direct_kernel, gemm.hip): both operands are K-contiguous rows, so lane (i = l & 15, g = l >> 4)
+// reads the float4 [row i of a 16-row tile][k0 + 4g .. 4g + 3] of its RT state-row tiles and of the three gate rows of its 16 hidden units
+// straight from memory; MFMA j of a 16-k step takes element j of every lane (a permutation of the step's k values, the same for A and B).
+// The staged kernel above spends a K = 512 product on 16 barrier-separated tiles (37 / 67 us for the two layers of a 2048-row token
+// against 22 / 44 us of MFMA time); here PF steps (RT + 3 loads each) are in flight behind counted waits, nothing else waits.
+// One wave = 16 RT rows x 16 units x {r, z, n}: r and z accumulate the x part and the h part in ONE tile, the n gate keeps them apart
+// (tanh(gi_n + r * gh_n)); a workgroup = 2 x 2 waves = 32 RT rows x 32 units.  Loads use a scalar base (64 bytes per step) + a fixed
+// 32-bit lane offset.  Needs K1, H multiples of 16, 16-byte aligned operands, row strides multiples of 4 floats, spans below 4 GB.
+FN_DEVINL void fn_gld4_sb(f32x4& dst, unsigned voff, const float* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+
+template <int RT, int PF, bool HAS_TAB, bool HAS_RB>
+__global__ __launch_bounds__(NT, RT >= 4 ? 1 : 2) void gru_cell_direct_kernel(const CellArgs a) {
+    const int nut = a.H >> 5, ntm = (a.B + 32 * RT - 1) / (32 * RT);
+    const int v = fn_xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tu;
+    if ((ntm % 4) == 0 && (nut % 8) == 0) {          // 4 x 8 super-tiles (row panels x unit tiles) in consecutive virtual ids = on one XCD
+        const int sb = v >> 5, l = v & 31, sbu = nut >> 3;
+        tm = (sb / sbu) * 4 + (l >> 3);
+        tu = (sb % sbu) * 8 + (l & 7);
+    } else {
+        tm = v / nut;
+        tu = v % nut;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = tm * 32 * RT + (wave >> 1) * 16 * RT, u0 = tu * 32 + (wave & 1) * 16;
+    const int li = lane & 15, lg = lane >> 4;
+    f32x4 arz[RT][2], anx[RT], anh[RT];
+#pragma unroll
+    for (int m = 0; m < RT; ++m) arz[m][0] = arz[m][1] = anx[m] = anh[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 fa[PF][RT], fb[PF][3];
+    // one K phase: acc_rz += A W[r, z rows]^T, accn += A W[n rows]^T over nks steps of 16 k
+    auto phase = [&](const float* A, long lda, const float* W, long ldw, int nks, f32x4 (&accn)[RT]) {
+        unsigned oa[RT], ob[3];
+#pragma unroll
+        for (int m = 0; m < RT; ++m) oa[m] = (unsigned)(((long)min(m0 + 16 * m + li, a.B - 1) * lda + 4 * lg) * 4);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) ob[q] = (unsigned)(((long)(q * a.H + u0 + li) * ldw + 4 * lg) * 4);
+        const float* pa = A;
+        const float* pb = W;
+        auto load = [&](int set) {
+#pragma unroll
+            for (int m = 0; m < RT; ++m) fn_gld4_sb(fa[set][m], oa[m], pa);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) fn_gld4_sb(fb[set][q], ob[q], pb);
+            pa += 16;
+            pb += 16;
+        };
+        auto mma = [&](int u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int m = 0; m < RT; ++m) {
+                    arz[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][m][j], fb[u][0][j], arz[m][0], 0, 0, 0);
+                    arz[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][m][j], fb[u][1][j], arz[m][1], 0, 0, 0);
+                    accn[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][m][j], fb[u][2][j], accn[m], 0, 0, 0);
+                }
+        };
+        constexpr int NL = RT + 3;
+        const int nmain = nks / PF * PF;
+        if (nmain > 0) {
+#pragma unroll
+            for (int s = 0; s < PF; ++s) load(s);
+            for (int base = 0; base + PF < nmain; base += PF) {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    fn_wait_vm<NL * (PF - 1)>();
+                    mma(u);
+                    load(u);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                if (u == 0) fn_wait_vm<NL * (PF - 1)>();
+                else if (u == 1 && PF > 1) fn_wait_vm<(PF > 1 ? NL * (PF - 2) : 0)>();
+                else if (u == 2 && PF > 2) fn_wait_vm<(PF > 2 ? NL * (PF - 3) : 0)>();
+                else fn_wait_vm<0>();
+                mma(u);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int s = 0; s < PF; ++s) {
+#pragma unroll
+                for (int m = 0; m < RT; ++m) fn_keep(fa[s][m]);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) fn_keep(fb[s][q]);
+            }
+        }
+        for (int ks = nmain; ks < nks; ++ks) {
+            load(0);
+            fn_wait_vm<0>();
+            mma(0);
+#pragma unroll
+            for (int m = 0; m < RT; ++m) fn_keep(fa[0][m]);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) fn_keep(fb[0][q]);
+        }
+    };
+    // Epilogue on (row, 4 units) items: the accumulator tiles of row tile m go through a wave-private LDS tile (D layout in, lane
+    // (row = l >> 2, units 4 (l & 3) ..) out), so every other operand - old state, token row, row constant - is ONE 16-byte load per
+    // gate and item and the new state one 16-byte store (the element-per-lane form issued 7 scalar loads per (row, unit), 112 per lane).
+    // All of them are requested HERE, in front of the K loops (plain loads: older than every ring load, so the counted waits cover them);
+    // absent sources are not loaded (HAS_TAB / HAS_RB).
+    const int er = lane >> 2, eu = u0 + 4 * (lane & 3);
+    f32x4 bi[3], bh[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        bh[q] = *reinterpret_cast<const f32x4*>(a.b_hh + q * a.H + eu);
+        bi[q] = a.b_ih ? *reinterpret_cast<const f32x4*>(a.b_ih + q * a.H + eu) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const long H3 = 3L * a.H;
+    f32x4 hv[RT], tv[RT][3], rv[RT][3];
+    int rows[RT];
+#pragma unroll
+    for (int m = 0; m < RT; ++m) {
+        rows[m] = m0 + 16 * m + er;
+        const int rc = min(rows[m], a.B - 1);
+        hv[m] = *reinterpret_cast<const f32x4*>(a.h_prev + (long)rc * a.ldh + eu);
+        if (HAS_TAB) {
+            const int tok = a.idx ? a.idx[(long)rc * a.idx_ld] : a.tok_const;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) tv[m][q] = *reinterpret_cast<const f32x4*>(a.gx_table + (long)tok * H3 + q * a.H + eu);
+        }
+        if (HAS_RB) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) rv[m][q] = *reinterpret_cast<const f32x4*>(a.gx_rowbias + (long)rc * H3 + q * a.H + eu);
+        }
+    }
+    if (a.x) phase(a.x, a.ldx, a.w_ih, a.ldw_ih, a.K1 >> 4, anx);
+    phase(a.h_prev, a.ldh, a.w_hh, a.ldw_hh, a.H >> 4, anh);
+    __shared__ __attribute__((aligned(16))) float tr[4][4][16 * 20];     // [wave][tile of the row tile: r, z, n(x), n(h)][16 rows x (16 + 4 pad)]
+    float* tw = &tr[wave][0][0];
+#pragma unroll
+    for (int m = 0; m < RT; ++m) {
+        // D layout: lane (li, lg) holds rows 4 lg + i, column li
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            tw[0 * 320 + (4 * lg + i) * 20 + li] = arz[m][0][i];
+            tw[1 * 320 + (4 * lg + i) * 20 + li] = arz[m][1][i];
+            tw[2 * 320 + (4 * lg + i) * 20 + li] = anx[m][i];
+            tw[3 * 320 + (4 * lg + i) * 20 + li] = anh[m][i];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const f32x4 g_r = *reinterpret_cast<const f32x4*>(tw + 0 * 320 + er * 20 + 4 * (lane & 3));
+        const f32x4 g_z = *reinterpret_cast<const f32x4*>(tw + 1 * 320 + er * 20 + 4 * (lane & 3));
+        const f32x4 g_nx = *reinterpret_cast<const f32x4*>(tw + 2 * 320 + er * 20 + 4 * (lane & 3));
+        const f32x4 g_nh = *reinterpret_cast<const f32x4*>(tw + 3 * 320 + er * 20 + 4 * (lane & 3));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        f32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float gi[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                float e = bi[q][c];
+                if (HAS_TAB) e += tv[m][q][c];
+                if (HAS_RB) e += rv[m][q][c];
+                gi[q] = e;
+            }
+            const float r = fn_sigmoid((gi[0] + bh[0][c]) + g_r[c]);
+            const float z = fn_sigmoid((gi[1] + bh[1][c]) + g_z[c]);
+            const float n = fn_tanh((gi[2] + g_nx[c]) + r * (g_nh[c] + bh[2][c]));
+            o[c] = (1.0f - z) * n + z * hv[m][c];
+        }
+        if (rows[m] < a.B) *reinterpret_cast<f32x4*>(a.h_out + (long)rows[m] * a.ldo + eu) = o;
+    }
+}
+
+static bool cell_direct_ok(const CellArgs& a) {
+    auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+    if ((a.H % 32) != 0 || !al(a.h_prev) || !al(a.w_hh) || (a.ldh & 3) || (a.ldw_hh & 3)) return false;
+    if (!al(a.h_out) || (a.ldo & 3) || !al(a.b_hh) || (a.b_ih && !al(a.b_ih)) || (a.gx_table && !al(a.gx_table)) || (a.gx_rowbias && !al(a.gx_rowbias))) return false;
+    if ((long)a.B * a.ldh * 4 >= (1L << 32) || 3L * a.H * a.ldw_hh * 4 >= (1L << 32)) return false;
+    if (a.x) {
+        if ((a.K1 % 16) != 0 || !al(a.x) || !al(a.w_ih) || (a.ldx & 3) || (a.ldw_ih & 3)) return false;
+        if ((long)a.B * a.ldx * 4 >= (1L << 32) || 3L * a.H * a.ldw_ih * 4 >= (1L << 32)) return false;
+    }
+    return true;
+}
+
+template <int RT, int PF>
+int launch_cell_direct(const CellArgs& a, hipStream_t st) {
+    const int tiles = ((a.B + 32 * RT - 1) / (32 * RT)) * (a.H / 32);
+    const bool tab = a.gx_table != nullptr, rb = a.gx_rowbias != nullptr;
+    if (tab && rb) hipLaunchKernelGGL((gru_cell_direct_kernel<RT, PF, true, true>), dim3(tiles), dim3(NT), 0, st, a);
+    else if (tab) hipLaunchKernelGGL((gru_cell_direct_kernel<RT, PF, true, false>), dim3(tiles), dim3(NT), 0, st, a);
+    else if (rb) hipLaunchKernelGGL((gru_cell_direct_kernel<RT, PF, false, true>), dim3(tiles), dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((gru_cell_direct_kernel<RT, PF, false, false>), dim3(tiles), dim3(NT), 0, st, a);
+    FN_CHECK_LAUNCH();
+    return FN_OK;
+}
+
 template <int BM, int WM, int WN>
 int launch_cell(const CellArgs& a, hipStream_t st) {
     const size_t lds = (size_t)2 * (Stage<BM, GC_BK, true, NT>::WORDS + Stage<GC_BN, GC_BK, true, NT>::WORDS) * sizeof(float);
@@ -762,7 +956,18 @@ int fn_gru_cell_f32(const FnGruCell* c, void* stream) {
     a.gx_table = c->gx_table; a.idx = c->idx; a.idx_ld = c->idx_ld; a.tok_const = c->start_token; a.gx_rowbias = c->gx_rowbias;
     a.h_prev = c->h_prev; a.ldh = c->ldh; a.w_hh = c->w_hh; a.ldw_hh = c->ldw_hh; a.b_ih = c->b_ih; a.b_hh = c->b_hh;
     a.h_out = c->h_out; a.ldo = c->ldo; a.B = c->B; a.H = c->H;
-    switch (c->variant) {                                  // tuning / tests; results do not depend on it
+    // measured (scratch/prof_decode_cells.sh, us per token of the 4-launch decode): 2048 rows 125 staged / 111 LDS-free 128-row form / 143 64-row form;
+    // 1536 rows 125 / 110 / 142; 1024 rows 82 / 104 / 80; 800 rows 82 / 104 / 80
+    if (c->variant == 0 && c->B > 512 && cell_direct_ok(a))
+        return c->B > 1024 ? launch_cell_direct<4, 2>(a, (hipStream_t)stream) : launch_cell_direct<2, 4>(a, (hipStream_t)stream);
+    switch (c->variant) {                                  // tuning / tests: the staged forms agree bit for bit, the LDS-free forms 4-7 among themselves (another k order)
+        case 4: if (cell_direct_ok(a)) return launch_cell_direct<4, 4>(a, (hipStream_t)stream); break;
+        case 5: if (cell_direct_ok(a)) return launch_cell_direct<2, 4>(a, (hipStream_t)stream); break;
+        case 6: if (cell_direct_ok(a)) return launch_cell_direct<4, 2>(a, (hipStream_t)stream); break;
+        case 7: if (cell_direct_ok(a)) return launch_cell_direct<2, 6>(a, (hipStream_t)stream); break;
+        default: break;
+    }
+    switch (c->variant) {
         case 1: return launch_cell<128, 4, 1>(a, (hipStream_t)stream);
         case 2: return launch_cell<128, 2, 2>(a, (hipStream_t)stream);
         case 3: return launch_cell<64, 4, 1>(a, (hipStream_t)stream);

@@ -100,7 +100,7 @@ def _decode_body(eng, z, steps, want_logp, logp, tokens):
     hf0 = [eng.buf("dec_hf0_a", (nf,)), eng.buf("dec_hf0_b", (nf,))]
     hf1 = [eng.buf("dec_hf1_a", (nf,)), eng.buf("dec_hf1_b", (nf,))]
     if Bi >= eng.cell_decode_rows:
-        # thousands of rows: every cell is ONE staged-GEMM launch with the gates in its epilogue (fn_gru_cell_f32); layer 2 takes its input
+        # thousands of rows: every cell is ONE MFMA launch with the gates in its epilogue (fn_gru_cell_f32: LDS-free loop above 512 rows); layer 2 takes its input
         # projection in the same K loop - 3 launches + argmax per token instead of 4 + argmax, and no [B][3H] round trip
         for i in range(steps):
             cur, prv = i & 1, (i & 1) ^ 1

@@ -112,10 +112,12 @@ def test_out_head_fused(ops, B, T, H, V, ld):
     assert torch.equal(nll1, nll2)
 
 
-@pytest.mark.parametrize("B,H,K1,mode", [(300, 64, 64, "dense"), (2048, 512, 512, "dense"), (130, 96, 0, "table"), (1030, 512, 0, "table0")])
-def test_gru_cell_dense(ops, B, H, K1, mode):
-    """fn_gru_cell_f32 (one GRUCell step of a large batch as a staged GEMM with the gates in its epilogue) against tests/fake_ops.py
-    (= torch nn.GRUCell semantics with the optional token-row / row-constant input parts), ragged row / unit tiles."""
+@pytest.mark.parametrize("variant", [0, 2, 4, 5, 6, 7])
+@pytest.mark.parametrize("B,H,K1,mode", [(300, 64, 64, "dense"), (2048, 512, 512, "dense"), (130, 96, 0, "table"), (1030, 512, 0, "table0"), (77, 64, 48, "dense")])
+def test_gru_cell_dense(ops, B, H, K1, mode, variant):
+    """fn_gru_cell_f32 (one GRUCell step of a large batch: a staged GEMM - variants 0-3 - or the LDS-free loop - variants 4-7 - with the gates
+    in the epilogue) against tests/fake_ops.py (= torch nn.GRUCell semantics with the optional token-row / row-constant input parts), ragged
+    row / unit tiles, K tails of the pipelined loop."""
     from fake_ops import FakeOps
     torch.manual_seed(B + H)
     V = 50
@@ -132,7 +134,7 @@ def test_gru_cell_dense(ops, B, H, K1, mode):
     FakeOps().gru_cell(hp, whh, bhh, ref, **kw)
     out = torch.zeros(B, H, device=DEV)
     ops.gru_cell(g(hp), g(whh), g(bhh), out, **{k: (g(v) if torch.is_tensor(v) and k != "idx" else v) for k, v in kw.items() if k != "idx"},
-                 idx=(g(toks)[:, 3] if mode == "table" else None) if mode != "dense" else None)
+                 idx=(g(toks)[:, 3] if mode == "table" else None) if mode != "dense" else None, variant=variant)
     close(out, ref, 2e-5, "gru_cell")
 
 
