@@ -230,7 +230,7 @@ typedef struct FnGruCell {
     float* h_out;             /* [B][ldo]                                                     */
     int32_t ldo;
     int32_t variant;          /* 0 = automatic.  Tuning / tests: 1-3, 8 force a staged tiling (8 = its default: 64 rows x 32 units), 4-7 the LDS-free
-                                 loop (4, 6: 128 rows x 32 units per workgroup, 4 / 2 k steps in flight; 5, 7: 64 rows, 4 / 6) where eligible */
+                                 loop (4, 6: 128 rows x 32 units per workgroup, 1 / 2 k steps in flight; 5, 7: 64 rows, 4 / 2) where eligible */
 } FnGruCell;
 int fn_gru_cell_f32(const FnGruCell* c, void* stream);
 

@@ -761,6 +761,9 @@ __global__ __launch_bounds__(NT, RT >= 4 ? 1 : 2) void gru_cell_direct_kernel(co
     // gate and item and the new state one 16-byte store (the element-per-lane form issued 7 scalar loads per (row, unit), 112 per lane).
     // All of them are requested HERE, in front of the K loops (plain loads: older than every ring load, so the counted waits cover them);
     // absent sources are not loaded (HAS_TAB / HAS_RB).
+    // (128-row form with both a token row and a row constant: the row constants would push the ring into AGPR copies - an asm-load
+    // destination must never be moved before its counted wait - so they are requested behind the K loops there)
+    constexpr bool RB_LATE = RT >= 4 && HAS_TAB && HAS_RB;
     const int er = lane >> 2, eu = u0 + 4 * (lane & 3);
     f32x4 bi[3], bh[3];
 #pragma unroll
@@ -781,13 +784,19 @@ __global__ __launch_bounds__(NT, RT >= 4 ? 1 : 2) void gru_cell_direct_kernel(co
 #pragma unroll
             for (int q = 0; q < 3; ++q) tv[m][q] = *reinterpret_cast<const f32x4*>(a.gx_table + (long)tok * H3 + q * a.H + eu);
         }
-        if (HAS_RB) {
+        if (HAS_RB && !RB_LATE) {
 #pragma unroll
             for (int q = 0; q < 3; ++q) rv[m][q] = *reinterpret_cast<const f32x4*>(a.gx_rowbias + (long)rc * H3 + q * a.H + eu);
         }
     }
     if (a.x) phase(a.x, a.ldx, a.w_ih, a.ldw_ih, a.K1 >> 4, anx);
     phase(a.h_prev, a.ldh, a.w_hh, a.ldw_hh, a.H >> 4, anh);
+    if (HAS_RB && RB_LATE) {
+#pragma unroll
+        for (int m = 0; m < RT; ++m)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) rv[m][q] = *reinterpret_cast<const f32x4*>(a.gx_rowbias + (long)min(rows[m], a.B - 1) * H3 + q * a.H + eu);
+    }
     __shared__ __attribute__((aligned(16))) float tr[4][4][16 * 20];     // [wave][tile of the row tile: r, z, n(x), n(h)][16 rows x (16 + 4 pad)]
     float* tw = &tr[wave][0][0];
 #pragma unroll
@@ -961,10 +970,10 @@ int fn_gru_cell_f32(const FnGruCell* c, void* stream) {
     if (c->variant == 0 && c->B > 512 && cell_direct_ok(a))
         return c->B > 1024 ? launch_cell_direct<4, 2>(a, (hipStream_t)stream) : launch_cell_direct<2, 4>(a, (hipStream_t)stream);
     switch (c->variant) {                                  // tuning / tests: the staged forms agree bit for bit, the LDS-free forms 4-7 among themselves (another k order)
-        case 4: if (cell_direct_ok(a)) return launch_cell_direct<4, 4>(a, (hipStream_t)stream); break;
+        case 4: if (cell_direct_ok(a)) return launch_cell_direct<4, 1>(a, (hipStream_t)stream); break;
         case 5: if (cell_direct_ok(a)) return launch_cell_direct<2, 4>(a, (hipStream_t)stream); break;
         case 6: if (cell_direct_ok(a)) return launch_cell_direct<4, 2>(a, (hipStream_t)stream); break;
-        case 7: if (cell_direct_ok(a)) return launch_cell_direct<2, 6>(a, (hipStream_t)stream); break;
+        case 7: if (cell_direct_ok(a)) return launch_cell_direct<2, 2>(a, (hipStream_t)stream); break;
         default: break;
     }
     switch (c->variant) {
