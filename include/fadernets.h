@@ -231,8 +231,22 @@ typedef struct FnGruCell {
     int32_t ldo;
     int32_t variant;          /* 0 = automatic.  Tuning / tests: 1-3, 8 force a staged tiling (8 = its default: 64 rows x 32 units), 4-7 the LDS-free
                                  loop (4, 6: 128 rows x 32 units per workgroup, 1 / 2 k steps in flight; 5, 7: 64 rows, 4 / 2) where eligible */
+    const uint64_t* idx_best; /* NULL, or the packed argmax words of the previous token (fn_out_argmax_f32): the token of row b is
+                                 best_v - 1 - (uint32_t)idx_best[b]; takes precedence over idx                                */
+    int32_t best_v;           /* vocabulary size the words were packed with                                                   */
 } FnGruCell;
 int fn_gru_cell_f32(const FnGruCell* c, void* stream);
+
+/* Output layer of the eval-mode decode with the argmax in its epilogue (gmm_model.py:137 + 73-80 when only the tokens are wanted; the
+ * log-softmax is monotone, so argmax(log_softmax(logits)) = argmax(logits)): for every row b
+ *     best[b] = max(best[b], max_v pack(h[b] . W[v] + bias[v], v)),   pack(x, v) = (uint64_t)key(x) << 32 | (uint32_t)(V - 1 - v),
+ *     key(x)  = bits(x) ^ (bits(x) >> 31 ? 0xffffffff : 0x80000000)                (order-preserving; first index wins a tie)
+ * by 64-bit atomic max: ZERO best[0 .. B) before the call; the logits are never written.  h [B][ldh], W [V][ldw] K-contiguous rows
+ * (the torch matrix), 16-byte aligned, K % 16 == 0, ldh % 4 == ldw % 4 == 0.  One launch, LDS-free loop (as fn_gru_cell_f32's).
+ * fn_best_tokens: tokens[b * tok_ld + t] = V - 1 - (uint32_t)best[t * B + b] for steps x B words. */
+int fn_out_argmax_f32(const float* h, int ldh, const float* W, int ldw, const float* bias, int B, int V, int K, uint64_t* best,
+                      void* stream);
+int fn_best_tokens(const uint64_t* best, int steps, int B, int V, int32_t* tokens, int tok_ld, void* stream);
 
 /* Backward of the same scans (autograd of nn.GRU / GRUCell in loss.backward(), trainer_gmm.py:249).
  *   dh_p = dh_ext[p] (+ dh_last at p = T-1) + carried gradient

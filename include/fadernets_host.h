@@ -55,6 +55,9 @@ int fn_pairwise_reg_host(const float* z0_all, const double* attr_all, int n_all,
                          float grad_scale, float* dz0, void* stream);                                    /* fn_pairwise_reg */
 /* eval-mode decode */
 int fn_gru_cell_f32_host(const FnGruCell* c, void* stream);                                              /* fn_gru_cell_f32 */
+int fn_out_argmax_f32_host(const float* h, int ldh, const float* W, int ldw, const float* bias, int B, int V, int K, uint64_t* best,
+                           void* stream);                                                                /* fn_out_argmax_f32 */
+int fn_best_tokens_host(const uint64_t* best, int steps, int B, int V, int32_t* tokens, int tok_ld, void* stream);   /* fn_best_tokens */
 size_t fn_decode_ws_bytes_host(int B, int H, int V);                                                     /* fn_decode_ws_bytes */
 size_t fn_decode_sync_ws_bytes_host(void);                                                               /* fn_decode_sync_ws_bytes */
 int fn_decode_greedy_host(const FnDecode* d, void* stream);                                              /* fn_decode_greedy */

@@ -58,7 +58,8 @@ class FnColsumJob(C.Structure):
 class FnGruCell(C.Structure):
     _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("x", vp), ("ldx", C.c_int32), ("K1", C.c_int32), ("w_ih", vp), ("ldw_ih", C.c_int32),
                 ("gx_table", vp), ("idx", vp), ("idx_ld", C.c_int32), ("start_token", C.c_int32), ("gx_rowbias", vp), ("h_prev", vp),
-                ("ldh", C.c_int32), ("w_hh", vp), ("ldw_hh", C.c_int32), ("b_ih", vp), ("b_hh", vp), ("h_out", vp), ("ldo", C.c_int32), ("variant", C.c_int32)]
+                ("ldh", C.c_int32), ("w_hh", vp), ("ldw_hh", C.c_int32), ("b_ih", vp), ("b_hh", vp), ("h_out", vp), ("ldo", C.c_int32), ("variant", C.c_int32),
+                ("idx_best", vp), ("best_v", C.c_int32)]
 
 
 class FnWeightImage(C.Structure):
@@ -94,6 +95,8 @@ SIGNATURES = {
     "fn_gru_sync_ws_bytes": (C.c_size_t, []),
     "fn_gru_seq_fwd": (C.c_int, [C.POINTER(FnGruFwd), C.c_int, vp]),
     "fn_gru_cell_f32": (C.c_int, [C.POINTER(FnGruCell), vp]),
+    "fn_out_argmax_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "fn_best_tokens": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     "fn_gru_seq_bwd": (C.c_int, [C.POINTER(FnGruBwd), C.c_int, vp]),
     "fn_decode_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "fn_decode_sync_ws_bytes": (C.c_size_t, []),

@@ -547,6 +547,10 @@ struct CellArgs {
     const float* b_ih; const float* b_hh;            // [3H] (b_ih may be NULL)
     float* h_out; long ldo;
     int B, H;
+    const unsigned long long* best; int best_v;      // optional packed argmax words of the previous token (fn_out_argmax_f32)
+    FN_DEVINL int token(int rc) const {
+        return best ? best_v - 1 - (int)(unsigned)(best[rc] & 0xffffffffull) : (idx ? idx[(long)rc * idx_ld] : tok_const);
+    }
 };
 
 constexpr int GC_BN = 96, GC_BK = 32;
@@ -623,7 +627,7 @@ __global__ __launch_bounds__(NT, 2) void gru_cell_kernel(const CellArgs a) {
         for (int i = 0; i < 4; ++i) {
             const int row = m0 + arow0 + 16 * m + rq + i;
             const int rc = min(row, a.B - 1);
-            const int tok = (has_tab && a.idx) ? a.idx[(long)rc * a.idx_ld] : a.tok_const;
+            const int tok = has_tab ? a.token(rc) : 0;
             const long toff = has_tab ? (long)tok * H3 : 0, roff = has_rb ? (long)rc * H3 : 0;
             float tv[UT][3], rv[UT][3], hv[UT];
 #pragma unroll
@@ -780,7 +784,7 @@ __global__ __launch_bounds__(NT, RT >= 4 ? 1 : 2) void gru_cell_direct_kernel(co
         const int rc = min(rows[m], a.B - 1);
         hv[m] = *reinterpret_cast<const f32x4*>(a.h_prev + (long)rc * a.ldh + eu);
         if (HAS_TAB) {
-            const int tok = a.idx ? a.idx[(long)rc * a.idx_ld] : a.tok_const;
+            const int tok = a.token(rc);
 #pragma unroll
             for (int q = 0; q < 3; ++q) tv[m][q] = *reinterpret_cast<const f32x4*>(a.gx_table + (long)tok * H3 + q * a.H + eu);
         }
@@ -832,6 +836,242 @@ __global__ __launch_bounds__(NT, RT >= 4 ? 1 : 2) void gru_cell_direct_kernel(co
             o[c] = (1.0f - z) * n + z * hv[m][c];
         }
         if (rows[m] < a.B) *reinterpret_cast<f32x4*>(a.h_out + (long)rows[m] * a.ldo + eu) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Output layer of the large-batch decode with the argmax in its epilogue (fn_out_argmax_f32): the same LDS-free loop; a wave owns
+// 16 rows x 48 vocabulary columns (weight rows past V are the last row again, masked below), a workgroup 2 x 2 waves = 32 rows x 96
+// columns - 256 workgroups at 2048 rows.  Lane (li, lg) ends up with the logits of rows 4 lg + i, columns n0 + 16 q + li: the best
+// packed word of its three columns per row, a 16-lane butterfly over li, one 64-bit atomic max per row and wave.  The staged GEMM
+// took 16 us for this 0.7-GFLOP product (16 barrier-separated tiles) and the separate argmax kernel 5 us per token.
+FN_DEVINL unsigned long long fn_pack_best(float x, int v, int V) {
+    const unsigned b = __float_as_uint(x);
+    const unsigned key = b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+    return ((unsigned long long)key << 32) | (unsigned)(V - 1 - v);
+}
+
+template <int PF>
+__global__ __launch_bounds__(NT, 2) void out_argmax_direct_kernel(const float* __restrict__ h, long ldh, const float* __restrict__ W, long ldw,
+                                                                 const float* __restrict__ bias, int B, int V, int K,
+                                                                 unsigned long long* __restrict__ best) {
+    const int ncb = (V + 95) / 96;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = (blockIdx.x / ncb) * 32 + (wave >> 1) * 16, n0 = (blockIdx.x % ncb) * 96 + (wave & 1) * 48;
+    const int li = lane & 15, lg = lane >> 4;
+    f32x4 acc[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned oa = (unsigned)(((long)min(m0 + li, B - 1) * ldh + 4 * lg) * 4);
+    unsigned ob[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) ob[q] = (unsigned)(((long)min(n0 + 16 * q + li, V - 1) * ldw + 4 * lg) * 4);
+    f32x4 fa[PF], fb[PF][3];
+    const float* pa = h;
+    const float* pb = W;
+    auto load = [&](int set) {
+        fn_gld4_sb(fa[set], oa, pa);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) fn_gld4_sb(fb[set][q], ob[q], pb);
+        pa += 16;
+        pb += 16;
+    };
+    auto mma = [&](int u) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][j], fb[u][q][j], acc[q], 0, 0, 0);
+    };
+    auto keep = [&](int set) {
+        fn_keep(fa[set]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) fn_keep(fb[set][q]);
+    };
+    const int nks = K >> 4, nmain = nks / PF * PF;
+    if (nmain > 0) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) load(s);
+        for (int base = 0; base + PF < nmain; base += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                fn_wait_vm<4 * (PF - 1)>();
+                mma(u);
+                load(u);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if (u == 0) fn_wait_vm<4 * (PF - 1)>();
+            else if (u == 1 && PF > 1) fn_wait_vm<(PF > 1 ? 4 * (PF - 2) : 0)>();
+            else if (u == 2 && PF > 2) fn_wait_vm<(PF > 2 ? 4 * (PF - 3) : 0)>();
+            else fn_wait_vm<0>();
+            mma(u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int s = 0; s < PF; ++s) keep(s);
+    }
+    for (int ks = nmain; ks < nks; ++ks) {
+        load(0);
+        fn_wait_vm<0>();
+        mma(0);
+        keep(0);
+    }
+    float bv[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) bv[q] = bias[min(n0 + 16 * q + li, V - 1)];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned long long w = 0ull;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int col = n0 + 16 * q + li;
+            const unsigned long long c = col < V ? fn_pack_best(acc[q][i] + bv[q], col, V) : 0ull;
+            w = c > w ? c : w;
+        }
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const unsigned lo = __shfl_xor((unsigned)(w & 0xffffffffull), d, 64), hi = __shfl_xor((unsigned)(w >> 32), d, 64);
+            const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+            w = o > w ? o : w;
+        }
+        const int row = m0 + 4 * lg + i;
+        if (li == 0 && row < B) atomicMax(best + row, w);
+    }
+}
+
+// The same product with the WEIGHT operand resident in LDS: the LDS-free loops of this file all run at about 8 TB/s of operand loads
+// (16 rows x 64 bytes per instruction), and at 16 x 48 outputs per wave that is 134 MB per launch - 17.6 us, no faster than the
+// staged GEMM.  Here a workgroup owns 64 rows x 48 columns: its 48 weight rows (48 x K floats, 96 KB at K = 512) are laid out once as
+// MFMA fragments [k step][column tile][lane] (16-byte LDS reads, conflict-free), only the state rows are read from memory in the loop
+// (one 16-byte load per lane and 12 MFMAs, PF steps in flight).
+template <int PF>
+__global__ __launch_bounds__(NT) void out_argmax_lds_kernel(const float* __restrict__ h, long ldh, const float* __restrict__ W, long ldw,
+                                                            const float* __restrict__ bias, int B, int V, int K,
+                                                            unsigned long long* __restrict__ best) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    f32x4* wl = reinterpret_cast<f32x4*>(dsm);       // [K / 16][3][64]
+    const int ncb = (V + 47) / 48;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = (blockIdx.x / ncb) * 64 + wave * 16, n0 = (blockIdx.x % ncb) * 48;
+    const int li = lane & 15, lg = lane >> 4;
+    const int nks = K >> 4;
+    const unsigned oa = (unsigned)(((long)min(m0 + li, B - 1) * ldh + 4 * lg) * 4);
+    f32x4 fa[PF];
+    const float* pa = h;
+    auto load = [&](int set) {
+        fn_gld4_sb(fa[set], oa, pa);
+        pa += 16;
+    };
+    const int npro = min(PF, nks);
+#pragma unroll
+    for (int s = 0; s < PF; ++s)
+        if (s < npro) load(s);
+    // weight fragments: item (row r of 48, k quad c of K / 4) -> step c >> 2, tile r >> 4, lane group c & 3, slot (r & 15) rotated; consecutive threads read one row
+    const int kq = K >> 2;
+    // eight independent 16-byte loads per thread in flight, then their eight LDS writes (a load -> write pair per iteration serialised 24
+    // memory latencies: 7.4 us of a 19 us launch); (row, quad) advance by NT items without a division
+    const int total = 48 * kq, dq = NT / kq, dr = NT % kq;
+    int fr = threadIdx.x / kq, fc = threadIdx.x % kq;
+    for (int base = threadIdx.x; base < total; base += NT * 8) {
+        f32x4 v[8];
+        int rr[8], cc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            rr[u] = fr;
+            cc[u] = fc;
+            v[u] = *reinterpret_cast<const f32x4*>(W + (long)min(n0 + min(fr, 47), V - 1) * ldw + 4 * fc);
+            fc += dr;
+            fr += dq;
+            if (fc >= kq) { fc -= kq; ++fr; }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = rr[u], c = cc[u];
+            if (r < 48) wl[(c >> 2) * 192 + (r >> 4) * 64 + (c & 3) * 16 + (((r & 15) + 4 * (c & 3) + (c >> 2)) & 15)] = v[u];     // slot rotated by the k quad: 16 consecutive quads of a row hit 16 bank groups
+        }
+    }
+    __syncthreads();
+    f32x4 acc[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](int u, int s) {
+        const int sl = lg * 16 + ((li + 4 * lg + s) & 15);
+        const f32x4 b0 = wl[s * 192 + sl], b1 = wl[s * 192 + 64 + sl], b2 = wl[s * 192 + 128 + sl];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][j], b0[j], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][j], b1[j], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][j], b2[j], acc[2], 0, 0, 0);
+        }
+    };
+    // the plain loads of the fill are older than nothing of the ring that is still needed: every counted wait below also covers them
+    const int nmain = nks / PF * PF;
+    int s = 0;
+    if (nmain > 0) {
+        for (; s + PF < nmain; s += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                fn_wait_vm<PF - 1>();
+                mma(u, s + u);
+                load(u);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // the ring holds steps s .. s + PF - 1
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if (u == 0) fn_wait_vm<PF - 1>();
+            else if (u == 1 && PF > 1) fn_wait_vm<(PF > 1 ? PF - 2 : 0)>();
+            else if (u == 2 && PF > 2) fn_wait_vm<(PF > 2 ? PF - 3 : 0)>();
+            else fn_wait_vm<0>();
+            mma(u, s + u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        s += PF;
+    } else {
+        fn_wait_vm<0>();                             // fewer steps than ring slots (K < 16 PF)
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+            if (u < npro) mma(u, u);
+        s = npro;
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) fn_keep(fa[u]);
+    for (; s < nks; ++s) {                           // < PF leftover steps, unpipelined
+        load(0);
+        fn_wait_vm<0>();
+        mma(0, s);
+        fn_keep(fa[0]);
+    }
+    float bv[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) bv[q] = bias[min(n0 + 16 * q + li, V - 1)];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned long long w = 0ull;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int col = n0 + 16 * q + li;
+            const unsigned long long c = col < V ? fn_pack_best(acc[q][i] + bv[q], col, V) : 0ull;
+            w = c > w ? c : w;
+        }
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const unsigned lo = __shfl_xor((unsigned)(w & 0xffffffffull), d, 64), hi = __shfl_xor((unsigned)(w >> 32), d, 64);
+            const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+            w = o > w ? o : w;
+        }
+        const int row = m0 + 4 * lg + i;
+        if (li == 0 && row < B) atomicMax(best + row, w);
+    }
+}
+
+__global__ __launch_bounds__(256) void best_tokens_kernel(const unsigned long long* __restrict__ best, long n, int B, int V, int* __restrict__ tokens, long tok_ld) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+        const long t = i / B, b = i - t * B;
+        tokens[b * tok_ld + t] = V - 1 - (int)(unsigned)(best[i] & 0xffffffffull);
     }
 }
 
@@ -965,6 +1205,8 @@ int fn_gru_cell_f32(const FnGruCell* c, void* stream) {
     a.gx_table = c->gx_table; a.idx = c->idx; a.idx_ld = c->idx_ld; a.tok_const = c->start_token; a.gx_rowbias = c->gx_rowbias;
     a.h_prev = c->h_prev; a.ldh = c->ldh; a.w_hh = c->w_hh; a.ldw_hh = c->ldw_hh; a.b_ih = c->b_ih; a.b_hh = c->b_hh;
     a.h_out = c->h_out; a.ldo = c->ldo; a.B = c->B; a.H = c->H;
+    a.best = reinterpret_cast<const unsigned long long*>(c->idx_best); a.best_v = c->best_v;
+    if (c->idx_best && (c->best_v <= 0 || !c->gx_table)) return FN_E_SHAPE;
     // measured (scratch/prof_decode_cells.sh, us per token of the 4-launch decode): 2048 rows 125 staged / 111 LDS-free 128-row form / 143 64-row form;
     // 1536 rows 125 / 110 / 142; 1024 rows 82 / 104 / 80; 800 rows 82 / 104 / 80
     if (c->variant == 0 && c->B > 512 && cell_direct_ok(a))
@@ -982,6 +1224,47 @@ int fn_gru_cell_f32(const FnGruCell* c, void* stream) {
         case 3: return launch_cell<64, 4, 1>(a, (hipStream_t)stream);
         default: return launch_cell<64, 2, 2>(a, (hipStream_t)stream);
     }
+}
+
+static bool fn_out_argmax_force_direct = getenv("FN_OUT_ARGMAX_DIRECT") != nullptr;     // measurements: the LDS-free form
+int fn_out_argmax_f32(const float* h, int ldh, const float* W, int ldw, const float* bias, int B, int V, int K, uint64_t* best, void* stream) {
+    if (!h || !W || !bias || !best) return FN_E_NULL;
+    if (B <= 0 || V <= 0 || K <= 0 || (K % 16) != 0 || ldh < K || ldw < K || (ldh & 3) || (ldw & 3)) return FN_E_SHAPE;
+    if ((long)B * ldh * 4 >= (1L << 32) || (long)V * ldw * 4 >= (1L << 32)) return FN_E_SHAPE;
+    if (((((uintptr_t)h) | ((uintptr_t)W)) & 15) || (((uintptr_t)best) & 7)) return FN_E_ALIGN;
+    const size_t lds = (size_t)48 * K * sizeof(float);
+    if (lds <= (size_t)128 * 1024 && !fn_out_argmax_force_direct) {          // weight slice of a workgroup resident in LDS
+        static std::atomic<bool> attr_set[32];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return FN_E_SHAPE;
+        auto k = out_argmax_lds_kernel<8>;
+        if (!attr_set[dev].load(std::memory_order_acquire)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr_set[dev].store(true, std::memory_order_release);
+        }
+        const int grid = ((B + 63) / 64) * ((V + 47) / 48);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, (hipStream_t)stream, h, (long)ldh, W, (long)ldw, bias, B, V, K,
+                           reinterpret_cast<unsigned long long*>(best));
+        FN_CHECK_LAUNCH();
+        return FN_OK;
+    }
+    const int grid = ((B + 31) / 32) * ((V + 95) / 96);
+    hipLaunchKernelGGL((out_argmax_direct_kernel<4>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, h, (long)ldh, W, (long)ldw, bias, B, V, K,
+                       reinterpret_cast<unsigned long long*>(best));
+    FN_CHECK_LAUNCH();
+    return FN_OK;
+}
+
+int fn_best_tokens(const uint64_t* best, int steps, int B, int V, int32_t* tokens, int tok_ld, void* stream) {
+    if (!best || !tokens) return FN_E_NULL;
+    if (steps <= 0 || B <= 0 || V <= 0 || tok_ld < steps) return FN_E_SHAPE;
+    const long n = (long)steps * B;
+    const long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(best_tokens_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const unsigned long long*>(best), n, B, V, tokens, (long)tok_ld);
+    FN_CHECK_LAUNCH();
+    return FN_OK;
 }
 
 size_t fn_gru_gates_floats(int B, int H) { return (size_t)4 * H * (((size_t)B + 15) / 16 * 16); }

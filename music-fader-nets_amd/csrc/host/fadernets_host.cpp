@@ -505,11 +505,12 @@ int fn_gru_cell_f32_host(const FnGruCell* c, void*) {
     if (c->B <= 0 || c->H <= 0 || (c->H % 32) != 0 || c->ldh < c->H || c->ldo < c->H || c->ldw_hh < c->H) return FN_E_SHAPE;
     if (c->x && (!c->w_ih || c->K1 <= 0 || c->ldx < c->K1 || c->ldw_ih < c->K1)) return FN_E_SHAPE;
     if (c->h_out == c->h_prev) return FN_E_SHAPE;
+    if (c->idx_best && (c->best_v <= 0 || !c->gx_table)) return FN_E_SHAPE;
     const int B = c->B, H = c->H;
     std::vector<float> gi(3 * (size_t)H), gh(3 * (size_t)H);
     for (int b = 0; b < B; ++b) {
         const float* hp = c->h_prev + (long)b * c->ldh;
-        const int tok = c->idx ? c->idx[(long)b * c->idx_ld] : c->start_token;
+        const int tok = c->idx_best ? c->best_v - 1 - (int)(uint32_t)(c->idx_best[b] & 0xffffffffull) : (c->idx ? c->idx[(long)b * c->idx_ld] : c->start_token);
         for (int j = 0; j < 3 * H; ++j) {
             float a = 0.0f;
             for (int k = 0; k < H; ++k) a = std::fmaf(hp[k], c->w_hh[(long)j * c->ldw_hh + k], a);
@@ -529,6 +530,31 @@ int fn_gru_cell_f32_host(const FnGruCell* c, void*) {
             c->h_out[(long)b * c->ldo + u] = (1.0f - z) * n + z * hp[u];
         }
     }
+    return FN_OK;
+}
+
+int fn_out_argmax_f32_host(const float* h, int ldh, const float* W, int ldw, const float* bias, int B, int V, int K, uint64_t* best, void*) {
+    if (!h || !W || !bias || !best) return FN_E_NULL;
+    if (B <= 0 || V <= 0 || K <= 0 || (K % 16) != 0 || ldh < K || ldw < K || (ldh & 3) || (ldw & 3)) return FN_E_SHAPE;
+    for (int b = 0; b < B; ++b)
+        for (int v = 0; v < V; ++v) {
+            float a = 0.0f;
+            for (int k = 0; k < K; ++k) a = std::fmaf(h[(long)b * ldh + k], W[(long)v * ldw + k], a);
+            a += bias[v];
+            uint32_t bits;
+            std::memcpy(&bits, &a, 4);
+            const uint32_t key = bits ^ ((bits >> 31) ? 0xffffffffu : 0x80000000u);
+            const uint64_t w = ((uint64_t)key << 32) | (uint32_t)(V - 1 - v);
+            if (w > best[b]) best[b] = w;
+        }
+    return FN_OK;
+}
+
+int fn_best_tokens_host(const uint64_t* best, int steps, int B, int V, int32_t* tokens, int tok_ld, void*) {
+    if (!best || !tokens) return FN_E_NULL;
+    if (steps <= 0 || B <= 0 || V <= 0 || tok_ld < steps) return FN_E_SHAPE;
+    for (int t = 0; t < steps; ++t)
+        for (int b = 0; b < B; ++b) tokens[(long)b * tok_ld + t] = V - 1 - (int)(uint32_t)(best[(long)t * B + b] & 0xffffffffull);
     return FN_OK;
 }
 

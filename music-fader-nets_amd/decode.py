@@ -18,7 +18,8 @@ def greedy_decode(model, z, steps, want_logp=True, use_graph=None):
     Bi <= Engine.single_launch_rows: ONE launch for the whole decode (fn_decode_greedy; above 32 rows a pipeline of 32- / 64-row blocks through
     its role workgroups).  Larger batches: steps x {layer-1 cell, W_ih2 projection,
     layer-2 cell, output GEMM, log_softmax+argmax} (from Engine.cell_decode_rows sequences on: steps x {layer-1 cell, layer-2 cell incl.
-    its projection - fn_gru_cell_f32 -, output GEMM, argmax}) captured once per (Bi, steps) into a hipGraph and replayed.  The captured
+    its projection - fn_gru_cell_f32 -, output GEMM, argmax}; with want_logp=False: {layer-1 cell, layer-2 cell, output layer with the
+    argmax in its epilogue - fn_out_argmax_f32}) captured once per (Bi, steps) into a hipGraph and replayed.  The captured
     kernels read the parameters and the engine's weight images IN PLACE (stable addresses, refreshed by Engine.refresh_weights
     after every optimiser step / load_state_dict), so a graph stays valid when the weights change."""
     eng = model.engine()
@@ -102,14 +103,27 @@ def _decode_body(eng, z, steps, want_logp, logp, tokens):
     if Bi >= eng.cell_decode_rows:
         # thousands of rows: every cell is ONE MFMA launch with the gates in its epilogue (fn_gru_cell_f32: LDS-free loop above 512 rows); layer 2 takes its input
         # projection in the same K loop - 3 launches + argmax per token instead of 4 + argmax, and no [B][3H] round trip
+        # tokens only (the evaluators' sweeps): the output layer takes the argmax into its epilogue (fn_out_argmax_f32: packed (logit, column)
+        # words by 64-bit atomic max, no logits, no argmax launch) and the next layer-1 cell reads its token from the packed word -
+        # 3 launches per token; the int32 tokens are unpacked once at the end
+        fused = not want_logp and getattr(eng, "fused_argmax", True) and hasattr(ops, "out_argmax")
+        best = eng.buf("dec_best", (steps, Bi), dtype=torch.int64) if fused else None
+        if fused:
+            best.zero_()
         for i in range(steps):
             cur, prv = i & 1, (i & 1) ^ 1
+            tok_src = dict(idx_best=best[i - 1], best_v=E_VOCAB) if fused and i > 0 else dict(idx=tokens[:, i - 1] if i > 0 else None)
             ops.gru_cell(h0g if i == 0 else hx0[prv][0], P["grucell_g.weight_hh"], P["grucell_g.bias_hh"], hx0[cur][0], b_ih=P["grucell_g.bias_ih"],
-                         gx_table=eng.tab["g"], idx=tokens[:, i - 1] if i > 0 else None, start_token=E_VOCAB - 1, gx_rowbias=rbg)
+                         gx_table=eng.tab["g"], start_token=E_VOCAB - 1, gx_rowbias=rbg, **tok_src)
             ops.gru_cell(hx0[cur][0] if i == 0 else hx1[prv][0], P["grucell_g_2.weight_hh"], P["grucell_g_2.bias_hh"], hx1[cur][0],
                          x=hx0[cur][0], w_ih=P["grucell_g_2.weight_ih"], b_ih=P["grucell_g_2.bias_ih"])
-            ops.gemm(hx1[cur][0], P["linear_out_g.weight"], logits[:, :E_VOCAB], bias=P["linear_out_g.bias"])
-            ops.vocab_argmax(logits, E_VOCAB, logp[:, i, :] if want_logp else None, tokens[:, i])
+            if fused:
+                ops.out_argmax(hx1[cur][0], P["linear_out_g.weight"], P["linear_out_g.bias"], best[i])
+            else:
+                ops.gemm(hx1[cur][0], P["linear_out_g.weight"], logits[:, :E_VOCAB], bias=P["linear_out_g.bias"])
+                ops.vocab_argmax(logits, E_VOCAB, logp[:, i, :] if want_logp else None, tokens[:, i])
+        if fused:
+            ops.best_tokens(best, E_VOCAB, tokens)
         return logp, tokens
     for i in range(steps):
         cur, prv = i & 1, (i & 1) ^ 1

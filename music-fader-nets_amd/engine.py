@@ -49,6 +49,7 @@ class Engine:
         self.single_launch_decode = True   # decode.py: small / medium batches decode as ONE launch (False: per-token kernels; tests)
         self.single_launch_rows = 1408     # ... up to this many sequences (fn_decode_greedy takes <= 2048; 32-row blocks below 353 rows, 64-row blocks from there; measured us per token, one launch vs the per-token cells (scratch/decode_crossover.py, round 4): 512 rows 41 / 81, 800 rows 70 / 80, 1024 rows 80 / 80, 1280 rows 99 / 105, 1408 rows 108 / 109, 1536 rows 119 / 109, 2048 rows 157 / 111); above: fn_gru_cell_f32 per token
         self._lane_alias = {}           # lane -> lane it is folded into (debug)
+        self.fused_argmax = True        # decode.py, tokens-only decode on the per-token cells: output layer + argmax as ONE launch (fn_out_argmax_f32); False: GEMM + fn_vocab_argmax (tests)
         self.cell_decode_rows = 768     # decode.py: from this many sequences on, the per-token cells are one-launch GEMM cells (fn_gru_cell_f32: LDS-free loop above 512 rows, staged below); measured crossover against the scan-step kernels (scratch/bench_decode_rows.py): 512 rows 67 vs 87 us per token, 768 rows 97 vs 88
         self.fused_head = True          # trainers: output projection + log-softmax + NLL + gradient seed as ONE kernel (fn_out_head_f32); False: GEMM -> logits in HBM -> fn_vocab_logsoftmax
         self.lean_dw = False            # decoder-side weight-gradient GEMMs as the <= 128-register instance.  Paid while an encoder-scan wavefront left 138 of a SIMD's 512 registers free (round 2: 9 % packing gain); the hand-placed K loops hold all of them, the side lane's GEMMs run once the scan has ended and the 194-register instance is the faster one (A/B in one session, scratch/ab_dw.py: 23.65 vs 24.29 ms per step)

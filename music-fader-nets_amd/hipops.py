@@ -287,10 +287,12 @@ class HipOps:
             raise RuntimeError("frag3_pack: dst too small")
         _lib.check(self.lib.fn_frag3_pack(ps, R, K, ld, _p(dst), self.stream()), "fn_frag3_pack")
 
-    def gru_cell(self, h_prev, w_hh, b_hh, h_out, x=None, w_ih=None, b_ih=None, gx_table=None, idx=None, start_token=0, gx_rowbias=None, variant=None):
+    def gru_cell(self, h_prev, w_hh, b_hh, h_out, x=None, w_ih=None, b_ih=None, gx_table=None, idx=None, start_token=0, gx_rowbias=None, variant=None,
+                 idx_best=None, best_v=0):
         """one GRUCell step of a large batch (fn_gru_cell_f32): h_out [B][H] from h_prev [B][H], optional dense input x [B][K1] with the
         torch matrix w_ih [3H][K1], optional token rows gx_table [V][3H] picked by idx (a [B] int32 column view, e.g. tokens[:, i - 1];
-        None = start_token) and per-row constants gx_rowbias [B][3H]; w_hh [3H][H] is the torch matrix itself"""
+        None = start_token; or idx_best: the [B] int64 packed argmax words out_argmax left for the previous token, packed with best_v
+        columns) and per-row constants gx_rowbias [B][3H]; w_hh [3H][H] is the torch matrix itself"""
         c = _lib.FnGruCell()
         ph, B, H, ldh = _mat(h_prev, "h_prev")
         pw, r3, Hw, ldw = _mat(w_hh, "w_hh")
@@ -311,7 +313,29 @@ class HipOps:
             if idx.dtype != torch.int32 or idx.dim() != 1 or idx.shape[0] != B:
                 raise RuntimeError("gru_cell: idx must be a [B] int32 column")
             c.idx, c.idx_ld = idx.data_ptr(), idx.stride(0)
+        if idx_best is not None:
+            if idx_best.dtype != torch.int64 or idx_best.dim() != 1 or idx_best.shape[0] != B or not idx_best.is_contiguous():
+                raise RuntimeError("gru_cell: idx_best must be a contiguous [B] int64 row")
+            c.idx_best, c.best_v = idx_best.data_ptr(), int(best_v)
         _lib.check(self.lib.fn_gru_cell_f32(C.byref(c), self.stream()), "fn_gru_cell_f32")
+
+    def out_argmax(self, h, W, bias, best):
+        """fn_out_argmax_f32: best[b] = max(best[b], packed (logit, column) words of h[b] W^T + bias) - best: a ZEROED contiguous [B] int64 row"""
+        ph, B, K, ldh = _mat(h, "h")
+        pw, V, Kw, ldw = _mat(W, "W")
+        _dense(bias, name="bias")
+        if Kw != K or bias.numel() != V or best.dtype != torch.int64 or best.dim() != 1 or best.shape[0] != B or not best.is_contiguous():
+            raise RuntimeError("out_argmax shape mismatch h%s W%s best%s" % (tuple(h.shape), tuple(W.shape), tuple(best.shape)))
+        _lib.check(self.lib.fn_out_argmax_f32(ph, ldh, pw, ldw, _p(bias), B, V, K, best.data_ptr(), self.stream()), "fn_out_argmax_f32")
+
+    def best_tokens(self, best, V, tokens):
+        """fn_best_tokens: best [steps][B] int64 packed words -> tokens [B][steps] int32 (row stride tokens.stride(0))"""
+        if best.dtype != torch.int64 or best.dim() != 2 or not best.is_contiguous() or tokens.dtype != torch.int32 or tokens.dim() != 2:
+            raise RuntimeError("best_tokens: best [steps][B] int64, tokens [B][>= steps] int32")
+        steps, B = best.shape
+        if tokens.shape[0] != B or tokens.shape[1] < steps or tokens.stride(1) != 1:
+            raise RuntimeError("best_tokens: tokens%s does not take %d x %d words" % (tuple(tokens.shape), steps, B))
+        _lib.check(self.lib.fn_best_tokens(best.data_ptr(), steps, B, int(V), tokens.data_ptr(), tokens.stride(0), self.stream()), "fn_best_tokens")
 
     def gru_seq_bwd(self, scans, persistent=True, cu_budget=0, variant=None):
         arr = (_lib.FnGruBwd * len(scans))()

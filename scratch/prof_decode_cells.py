@@ -14,6 +14,7 @@ eng.single_launch_decode, eng.cell_decode_rows = False, 1
 eng.ops.cell_variant = variant
 z = torch.randn(Bi, 280, device=dev)
 steps = 100
+eng.fused_argmax = os.environ.get("FUSED", "1") == "1"
 for _ in range(2): pkg.greedy_decode(m, z, steps, want_logp=False)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(3): pkg.greedy_decode(m, z, steps, want_logp=False)

@@ -139,8 +139,11 @@ class FakeOps:
             if s.get("dh0") is not None:
                 s["dh0"].copy_(carry)
 
-    def gru_cell(self, h_prev, w_hh, b_hh, h_out, x=None, w_ih=None, b_ih=None, gx_table=None, idx=None, start_token=0, gx_rowbias=None, variant=None):
+    def gru_cell(self, h_prev, w_hh, b_hh, h_out, x=None, w_ih=None, b_ih=None, gx_table=None, idx=None, start_token=0, gx_rowbias=None, variant=None,
+                 idx_best=None, best_v=0):
         B, H = h_prev.shape
+        if idx_best is not None:
+            idx = (best_v - 1 - (idx_best & 0xffffffff)).to(torch.int32)
         gi = torch.zeros(B, 3 * H)
         if x is not None:
             gi = gi + x @ w_ih.t()
@@ -230,6 +233,22 @@ class FakeOps:
         B, T, E = logp_bt.shape
         g = gout_bt - logp_bt.exp() * gout_bt.sum(-1, keepdim=True)
         dlogits[:, :E].copy_(g.permute(1, 0, 2).reshape(T * B, E))
+
+    def out_argmax(self, h, W, bias, best):
+        """fn_out_argmax_f32 semantics: packed (order-preserving key of the logit) << 32 | (V - 1 - column), max-combined into best"""
+        V = W.shape[0]
+        logits = h @ W.t() + bias
+        bits = logits.contiguous().view(torch.int32).to(torch.int64) & 0xffffffff
+        key = torch.where(bits >> 31 != 0, bits ^ 0xffffffff, bits ^ 0x80000000)
+        words = (key << 32) | (V - 1 - torch.arange(V, dtype=torch.int64)).view(1, -1)
+        # unsigned comparison of 64-bit words held in int64: flip the sign bit
+        flip = torch.tensor(-0x8000000000000000, dtype=torch.int64)
+        m = ((words ^ flip).max(1)[0]) ^ flip
+        best.copy_(torch.where((best ^ flip) > (m ^ flip), best, m))
+
+    def best_tokens(self, best, V, tokens):
+        steps = best.shape[0]
+        tokens[:, :steps] = (V - 1 - (best & 0xffffffff)).t().to(torch.int32)
 
     def vocab_argmax(self, logits, E, logp_out, tok_out):
         lp = torch.log_softmax(logits[:, :E], dim=-1)

@@ -327,6 +327,37 @@ def test_c0_global_decoder_cells_and_greedy_decode(g, sd, dims):
     assert checked >= 0.9 * nb * steps
     d.steps = 0
     assert lib.fn_decode_greedy_host(C.byref(d), None) == L.FN_E_SHAPE
+    # the same decode on the per-token cells with the argmax packed by the output layer (fn_out_argmax_f32 -> FnGruCell.idx_best -> fn_best_tokens)
+    best = np.zeros((steps, nb), np.uint64)
+    s1, s2 = keep["h0"].copy(), None
+    for i in range(steps):
+        c = L.FnGruCell()
+        o1 = np.zeros((nb, H), np.float32)
+        c.B, c.H, c.gx_table, c.start_token = nb, H, P(table), 341
+        if i > 0:
+            c.idx_best, c.best_v = best[i - 1].ctypes.data, 342
+        c.gx_rowbias, c.h_prev, c.ldh, c.w_hh, c.ldw_hh = P(keep["rb"]), P(s1), H, P(sd["grucell_g.weight_hh"]), H
+        c.b_ih, c.b_hh, c.h_out, c.ldo = P(sd["grucell_g.bias_ih"]), P(sd["grucell_g.bias_hh"]), P(o1), H
+        assert lib.fn_gru_cell_f32_host(C.byref(c), None) == 0
+        s1 = o1
+        if i == 0:
+            s2 = s1.copy()
+        c2 = L.FnGruCell()
+        o2 = np.zeros((nb, H), np.float32)
+        c2.B, c2.H, c2.x, c2.ldx, c2.K1, c2.w_ih, c2.ldw_ih = nb, H, P(s1), H, H, P(sd["grucell_g_2.weight_ih"]), H
+        c2.h_prev, c2.ldh, c2.w_hh, c2.ldw_hh = P(s2), H, P(sd["grucell_g_2.weight_hh"]), H
+        c2.b_ih, c2.b_hh, c2.h_out, c2.ldo = P(sd["grucell_g_2.bias_ih"]), P(sd["grucell_g_2.bias_hh"]), P(o2), H
+        assert lib.fn_gru_cell_f32_host(C.byref(c2), None) == 0
+        s2 = o2
+        assert lib.fn_out_argmax_f32_host(P(s2), H, P(sd["linear_out_g.weight"]), H, P(sd["linear_out_g.bias"]), nb, 342, H, best[i].ctypes.data, None) == 0
+    tok2 = np.zeros((nb, steps), np.int32)
+    assert lib.fn_best_tokens_host(best.ctypes.data, steps, nb, 342, P(tok2), steps, None) == 0
+    for i in range(nb):
+        tight = np.nonzero(g["dec_gap"][i, :steps] < 1e-4)[0]
+        upto = int(tight[0]) if len(tight) else steps
+        assert np.array_equal(tok2[i, :upto], g["dec_tokens"][i, :upto]), (i, upto, tok2[i], g["dec_tokens"][i, :steps])
+    assert lib.fn_out_argmax_f32_host(None, H, None, H, None, nb, 342, H, None, None) == L.FN_E_NULL
+    assert lib.fn_best_tokens_host(best.ctypes.data, steps, nb, 342, P(tok2), steps - 1, None) == L.FN_E_SHAPE
     print("c0: teacher-forced decoder cells (%d steps) + greedy decode (%d x %d tokens, %d compared bit for bit) through the host twins OK" % (NS, nb, steps, checked))
 
 

@@ -900,6 +900,73 @@ def test_large_batch_decode_cells_match_per_token_kernels(H, Bi, steps):
     close(lp1[keep], lp0[keep], 2e-5)
 
 
+@pytest.mark.parametrize("B,V,K", [(2048, 342, 512), (77, 342, 512), (300, 50, 64), (33, 97, 48), (130, 342, 112), (70, 60, 1024)])
+def test_out_argmax_packed_words(ops, B, V, K):
+    """fn_out_argmax_f32 (output layer with the argmax in its epilogue: packed (logit, column) words by 64-bit atomic max) + fn_best_tokens
+    against the fp64 logits: the winning column wherever the fp64 top-2 gap is above 1e-4, the packed key = the order-preserving image of a
+    logit within 2e-5 of the fp64 one; ragged row / column tiles, K tails of the pipelined loop, exact ties -> first column, max-combining
+    with what the word already holds."""
+    torch.manual_seed(B + V)
+    h, W, bias = torch.randn(B, K), torch.randn(V, K) / K ** 0.5, torch.randn(V) * 0.1
+    W[V - 1] = W[3]
+    bias[V - 1] = bias[3]                                   # an exact tie between columns 3 and V - 1 in every row
+    ref = h.double() @ W.double().t() + bias.double()
+    best = torch.zeros(2, B, dtype=torch.int64, device=DEV)
+    ops.out_argmax(g(h), g(W), g(bias), best[0])
+    best[1].fill_(-1)                                       # the all-ones word is above every packed logit and stays
+    best[1, : B // 2] = 0
+    ops.out_argmax(g(h), g(W), g(bias), best[1])
+    tok = torch.full((B, 3), -1, dtype=torch.int32, device=DEV)
+    ops.best_tokens(best, V, tok)
+    assert int(tok[:, 2].min()) == -1 and int(tok[:, 2].max()) == -1
+    got = tok[:, 0].cpu().long()
+    top2 = ref.topk(2, dim=1)
+    clear = (top2.values[:, 0] - top2.values[:, 1]) > 1e-4
+    assert float(clear.float().mean()) > 0.9
+    assert torch.equal(got[clear], top2.indices[:, 0][clear])
+    assert int((got == V - 1).sum()) == 0                   # the tie goes to column 3
+    key = (best[0].cpu() >> 32) & 0xffffffff
+    bits = torch.where(key >> 31 != 0, key ^ 0x80000000, key ^ 0xffffffff).to(torch.int32)
+    val = bits.view(torch.float32)
+    close(val, ref.gather(1, got.view(-1, 1)).squeeze(1).float(), 2e-5, "packed logit")
+    assert torch.equal(tok[: B // 2, 1], tok[: B // 2, 0]) and bool((best[1, B // 2:] == -1).all())
+
+
+def test_tokens_only_decode_on_the_cells_fused_argmax():
+    """greedy_decode(want_logp=False) on the per-token cells (2048 rows, hidden 512): output layer + argmax as one launch, the next cell reads
+    its token from the packed word - against the same path with the GEMM + fn_vocab_argmax launches (Engine.fused_argmax = False) up to each
+    row's first near-tie, bit-reproducible, and directly against the oracle."""
+    from oracle import gmvae_oracle as orc
+    pkg = load_package()
+    m = make_model(512, 128, device=DEV, seed=1234)
+    m.eval()
+    torch.manual_seed(22)
+    Bi, steps = 2048, 20
+    z = torch.randn(Bi, 2 * m.latent_dim + 24)
+    eng = m.engine()
+    eng.single_launch_decode, eng.cell_decode_rows = False, 768
+    _, tk = pkg.greedy_decode(m, z.to(DEV), steps, want_logp=False)
+    _, tk2 = pkg.greedy_decode(m, z.to(DEV), steps, want_logp=False)
+    assert torch.equal(tk, tk2) and int(tk.min()) >= 0 and int(tk.max()) < 342
+    eng.fused_argmax = False
+    lp0, tk0 = pkg.greedy_decode(m, z.to(DEV), steps, want_logp=True)
+    eng.fused_argmax = True
+    gap = lp0.topk(2, dim=-1).values
+    unclear = (gap[..., 0] - gap[..., 1]) <= 1e-4
+    first = torch.where(unclear.any(1), unclear.float().argmax(1), torch.full((Bi,), steps, device=DEV))
+    keep = torch.arange(steps, device=DEV).view(1, -1) < first.view(-1, 1)
+    assert float(keep.float().mean()) > 0.95
+    assert torch.equal(tk[keep], tk0[keep])
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    ref_lp, ref_tk = orc.greedy_decode(sd, z[:256], steps)
+    top2 = ref_lp.topk(2, dim=-1).values
+    unc = (top2[..., 0] - top2[..., 1]) < 1e-4
+    fst = torch.where(unc.any(1), unc.float().argmax(1), torch.full((256,), steps))
+    kp = torch.arange(steps).view(1, -1) < fst.view(-1, 1)
+    assert torch.equal(tk[:256].cpu().long()[kp], ref_tk[kp])
+
+
 @pytest.mark.parametrize("path,Bi,steps", [("cells", 2048, 20), ("pipeline", 800, 16), ("pipeline", 1536, 12)])
 def test_large_decode_paths_vs_oracle(path, Bi, steps):
     """The decode paths BASELINE configs[4] is timed on, checked DIRECTLY against the oracle's eval-mode global_decoder (gmm_model.py:119-149,
