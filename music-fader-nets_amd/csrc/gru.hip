@@ -1099,6 +1099,231 @@ int launch_cell_direct(const CellArgs& a, hipStream_t st) {
     return FN_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The cell with the WEIGHT operand of a K phase resident in LDS (as out_argmax_lds_kernel): the LDS-free loop above is bound by its
+// operand loads (~8 TB/s of 16 x 64-byte pieces per instruction: 7 loads per 48 MFMAs), not by the MFMA pipe.  Here a workgroup owns
+// 64 RT rows x 16 hidden units: the 48 weight rows of its units (48 x K floats, 96 KB at K = 512) are laid out once per phase as MFMA
+// fragments [k step][gate][lane] (16-byte LDS reads, slots rotated against bank conflicts), and only the RT state-row tiles of a wave are
+// read from memory in the loop (RT loads per 12 RT MFMAs).  Layer 2 fills the slice twice (W_ih, then W_hh after a barrier).
+template <int RT, int PF, bool HAS_TAB, bool HAS_RB>
+__global__ __launch_bounds__(NT) void gru_cell_wlds_kernel(const CellArgs a, int kmax) {
+    static_assert(PF >= 2 && (PF % 2) == 0, "the fragment double buffer follows the parity of the ring slot");
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    f32x4* wl = reinterpret_cast<f32x4*>(dsm);       // [K / 16][3][64]
+    float* tr = dsm + (long)48 * kmax;               // [wave][4 tiles][16 x 20]
+    const int nut = a.H >> 4;
+    const int tm = blockIdx.x / nut, tu = blockIdx.x % nut;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = tm * 64 * RT + wave * 16 * RT, u0 = tu * 16;
+    const int li = lane & 15, lg = lane >> 4;
+    f32x4 arz[RT][2], anx[RT], anh[RT];
+#pragma unroll
+    for (int m = 0; m < RT; ++m) arz[m][0] = arz[m][1] = anx[m] = anh[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 fa[PF][RT];
+    auto phase = [&](const float* A, long lda, const float* W, long ldw, int K, f32x4 (&accn)[RT], bool refill) {
+        const int nks = K >> 4, kq = K >> 2;
+        unsigned oa[RT];
+#pragma unroll
+        for (int m = 0; m < RT; ++m) oa[m] = (unsigned)(((long)min(m0 + 16 * m + li, a.B - 1) * lda + 4 * lg) * 4);
+        const float* pa = A;
+        auto load = [&](int set) {
+#pragma unroll
+            for (int m = 0; m < RT; ++m) fn_gld4_sb(fa[set][m], oa[m], pa);
+            pa += 16;
+        };
+        const int npro = min(PF, nks);
+#pragma unroll
+        for (int s = 0; s < PF; ++s)
+            if (s < npro) load(s);
+        if (refill) __syncthreads();                 // every wave has left the previous phase's loop
+        // weight fragments: item (row r of 48 = gate r >> 4, unit r & 15; k quad c) -> step c >> 2, gate, lane group c & 3, slot (r & 15) rotated
+        const int total = 48 * kq, dq = NT / kq, dr = NT % kq;
+        int fr = threadIdx.x / kq, fc = threadIdx.x % kq;
+        for (int base = threadIdx.x; base < total; base += NT * 8) {
+            f32x4 v[8];
+            int rr[8], cc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                rr[u] = fr;
+                cc[u] = fc;
+                const int r = min(fr, 47);
+                v[u] = *reinterpret_cast<const f32x4*>(W + (long)((r >> 4) * a.H + u0 + (r & 15)) * ldw + 4 * fc);
+                fc += dr;
+                fr += dq;
+                if (fc >= kq) { fc -= kq; ++fr; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = rr[u], c = cc[u];
+                if (r < 48) wl[(c >> 2) * 192 + (r >> 4) * 64 + (c & 3) * 16 + (((r & 15) + 4 * (c & 3) + (c >> 2)) & 15)] = v[u];
+            }
+        }
+        __syncthreads();
+        // weight fragments of step s + 1 are read while the MFMAs of step s run (bq[parity]); PF is even, so the parity of a step is its ring slot's
+        f32x4 bq[2][3];
+        auto bread = [&](int buf, int s) {
+            const int sl = lg * 16 + ((li + 4 * lg + s) & 15);
+            bq[buf][0] = wl[s * 192 + sl];
+            bq[buf][1] = wl[s * 192 + 64 + sl];
+            bq[buf][2] = wl[s * 192 + 128 + sl];
+        };
+        auto mma = [&](int u, int s) {
+            if (s + 1 < nks) bread((u & 1) ^ 1, s + 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int m = 0; m < RT; ++m) {
+                    arz[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][m][j], bq[u & 1][0][j], arz[m][0], 0, 0, 0);
+                    arz[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][m][j], bq[u & 1][1][j], arz[m][1], 0, 0, 0);
+                    accn[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][m][j], bq[u & 1][2][j], accn[m], 0, 0, 0);
+                }
+        };
+        bread(0, 0);
+        const int nmain = nks / PF * PF;
+        int s = 0;
+        if (nmain > 0) {
+            for (; s + PF < nmain; s += PF) {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    fn_wait_vm<RT * (PF - 1)>();
+                    mma(u, s + u);
+                    load(u);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                if (u == 0) fn_wait_vm<RT * (PF - 1)>();
+                else if (u == 1 && PF > 1) fn_wait_vm<(PF > 1 ? RT * (PF - 2) : 0)>();
+                else if (u == 2 && PF > 2) fn_wait_vm<(PF > 2 ? RT * (PF - 3) : 0)>();
+                else fn_wait_vm<0>();
+                mma(u, s + u);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            s += PF;
+        } else {
+            fn_wait_vm<0>();                         // fewer steps than ring slots
+#pragma unroll
+            for (int u = 0; u < PF; ++u)
+                if (u < npro) mma(u, u);
+            s = npro;
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+#pragma unroll
+            for (int m = 0; m < RT; ++m) fn_keep(fa[u][m]);
+        for (; s < nks; ++s) {                       // < PF leftover steps, unpipelined; ring slot = parity of the step (bq[parity] holds its fragments)
+            if (s & 1) {
+                load(1);
+                fn_wait_vm<0>();
+                mma(1, s);
+            } else {
+                load(0);
+                fn_wait_vm<0>();
+                mma(0, s);
+            }
+#pragma unroll
+            for (int m = 0; m < RT; ++m) { fn_keep(fa[0][m]); fn_keep(fa[1][m]); }
+        }
+    };
+    if (a.x) phase(a.x, a.ldx, a.w_ih, a.ldw_ih, a.K1, anx, false);
+    phase(a.h_prev, a.ldh, a.w_hh, a.ldw_hh, a.H, anh, a.x != nullptr);
+    // epilogue on (row, 4 units) items through a wave-private LDS tile, as gru_cell_direct_kernel (its operands are requested here: the fill's
+    // loads and barriers sit between them and the loop anyway)
+    const int er = lane >> 2, eu = u0 + 4 * (lane & 3);
+    f32x4 bi[3], bh[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        bh[q] = *reinterpret_cast<const f32x4*>(a.b_hh + q * a.H + eu);
+        bi[q] = a.b_ih ? *reinterpret_cast<const f32x4*>(a.b_ih + q * a.H + eu) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const long H3 = 3L * a.H;
+    f32x4 hv[RT], tv[RT][3], rv[RT][3];
+    int rows[RT];
+#pragma unroll
+    for (int m = 0; m < RT; ++m) {
+        rows[m] = m0 + 16 * m + er;
+        const int rc = min(rows[m], a.B - 1);
+        hv[m] = *reinterpret_cast<const f32x4*>(a.h_prev + (long)rc * a.ldh + eu);
+        if (HAS_TAB) {
+            const int tok = a.token(rc);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) tv[m][q] = *reinterpret_cast<const f32x4*>(a.gx_table + (long)tok * H3 + q * a.H + eu);
+        }
+        if (HAS_RB) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) rv[m][q] = *reinterpret_cast<const f32x4*>(a.gx_rowbias + (long)rc * H3 + q * a.H + eu);
+        }
+    }
+    float* tw = tr + wave * 4 * 320;
+#pragma unroll
+    for (int m = 0; m < RT; ++m) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            tw[0 * 320 + (4 * lg + i) * 20 + li] = arz[m][0][i];
+            tw[1 * 320 + (4 * lg + i) * 20 + li] = arz[m][1][i];
+            tw[2 * 320 + (4 * lg + i) * 20 + li] = anx[m][i];
+            tw[3 * 320 + (4 * lg + i) * 20 + li] = anh[m][i];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const f32x4 g_r = *reinterpret_cast<const f32x4*>(tw + 0 * 320 + er * 20 + 4 * (lane & 3));
+        const f32x4 g_z = *reinterpret_cast<const f32x4*>(tw + 1 * 320 + er * 20 + 4 * (lane & 3));
+        const f32x4 g_nx = *reinterpret_cast<const f32x4*>(tw + 2 * 320 + er * 20 + 4 * (lane & 3));
+        const f32x4 g_nh = *reinterpret_cast<const f32x4*>(tw + 3 * 320 + er * 20 + 4 * (lane & 3));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        f32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float gi[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                float e = bi[q][c];
+                if (HAS_TAB) e += tv[m][q][c];
+                if (HAS_RB) e += rv[m][q][c];
+                gi[q] = e;
+            }
+            const float r = fn_sigmoid((gi[0] + bh[0][c]) + g_r[c]);
+            const float z = fn_sigmoid((gi[1] + bh[1][c]) + g_z[c]);
+            const float n = fn_tanh((gi[2] + g_nx[c]) + r * (g_nh[c] + bh[2][c]));
+            o[c] = (1.0f - z) * n + z * hv[m][c];
+        }
+        if (rows[m] < a.B) *reinterpret_cast<f32x4*>(a.h_out + (long)rows[m] * a.ldo + eu) = o;
+    }
+}
+
+template <int RT, int PF, bool HAS_TAB, bool HAS_RB>
+int launch_cell_wlds_inst(const CellArgs& a, int kmax, size_t lds, hipStream_t st) {
+    static std::atomic<bool> attr_set[32];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return FN_E_SHAPE;
+    auto k = gru_cell_wlds_kernel<RT, PF, HAS_TAB, HAS_RB>;
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set[dev].store(true, std::memory_order_release);
+    }
+    const int tiles = ((a.B + 64 * RT - 1) / (64 * RT)) * (a.H / 16);
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(NT), lds, st, a, kmax);
+    FN_CHECK_LAUNCH();
+    return FN_OK;
+}
+
+static bool cell_wlds_ok(const CellArgs& a) {
+    const int kmax = a.x ? (a.K1 > a.H ? a.K1 : a.H) : a.H;
+    return (size_t)48 * kmax * 4 + 4 * 4 * 320 * 4 <= (size_t)160 * 1024;
+}
+
+template <int RT, int PF>
+int launch_cell_wlds(const CellArgs& a, hipStream_t st) {
+    const int kmax = a.x ? (a.K1 > a.H ? a.K1 : a.H) : a.H;
+    const size_t lds = (size_t)48 * kmax * 4 + 4 * 4 * 320 * 4;
+    const bool tab = a.gx_table != nullptr, rb = a.gx_rowbias != nullptr;
+    if (tab && rb) return launch_cell_wlds_inst<RT, PF, true, true>(a, kmax, lds, st);
+    if (tab) return launch_cell_wlds_inst<RT, PF, true, false>(a, kmax, lds, st);
+    if (rb) return launch_cell_wlds_inst<RT, PF, false, true>(a, kmax, lds, st);
+    return launch_cell_wlds_inst<RT, PF, false, false>(a, kmax, lds, st);
+}
+
 template <int BM, int WM, int WN>
 int launch_cell(const CellArgs& a, hipStream_t st) {
     const size_t lds = (size_t)2 * (Stage<BM, GC_BK, true, NT>::WORDS + Stage<GC_BN, GC_BK, true, NT>::WORDS) * sizeof(float);
@@ -1207,11 +1432,17 @@ int fn_gru_cell_f32(const FnGruCell* c, void* stream) {
     a.h_out = c->h_out; a.ldo = c->ldo; a.B = c->B; a.H = c->H;
     a.best = reinterpret_cast<const unsigned long long*>(c->idx_best); a.best_v = c->best_v;
     if (c->idx_best && (c->best_v <= 0 || !c->gx_table)) return FN_E_SHAPE;
-    // measured (scratch/prof_decode_cells.sh, us per token of the 4-launch decode): 2048 rows 125 staged / 111 LDS-free 128-row form / 143 64-row form;
-    // 1536 rows 125 / 110 / 142; 1024 rows 82 / 104 / 80; 800 rows 82 / 104 / 80
-    if (c->variant == 0 && c->B > 512 && cell_direct_ok(a))
-        return c->B > 1024 ? launch_cell_direct<4, 2>(a, (hipStream_t)stream) : launch_cell_direct<2, 4>(a, (hipStream_t)stream);
+    // measured (scratch/prof_decode_cells.sh, us per token of the tokens-only decode, profiles/r04_decode_cells_lds_free.txt): 2048 rows 125 staged /
+    // 103 LDS-free 128-row form / 108 weights in LDS; 1024 rows 82 staged / 77 LDS-free 64-row form / 71.5 weights in LDS (128 rows x 16 units)
+    if (c->variant == 0 && c->B > 512 && cell_direct_ok(a)) {
+        if (c->B > 1024) return launch_cell_direct<4, 2>(a, (hipStream_t)stream);
+        return cell_wlds_ok(a) ? launch_cell_wlds<2, 4>(a, (hipStream_t)stream) : launch_cell_direct<2, 4>(a, (hipStream_t)stream);
+    }
     switch (c->variant) {                                  // tuning / tests: the staged forms agree bit for bit, the LDS-free forms 4-7 among themselves (another k order)
+        case 9: if (cell_direct_ok(a) && cell_wlds_ok(a)) return launch_cell_wlds<4, 4>(a, (hipStream_t)stream); break;
+        case 10: if (cell_direct_ok(a) && cell_wlds_ok(a)) return launch_cell_wlds<2, 4>(a, (hipStream_t)stream); break;
+        case 11: if (cell_direct_ok(a) && cell_wlds_ok(a)) return launch_cell_wlds<4, 2>(a, (hipStream_t)stream); break;
+        case 12: if (cell_direct_ok(a) && cell_wlds_ok(a)) return launch_cell_wlds<2, 8>(a, (hipStream_t)stream); break;
         case 4: if (cell_direct_ok(a)) return launch_cell_direct<4, 1>(a, (hipStream_t)stream); break;
         case 5: if (cell_direct_ok(a)) return launch_cell_direct<2, 4>(a, (hipStream_t)stream); break;
         case 6: if (cell_direct_ok(a)) return launch_cell_direct<4, 2>(a, (hipStream_t)stream); break;

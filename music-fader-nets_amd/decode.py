@@ -54,7 +54,9 @@ def greedy_decode(model, z, steps, want_logp=True, use_graph=None):
 
 def _single_launch_ok(eng, z):
     """small batches decode as ONE launch (fn_decode_greedy: weight slices resident in LDS, activations handed over through L2)"""
-    return hasattr(eng.ops, "decode_greedy") and z.is_cuda and z.shape[0] <= eng.single_launch_rows and eng.H <= 512 and eng.single_launch_decode
+    lo, hi = getattr(eng, "single_launch_skip", (0, -1))
+    return (hasattr(eng.ops, "decode_greedy") and z.is_cuda and z.shape[0] <= eng.single_launch_rows and not (lo <= z.shape[0] <= hi)
+            and eng.H <= 512 and eng.single_launch_decode)
 
 
 def _decode_single_launch(eng, z, steps, want_logp):

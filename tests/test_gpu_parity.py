@@ -112,7 +112,7 @@ def test_out_head_fused(ops, B, T, H, V, ld):
     assert torch.equal(nll1, nll2)
 
 
-@pytest.mark.parametrize("variant", [0, 2, 8, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [0, 2, 8, 4, 5, 6, 7, 9, 10, 11, 12])
 @pytest.mark.parametrize("B,H,K1,mode", [(300, 64, 64, "dense"), (2048, 512, 512, "dense"), (130, 96, 0, "table"), (1030, 512, 0, "table0"), (77, 64, 48, "dense")])
 def test_gru_cell_dense(ops, B, H, K1, mode, variant):
     """fn_gru_cell_f32 (one GRUCell step of a large batch: a staged GEMM - variants 0-3 - or the LDS-free loop - variants 4-7 - with the gates
@@ -857,7 +857,7 @@ def test_single_launch_decode_block_pipeline(H, Bi, steps):
     eng = m.engine()
     eng.single_launch_decode, eng.cell_decode_rows = False, 1 << 30
     lp0, tk0 = pkg.greedy_decode(m, z, steps)
-    eng.single_launch_decode, eng.single_launch_rows = True, 2048       # force the one-launch pipeline whatever the default threshold
+    eng.single_launch_decode, eng.single_launch_rows, eng.single_launch_skip = True, 2048, (0, -1)       # force the one-launch pipeline whatever the default thresholds
     lp1, tk1 = pkg.greedy_decode(m, z, steps)
     lp2, tk2 = pkg.greedy_decode(m, z, steps)
     assert not eng.ops.gru_sync_error()
@@ -983,7 +983,7 @@ def test_large_decode_paths_vs_oracle(path, Bi, steps):
     if path == "cells":
         eng.single_launch_decode, eng.cell_decode_rows = False, 768
     else:
-        eng.single_launch_decode, eng.single_launch_rows = True, 2048
+        eng.single_launch_decode, eng.single_launch_rows, eng.single_launch_skip = True, 2048, (0, -1)
     lp, tk = pkg.greedy_decode(m, z.to(DEV), steps)
     assert not eng.ops.gru_sync_error()
     sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
