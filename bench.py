@@ -522,7 +522,7 @@ def bench_decode(args, pkg, ctx, local, rank, world, log):
                                "of z_r[:,0] each, 2048 rows x 300 greedy steps, hipGraph replay; replicas only for N>1",
                    "global_batch": rows * world, "seq_len": DEC_STEPS, "parallelism": "replicas%d" % world},
         "roofline": dict(bound="mfma", kernel="greedy decode of 2048 rows x 300 steps (graph of gru_cell_direct_kernel x2 - layer 2 with its input projection - , "
-                                              "gemm_kernel (output layer), vocab_argmax_kernel per token)", achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS,
+                                              "out_argmax_lds_kernel (output layer with the argmax in its epilogue) per token)", achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS,
                          unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), avg_launch_us=round(ms * 1e3, 1), traffic=None,
                          flop_per_launch=rows * DEC_STEPS * F_ALG_DECODE_PER_TOKEN,
                          weight_stream_GBs=round(DEC_STEPS * DECODE_WEIGHT_BYTES / (ms * 1e-3) / 1e9, 1)),
