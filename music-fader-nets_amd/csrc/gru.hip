@@ -1432,13 +1432,16 @@ int fn_gru_cell_f32(const FnGruCell* c, void* stream) {
     a.h_out = c->h_out; a.ldo = c->ldo; a.B = c->B; a.H = c->H;
     a.best = reinterpret_cast<const unsigned long long*>(c->idx_best); a.best_v = c->best_v;
     if (c->idx_best && (c->best_v <= 0 || !c->gx_table)) return FN_E_SHAPE;
-    // measured (scratch/prof_decode_cells.sh, us per token of the tokens-only decode, profiles/r04_decode_cells_lds_free.txt): 2048 rows 125 staged /
-    // 103 LDS-free 128-row form / 108 weights in LDS; 1024 rows 82 staged / 77 LDS-free 64-row form / 71.5 weights in LDS (128 rows x 16 units)
+    // measured (scratch/prof_decode_cells.sh, us per token of the tokens-only decode, profiles/r04_decode_cells_lds_free.txt): the form with the weight slice in
+    // LDS wants ONE workgroup per CU: 64 RT rows x 16 units with RT = ceil(rows / 512) - 1024 rows 71.5 (staged 82, LDS-free 77), 1152-1536 rows 88-89 (LDS-free 101-102);
+    // at 2048 rows (RT = 4) it is behind the LDS-free 128-row form (108 against 103)
     if (c->variant == 0 && c->B > 512 && cell_direct_ok(a)) {
-        if (c->B > 1024) return launch_cell_direct<4, 2>(a, (hipStream_t)stream);
-        return cell_wlds_ok(a) ? launch_cell_wlds<2, 4>(a, (hipStream_t)stream) : launch_cell_direct<2, 4>(a, (hipStream_t)stream);
+        if (c->B > 1536 || !cell_wlds_ok(a)) return c->B > 1024 ? launch_cell_direct<4, 2>(a, (hipStream_t)stream) : launch_cell_direct<2, 4>(a, (hipStream_t)stream);
+        return c->B > 1024 ? launch_cell_wlds<3, 2>(a, (hipStream_t)stream) : launch_cell_wlds<2, 4>(a, (hipStream_t)stream);
     }
     switch (c->variant) {                                  // tuning / tests: the staged forms agree bit for bit, the LDS-free forms 4-7 among themselves (another k order)
+        case 13: if (cell_direct_ok(a) && cell_wlds_ok(a)) return launch_cell_wlds<3, 4>(a, (hipStream_t)stream); break;
+        case 14: if (cell_direct_ok(a) && cell_wlds_ok(a)) return launch_cell_wlds<3, 2>(a, (hipStream_t)stream); break;
         case 9: if (cell_direct_ok(a) && cell_wlds_ok(a)) return launch_cell_wlds<4, 4>(a, (hipStream_t)stream); break;
         case 10: if (cell_direct_ok(a) && cell_wlds_ok(a)) return launch_cell_wlds<2, 4>(a, (hipStream_t)stream); break;
         case 11: if (cell_direct_ok(a) && cell_wlds_ok(a)) return launch_cell_wlds<4, 2>(a, (hipStream_t)stream); break;

@@ -112,7 +112,7 @@ def test_out_head_fused(ops, B, T, H, V, ld):
     assert torch.equal(nll1, nll2)
 
 
-@pytest.mark.parametrize("variant", [0, 2, 8, 4, 5, 6, 7, 9, 10, 11, 12])
+@pytest.mark.parametrize("variant", [0, 2, 8, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14])
 @pytest.mark.parametrize("B,H,K1,mode", [(300, 64, 64, "dense"), (2048, 512, 512, "dense"), (130, 96, 0, "table"), (1030, 512, 0, "table0"), (77, 64, 48, "dense")])
 def test_gru_cell_dense(ops, B, H, K1, mode, variant):
     """fn_gru_cell_f32 (one GRUCell step of a large batch: a staged GEMM - variants 0-3 - or the LDS-free loop - variants 4-7 - with the gates
@@ -967,7 +967,7 @@ def test_tokens_only_decode_on_the_cells_fused_argmax():
     assert torch.equal(tk[:256].cpu().long()[kp], ref_tk[kp])
 
 
-@pytest.mark.parametrize("path,Bi,steps", [("cells", 2048, 20), ("pipeline", 800, 16), ("pipeline", 1536, 12)])
+@pytest.mark.parametrize("path,Bi,steps", [("cells", 2048, 20), ("cells", 1280, 12), ("cells", 1000, 12), ("pipeline", 800, 16), ("pipeline", 1536, 12)])
 def test_large_decode_paths_vs_oracle(path, Bi, steps):
     """The decode paths BASELINE configs[4] is timed on, checked DIRECTLY against the oracle's eval-mode global_decoder (gmm_model.py:119-149,
     73-80; the oracle is pinned to the reference's greedy tokens by c0 / eval.npz) at hidden 512: the staged-GEMM cells (fn_gru_cell_f32,
