@@ -1324,6 +1324,218 @@ int launch_cell_wlds(const CellArgs& a, hipStream_t st) {
     return launch_cell_wlds_inst<RT, PF, false, false>(a, kmax, lds, st);
 }
 
+FN_DEVINL void fn_wait_vm_n(int n) {                // n folds to a constant in fully unrolled loops
+    switch (n) {
+#define FN_WV(k) case k: fn_wait_vm<k>(); break;
+        FN_WV(0) FN_WV(1) FN_WV(2) FN_WV(3) FN_WV(4) FN_WV(5) FN_WV(6) FN_WV(7) FN_WV(8) FN_WV(9) FN_WV(10) FN_WV(11) FN_WV(12)
+        FN_WV(13) FN_WV(14) FN_WV(15) FN_WV(16) FN_WV(17) FN_WV(18) FN_WV(19) FN_WV(20)
+#undef FN_WV
+        default: fn_wait_vm<0>(); break;
+    }
+}
+
+// gru_cell_wlds_kernel for K1 = H = 512 with the slice fills UNDER the K loops: the slice is filled in halves of 16 k steps; only the first
+// half of the first phase is filled in front of its loop, every other half is requested one 16-byte load per thread and step during the
+// 16 steps before it is needed (asm loads into 12 registers, counted together with the state-row ring), written to LDS and published by one
+// barrier at the half boundary - layer 2 pays 1.5 us of fill instead of 6.  Fully unrolled (the counted waits differ from step to step).
+template <int RT, int PF, bool HAS_TAB, bool HAS_RB>
+__global__ __launch_bounds__(NT) void gru_cell_wlds_ovl_kernel(const CellArgs a) {
+    constexpr int K = 512, NKS = K / 16, HALF = NKS / 2, NF = 12;     // NF = 48 rows x 64 quads of a half / 256 threads
+    static_assert(PF >= 2 && (PF % 2) == 0 && PF <= 4 && NF + PF <= HALF, "ring / fill schedule");
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    f32x4* wl = reinterpret_cast<f32x4*>(dsm);       // [K / 16][3][64]
+    float* tr = dsm + 48 * K;
+    const int nut = a.H >> 4;
+    const int tm = blockIdx.x / nut, tu = blockIdx.x % nut;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = tm * 64 * RT + wave * 16 * RT, u0 = tu * 16;
+    const int li = lane & 15, lg = lane >> 4;
+    f32x4 arz[RT][2], anx[RT], anh[RT];
+#pragma unroll
+    for (int m = 0; m < RT; ++m) arz[m][0] = arz[m][1] = anx[m] = anh[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 fa[PF][RT], fv[NF];
+    // fill item j of a thread: weight row r = wave + 4 j of the 48 (gate r >> 4 = j >> 2, unit r & 15 = wave + 4 (j & 3)), k quad 64 half + lane:
+    // one lane offset for all items, the item's part of the address in a scalar base (no vector address arithmetic, no pointer registers)
+    auto f_off = [&](long ldw) { return (unsigned)((((long)(u0 + wave) * ldw) + 4 * lane) * 4); };
+    auto f_base = [&](const float* W, long ldw, int half, int j) { return W + ((long)(j >> 2) * a.H + 4 * (j & 3)) * ldw + 256 * half; };
+    auto fill_store = [&](int half) {
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int r = wave + 4 * j, c = 64 * half + lane;
+            wl[(c >> 2) * 192 + (r >> 4) * 64 + (c & 3) * 16 + (((r & 15) + 4 * (c & 3) + (c >> 2)) & 15)] = fv[j];
+        }
+    };
+    auto phase = [&](const float* A, long lda, const float* W, long ldw, f32x4 (&accn)[RT], auto FIRST, auto PRE2, const float* Wn, long ldwn) {
+        constexpr bool first = decltype(FIRST)::value, pre2 = decltype(PRE2)::value;
+        unsigned oa[RT];
+#pragma unroll
+        for (int m = 0; m < RT; ++m) oa[m] = (unsigned)(((long)min(m0 + 16 * m + li, a.B - 1) * lda + 4 * lg) * 4);
+        const float* pa = A;
+        auto load = [&](int set) {
+#pragma unroll
+            for (int m = 0; m < RT; ++m) fn_gld4_sb(fa[set][m], oa[m], pa);
+            pa += 16;
+        };
+#pragma unroll
+        for (int s = 0; s < PF; ++s) load(s);
+        if (first) {
+#pragma unroll
+            for (int j = 0; j < NF; ++j) fv[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(f_base(W, ldw, 0, j)) + f_off(ldw));
+        }
+        fill_store(0);                               // (every reader of these steps' fragments passed the previous phase's half barrier)
+        __syncthreads();
+        f32x4 bq[2][3];
+        auto bread = [&](int buf, int s) {
+            const int sl = lg * 16 + ((li + 4 * lg + s) & 15);
+            bq[buf][0] = wl[s * 192 + sl];
+            bq[buf][1] = wl[s * 192 + 64 + sl];
+            bq[buf][2] = wl[s * 192 + 128 + sl];
+        };
+        bread(0, 0);
+        const unsigned fo = f_off(ldw), fon = pre2 ? f_off(ldwn) : 0u;
+        auto step = [&](const int u) __attribute__((always_inline)) {
+            // loads younger than the ring loads of step u: the fill load issued with them, then everything issued behind steps u - PF + 1 .. u - 1
+            auto fillf = [&](int j) { return j < HALF ? (j < NF ? 1 : 0) : ((pre2 && j - HALF < NF) ? 1 : 0); };
+            auto ringf = [&](int j) { return j + PF < NKS ? RT : 0; };
+            int allowed = u >= PF ? fillf(u - PF) : (PF - 1 - u) * RT;
+#pragma unroll
+            for (int d = 1; d < PF; ++d)
+                if (u - d >= 0) allowed += ringf(u - d) + fillf(u - d);
+            fn_wait_vm_n(allowed);
+            if (u != HALF - 1 && u != NKS - 1) bread((u & 1) ^ 1, u + 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int m = 0; m < RT; ++m) {
+                    arz[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u % PF][m][j], bq[u & 1][0][j], arz[m][0], 0, 0, 0);
+                    arz[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u % PF][m][j], bq[u & 1][1][j], arz[m][1], 0, 0, 0);
+                    accn[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u % PF][m][j], bq[u & 1][2][j], accn[m], 0, 0, 0);
+                }
+            if (u + PF < NKS) load(u % PF);
+            if (u < HALF) {
+                if (u < NF) fn_gld4_sb(fv[u], fo, f_base(W, ldw, 1, u));
+            } else if (pre2 && u - HALF < NF) {
+                fn_gld4_sb(fv[u - HALF], fon, f_base(Wn, ldwn, 0, u - HALF));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+#pragma unroll
+        for (int u = 0; u < HALF; ++u) step(u);
+        // second half of the slice: requested during steps 0 .. NF - 1, complete behind step HALF - 1's wait
+#pragma unroll
+        for (int j = 0; j < NF; ++j) fn_keep(fv[j]);
+        fill_store(1);
+        __syncthreads();
+        bread(0, HALF);
+#pragma unroll
+        for (int u = HALF; u < NKS; ++u) step(u);
+#pragma unroll
+        for (int s = 0; s < PF; ++s)
+#pragma unroll
+            for (int m = 0; m < RT; ++m) fn_keep(fa[s][m]);
+        if (pre2) {
+#pragma unroll
+            for (int j = 0; j < NF; ++j) fn_keep(fv[j]);
+        }
+    };
+    using T_ = std::integral_constant<bool, true>;
+    using F_ = std::integral_constant<bool, false>;
+    if (a.x) {
+        phase(a.x, a.ldx, a.w_ih, a.ldw_ih, anx, T_{}, T_{}, a.w_hh, a.ldw_hh);
+        phase(a.h_prev, a.ldh, a.w_hh, a.ldw_hh, anh, F_{}, F_{}, nullptr, 0);
+    } else {
+        phase(a.h_prev, a.ldh, a.w_hh, a.ldw_hh, anh, T_{}, F_{}, nullptr, 0);
+    }
+    // epilogue as gru_cell_wlds_kernel
+    const int er = lane >> 2, eu = u0 + 4 * (lane & 3);
+    f32x4 bi[3], bh[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        bh[q] = *reinterpret_cast<const f32x4*>(a.b_hh + q * a.H + eu);
+        bi[q] = a.b_ih ? *reinterpret_cast<const f32x4*>(a.b_ih + q * a.H + eu) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const long H3 = 3L * a.H;
+    f32x4 hv[RT], tv[RT][3], rv[RT][3];
+    int rows[RT];
+#pragma unroll
+    for (int m = 0; m < RT; ++m) {
+        rows[m] = m0 + 16 * m + er;
+        const int rc = min(rows[m], a.B - 1);
+        hv[m] = *reinterpret_cast<const f32x4*>(a.h_prev + (long)rc * a.ldh + eu);
+        if (HAS_TAB) {
+            const int tok = a.token(rc);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) tv[m][q] = *reinterpret_cast<const f32x4*>(a.gx_table + (long)tok * H3 + q * a.H + eu);
+        }
+        if (HAS_RB) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) rv[m][q] = *reinterpret_cast<const f32x4*>(a.gx_rowbias + (long)rc * H3 + q * a.H + eu);
+        }
+    }
+    float* tw = tr + wave * 4 * 320;
+#pragma unroll
+    for (int m = 0; m < RT; ++m) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            tw[0 * 320 + (4 * lg + i) * 20 + li] = arz[m][0][i];
+            tw[1 * 320 + (4 * lg + i) * 20 + li] = arz[m][1][i];
+            tw[2 * 320 + (4 * lg + i) * 20 + li] = anx[m][i];
+            tw[3 * 320 + (4 * lg + i) * 20 + li] = anh[m][i];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const f32x4 g_r = *reinterpret_cast<const f32x4*>(tw + 0 * 320 + er * 20 + 4 * (lane & 3));
+        const f32x4 g_z = *reinterpret_cast<const f32x4*>(tw + 1 * 320 + er * 20 + 4 * (lane & 3));
+        const f32x4 g_nx = *reinterpret_cast<const f32x4*>(tw + 2 * 320 + er * 20 + 4 * (lane & 3));
+        const f32x4 g_nh = *reinterpret_cast<const f32x4*>(tw + 3 * 320 + er * 20 + 4 * (lane & 3));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        f32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float gi[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                float e = bi[q][c];
+                if (HAS_TAB) e += tv[m][q][c];
+                if (HAS_RB) e += rv[m][q][c];
+                gi[q] = e;
+            }
+            const float r = fn_sigmoid((gi[0] + bh[0][c]) + g_r[c]);
+            const float z = fn_sigmoid((gi[1] + bh[1][c]) + g_z[c]);
+            const float n = fn_tanh((gi[2] + g_nx[c]) + r * (g_nh[c] + bh[2][c]));
+            o[c] = (1.0f - z) * n + z * hv[m][c];
+        }
+        if (rows[m] < a.B) *reinterpret_cast<f32x4*>(a.h_out + (long)rows[m] * a.ldo + eu) = o;
+    }
+}
+
+template <int RT, int PF, bool HAS_TAB, bool HAS_RB>
+int launch_cell_wlds_ovl_inst(const CellArgs& a, hipStream_t st) {
+    static std::atomic<bool> attr_set[32];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return FN_E_SHAPE;
+    auto k = gru_cell_wlds_ovl_kernel<RT, PF, HAS_TAB, HAS_RB>;
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set[dev].store(true, std::memory_order_release);
+    }
+    const int tiles = ((a.B + 64 * RT - 1) / (64 * RT)) * (a.H / 16);
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(NT), (size_t)48 * 512 * 4 + 4 * 4 * 320 * 4, st, a);
+    FN_CHECK_LAUNCH();
+    return FN_OK;
+}
+
+static bool cell_wlds_ovl_ok(const CellArgs& a) { return a.H == 512 && (!a.x || a.K1 == 512); }
+
+template <int RT, int PF>
+int launch_cell_wlds_ovl(const CellArgs& a, hipStream_t st) {
+    const bool tab = a.gx_table != nullptr, rb = a.gx_rowbias != nullptr;
+    if (tab && rb) return launch_cell_wlds_ovl_inst<RT, PF, true, true>(a, st);
+    if (tab) return launch_cell_wlds_ovl_inst<RT, PF, true, false>(a, st);
+    if (rb) return launch_cell_wlds_ovl_inst<RT, PF, false, true>(a, st);
+    return launch_cell_wlds_ovl_inst<RT, PF, false, false>(a, st);
+}
+
 template <int BM, int WM, int WN>
 int launch_cell(const CellArgs& a, hipStream_t st) {
     const size_t lds = (size_t)2 * (Stage<BM, GC_BK, true, NT>::WORDS + Stage<GC_BN, GC_BK, true, NT>::WORDS) * sizeof(float);
@@ -1435,11 +1647,21 @@ int fn_gru_cell_f32(const FnGruCell* c, void* stream) {
     // measured (scratch/prof_decode_cells.sh, us per token of the tokens-only decode, profiles/r04_decode_cells_lds_free.txt): the form with the weight slice in
     // LDS wants ONE workgroup per CU: 64 RT rows x 16 units with RT = ceil(rows / 512) - 1024 rows 71.5 (staged 82, LDS-free 77), 1152-1536 rows 88-89 (LDS-free 101-102);
     // at 2048 rows (RT = 4) it is behind the LDS-free 128-row form (108 against 103)
+    if (c->variant == 0 && c->B > 512 && c->B <= 2048 && cell_direct_ok(a) && cell_wlds_ovl_ok(a)) {
+        // K1 = H = 512: the slice fills under the K loops - 640-1024 rows 60 (71), 1280-1536 rows 78-80 (88), 2048 rows 99.8 (102.9 LDS-free)
+        if (c->B <= 1024) return launch_cell_wlds_ovl<2, 2>(a, (hipStream_t)stream);
+        if (c->B <= 1536) return launch_cell_wlds_ovl<3, 2>(a, (hipStream_t)stream);
+        return launch_cell_wlds_ovl<4, 2>(a, (hipStream_t)stream);
+    }
     if (c->variant == 0 && c->B > 512 && cell_direct_ok(a)) {
         if (c->B > 1536 || !cell_wlds_ok(a)) return c->B > 1024 ? launch_cell_direct<4, 2>(a, (hipStream_t)stream) : launch_cell_direct<2, 4>(a, (hipStream_t)stream);
         return c->B > 1024 ? launch_cell_wlds<3, 2>(a, (hipStream_t)stream) : launch_cell_wlds<2, 4>(a, (hipStream_t)stream);
     }
     switch (c->variant) {                                  // tuning / tests: the staged forms agree bit for bit, the LDS-free forms 4-7 among themselves (another k order)
+        case 15: if (cell_direct_ok(a) && cell_wlds_ovl_ok(a)) return launch_cell_wlds_ovl<2, 4>(a, (hipStream_t)stream); break;
+        case 16: if (cell_direct_ok(a) && cell_wlds_ovl_ok(a)) return launch_cell_wlds_ovl<3, 2>(a, (hipStream_t)stream); break;
+        case 17: if (cell_direct_ok(a) && cell_wlds_ovl_ok(a)) return launch_cell_wlds_ovl<4, 2>(a, (hipStream_t)stream); break;
+        case 18: if (cell_direct_ok(a) && cell_wlds_ovl_ok(a)) return launch_cell_wlds_ovl<2, 2>(a, (hipStream_t)stream); break;
         case 13: if (cell_direct_ok(a) && cell_wlds_ok(a)) return launch_cell_wlds<3, 4>(a, (hipStream_t)stream); break;
         case 14: if (cell_direct_ok(a) && cell_wlds_ok(a)) return launch_cell_wlds<3, 2>(a, (hipStream_t)stream); break;
         case 9: if (cell_direct_ok(a) && cell_wlds_ok(a)) return launch_cell_wlds<4, 4>(a, (hipStream_t)stream); break;

@@ -47,8 +47,8 @@ class Engine:
         self.fill_edges = True          # the attribute decoders' chunks ride in the half-empty head / tail launches of the global decoder's
                                         # two-layer pipeline (same results; False: one launch of their own)
         self.single_launch_decode = True   # decode.py: small / medium batches decode as ONE launch (False: per-token kernels; tests)
-        self.single_launch_rows = 896      # ... up to this many sequences (fn_decode_greedy takes <= 2048; 32-row blocks below 353 rows, 64-row blocks from there), above: fn_gru_cell_f32 per token.  Measured us per token, one launch vs the per-token cells with the tokens-only output layer (scratch/decode_crossover.py, round 4): 512 rows 42 / 78, 640 rows 50 / 70, 800 rows 70 / 70, 896 rows 71 / 71, 1024 rows 80 / 72, 1152 rows 89 / 88, 1280 rows 99 / 88, 1536 rows 119 / 89, 2048 rows 157 / 103
-        self.single_launch_skip = (0, -1)  # (a window of row counts inside single_launch_rows that goes to the cells anyway; unused since the 192-row cell form)
+        self.single_launch_rows = 704      # ... up to this many sequences (fn_decode_greedy takes <= 2048; 32-row blocks below 353 rows, 64-row blocks from there), above: fn_gru_cell_f32 per token.  Measured us per token, one launch vs the per-token cells with the tokens-only output layer (scratch/decode_crossover.py, round 4, final): 512 rows 41 / 78, 640 rows 51 / 59, 768 rows 60 / 59, 800 rows 71 / 59, 1024 rows 80 / 60, 1280 rows 100 / 78, 1536 rows 120 / 80, 2048 rows 157 / 99
+        self.single_launch_skip = (0, -1)  # (a window of row counts inside single_launch_rows that goes to the cells anyway; unused since the cells with ceil(rows / 512) x 64 rows per workgroup)
         self._lane_alias = {}           # lane -> lane it is folded into (debug)
         self.fused_argmax = True        # decode.py, tokens-only decode on the per-token cells: output layer + argmax as ONE launch (fn_out_argmax_f32); False: GEMM + fn_vocab_argmax (tests)
         self.cell_decode_rows = 768     # decode.py: from this many sequences on, the per-token cells are one-launch GEMM cells (fn_gru_cell_f32: LDS-free loop above 512 rows, staged below); measured crossover against the scan-step kernels (scratch/bench_decode_rows.py): 512 rows 67 vs 87 us per token, 768 rows 97 vs 88

@@ -112,8 +112,8 @@ def test_out_head_fused(ops, B, T, H, V, ld):
     assert torch.equal(nll1, nll2)
 
 
-@pytest.mark.parametrize("variant", [0, 2, 8, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14])
-@pytest.mark.parametrize("B,H,K1,mode", [(300, 64, 64, "dense"), (2048, 512, 512, "dense"), (130, 96, 0, "table"), (1030, 512, 0, "table0"), (77, 64, 48, "dense")])
+@pytest.mark.parametrize("variant", [0, 2, 8, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("B,H,K1,mode", [(300, 64, 64, "dense"), (2048, 512, 512, "dense"), (130, 96, 0, "table"), (1030, 512, 0, "table0"), (77, 64, 48, "dense"), (700, 512, 0, "table")])
 def test_gru_cell_dense(ops, B, H, K1, mode, variant):
     """fn_gru_cell_f32 (one GRUCell step of a large batch: a staged GEMM - variants 0-3 - or the LDS-free loop - variants 4-7 - with the gates
     in the epilogue) against tests/fake_ops.py (= torch nn.GRUCell semantics with the optional token-row / row-constant input parts), ragged
