@@ -1068,6 +1068,141 @@ __global__ __launch_bounds__(NT) void out_argmax_lds_kernel(const float* __restr
     }
 }
 
+template <int PF>
+__global__ __launch_bounds__(2 * NT) void out_argmax_lds8_kernel(const float* __restrict__ h, long ldh, const float* __restrict__ W, long ldw,
+                                                            const float* __restrict__ bias, int B, int V, int K,
+                                                            unsigned long long* __restrict__ best) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    f32x4* wl = reinterpret_cast<f32x4*>(dsm);       // [K / 16][3][64]
+    const int ncb = (V + 47) / 48;
+    // eight waves: waves 4-7 take the second half of K for the row tiles of waves 0-3 and hand their accumulators over through LDS
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, kh = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+    const int m0 = (blockIdx.x / ncb) * 64 + wave * 16, n0 = (blockIdx.x % ncb) * 48;
+    const int li = lane & 15, lg = lane >> 4;
+    const int nks_all = K >> 4, s_first = kh ? nks_all / 2 : 0, nks = kh ? nks_all - nks_all / 2 : nks_all / 2;
+    const unsigned oa = (unsigned)(((long)min(m0 + li, B - 1) * ldh + 4 * lg) * 4);
+    f32x4 fa[PF];
+    const float* pa = h + 16 * s_first;
+    auto load = [&](int set) {
+        fn_gld4_sb(fa[set], oa, pa);
+        pa += 16;
+    };
+    const int npro = min(PF, nks);
+#pragma unroll
+    for (int s = 0; s < PF; ++s)
+        if (s < npro) load(s);
+    // weight fragments: item (row r of 48, k quad c of K / 4) -> step c >> 2, tile r >> 4, lane group c & 3, slot (r & 15) rotated; consecutive threads read one row
+    const int kq = K >> 2;
+    // eight independent 16-byte loads per thread in flight, then their eight LDS writes (a load -> write pair per iteration serialised 24
+    // memory latencies: 7.4 us of a 19 us launch); (row, quad) advance by NT items without a division
+    const int total = 48 * kq, dq = (2 * NT) / kq, dr = (2 * NT) % kq;
+    int fr = threadIdx.x / kq, fc = threadIdx.x % kq;
+    for (int base = threadIdx.x; base < total; base += 2 * NT * 8) {
+        f32x4 v[8];
+        int rr[8], cc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            rr[u] = fr;
+            cc[u] = fc;
+            v[u] = *reinterpret_cast<const f32x4*>(W + (long)min(n0 + min(fr, 47), V - 1) * ldw + 4 * fc);
+            fc += dr;
+            fr += dq;
+            if (fc >= kq) { fc -= kq; ++fr; }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = rr[u], c = cc[u];
+            if (r < 48) wl[(c >> 2) * 192 + (r >> 4) * 64 + (c & 3) * 16 + (((r & 15) + 4 * (c & 3) + (c >> 2)) & 15)] = v[u];     // slot rotated by the k quad: 16 consecutive quads of a row hit 16 bank groups
+        }
+    }
+    __syncthreads();
+    f32x4 acc[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](int u, int srel) {
+        const int s = s_first + srel;
+        const int sl = lg * 16 + ((li + 4 * lg + s) & 15);
+        const f32x4 b0 = wl[s * 192 + sl], b1 = wl[s * 192 + 64 + sl], b2 = wl[s * 192 + 128 + sl];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][j], b0[j], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][j], b1[j], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][j], b2[j], acc[2], 0, 0, 0);
+        }
+    };
+    // the plain loads of the fill are older than nothing of the ring that is still needed: every counted wait below also covers them
+    const int nmain = nks / PF * PF;
+    int s = 0;
+    if (nmain > 0) {
+        for (; s + PF < nmain; s += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                fn_wait_vm<PF - 1>();
+                mma(u, s + u);
+                load(u);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // the ring holds steps s .. s + PF - 1
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if (u == 0) fn_wait_vm<PF - 1>();
+            else if (u == 1 && PF > 1) fn_wait_vm<(PF > 1 ? PF - 2 : 0)>();
+            else if (u == 2 && PF > 2) fn_wait_vm<(PF > 2 ? PF - 3 : 0)>();
+            else fn_wait_vm<0>();
+            mma(u, s + u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        s += PF;
+    } else {
+        fn_wait_vm<0>();                             // fewer steps than ring slots (K < 16 PF)
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+            if (u < npro) mma(u, u);
+        s = npro;
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) fn_keep(fa[u]);
+    for (; s < nks; ++s) {                           // < PF leftover steps, unpipelined
+        load(0);
+        fn_wait_vm<0>();
+        mma(0, s);
+        fn_keep(fa[0]);
+    }
+    {
+        f32x4* rd = reinterpret_cast<f32x4*>(dsm + (long)48 * K) + (wave * 3) * 64 + lane;     // behind the weight fragments
+        if (kh) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) rd[q * 64] = acc[q];
+        }
+        __syncthreads();
+        if (kh) return;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) acc[q] += rd[q * 64];
+    }
+    float bv[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) bv[q] = bias[min(n0 + 16 * q + li, V - 1)];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned long long w = 0ull;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int col = n0 + 16 * q + li;
+            const unsigned long long c = col < V ? fn_pack_best(acc[q][i] + bv[q], col, V) : 0ull;
+            w = c > w ? c : w;
+        }
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const unsigned lo = __shfl_xor((unsigned)(w & 0xffffffffull), d, 64), hi = __shfl_xor((unsigned)(w >> 32), d, 64);
+            const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+            w = o > w ? o : w;
+        }
+        const int row = m0 + 4 * lg + i;
+        if (li == 0 && row < B) atomicMax(best + row, w);
+    }
+}
+
 __global__ __launch_bounds__(256) void best_tokens_kernel(const unsigned long long* __restrict__ best, long n, int B, int V, int* __restrict__ tokens, long tok_ld) {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
         const long t = i / B, b = i - t * B;
@@ -1438,6 +1573,10 @@ __global__ __launch_bounds__(NT) void gru_cell_wlds_ovl_kernel(const CellArgs a)
             for (int j = 0; j < NF; ++j) fn_keep(fv[j]);
         }
     };
+    // the token of every epilogue row now (the table-row loads of the epilogue then cost one memory latency, not two)
+    int tok[RT];
+#pragma unroll
+    for (int m = 0; m < RT; ++m) tok[m] = HAS_TAB ? a.token(min(m0 + 16 * m + (lane >> 2), a.B - 1)) : 0;
     using T_ = std::integral_constant<bool, true>;
     using F_ = std::integral_constant<bool, false>;
     if (a.x) {
@@ -1463,9 +1602,8 @@ __global__ __launch_bounds__(NT) void gru_cell_wlds_ovl_kernel(const CellArgs a)
         const int rc = min(rows[m], a.B - 1);
         hv[m] = *reinterpret_cast<const f32x4*>(a.h_prev + (long)rc * a.ldh + eu);
         if (HAS_TAB) {
-            const int tok = a.token(rc);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) tv[m][q] = *reinterpret_cast<const f32x4*>(a.gx_table + (long)tok * H3 + q * a.H + eu);
+            for (int q = 0; q < 3; ++q) tv[m][q] = *reinterpret_cast<const f32x4*>(a.gx_table + (long)tok[m] * H3 + q * a.H + eu);
         }
         if (HAS_RB) {
 #pragma unroll
@@ -1690,17 +1828,18 @@ int fn_out_argmax_f32(const float* h, int ldh, const float* W, int ldw, const fl
     if (((((uintptr_t)h) | ((uintptr_t)W)) & 15) || (((uintptr_t)best) & 7)) return FN_E_ALIGN;
     const size_t lds = (size_t)48 * K * sizeof(float);
     if (lds <= (size_t)128 * 1024 && !fn_out_argmax_force_direct) {          // weight slice of a workgroup resident in LDS
-        static std::atomic<bool> attr_set[32];
+        static std::atomic<bool> attr_set[2][32];
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return FN_E_SHAPE;
-        auto k = out_argmax_lds_kernel<8>;
-        if (!attr_set[dev].load(std::memory_order_acquire)) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        const bool eight = (K % 32) == 0 && !getenv("FN_OUT_ARGMAX_4WAVES");
+        auto k = eight ? out_argmax_lds8_kernel<4> : out_argmax_lds_kernel<8>;
+        if (!attr_set[eight][dev].load(std::memory_order_acquire)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
             if (e != hipSuccess) return (int)e;
-            attr_set[dev].store(true, std::memory_order_release);
+            attr_set[eight][dev].store(true, std::memory_order_release);
         }
         const int grid = ((B + 63) / 64) * ((V + 47) / 48);
-        hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, (hipStream_t)stream, h, (long)ldh, W, (long)ldw, bias, B, V, K,
+        hipLaunchKernelGGL(k, dim3(grid), dim3(eight ? 2 * NT : NT), lds + (eight ? 4 * 3 * 64 * 16 : 0), (hipStream_t)stream, h, (long)ldh, W, (long)ldw, bias, B, V, K,
                            reinterpret_cast<unsigned long long*>(best));
         FN_CHECK_LAUNCH();
         return FN_OK;
