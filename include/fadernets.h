@@ -207,8 +207,8 @@ int fn_gru_seq_fwd(const FnGruFwd* scans, int n_scans, void* stream);
  *    r = sigmoid(gi_r + gh_r), z = sigmoid(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h_out = (1 - z) n + z h_prev
  * as ONE MFMA launch with the gates in its epilogue (both products in its K loops: layer 2 of the decoder needs no separate W_ih
  * projection launch and no [B][3H] round trip).  Three kernels: above 512 rows (16-byte aligned operands, K1 % 16 == 0, row strides
- * % 4 == 0) loops whose lanes read their state-row operands straight from the K-contiguous rows - weights likewise (above 1536 rows)
- * or as an LDS-resident slice (up to 1536 rows: one workgroup of ceil(rows / 512) x 64 rows x 16 units per CU) -, otherwise an LDS-staged GEMM; they sum k in different orders (fp32 rounding apart).  Weights are the torch matrices themselves ([3H][K] row-major),
+ * % 4 == 0) loops whose lanes read their state-row operands straight from the K-contiguous rows - weights likewise, or as an
+ * LDS-resident slice (one workgroup of ceil(rows / 512) x 64 rows x 16 units per CU; at K1 = H = 512 filled under the K loops, up to 2048 rows) -, otherwise an LDS-staged GEMM; they sum k in different orders (fp32 rounding apart).  Weights are the torch matrices themselves ([3H][K] row-major),
  * states row-major; h_out must not alias h_prev.  H % 32 == 0.
  * tok = idx ? idx[b * idx_ld] : start_token (point idx at the column of the previous step's tokens). */
 typedef struct FnGruCell {
@@ -231,7 +231,8 @@ typedef struct FnGruCell {
     int32_t ldo;
     int32_t variant;          /* 0 = automatic.  Tuning / tests: 1-3, 8 force a staged tiling (8 = its default: 64 rows x 32 units), 4-7 the LDS-free
                                  loop (4, 6: 128 rows x 32 units per workgroup, 1 / 2 k steps in flight; 5, 7: 64 rows, 4 / 2), 9-12 the loop with
-                                 the weight slice in LDS (9, 11: 256 rows x 16 units, 4 / 2 steps; 10, 12: 128 rows, 4 / 8; 13, 14: 192 rows, 4 / 2) where eligible */
+                                 the weight slice in LDS (9, 11: 256 rows x 16 units, 2 steps; 10, 12: 128 rows, 4 / 8; 13, 14: 192 rows, 4 / 2), 15-18 the same with
+                                 the slice fills under the K loops (K1 = H = 512; 15, 18: 128 rows, 4 / 2 steps; 16: 192 rows; 17: 256 rows) where eligible */
     const uint64_t* idx_best; /* NULL, or the packed argmax words of the previous token (fn_out_argmax_f32): the token of row b is
                                  best_v - 1 - (uint32_t)idx_best[b]; takes precedence over idx                                */
     int32_t best_v;           /* vocabulary size the words were packed with                                                   */

@@ -1234,6 +1234,72 @@ int launch_cell_direct(const CellArgs& a, hipStream_t st) {
     return FN_OK;
 }
 
+// Gate epilogue of the cells with an LDS-resident weight slice, on (row, 4 units) items: the accumulator tiles of row tile m go through the
+// wave-private LDS tile tw (D layout in, lane (row = l >> 2, units 4 (l & 3) ..) out), every other operand - old state, token row, row
+// constant - is ONE 16-byte load per gate and item, the new state one 16-byte store.  tok[m]: the token of the lane's row of tile m.
+template <int RT, bool HAS_TAB, bool HAS_RB>
+FN_DEVINL void cell_epilogue_items(const CellArgs& a, int m0, int u0, int lane, float* tw, const int (&tok)[RT], const f32x4 (&arz)[RT][2],
+                                   const f32x4 (&anx)[RT], const f32x4 (&anh)[RT]) {
+    const int li = lane & 15, lg = lane >> 4;
+    const int er = lane >> 2, eu = u0 + 4 * (lane & 3);
+    f32x4 bi[3], bh[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        bh[q] = *reinterpret_cast<const f32x4*>(a.b_hh + q * a.H + eu);
+        bi[q] = a.b_ih ? *reinterpret_cast<const f32x4*>(a.b_ih + q * a.H + eu) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const long H3 = 3L * a.H;
+    f32x4 hv[RT], tv[RT][3], rv[RT][3];
+    int rows[RT];
+#pragma unroll
+    for (int m = 0; m < RT; ++m) {
+        rows[m] = m0 + 16 * m + er;
+        const int rc = min(rows[m], a.B - 1);
+        hv[m] = *reinterpret_cast<const f32x4*>(a.h_prev + (long)rc * a.ldh + eu);
+        if (HAS_TAB) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) tv[m][q] = *reinterpret_cast<const f32x4*>(a.gx_table + (long)tok[m] * H3 + q * a.H + eu);
+        }
+        if (HAS_RB) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) rv[m][q] = *reinterpret_cast<const f32x4*>(a.gx_rowbias + (long)rc * H3 + q * a.H + eu);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < RT; ++m) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            tw[0 * 320 + (4 * lg + i) * 20 + li] = arz[m][0][i];
+            tw[1 * 320 + (4 * lg + i) * 20 + li] = arz[m][1][i];
+            tw[2 * 320 + (4 * lg + i) * 20 + li] = anx[m][i];
+            tw[3 * 320 + (4 * lg + i) * 20 + li] = anh[m][i];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const f32x4 g_r = *reinterpret_cast<const f32x4*>(tw + 0 * 320 + er * 20 + 4 * (lane & 3));
+        const f32x4 g_z = *reinterpret_cast<const f32x4*>(tw + 1 * 320 + er * 20 + 4 * (lane & 3));
+        const f32x4 g_nx = *reinterpret_cast<const f32x4*>(tw + 2 * 320 + er * 20 + 4 * (lane & 3));
+        const f32x4 g_nh = *reinterpret_cast<const f32x4*>(tw + 3 * 320 + er * 20 + 4 * (lane & 3));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        f32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float gi[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                float e = bi[q][c];
+                if (HAS_TAB) e += tv[m][q][c];
+                if (HAS_RB) e += rv[m][q][c];
+                gi[q] = e;
+            }
+            const float r = fn_sigmoid((gi[0] + bh[0][c]) + g_r[c]);
+            const float z = fn_sigmoid((gi[1] + bh[1][c]) + g_z[c]);
+            const float n = fn_tanh((gi[2] + g_nx[c]) + r * (g_nh[c] + bh[2][c]));
+            o[c] = (1.0f - z) * n + z * hv[m][c];
+        }
+        if (rows[m] < a.B) *reinterpret_cast<f32x4*>(a.h_out + (long)rows[m] * a.ldo + eu) = o;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // The cell with the WEIGHT operand of a K phase resident in LDS (as out_argmax_lds_kernel): the LDS-free loop above is bound by its
 // operand loads (~8 TB/s of 16 x 64-byte pieces per instruction: 7 loads per 48 MFMAs), not by the MFMA pipe.  Here a workgroup owns
@@ -1361,69 +1427,13 @@ __global__ __launch_bounds__(NT) void gru_cell_wlds_kernel(const CellArgs a, int
             for (int m = 0; m < RT; ++m) { fn_keep(fa[0][m]); fn_keep(fa[1][m]); }
         }
     };
+    // the token of every epilogue row now (the table-row loads of the epilogue then cost one memory latency, not two)
+    int tok[RT];
+#pragma unroll
+    for (int m = 0; m < RT; ++m) tok[m] = HAS_TAB ? a.token(min(m0 + 16 * m + (lane >> 2), a.B - 1)) : 0;
     if (a.x) phase(a.x, a.ldx, a.w_ih, a.ldw_ih, a.K1, anx, false);
     phase(a.h_prev, a.ldh, a.w_hh, a.ldw_hh, a.H, anh, a.x != nullptr);
-    // epilogue on (row, 4 units) items through a wave-private LDS tile, as gru_cell_direct_kernel (its operands are requested here: the fill's
-    // loads and barriers sit between them and the loop anyway)
-    const int er = lane >> 2, eu = u0 + 4 * (lane & 3);
-    f32x4 bi[3], bh[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        bh[q] = *reinterpret_cast<const f32x4*>(a.b_hh + q * a.H + eu);
-        bi[q] = a.b_ih ? *reinterpret_cast<const f32x4*>(a.b_ih + q * a.H + eu) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    const long H3 = 3L * a.H;
-    f32x4 hv[RT], tv[RT][3], rv[RT][3];
-    int rows[RT];
-#pragma unroll
-    for (int m = 0; m < RT; ++m) {
-        rows[m] = m0 + 16 * m + er;
-        const int rc = min(rows[m], a.B - 1);
-        hv[m] = *reinterpret_cast<const f32x4*>(a.h_prev + (long)rc * a.ldh + eu);
-        if (HAS_TAB) {
-            const int tok = a.token(rc);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) tv[m][q] = *reinterpret_cast<const f32x4*>(a.gx_table + (long)tok * H3 + q * a.H + eu);
-        }
-        if (HAS_RB) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) rv[m][q] = *reinterpret_cast<const f32x4*>(a.gx_rowbias + (long)rc * H3 + q * a.H + eu);
-        }
-    }
-    float* tw = tr + wave * 4 * 320;
-#pragma unroll
-    for (int m = 0; m < RT; ++m) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            tw[0 * 320 + (4 * lg + i) * 20 + li] = arz[m][0][i];
-            tw[1 * 320 + (4 * lg + i) * 20 + li] = arz[m][1][i];
-            tw[2 * 320 + (4 * lg + i) * 20 + li] = anx[m][i];
-            tw[3 * 320 + (4 * lg + i) * 20 + li] = anh[m][i];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const f32x4 g_r = *reinterpret_cast<const f32x4*>(tw + 0 * 320 + er * 20 + 4 * (lane & 3));
-        const f32x4 g_z = *reinterpret_cast<const f32x4*>(tw + 1 * 320 + er * 20 + 4 * (lane & 3));
-        const f32x4 g_nx = *reinterpret_cast<const f32x4*>(tw + 2 * 320 + er * 20 + 4 * (lane & 3));
-        const f32x4 g_nh = *reinterpret_cast<const f32x4*>(tw + 3 * 320 + er * 20 + 4 * (lane & 3));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        f32x4 o;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float gi[3];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                float e = bi[q][c];
-                if (HAS_TAB) e += tv[m][q][c];
-                if (HAS_RB) e += rv[m][q][c];
-                gi[q] = e;
-            }
-            const float r = fn_sigmoid((gi[0] + bh[0][c]) + g_r[c]);
-            const float z = fn_sigmoid((gi[1] + bh[1][c]) + g_z[c]);
-            const float n = fn_tanh((gi[2] + g_nx[c]) + r * (g_nh[c] + bh[2][c]));
-            o[c] = (1.0f - z) * n + z * hv[m][c];
-        }
-        if (rows[m] < a.B) *reinterpret_cast<f32x4*>(a.h_out + (long)rows[m] * a.ldo + eu) = o;
-    }
+    cell_epilogue_items<RT, HAS_TAB, HAS_RB>(a, m0, u0, lane, tr + wave * 4 * 320, tok, arz, anx, anh);
 }
 
 template <int RT, int PF, bool HAS_TAB, bool HAS_RB>
@@ -1585,65 +1595,7 @@ __global__ __launch_bounds__(NT) void gru_cell_wlds_ovl_kernel(const CellArgs a)
     } else {
         phase(a.h_prev, a.ldh, a.w_hh, a.ldw_hh, anh, T_{}, F_{}, nullptr, 0);
     }
-    // epilogue as gru_cell_wlds_kernel
-    const int er = lane >> 2, eu = u0 + 4 * (lane & 3);
-    f32x4 bi[3], bh[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        bh[q] = *reinterpret_cast<const f32x4*>(a.b_hh + q * a.H + eu);
-        bi[q] = a.b_ih ? *reinterpret_cast<const f32x4*>(a.b_ih + q * a.H + eu) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    const long H3 = 3L * a.H;
-    f32x4 hv[RT], tv[RT][3], rv[RT][3];
-    int rows[RT];
-#pragma unroll
-    for (int m = 0; m < RT; ++m) {
-        rows[m] = m0 + 16 * m + er;
-        const int rc = min(rows[m], a.B - 1);
-        hv[m] = *reinterpret_cast<const f32x4*>(a.h_prev + (long)rc * a.ldh + eu);
-        if (HAS_TAB) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) tv[m][q] = *reinterpret_cast<const f32x4*>(a.gx_table + (long)tok[m] * H3 + q * a.H + eu);
-        }
-        if (HAS_RB) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) rv[m][q] = *reinterpret_cast<const f32x4*>(a.gx_rowbias + (long)rc * H3 + q * a.H + eu);
-        }
-    }
-    float* tw = tr + wave * 4 * 320;
-#pragma unroll
-    for (int m = 0; m < RT; ++m) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            tw[0 * 320 + (4 * lg + i) * 20 + li] = arz[m][0][i];
-            tw[1 * 320 + (4 * lg + i) * 20 + li] = arz[m][1][i];
-            tw[2 * 320 + (4 * lg + i) * 20 + li] = anx[m][i];
-            tw[3 * 320 + (4 * lg + i) * 20 + li] = anh[m][i];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const f32x4 g_r = *reinterpret_cast<const f32x4*>(tw + 0 * 320 + er * 20 + 4 * (lane & 3));
-        const f32x4 g_z = *reinterpret_cast<const f32x4*>(tw + 1 * 320 + er * 20 + 4 * (lane & 3));
-        const f32x4 g_nx = *reinterpret_cast<const f32x4*>(tw + 2 * 320 + er * 20 + 4 * (lane & 3));
-        const f32x4 g_nh = *reinterpret_cast<const f32x4*>(tw + 3 * 320 + er * 20 + 4 * (lane & 3));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        f32x4 o;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float gi[3];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                float e = bi[q][c];
-                if (HAS_TAB) e += tv[m][q][c];
-                if (HAS_RB) e += rv[m][q][c];
-                gi[q] = e;
-            }
-            const float r = fn_sigmoid((gi[0] + bh[0][c]) + g_r[c]);
-            const float z = fn_sigmoid((gi[1] + bh[1][c]) + g_z[c]);
-            const float n = fn_tanh((gi[2] + g_nx[c]) + r * (g_nh[c] + bh[2][c]));
-            o[c] = (1.0f - z) * n + z * hv[m][c];
-        }
-        if (rows[m] < a.B) *reinterpret_cast<f32x4*>(a.h_out + (long)rows[m] * a.ldo + eu) = o;
-    }
+    cell_epilogue_items<RT, HAS_TAB, HAS_RB>(a, m0, u0, lane, tr + wave * 4 * 320, tok, arz, anx, anh);
 }
 
 template <int RT, int PF, bool HAS_TAB, bool HAS_RB>
@@ -1802,7 +1754,7 @@ int fn_gru_cell_f32(const FnGruCell* c, void* stream) {
         case 18: if (cell_direct_ok(a) && cell_wlds_ovl_ok(a)) return launch_cell_wlds_ovl<2, 2>(a, (hipStream_t)stream); break;
         case 13: if (cell_direct_ok(a) && cell_wlds_ok(a)) return launch_cell_wlds<3, 4>(a, (hipStream_t)stream); break;
         case 14: if (cell_direct_ok(a) && cell_wlds_ok(a)) return launch_cell_wlds<3, 2>(a, (hipStream_t)stream); break;
-        case 9: if (cell_direct_ok(a) && cell_wlds_ok(a)) return launch_cell_wlds<4, 4>(a, (hipStream_t)stream); break;
+        case 9: if (cell_direct_ok(a) && cell_wlds_ok(a)) return launch_cell_wlds<4, 2>(a, (hipStream_t)stream); break;      // (<4, 4> needs AGPR copies: not built)
         case 10: if (cell_direct_ok(a) && cell_wlds_ok(a)) return launch_cell_wlds<2, 4>(a, (hipStream_t)stream); break;
         case 11: if (cell_direct_ok(a) && cell_wlds_ok(a)) return launch_cell_wlds<4, 2>(a, (hipStream_t)stream); break;
         case 12: if (cell_direct_ok(a) && cell_wlds_ok(a)) return launch_cell_wlds<2, 8>(a, (hipStream_t)stream); break;
