@@ -1087,6 +1087,9 @@ __global__ __launch_bounds__(2 * NT) void out_argmax_lds8_kernel(const float* __
         fn_gld4_sb(fa[set], oa, pa);
         pa += 16;
     };
+    float bv[3];                                     // requested in front of everything: the epilogue then waits for nothing
+#pragma unroll
+    for (int q = 0; q < 3; ++q) bv[q] = bias[min(n0 + 16 * q + li, V - 1)];
     const int npro = min(PF, nks);
 #pragma unroll
     for (int s = 0; s < PF; ++s)
@@ -1180,9 +1183,6 @@ __global__ __launch_bounds__(2 * NT) void out_argmax_lds8_kernel(const float* __
 #pragma unroll
         for (int q = 0; q < 3; ++q) acc[q] += rd[q * 64];
     }
-    float bv[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) bv[q] = bias[min(n0 + 16 * q + li, V - 1)];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         unsigned long long w = 0ull;
@@ -1237,25 +1237,36 @@ int launch_cell_direct(const CellArgs& a, hipStream_t st) {
 // Gate epilogue of the cells with an LDS-resident weight slice, on (row, 4 units) items: the accumulator tiles of row tile m go through the
 // wave-private LDS tile tw (D layout in, lane (row = l >> 2, units 4 (l & 3) ..) out), every other operand - old state, token row, row
 // constant - is ONE 16-byte load per gate and item, the new state one 16-byte store.  tok[m]: the token of the lane's row of tile m.
-template <int RT, bool HAS_TAB, bool HAS_RB>
-FN_DEVINL void cell_epilogue_items(const CellArgs& a, int m0, int u0, int lane, float* tw, const int (&tok)[RT], const f32x4 (&arz)[RT][2],
-                                   const f32x4 (&anx)[RT], const f32x4 (&anh)[RT]) {
-    const int li = lane & 15, lg = lane >> 4;
+// biases and old-state rows of the epilogue items: requested in front of the last K phase where the registers allow it (EARLY)
+template <int RT>
+struct CellEpiPre { f32x4 bi[3], bh[3], hv[RT]; };
+template <int RT>
+FN_DEVINL void cell_epilogue_request(const CellArgs& a, int m0, int u0, int lane, CellEpiPre<RT>& p) {
     const int er = lane >> 2, eu = u0 + 4 * (lane & 3);
-    f32x4 bi[3], bh[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-        bh[q] = *reinterpret_cast<const f32x4*>(a.b_hh + q * a.H + eu);
-        bi[q] = a.b_ih ? *reinterpret_cast<const f32x4*>(a.b_ih + q * a.H + eu) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        p.bh[q] = *reinterpret_cast<const f32x4*>(a.b_hh + q * a.H + eu);
+        p.bi[q] = a.b_ih ? *reinterpret_cast<const f32x4*>(a.b_ih + q * a.H + eu) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+#pragma unroll
+    for (int m = 0; m < RT; ++m) p.hv[m] = *reinterpret_cast<const f32x4*>(a.h_prev + (long)min(m0 + 16 * m + er, a.B - 1) * a.ldh + eu);
+}
+
+template <int RT, bool HAS_TAB, bool HAS_RB>
+FN_DEVINL void cell_epilogue_items(const CellArgs& a, int m0, int u0, int lane, float* tw, const int (&tok)[RT], const f32x4 (&arz)[RT][2],
+                                   const f32x4 (&anx)[RT], const f32x4 (&anh)[RT], const CellEpiPre<RT>& pre) {
+    const int li = lane & 15, lg = lane >> 4;
+    const int er = lane >> 2, eu = u0 + 4 * (lane & 3);
+    const f32x4 (&bi)[3] = pre.bi;
+    const f32x4 (&bh)[3] = pre.bh;
+    const f32x4 (&hv)[RT] = pre.hv;
     const long H3 = 3L * a.H;
-    f32x4 hv[RT], tv[RT][3], rv[RT][3];
+    f32x4 tv[RT][3], rv[RT][3];
     int rows[RT];
 #pragma unroll
     for (int m = 0; m < RT; ++m) {
         rows[m] = m0 + 16 * m + er;
         const int rc = min(rows[m], a.B - 1);
-        hv[m] = *reinterpret_cast<const f32x4*>(a.h_prev + (long)rc * a.ldh + eu);
         if (HAS_TAB) {
 #pragma unroll
             for (int q = 0; q < 3; ++q) tv[m][q] = *reinterpret_cast<const f32x4*>(a.gx_table + (long)tok[m] * H3 + q * a.H + eu);
@@ -1433,7 +1444,9 @@ __global__ __launch_bounds__(NT) void gru_cell_wlds_kernel(const CellArgs a, int
     for (int m = 0; m < RT; ++m) tok[m] = HAS_TAB ? a.token(min(m0 + 16 * m + (lane >> 2), a.B - 1)) : 0;
     if (a.x) phase(a.x, a.ldx, a.w_ih, a.ldw_ih, a.K1, anx, false);
     phase(a.h_prev, a.ldh, a.w_hh, a.ldw_hh, a.H, anh, a.x != nullptr);
-    cell_epilogue_items<RT, HAS_TAB, HAS_RB>(a, m0, u0, lane, tr + wave * 4 * 320, tok, arz, anx, anh);
+    CellEpiPre<RT> pre;
+    cell_epilogue_request<RT>(a, m0, u0, lane, pre);
+    cell_epilogue_items<RT, HAS_TAB, HAS_RB>(a, m0, u0, lane, tr + wave * 4 * 320, tok, arz, anx, anh, pre);
 }
 
 template <int RT, int PF, bool HAS_TAB, bool HAS_RB>
@@ -1589,13 +1602,18 @@ __global__ __launch_bounds__(NT) void gru_cell_wlds_ovl_kernel(const CellArgs a)
     for (int m = 0; m < RT; ++m) tok[m] = HAS_TAB ? a.token(min(m0 + 16 * m + (lane >> 2), a.B - 1)) : 0;
     using T_ = std::integral_constant<bool, true>;
     using F_ = std::integral_constant<bool, false>;
+    constexpr bool EARLY = RT <= 2;                  // (the 192- and 256-row forms have no registers left beside their rings: no AGPR copies next to asm loads)
+    CellEpiPre<RT> pre;
     if (a.x) {
         phase(a.x, a.ldx, a.w_ih, a.ldw_ih, anx, T_{}, T_{}, a.w_hh, a.ldw_hh);
+        if (EARLY) cell_epilogue_request<RT>(a, m0, u0, lane, pre);
         phase(a.h_prev, a.ldh, a.w_hh, a.ldw_hh, anh, F_{}, F_{}, nullptr, 0);
     } else {
+        if (EARLY) cell_epilogue_request<RT>(a, m0, u0, lane, pre);
         phase(a.h_prev, a.ldh, a.w_hh, a.ldw_hh, anh, T_{}, F_{}, nullptr, 0);
     }
-    cell_epilogue_items<RT, HAS_TAB, HAS_RB>(a, m0, u0, lane, tr + wave * 4 * 320, tok, arz, anx, anh);
+    if (!EARLY) cell_epilogue_request<RT>(a, m0, u0, lane, pre);
+    cell_epilogue_items<RT, HAS_TAB, HAS_RB>(a, m0, u0, lane, tr + wave * 4 * 320, tok, arz, anx, anh, pre);
 }
 
 template <int RT, int PF, bool HAS_TAB, bool HAS_RB>
