@@ -1165,236 +1165,6 @@ __global__ __launch_bounds__(NT) void gru_fwd_pp_kernel(const PArgs args) {
     flush_stores();                                  // the last epilogue's (no K loop follows)
 }
 
-// backward scan, ping-pong form (see gru_fwd_pp_kernel): iteration `it` handles step q = T - 1 - it; phase = (half, it)
-template <int WK>
-__global__ __launch_bounds__(NT) void gru_bwd_pp_kernel(const QArgs args) {
-    static_assert(WK == 1 || WK == 2, "128-row groups (one wave over all of K) or 64-row groups (K split in two)");
-    constexpr int WM = 4 / WK, EM = 2 * WM;
-    constexpr int H = 512, nk3 = 48, nslices = 32;
-    static_assert(WK * EM == 8, "kloop2_asm.h: the odd-k accumulator plane sits 8 tiles behind the even-k one");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* wl = smem;                                // [nk3][2][64][4]  W_hh^T slice, B-fragment order
-    float* red = smem + 3 * H * 16;                  // [2][WK][EM][RT]
-    const unsigned dead = lds_addr(red + 2 * WK * EM * RT);
-
-    const int g = blockIdx.x % args.ngroups, slice = blockIdx.x / args.ngroups;
-    int si = 0;
-#pragma unroll
-    for (int k = 1; k < FN_MAX_SCANS; ++k)
-        if (k < args.n && g >= args.s[k].group0) si = k;
-    const QScan& S = args.s[si];
-    const int B = S.B, T = S.T;
-    const int m0 = (g - S.group0) * (16 * EM), hh0 = slice * 16;
-    const int nrt = B >> 4;
-    const long FS3 = (long)nrt * 16 * 3 * H;
-    const long BH = (long)B * H;
-    const long GS = (long)4 * H * nrt * 16;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave % WM, wk = wave / WM;
-    u32* cnt[2] = {args.sync + (2 * g) * 32, args.sync + (2 * g + 1) * 32};
-    u32* err = args.err;
-
-    if (tid == 0) lds_st(dead, 0);
-    {
-        const float4* src = reinterpret_cast<const float4*>(S.wt_frag + (long)slice * nk3 * 512);
-        float4* dst = reinterpret_cast<float4*>(wl);
-        for (int i = tid; i < nk3 * 128; i += NT) dst[i] = src[i];
-    }
-
-    const bool has_item = WK == 1 || lane < 32;
-    const int item = WK == 1 ? tid : wave * 32 + (lane & 31);
-    const int rl = item >> 2, th = rl >> 4;
-    const int jj0 = hh0 + 4 * (item & 3);
-    int ib[2], icoff[2];
-    f32x4 carry[2], rs[2][3], rsn[2];
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int hx = 0; hx < 2; ++hx) {
-        const int tile = 2 * th + hx;
-        ib[hx] = m0 + tile * 16 + (rl & 15);
-        icoff[hx] = tile * RT + ((rl & 15) >> 2) * 68 + (item & 3) * 16 + (rl & 3);
-        carry[hx] = S.dh_last ? ldv4(S.dh_last + (long)ib[hx] * H + jj0) : z4;
-        rsn[hx] = z4;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) rs[hx][q] = z4;
-    }
-    __syncthreads();
-
-    const int c0 = nk3 * wk / WK;
-    unsigned vo[2], h_red[2];
-#pragma unroll
-    for (int hx = 0; hx < 2; ++hx) {
-        const int tw = 2 * wm + hx;
-        vo[hx] = (unsigned)((((long)(m0 >> 4) + tw) * nk3 * 512 + lane * 4) * 4);
-        h_red[hx] = lds_addr(red) + (((wk * EM + tw) * RT + lane * 4 + (lane >> 4) * 4) * 4);
-    }
-    const unsigned h_lp = lds_addr(wl) + c0 * 2048 + lane * 16, h_lq = h_lp + 49152u;
-    const int iters = T + (S.dh0 ? 1 : 0);
-
-    // stores of the last epilogue: issued by the NEXT phase's K loop statement (kloop2_asm.h), or by flush_stores() when none follows
-    bool st_valid = false;
-    float *st_base = S.xf, *st_g = nullptr, *st_n = nullptr;
-    unsigned st_o = 0;
-    f32x4 st_d[4];
-    auto flush_stores = [&]() __attribute__((always_inline)) {
-        if (st_valid && has_item) {
-            char* sb = reinterpret_cast<char*>(st_base) + st_o;
-            stv4_sc1(reinterpret_cast<float*>(sb), st_d[0]);
-            stv4_sc1(reinterpret_cast<float*>(sb + 0x8000), st_d[1]);
-            stv4_sc1(reinterpret_cast<float*>(sb + 0x10000), st_d[3]);
-            stv4(st_g - H, st_d[0]);
-            stv4(st_g, st_d[1]);
-            stv4(st_g + H, st_d[2]);
-            stv4(st_n, st_d[3]);
-        }
-        st_valid = false;
-    };
-    // gate backward of half hx at iteration it (step q): arithmetic and LDS reads only; q < 0: only dL/dh0 is left (stored here)
-    auto epilogue = [&](auto HX, const int it, const f32x4 (&gt)[4], const f32x4& hpv, const f32x4& ext, const bool hand) __attribute__((always_inline)) {
-        constexpr int hx = decltype(HX)::value;
-        const int q = T - 1 - it;
-        f32x4 dh;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float a = 0.f;
-            if (hand) {
-#pragma unroll
-                for (int w = 0; w < WK; ++w) {
-                    float x = red[(long)(w * EM) * RT + icoff[hx] + c * 4];
-                    x += red[(long)((WK + w) * EM) * RT + icoff[hx] + c * 4];      // even-k + odd-k accumulator
-                    a += x;
-                }
-            }
-            dh[c] = (a + carry[hx][c]) + ext[c];
-        }
-        if (q < 0) {
-            if (has_item) stv4(S.dh0 + (long)ib[hx] * H + jj0, dh);
-            st_valid = false;
-            return;
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float dr, dz, dnp, dnr, cy;
-            fn_gru_gate_bwd(dh[c], gt[0][c], gt[1][c], gt[2][c], gt[3][c], hpv[c], dr, dz, dnp, dnr, cy);
-            st_d[0][c] = dr; st_d[1][c] = dz; st_d[2][c] = dnp; st_d[3][c] = dnr; carry[hx][c] = cy;
-        }
-        rs[hx][0] += st_d[0]; rs[hx][1] += st_d[1]; rs[hx][2] += st_d[2]; rsn[hx] += st_d[3];
-        st_base = S.xf + (long)(it & 1) * FS3;
-        st_o = (unsigned)(frag_off(ib[hx], jj0, nk3) * 4);
-        st_g = S.dgx_all + (long)q * 3 * BH + (long)ib[hx] * 3 * H + jj0 + H;
-        st_n = S.dghn_all + (long)q * BH + (long)ib[hx] * H + jj0;
-        st_valid = true;
-    };
-
-    int pend = -1;
-    // ---- iteration 0: no K loop (dh = dh_last + dh_ext[T-1]); half A arrives at once, half B's arrival rides in the first K loop ----------
-    {
-        const int q = T - 1;
-        f32x4 g0[2][4], hp0[2], x0[2];
-#pragma unroll
-        for (int hx = 0; hx < 2; ++hx) {
-            const float* gq = S.gates + (long)q * GS + gate_off(ib[hx], 0, jj0, nrt);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) g0[hx][k] = ldv4(gq + k * 256);
-            hp0[hx] = q > 0 ? ldv4(S.h_all + (long)(q - 1) * BH + (long)ib[hx] * H + jj0) : (S.h0 ? ldv4(S.h0 + (long)ib[hx] * H + jj0) : z4);
-            x0[hx] = S.dh_ext ? ldv4(S.dh_ext + (long)q * BH + (long)ib[hx] * H + jj0) : z4;
-        }
-        const bool publish = iters > 1;
-        epilogue(std::integral_constant<int, 0>{}, 0, g0[0], hp0[0], x0[0], false);
-        flush_stores();
-        if (publish) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(cnt[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        epilogue(std::integral_constant<int, 1>{}, 0, g0[1], hp0[1], x0[1], false);
-        flush_stores();
-        pend = publish ? 1 : -1;
-    }
-    if (iters > 1) {
-        // every load the compiler knows about has to be complete before the loop (see gru_fwd_pp_kernel)
-#pragma unroll
-        for (int hx = 0; hx < 2; ++hx) {
-            fn_touch(carry[hx]);
-            fn_touch(rsn[hx]);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) fn_touch(rs[hx][q]);
-        }
-        {
-            const float* xin = S.xf + (long)c0 * 512;          // slab 0: iteration 0's gate gradients
-            pp_wait_counter(cnt[0], (u32)nslices, err, dead);
-            if (WK == 1) fn_pp_bwd_k1536_pro(xin, vo[0], h_lp, h_lq);
-            else fn_pp_bwd_k768_pro(xin, vo[0], h_lp, h_lq);
-        }
-
-        auto phase = [&](auto HX, const int it) __attribute__((always_inline)) -> bool {
-            constexpr int hx = decltype(HX)::value, hy = hx ^ 1;
-            const int q = T - 1 - it, qc = q > 0 ? q : 0;
-            const int it1 = it + hx;
-            const int p = it;                             // FN_PSTAMP
-            (void)p;
-            const bool next_k = it1 < iters;
-            const float* xin = S.xf + (long)((it - 1) & 1) * FS3 + (long)c0 * 512;
-            const float* xiny = S.xf + (long)((it1 - 1) & 1) * FS3 + (long)c0 * 512;
-            const unsigned ptgt = next_k ? (u32)nslices * (u32)it1 : 0xffffffffu;
-            const long ro = (long)ib[hx] * H + jj0;
-            const float* ga = S.gates + (long)qc * GS + gate_off(ib[hx], 0, jj0, nrt);
-            const float* ha = qc > 0 ? S.h_all + (long)(qc - 1) * BH + ro : (S.h0 ? S.h0 + ro : S.h_all + ro);      // unused values still come from a legal address
-            const float* xa = S.dh_ext ? S.dh_ext + (long)qc * BH + ro : S.h_all + ro;
-            const bool hzero = q < 0 || (q == 0 && !S.h0), xzero = q < 0 || !S.dh_ext;
-            f32x4 gt[4], hp2, xt2;
-            unsigned pv;
-            const int arr = pend >= 0 ? (wave == 0 ? 2 : 1) : 0;
-            u32* acnt = cnt[pend > 0 ? 1 : 0];
-            FN_PSTAMP(hx * 4 + 0);
-            if (WK == 1) {
-                if (!st_valid) fn_pp_bwd_k1536_first(xin, vo[hx], h_lp, h_lq, h_red[hx], arr, acnt, cnt[hy], ptgt, xiny, vo[hy], ga, ha, xa, gt, hp2, xt2, pv);
-                else fn_pp_bwd_k1536_main(xin, vo[hx], h_lp, h_lq, h_red[hx], arr, acnt, cnt[hy], ptgt, xiny, vo[hy], ga, ha, xa, st_base, st_o, st_g, st_n, st_d[0], st_d[1],
-                                          st_d[2], st_d[3], gt, hp2, xt2, pv);
-            } else {
-                if (!st_valid) fn_pp_bwd_k768_first(xin, vo[hx], h_lp, h_lq, h_red[hx], arr, acnt, cnt[hy], ptgt, xiny, vo[hy], ga, ha, xa, gt, hp2, xt2, pv);
-                else fn_pp_bwd_k768_main(xin, vo[hx], h_lp, h_lq, h_red[hx], arr, acnt, cnt[hy], ptgt, xiny, vo[hy], ga, ha, xa, st_base, st_o, st_g, st_n, st_d[0], st_d[1],
-                                         st_d[2], st_d[3], gt, hp2, xt2, pv);
-            }
-            st_valid = false;
-            FN_PSTAMP(hx * 4 + 1);
-            if (next_k && pv < ptgt) {               // rare: the other half's inputs were not all published yet - poll, then request its ring
-                FN_PCOUNT(0);
-                pp_wait_counter(cnt[hy], ptgt, err, dead);
-                if (WK == 1) fn_pp_bwd_k1536_pro(xiny, vo[hy], h_lp, h_lq);
-                else fn_pp_bwd_k768_pro(xiny, vo[hy], h_lp, h_lq);
-            }
-            lds_barrier();
-            FN_PSTAMP(hx * 4 + 2);
-            if (lds_ld(dead)) return false;
-            epilogue(HX, it, gt, hzero ? z4 : hp2, xzero ? z4 : xt2, true);
-            FN_PSTAMP(hx * 4 + 3);
-            pend = (q > 0 || (q == 0 && S.dh0 != nullptr)) ? hx : -1;
-            return true;
-        };
-
-#pragma unroll 1
-        for (int it = 1; it < iters; ++it) {
-            if (!phase(std::integral_constant<int, 0>{}, it)) return;
-            if (!phase(std::integral_constant<int, 1>{}, it)) return;
-        }
-        flush_stores();
-    }
-#pragma unroll
-    for (int hx = 0; hx < 2; ++hx) {
-        if (!has_item) continue;
-        if (S.rowsum) {
-            float* p = S.rowsum + (long)ib[hx] * 3 * H + jj0;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) stv4(p + q * H, ldv4(p + q * H) + rs[hx][q]);
-        }
-        if (S.rowsum_n) {
-            float* p = S.rowsum_n + (long)ib[hx] * H + jj0;
-            stv4(p, ldv4(p) + rsn[hx]);
-        }
-    }
-}
-
 // backward scan, ping-pong form with HALF of the W_hh^T slice register-stationary (kloop2_asm.h, GenRS): a workgroup owns 32 dh columns
 // (16 slices) of a 32 TH-row group; column tile 0 of its slice lives in AGPRs (every wave its K quarter), column tile 1 in LDS; every wave
 // multiplies all TH row tiles of the current half over its K quarter, the epilogue adds the four partial sums in wave order.  One operand
@@ -1895,12 +1665,6 @@ int fn_gru_bwd_persist(const FnGruBwd* scans, int n_scans, hipStream_t st) {
     const int grid = groups * nslices;
     const int wk = rpw == 16 ? 4 : rpw == 32 ? 2 : (rpw == 64 && !(scans[0].variant & 0x100)) ? 2 : 1;
     const size_t lds = ((size_t)3 * H * 16 + (size_t)2 * wk * (rpw / 16) * RT) * 4 + 16;
-    // ping-pong form (two halves per workgroup, kloop2_asm.h): H = 512, 128- or 64-row groups, full row groups
-    // (bit 12 selects it: measured no faster than the single-group loop - the backward K loop is bound by its operand stream, 768 KB per
-    // workgroup and step from L2, not by the hand-over latencies the ping-pong hides)
-    bool pp = H == 512 && (rpw == 128 || (rpw == 64 && wk == 2)) && !(scans[0].variant & 0xC00) && (scans[0].variant & 0x1000) && 2 * groups <= FN_MAX_GROUPS;
-    for (int s = 0; s < n_scans && pp; ++s) pp = scans[s].B % rpw == 0 && scans[s].T >= 2;
-    if (pp) return rpw == 128 ? launch_k<QArgs, gru_bwd_pp_kernel<1>>(a, grid, lds, cus, st) : launch_k<QArgs, gru_bwd_pp_kernel<2>>(a, grid, lds, cus, st);
     switch (rpw) {
         case 128: return launch_k<QArgs, gru_bwd_persist_kernel<4, 1, 2, 8>>(a, grid, lds, cus, st);
         case 64:

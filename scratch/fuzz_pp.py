@@ -18,7 +18,7 @@ while time.time() < t_end:
     B = int(rng.choice([64, 128, 192, 256]))
     nmax = {64: 8, 128: 8, 192: 5, 256: 4}[B]
     n = int(rng.randint(1, nmax + 1))
-    bvar = int(rng.choice([0, 0, 0x1000]))                    # backward: default dispatch (rs where eligible) or the 32-slice ping-pong form
+    bvar = int(rng.choice([0, 0, 0x2000]))                    # backward: default dispatch (rs where eligible) or the 32-slice loop
     scans, bws = [], []
     for s in range(n):
         T = int(rng.randint(2, 40))

@@ -1400,8 +1400,11 @@ def _pp_forward_scans(ops, n, B, H, Ts, seed, kinds):
                                           (2, 256, (8,), ("table_shift", "dense")), (2, 256, (3, 6), ("dense", "table")), (1, 512, (5,), ("table_shift",)),
                                           (3, 128, (4,), ("table", "dense", "table_rev")), (8, 128, (6, 3), ("table", "table_shift"))])
 def test_ping_pong_scans_are_bit_identical_to_the_single_group_loops(ops, n, B, Ts, kinds):
-    """round 4: the forward / backward scans whose workgroups alternate between two halves of their row group (gru_*_pp_kernel: H = 512,
-    128- and 64-row groups) against the round-3 loops (variant bit 0x800), three launches in a row on the same buffers"""
+    """round 4: the forward scans whose workgroups alternate between two halves of their row group (gru_fwd_pp_kernel: H = 512, 128- and 64-row
+    groups) against the round-3 loops (variant bit 0x800), three launches in a row on the same buffers: bit-identical; the backward scans of
+    the same shapes: the 32-slice loop bit-identical to the round-3 form, the register-stationary default within rounding and bit-stable from
+    launch to launch.  (A ping-pong form of the 32-slice backward existed until round 4: never the default, and it differed from the loop in
+    about 1 % of its launches at the encoder shape - removed, scratch/gru_bwd_pp_kernel_removed.hip.txt.)"""
     H = 512
     scans = _pp_forward_scans(ops, n, B, H, Ts, 7 * n + B, kinds)
     ops.gru_seq_fwd(scans, variant=0x800)
@@ -1436,7 +1439,7 @@ def test_ping_pong_scans_are_bit_identical_to_the_single_group_loops(ops, n, B, 
             for k in outs:
                 if b[k] is not None:
                     b[k].zero_() if "rowsum" in k else b[k].fill_(float("nan"))
-        ops.gru_seq_bwd(bw, variant=0x3000)            # bit 12: the ping-pong form of the 32-slice kernel, bit 13: not the register-stationary one
+        ops.gru_seq_bwd(bw, variant=0x2000)            # bit 13: not the register-stationary kernel - the 32-slice loop of the automatic dispatch
         assert not ops.gru_sync_error()
         for i, (r, b) in enumerate(zip(refb, bw)):
             for k, v in r.items():
@@ -1453,6 +1456,10 @@ def test_ping_pong_scans_are_bit_identical_to_the_single_group_loops(ops, n, B, 
         for i, (r, b) in enumerate(zip(refb, bw)):
             for k, v in r.items():
                 close(b[k], v, 2e-5, "register-stationary backward rep %d scan %d %s" % (rep, i, k))
+        if rep == 0:
+            first = [{k: b[k].clone() for k in outs if b[k] is not None} for b in bw]
+        else:                                              # ... and the same bits from launch to launch
+            assert all(torch.equal(b[k], v) for r, b in zip(first, bw) for k, v in r.items()), "register-stationary backward rep %d differs from rep 0" % rep
 
 
 def test_masked_prob_kernel(ops):
