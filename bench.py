@@ -150,7 +150,7 @@ ROW_INFO = {   # row -> (bound, unit of work, kernel, peak share of the chip)
     "subdec_fwd_scan": ("mfma", "flop", "gru_fwd_pp_kernel (both sub-decoders, 64 steps)", 1.0),
     "subdec_bwd_scan": ("mfma", "flop", "gru_bwd_rs_kernel (both sub-decoders, 64 steps)", 1.0),
     "dwhh_gemm_tn": ("mfma", "flop", "gemm_tn_kernel via fn_gru_dwhh_f32 (dW_hh of an encoder direction / a decoder layer: [3H x T*B] x [T*B x H], 48 tiles x 16 K ranges; 6 launches per step)", 1.0),
-    "dwhh_gemm_tn_attr": ("mfma", "flop", "gemm_tn_kernel via fn_gru_dwhh_f32 (dW_hh of the attribute decoders, K = Tr*B rows, 48 tiles x 8 K ranges)", 1.0),
+    "dwhh_gemm_tn_attr": ("mfma", "flop", "gemm_tn_kernel via fn_gru_dwhh_f32 (dW_hh of the attribute decoders, K = Tr*B rows, 48 tiles x 16 K ranges)", 1.0),
     "dwhh_gemm_tn_lean": ("mfma", "flop", "gemm_tn_lean_kernel via fn_gru_dwhh_f32 (dW_hh of the decoder-side scans, <= 128 registers)", 1.0),
     "gemm_tn": ("mfma", "flop", "gemm_tn_kernel (dW of dense layers)", 1.0),
     "gemm_nt": ("mfma", "flop", "gemm_kernel (X W^T: W_ih2 projection, output layer)", 1.0),

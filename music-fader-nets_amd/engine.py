@@ -497,7 +497,9 @@ class Engine:
 
     @staticmethod
     def _splitk(rows):
-        return 16 if rows >= 32768 else (8 if rows >= 4096 else (4 if rows >= 1024 else 1))
+        # 48 tiles x split depth workgroups at two per CU: 8 ranges = 384 workgroups leave half of the second round empty (rows = 16384: 264 us = 0.62 of the MFMA
+        # peak against 210 us = 0.78 with 16; scratch/sweep_dwhh_splitk.py)
+        return 16 if rows >= 8192 else (8 if rows >= 4096 else (4 if rows >= 1024 else 1))
 
     def _bwd_global_decoder_scans(self, S, fill=None):
         """Backward of global_decoder_tf up to the gate gradients (dlogits must already be in S['dec']['logits'], in place):
