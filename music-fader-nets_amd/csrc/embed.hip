@@ -15,7 +15,7 @@
 namespace {
 
 constexpr int EG_BLK = 1024;     // rows per sorting block
-constexpr int EG_PIECE = 128;    // rows per partial sum
+constexpr int EG_PIECE = 256;    // rows per partial sum (scratch/ab_eg_piece.sh, us per launch at the benchmark shape: 64 rows 177, 128 rows 144, 256 rows 130, 512 rows 140, 1024 rows 185)
 constexpr int EG_NT = 384;       // threads of the piece / final kernels: one float4 column each at N3 = 1536
 constexpr int EG_MAX_JOBS = 8;
 

@@ -359,7 +359,7 @@ int fn_gru_dwhh_f32_host(const float* dgx, const float* dghn, const float* hprev
 
 // ---- token sort + segment sums (embed.hip) --------------------------------------------------------------------------------------------
 namespace {
-constexpr int EG_PIECE_H = 128;                            // rows per partial sum (EG_PIECE of embed.hip: part of the image's contract)
+constexpr int EG_PIECE_H = 256;                            // rows per partial sum (EG_PIECE of embed.hip: part of the image's contract)
 }
 size_t fn_token_sort_ints_host(int64_t rows, int V) { return (size_t)2 * (V + 1) + 2 + (size_t)rows; }
 size_t fn_token_sort_ws_bytes_host(int64_t, int V) { return (size_t)V * sizeof(int32_t) + 16; }
