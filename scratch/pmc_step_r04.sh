@@ -14,7 +14,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_C
     for k in "gru_fwd_pp_kernel<1>" "gru_fwd_pp_kernel<2>" "gru_bwd_rs_kernel<2>" "gru_bwd_rs_kernel<1>" "gru_fwd_pp_kernel" "gru_bwd_rs_kernel" "gemm_tn_kernel" "gemm_kernel<128" "gemm_nt_direct_kernel<1" "gemm_nt_direct_kernel<4" "out_head_kernel" "eg_piece_kernel"; do
       echo "== $k"; python $R/scratch/pmc_avg.py $f "$k"
     done > $O/$tag.txt
-    echo "== gemm_tn_kernel grid 196608 (dW_hh / dW_ih2, K = 65280-65536 rows)" >> $O/$tag.txt; python $R/scratch/pmc_avg.py $f "gemm_tn_kernel" 196608 >> $O/$tag.txt
+    echo "== gemm_tn_kernel grid 196608 = 48 tiles x 16 K ranges (dW_hh / dW_ih2 at K = 65280-65536 rows and, since the 16-range split, the attribute decoders at K = 16384)" >> $O/$tag.txt; python $R/scratch/pmc_avg.py $f "gemm_tn_kernel" 196608 >> $O/$tag.txt
     rm -rf $O/$tag
   else echo "no csv for $grp"; tail -3 $O/$tag.log; fi
 done
