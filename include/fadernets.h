@@ -201,6 +201,10 @@ size_t fn_gru_gates_floats(int B, int H);
  * launch whose workgroups gave up waiting (results of that and later calls are invalid until it is cleared). */
 size_t fn_gru_sync_ws_bytes(void);
 int fn_gru_seq_fwd(const FnGruFwd* scans, int n_scans, void* stream);
+/* 1 when fn_gru_seq_fwd would take this call with variant bit 14 (bf16 x 6) on the current device, else 0 (shapes and gates != NULL only;
+ * nothing is enqueued).  A scan that is cut into several calls (time chunks with h_last_frag -> h0_frag hand-over) must run ALL of its
+ * calls on one arithmetic - the hand-over images differ (bf16 triples / fp32 fragments) - so the caller asks for every call of the chain first. */
+int fn_gru_fwd_x6_ok(const FnGruFwd* scans, int n_scans);
 
 /* ONE GRU cell step for a large batch (nn.GRUCell, gmm_model.py:131-136 in the eval-mode decode loop of thousands of rows):
  *    gi = x W_ih^T + b_ih + gx_table[tok] + gx_rowbias[b]      (every term optional)       gh = h_prev W_hh^T + b_hh
@@ -477,6 +481,10 @@ int fn_comm_init(void** comm_out, int world, int rank, const void* id);
 int fn_comm_destroy(void* comm);
 int fn_comm_all_reduce_f32(void* comm, float* buf, size_t n, void* stream);
 int fn_comm_all_gather(void* comm, const void* send, void* recv, size_t bytes_per_rank, void* stream);
+/* what RCCL itself reports for the communicator (ncclCommCount / ncclCommUserRank): bench.py prints them, so that a multi-GPU line
+ * proves that its gradient all-reduce (trainer_gmm.py:249-251) ran over N RCCL ranks */
+int fn_comm_count(void* comm, int* count_out);
+int fn_comm_rank(void* comm, int* rank_out);
 
 /* Diagnostic: `blocks` workgroups that each hold `lds_bytes` of LDS (<= 64 KB) and spin for about `cycles` clock ticks - a stand-in
  * for a foreign kernel (an RCCL channel, another process' launch) that is RESIDENT on some compute units when a weight-stationary

@@ -3,6 +3,7 @@
 The directory name contains '-' (it follows the upstream repo name), so import it through
 ``mfn_import.load_package()`` at the repo root, which registers it as ``music_fader_nets_amd``.
 """
+from . import arith  # noqa: F401
 from .gmm_model import MusicAttrRegGMVAE  # noqa: F401
 from .trainer import GMVAETrainer, VAETrainer, beta_schedule, convert_to_one_hot  # noqa: F401
 from .vae_model import MusicAttrRegVAE  # noqa: F401

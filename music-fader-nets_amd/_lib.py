@@ -94,6 +94,7 @@ SIGNATURES = {
     "fn_weight_images": (C.c_int, [C.POINTER(FnWeightImage), C.c_int, vp]),
     "fn_gru_sync_ws_bytes": (C.c_size_t, []),
     "fn_gru_seq_fwd": (C.c_int, [C.POINTER(FnGruFwd), C.c_int, vp]),
+    "fn_gru_fwd_x6_ok": (C.c_int, [C.POINTER(FnGruFwd), C.c_int]),
     "fn_gru_cell_f32": (C.c_int, [C.POINTER(FnGruCell), vp]),
     "fn_out_argmax_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "fn_best_tokens": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
@@ -133,6 +134,8 @@ SIGNATURES = {
     "fn_comm_destroy": (C.c_int, [vp]),
     "fn_comm_all_reduce_f32": (C.c_int, [vp, vp, C.c_size_t, vp]),
     "fn_comm_all_gather": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
+    "fn_comm_count": (C.c_int, [vp, C.POINTER(C.c_int)]),
+    "fn_comm_rank": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "fn_occupy_cus": (C.c_int, [C.c_int, C.c_int, C.c_longlong, vp]),
 }
 

@@ -24,6 +24,8 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
 };
@@ -51,7 +53,8 @@ const Rccl& rccl() {
         r.handle = h;
         r.ok = bind(h, "ncclGetUniqueId", r.GetUniqueId) && bind(h, "ncclCommInitRank", r.CommInitRank) &&
                bind(h, "ncclCommDestroy", r.CommDestroy) && bind(h, "ncclAllReduce", r.AllReduce) && bind(h, "ncclAllGather", r.AllGather) &&
-               bind(h, "ncclGetErrorString", r.GetErrorString);
+               bind(h, "ncclGetErrorString", r.GetErrorString) && bind(h, "ncclCommCount", r.CommCount) &&
+               bind(h, "ncclCommUserRank", r.CommUserRank);
     });
     return g_rccl;
 }
@@ -111,6 +114,21 @@ int fn_comm_all_gather(void* comm, const void* send, void* recv, size_t bytes_pe
     const Rccl& r = rccl();
     if (!r.ok) return FN_E_COMM;
     return rc(r.AllGather(send, recv, bytes_per_rank, ncclInt8, (ncclComm_t)comm, (hipStream_t)stream));
+}
+
+// what RCCL itself says about the communicator (bench.py prints it: the proof that a multi-GPU line really ran over N RCCL ranks)
+int fn_comm_count(void* comm, int* count_out) {
+    if (!comm || !count_out) return FN_E_NULL;
+    const Rccl& r = rccl();
+    if (!r.ok) return FN_E_COMM;
+    return rc(r.CommCount((ncclComm_t)comm, count_out));
+}
+
+int fn_comm_rank(void* comm, int* rank_out) {
+    if (!comm || !rank_out) return FN_E_NULL;
+    const Rccl& r = rccl();
+    if (!r.ok) return FN_E_COMM;
+    return rc(r.CommUserRank((ncclComm_t)comm, rank_out));
 }
 
 // ---- diagnostic: hold LDS on some compute units for a while (see fadernets.h) ----------------------------------------------

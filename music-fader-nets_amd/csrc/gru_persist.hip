@@ -1441,9 +1441,34 @@ int launch_k(const Args& a, int grid, size_t lds, int cus, hipStream_t st) {
     return FN_OK;
 }
 
+// bf16 x 6 forward scans: row tiles per wave (1 = 64-row groups, 2 = 128-row groups) of the launch, 0 = not eligible.  H = 512, every scan in
+// full row groups, saved gates, T >= 2, all row groups resident at once.
+int x6_row_tiles(const FnGruFwd* scans, int n_scans, int maxgroups) {
+    if (scans[0].H != 512) return 0;
+    long g64 = 0, g128 = 0;
+    bool d64 = true, d128 = true;
+    for (int s = 0; s < n_scans; ++s) {
+        const FnGruFwd& d = scans[s];
+        if (d.H != 512 || !d.gates || d.T < 2) return 0;
+        d64 = d64 && d.B % 64 == 0; d128 = d128 && d.B % 128 == 0;
+        g64 += d.B / 64; g128 += d.B / 128;
+    }
+    return (d64 && g64 <= maxgroups) ? 1 : ((d128 && g128 <= maxgroups) ? 2 : 0);
+}
+
 }  // namespace
 
 extern "C" size_t fn_gru_sync_ws_bytes() { return ((size_t)FN_MAX_GROUPS * 32 + 32) * 4; }
+
+// would fn_gru_seq_fwd run this call with variant bit 14 (bf16 x 6)?  Shapes only: pointers are not looked at beyond NULL-ness of `gates`.
+extern "C" int fn_gru_fwd_x6_ok(const FnGruFwd* scans, int n_scans) {
+    if (!scans || n_scans < 1 || n_scans > FN_MAX_SCANS) return 0;
+    int cus = cu_count();
+    if (scans[0].cu_budget > 0 && scans[0].cu_budget < cus) cus = scans[0].cu_budget;
+    if (cus < 32) return 0;
+    const int maxgroups = cus / 32 < FN_MAX_GROUPS ? cus / 32 : FN_MAX_GROUPS;
+    return x6_row_tiles(scans, n_scans, maxgroups) != 0;
+}
 
 int fn_gru_fwd_persist(const FnGruFwd* scans, int n_scans, hipStream_t st) {
     const int H = scans[0].H;
@@ -1467,20 +1492,14 @@ int fn_gru_fwd_persist(const FnGruFwd* scans, int n_scans, hipStream_t st) {
     if (cus <= 0 || nslices > cus) return FN_PERSIST_NA;
     const int maxgroups = cus / nslices < FN_MAX_GROUPS ? cus / nslices : FN_MAX_GROUPS;
     if (scans[0].variant & 0x4000) {
-        // OPT-IN: exact split products on the bf16 MFMA (gru_fwd_x6_kernel).  The caller hands over w_hh_frag = fn_frag3_pack image and
-        // frag_ws of 3 * fn_frag_floats(B, H) floats.  H = 512, full 64- / 128-row groups, saved gates, no initial state, T >= 2.
-        if (H != 512) return FN_E_UNSUPPORTED;
-        long g64 = 0, g128 = 0;
-        bool d64 = true, d128 = true;
+        // exact split products on the bf16 MFMA (gru_fwd_x6_kernel).  The caller hands over w_hh_frag = fn_frag3_pack image and
+        // frag_ws of 3 * fn_frag_floats(B, H) floats.  Eligibility: x6_row_tiles() (the same predicate fn_gru_fwd_x6_ok answers with).
         for (int s = 0; s < n_scans; ++s) {
             const FnGruFwd& d = scans[s];
-            if (!d.gates || d.T < 2) return FN_E_UNSUPPORTED;
             if (d.h0_frag && !d.h0) return FN_E_NULL;
             if ((((uintptr_t)d.h0_frag) | ((uintptr_t)d.h_last_frag) | (uintptr_t)d.h0) & 15) return FN_E_ALIGN;
-            d64 = d64 && d.B % 64 == 0; d128 = d128 && d.B % 128 == 0;
-            g64 += d.B / 64; g128 += d.B / 128;
         }
-        const int mt = (d64 && g64 <= maxgroups) ? 1 : ((d128 && g128 <= maxgroups) ? 2 : 0);
+        const int mt = x6_row_tiles(scans, n_scans, maxgroups);
         if (!mt) return FN_E_UNSUPPORTED;
         PArgs a;
         a.n = n_scans; a.H = H; a.no_hand = 0;

@@ -51,7 +51,7 @@ class Engine:
         self.single_launch_skip = (0, -1)  # (a window of row counts inside single_launch_rows that goes to the cells anyway; unused since the cells with ceil(rows / 512) x 64 rows per workgroup)
         self._lane_alias = {}           # lane -> lane it is folded into (debug)
         self.fused_argmax = True        # decode.py, tokens-only decode on the per-token cells: output layer + argmax as ONE launch (fn_out_argmax_f32); False: GEMM + fn_vocab_argmax (tests)
-        self.cell_decode_rows = 768     # decode.py: from this many sequences on, the per-token cells are one-launch GEMM cells (fn_gru_cell_f32: LDS-free loop above 512 rows, staged below); measured crossover against the scan-step kernels (scratch/bench_decode_rows.py): 512 rows 67 vs 87 us per token, 768 rows 97 vs 88
+        self.cell_decode_rows = self.single_launch_rows + 1     # (= 705: no window of row counts left to the T = 1 scan-step path) decode.py: from this many sequences on, the per-token cells are one-launch GEMM cells (fn_gru_cell_f32: LDS-free loop above 512 rows, staged below); measured crossover against the scan-step kernels (scratch/bench_decode_rows.py): 512 rows 67 vs 87 us per token, 768 rows 97 vs 88
         self.fused_head = True          # trainers: output projection + log-softmax + NLL + gradient seed as ONE kernel (fn_out_head_f32); False: GEMM -> logits in HBM -> fn_vocab_logsoftmax
         self.lean_dw = False            # decoder-side weight-gradient GEMMs as the <= 128-register instance.  Paid while an encoder-scan wavefront left 138 of a SIMD's 512 registers free (round 2: 9 % packing gain); the hand-placed K loops hold all of them, the side lane's GEMMs run once the scan has ended and the 194-register instance is the faster one (A/B in one session, scratch/ab_dw.py: 23.65 vs 24.29 ms per step)
         self.lean_proj = True           # layer-2 input projection beside the decoder pipeline's forward launches as the <= 128-register instance of the LDS-free NT kernel: 4 workgroups per CU (768 tiles = one round) and one of its wavefronts fits a SIMD beside a forward-scan wavefront (377 registers): 107 us beside a 351 us launch (the 248-register instance: 125 us in front of the launch)
@@ -387,6 +387,7 @@ class Engine:
         # (independent scans of the same batch) ride there - 'r' in the head, 'n' in the tail
         fill = fill or {}
         nsd = {e: (sc["T"] + CH - 1) // CH for e, sc in fill.items()}
+        launches = []
         for k in range(nch + 2):
             part = []
             if k < nch:
@@ -400,9 +401,17 @@ class Engine:
                 if k == 2:
                     c2["h0"] = hx0[0]
                 part.append(c2)
+            launches.append(part)
+        # ONE arithmetic for the whole pipeline: the chunks of a scan hand their state over as operand images (bf16 triples or fp32
+        # fragments), so a single launch the bf16 x 6 kernels do not take (a one-step tail chunk, more row groups than compute units) puts
+        # every launch on the fp32 MFMA
+        x6 = bool(pd and getattr(ops, "gru_fwd_x6_ok", None) and all(ops.gru_fwd_x6_ok(part) for part in launches if part))
+        xkw = {"x6": x6} if hasattr(ops, "gru_fwd_x6_ok") else {}
+        for k, part in enumerate(launches):
+            if k >= 2:
                 self.lane_wait("main", "aux%d" % (k & 1))            # the projection of chunk k-2 (issued two launches ago)
             if part:
-                ops.gru_seq_fwd(part, persistent=pd)
+                ops.gru_seq_fwd(part, persistent=pd, **xkw)
             if k < nch:
                 t0, t1 = starts[k], min(T, starts[k] + CH)
                 lane = "aux%d" % (k & 1)

@@ -64,6 +64,7 @@ class MusicAttrRegGMVAE(nn.Module):
         self._engine_key = None
         self._weights_version = None
         self._version = 0
+        self.arith = None                # arithmetic of the deep MFMA products (arith.py): None = the package default, "f32" or "bf16x6"
 
     # ------------------------------------------------------------------------------------------
     # engine plumbing
@@ -83,6 +84,14 @@ class MusicAttrRegGMVAE(nn.Module):
         from .hipops import HipOps
         return HipOps(dev)
 
+    def set_arith(self, name):
+        """choose the arithmetic of the deep MFMA products (arith.py: "f32", "bf16x6" or None = package default); takes effect with the
+        next ``engine()`` call: kernel table switched, weight images (bf16 triple images of the recurrent matrices) re-derived.  Captured
+        training steps are keyed by it (trainer.py)."""
+        from . import arith
+        self.arith = None if name is None else arith.check(name)
+        return self
+
     def _param_versions(self):
         """torch's in-place counters of the parameters: an ``optimizer.step()`` / ``copy_`` of an unmodified reference loop moves them, the
         fused trainer (which writes through the flat buffer and refreshes the images itself) does not"""
@@ -94,6 +103,11 @@ class MusicAttrRegGMVAE(nn.Module):
         if self._engine is None or self._engine_key != key:
             self._engine = self._make_engine(self._make_ops(dev), dev)
             self._engine_key = key
+            self._weights_version = None
+        from . import arith
+        want = arith.resolve(getattr(self, "arith", None)) == arith.BF16X6
+        if hasattr(self._engine.ops, "dw_x6") and bool(self._engine.ops.dw_x6) != want:
+            self._engine.ops.dw_x6 = want           # the engine's kernel table follows the model's choice, whichever engine is current
             self._weights_version = None
         # the engine keeps transposed / fragment-order images of the recurrent weights: re-derive them when the values changed -
         # announced (weights_changed(), load_state_dict) or detected (in-place updates by a torch optimiser)

@@ -54,7 +54,7 @@ class HipOps:
         self._ws = {}
         self._retired = []
         self.cell_variant = 0     # FnGruCell.variant (tuning / tests)
-        self.dw_x6 = False        # OPT-IN: the T*B-deep weight-gradient products on the bf16 MFMA with exact bf16 triple splits (FN_GEMM_BF16X6); default: fp32 MFMA
+        self.dw_x6 = False        # arithmetic of the deep products (set by the model: arith.py): True = exact bf16 triple splits on the bf16 MFMA (FN_GEMM_BF16X6, FnGruFwd.variant bit 14), False = fp32 MFMA
         self.variant = 0          # FnGruFwd.variant of every scan launch (tuning / tests only; results do not depend on it)
         self.lane = ""            # scratch namespace: kernels enqueued on different streams must not share workspaces
 
@@ -246,18 +246,14 @@ class HipOps:
                 t[-32:].zero_()
         return bad
 
-    def gru_seq_fwd(self, scans, persistent=True, cu_budget=0, variant=None):
+    def _fwd_descriptors(self, scans, cu_budget=0):
         arr = (_lib.FnGruFwd * len(scans))()
-        variant = self.variant if variant is None else variant
-        sync = self._sync_region() if persistent else None
         for i, (d, s) in enumerate(zip(arr, scans)):
             for k in ("w_hh_frag", "b_hh", "b_ih", "h0", "gx_dense", "gx_table", "gx_rowbias", "h_all", "gates", "h0_frag", "h_last_frag"):
                 _dense(s.get(k), name=k)
             for k in ("h0_frag", "h_last_frag"):
                 if s.get(k) is not None and s[k].numel() < self.frag_floats(s["B"], s["H"]):
                     raise RuntimeError("%s needs frag_floats(B, H) floats" % k)
-            d.frag_ws = _p(self._frag_ws("fragf", i, 3 * self.frag_floats(s["B"], s["H"])))      # 2 slabs of fp32 fragments, or 2 of bf16 triples (x6)
-            d.sync_ws, d.err_ws, d.variant = (_p(sync[0]), _p(sync[1]), int(variant) | sync[2]) if persistent else (None, None, int(variant))
             d.cu_budget = int(cu_budget)
             _dense(s.get("idx"), torch.int32, "idx")
             d.B, d.T, d.H, d.reverse = s["B"], s["T"], s["H"], int(s.get("reverse", 0))
@@ -267,17 +263,34 @@ class HipOps:
             d.idx_shift, d.start_token = int(s.get("idx_shift", 0)), int(s.get("start_token", 0))
             d.gx_rowbias, d.h_all, d.gates = _p(s.get("gx_rowbias")), _p(s["h_all"]), _p(s.get("gates"))
             d.h0_frag, d.h_last_frag = _p(s.get("h0_frag")), _p(s.get("h_last_frag"))
-        if persistent and self.dw_x6 and all(s.get("w_hh_frag3") is not None for s in scans):
-            # OPT-IN arithmetic: the bf16 x 6 forward scan where the configuration is eligible (variant bit 14), else the default kernels
-            for d, s in zip(arr, scans):
+        return arr
+
+    def gru_fwd_x6_ok(self, scans, cu_budget=0):
+        """would gru_seq_fwd run this launch on the bf16 x 6 kernels (fn_gru_fwd_x6_ok)?  The caller of a CHAIN of launches (time chunks that hand
+        their state over as operand images) asks for every launch first and runs the whole chain on one arithmetic."""
+        if not (self.dw_x6 and all(s.get("w_hh_frag3") is not None for s in scans)):
+            return False
+        return bool(self.lib.fn_gru_fwd_x6_ok(self._fwd_descriptors(scans, cu_budget), len(scans)))
+
+    def gru_seq_fwd(self, scans, persistent=True, cu_budget=0, variant=None, x6=None):
+        """x6: None = this launch decides for itself (bf16 x 6 where eligible, refused when it is part of a hand-over chain: h0_frag /
+        h_last_frag images depend on the arithmetic), True / False = the decision the caller made for the whole chain"""
+        arr = self._fwd_descriptors(scans, cu_budget)
+        variant = self.variant if variant is None else variant
+        sync = self._sync_region() if persistent else None
+        if x6 is None:
+            x6 = persistent and self.gru_fwd_x6_ok(scans, cu_budget)
+            if x6 is False and self.dw_x6 and any(s.get("h0_frag") is not None or s.get("h_last_frag") is not None for s in scans) \
+                    and all(s.get("w_hh_frag3") is not None for s in scans):
+                raise RuntimeError("gru_seq_fwd: a launch of a hand-over chain must be told the chain's arithmetic (x6=True / False)")
+        if x6 and not persistent:
+            raise RuntimeError("gru_seq_fwd: the bf16 x 6 scans are weight-stationary launches")
+        for i, (d, s) in enumerate(zip(arr, scans)):
+            d.frag_ws = _p(self._frag_ws("fragf", i, 3 * self.frag_floats(s["B"], s["H"])))      # 2 slabs of fp32 fragments, or 2 of bf16 triples (x6)
+            d.sync_ws, d.err_ws, d.variant = (_p(sync[0]), _p(sync[1]), int(variant) | sync[2]) if persistent else (None, None, int(variant))
+            if x6:
                 d.w_hh_frag, d.variant = _p(s["w_hh_frag3"]), d.variant | 0x4000
-            rc = self.lib.fn_gru_seq_fwd(arr, len(scans), self.stream())
-            if rc != _lib.FN_E_UNSUPPORTED:
-                _lib.check(rc, "fn_gru_seq_fwd (bf16 x 6)")
-                return
-            for d, s in zip(arr, scans):
-                d.w_hh_frag, d.variant = _p(s["w_hh_frag"]), d.variant & ~0x4000
-        _lib.check(self.lib.fn_gru_seq_fwd(arr, len(scans), self.stream()), "fn_gru_seq_fwd")
+        _lib.check(self.lib.fn_gru_seq_fwd(arr, len(scans), self.stream()), "fn_gru_seq_fwd (bf16 x 6)" if x6 else "fn_gru_seq_fwd")
 
     def frag3_pack(self, src, dst):
         """bf16 triple image of src [rows][K] (fn_frag3_pack); dst: 3/2 * frag_floats(rows, K) floats"""

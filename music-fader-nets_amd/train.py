@@ -161,9 +161,11 @@ def main(argv=None):
     ap.add_argument("--epochs", type=int, default=None, help="override n_epochs of the config")
     ap.add_argument("--out", default=".", help="where log/ and params/ live (default: the working directory, as the reference)")
     ap.add_argument("--seed", type=int, default=None)
-    ap.add_argument("--bf16x6", action="store_true",
-                    help="opt-in arithmetic: the T*B-deep weight-gradient products on the bf16 MFMA with exact bf16 triple splits (FN_GEMM_BF16X6; as "
-                         "accurate as the fp32 MFMA kernels against float64, about 7 %% faster per step; default: fp32 MFMA everywhere)")
+    ap.add_argument("--arith", choices=["f32", "bf16x6"], default=None,
+                    help="arithmetic of the deep MFMA products (arith.py): f32 = fp32 MFMA chains; bf16x6 = every fp32 operand cut exactly into three "
+                         "bf16 pieces, six partial products on the bf16 MFMA, fp32 accumulation (as accurate as the fp32 chains against float64). "
+                         "Default: the package default (arith.default())")
+    ap.add_argument("--bf16x6", action="store_true", help="same as --arith bf16x6")
     opts = ap.parse_args(argv)
 
     import importlib
@@ -202,8 +204,8 @@ def main(argv=None):
     model.to(dev)
     trainer = trainer_cls(model, lr=args["lr"], beta=args["beta"], **({} if opts.model == "glsr" else {"dist_ctx": ctx}))
     sync_replicas(trainer, ctx)
-    if opts.bf16x6:
-        model.engine().ops.dw_x6 = True
+    if opts.bf16x6 or opts.arith is not None:
+        model.set_arith("bf16x6" if opts.bf16x6 else opts.arith)        # lives on the model: survives engine rebuilds (.to(), re-homed parameters)
 
     say("Loading Yamaha..." if opts.data_root else "Building synthetic Yamaha / VGMIDI arrays...")
     dls, sizes = build_loaders(args, opts, rank, world, opts.model, seed)

@@ -190,17 +190,27 @@ class GMVAETrainer:
         B = d.shape[0]
         st = self.stats
         lat_up = {}
-        for slot, e, attr in ((S_L_R, "r", rd), (S_L_N, "n", nd)):
-            z0 = eng.buf("reg_z0_" + e, (B,))
-            z0.copy_(lat[e]["z"][:, 0])
+        # column 0 of both latents: one [2][B] buffer, and data parallel ONE all-gather for the two of them (it sits on the critical path
+        # between the encoder and the decoders; the densities - constants of the batch - were gathered once per batch, _gather_densities)
+        z0 = eng.buf("reg_z0", (2, B))
+        z0[0].copy_(lat["r"]["z"][:, 0])
+        z0[1].copy_(lat["n"]["z"][:, 0])
+        if self.dist is not None:
+            W = self.dist.world
+            z0_all = eng.buf("reg_z0_all", (2, W * B))
+            z0_all.view(2, W, B).copy_(self.dist.gather(z0.view(-1)).view(W, 2, B).permute(1, 0, 2))      # [rank][latent][row] -> [latent][global row]
+            row0 = self.dist.rank * B
+        else:
+            z0_all, row0 = z0, 0
+        for i, (slot, e, attr) in enumerate(((S_L_R, "r", rd), (S_L_N, "n", nd))):
             if self.dist is not None:
-                held = self._dens_all[0 if e == "r" else 1] if self._dens_all is not None else None
-                z0_all, a_all, row0 = self.dist.gather_rows(z0, attr, held)
+                held = self._dens_all[i] if self._dens_all is not None else None
+                a_all = held if held is not None else self.dist.gather(attr)
             else:
-                z0_all, a_all, row0 = z0, attr, 0
+                a_all = attr
             lrow = eng.buf("reg_rows_" + e, (B,))
             dz0 = eng.buf("reg_dz0_" + e, (B,)) if want_grads else None
-            ops.pairwise_reg(z0_all, a_all, row0, B, lrow, 1.0 / (Bg * Bg), dz0)
+            ops.pairwise_reg(z0_all[i], a_all, row0, B, lrow, 1.0 / (Bg * Bg), dz0)
             ops.sum(lrow, st[slot:slot + 1], 1.0 / (Bg * Bg))
             if want_grads:
                 gz = eng.zbuf("g_z_" + e, (B, Z))
@@ -325,7 +335,7 @@ class GMVAETrainer:
             self._step_body(step, batch, eps)
             m._weights_version = (m._version, m._param_versions())      # refresh_weights() already ran at the end of the step
             return beta0, Bg
-        key = (tuple(batch[0].shape), tuple(batch[1].shape), batch[6] is not None)
+        key = (tuple(batch[0].shape), tuple(batch[1].shape), batch[6] is not None, bool(getattr(m.engine().ops, "dw_x6", False)))
         st = self._static.get(key)
         if st is None:                              # first call with these shapes: static input buffers + one eager run
             st = dict(batch=[None if t is None else t.clone() for t in batch], eps=[None if e is None else e.clone() for e in eps], runs=0)

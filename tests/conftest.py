@@ -20,8 +20,9 @@ def golden_dir():
 
 def pytest_addoption(parser):
     parser.addoption("--x6", action="store_true", default=False,
-                     help="run the gpu suite with the opt-in bf16 x 6 weight-gradient products switched on in every kernel table (HipOps.dw_x6): "
-                          "evidence that every parity test holds with that arithmetic at the same tolerances")
+                     help="run the gpu suite with the bf16 x 6 arithmetic as the package default (arith.set_default) and in every bare kernel table: "
+                          "evidence that every parity test holds with that arithmetic at the same tolerances (the end-to-end parity tests are "
+                          "parametrised over both arithmetics anyway)")
 
 
 @pytest.fixture(scope="session", autouse=True)
@@ -31,8 +32,9 @@ def _x6_everywhere(request):
         return
     from mfn_import import load_package
     load_package()
-    from music_fader_nets_amd import hipops
+    from music_fader_nets_amd import arith, hipops
     init = hipops.HipOps.__init__
+    prev = arith.set_default(arith.BF16X6)          # models follow the package default; bare HipOps tables (the `ops` fixtures) are patched below
 
     def patched(self, *a, **k):
         init(self, *a, **k)
@@ -42,3 +44,4 @@ def _x6_everywhere(request):
         yield
     finally:
         hipops.HipOps.__init__ = init
+        arith.set_default(prev)

@@ -23,7 +23,7 @@ def batch_of(g):
     return {k: g[k] for k in ("d", "r", "n", "c", "r_density", "n_density", "a")}
 
 
-def make_model(hidden, zdim, sd=None, device="cpu", ops=None, seed=1234):
+def make_model(hidden, zdim, sd=None, device="cpu", ops=None, seed=1234, arith=None):
     pkg = load_package()
     torch.manual_seed(seed)
     m = pkg.MusicAttrRegGMVAE(roll_dims=342, rhythm_dims=3, note_dims=16, chroma_dims=24, hidden_dims=hidden, z_dims=zdim,
@@ -34,6 +34,8 @@ def make_model(hidden, zdim, sd=None, device="cpu", ops=None, seed=1234):
     if ops is not None:
         m._make_ops = lambda dev, _ops=ops: _ops          # test-side injection of the CPU stand-in for the kernel table
     m.train()
+    if arith is not None:
+        m.set_arith(arith)                                # "f32" / "bf16x6": arithmetic of the deep MFMA products (arith.py)
     return m
 
 

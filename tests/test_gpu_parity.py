@@ -465,11 +465,12 @@ def test_forward_scan_bf16x6(ops, n, B, T):
                 part = [chunk(d, 0, T1, True) for d in fw]
                 for c, hb in zip(part, hand):
                     c["h_last_frag"] = hb
-                ops.gru_seq_fwd(part)
+                assert ops.gru_fwd_x6_ok(part)
+                ops.gru_seq_fwd(part, x6=True)
                 part = [chunk(d, T1, T, False) for d in fw]
                 for c, hb in zip(part, hand):
                     c["h0_frag"] = hb
-                ops.gru_seq_fwd(part)
+                ops.gru_seq_fwd(part, x6=True)
                 torch.cuda.synchronize()
                 for d in fw:
                     i = scans.index(d)
@@ -483,6 +484,79 @@ def test_forward_scan_bf16x6(ops, n, B, T):
         assert all(torch.equal(a, d["h_all"]) for a, d in zip(ref, scans))
     finally:
         ops.dw_x6 = False
+
+
+@pytest.mark.parametrize("lo,hi", [(-100, 60), (-120, -90), (-30, 30)])
+@pytest.mark.parametrize("K,splitk", [(65536, 16), (4096, 4)])
+def test_bf16x6_adversarial_operands_vs_float64(ops, lo, hi, K, splitk):
+    """the bf16 x 6 product against float64 on operands chosen to hurt it: magnitudes spread over 2^lo .. 2^hi (per k the exponents of a and b are
+    tied so that the PRODUCTS stay within 2^-20 .. 2^20 - the sum must not overflow -, i.e. tiny a meet huge b: every piece of the split
+    travels the full exponent range; (-120, -90): lo pieces of values below 2^-103 are subnormal as bf16), heavy cancellation (every
+    product has a partner of opposite sign that differs in its last bits only, the exact sum is ~1e-7 of sum |a||b|), K = 65 536.  Bound:
+    the error in units of sum |a||b| is at most 1.25 x the fp32-MFMA kernel's own (+ 2^-30: both errors are of order 1e-8 .. 1e-7)."""
+    M = N = 256
+    g = torch.Generator(device="cpu").manual_seed(1000 * K + hi - lo)
+    half = K // 2
+    ea = torch.randint(lo, hi + 1, (half, 1), generator=g).double()
+    ma = 1.0 + torch.rand(half, M, generator=g, dtype=torch.float64)
+    sa = torch.where(torch.rand(half, M, generator=g) < 0.5, -1.0, 1.0).double()
+    a = (sa * ma * torch.pow(torch.tensor(2.0, dtype=torch.float64), ea)).float()
+    eb = -ea + torch.randint(-20, 21, (half, 1), generator=g).double()
+    eb = eb.clamp(-126 + 24, 120)
+    mb = 1.0 + torch.rand(half, N, generator=g, dtype=torch.float64)
+    b = (torch.where(torch.rand(half, N, generator=g) < 0.5, -1.0, 1.0).double() * mb * torch.pow(torch.tensor(2.0, dtype=torch.float64), eb)).float()
+    # partners: -a (1 + a few ulps), same b  -> pairwise the products cancel to ~2^-22 of their size
+    jitter = 1.0 + torch.randint(-3, 4, (half, M), generator=g).double() * 2.0 ** -23
+    a2 = (-(a.double() * jitter)).float()
+    perm = torch.randperm(K, generator=g)
+    A = torch.cat([a, a2], 0)[perm].contiguous().to(DEV)
+    Bm = torch.cat([b, b], 0)[perm].contiguous().to(DEV)
+    assert torch.isfinite(A).all() and torch.isfinite(Bm).all()
+    ref = A.double().t() @ Bm.double()
+    scale = A.double().abs().t() @ Bm.double().abs()
+    assert float((ref.abs() / scale).median()) < 1e-5          # heavy cancellation indeed
+    err = {}
+    try:
+        for x6 in (False, True):
+            ops.dw_x6 = x6
+            C = torch.full((M, N), float("nan"), device=DEV)
+            ops.gemm(A, Bm, C, a_k=False, b_k=False, splitk=splitk)
+            err[x6] = float(((C.double() - ref).abs() / scale).max())
+    finally:
+        ops.dw_x6 = False
+    assert err[True] <= 1.25 * err[False] + 2.0 ** -30, (lo, hi, K, err)
+    assert err[True] < 2e-6, err
+
+
+@pytest.mark.parametrize("B,T,Tr,fill", [(64, 33, 9, True), (128, 65, 33, True), (1024, 96, 8, False), (192, 64, 16, True)])
+def test_bf16x6_is_decided_once_per_decoder_pipeline(B, T, Tr, fill):
+    """the chunks of the decoder pipeline hand their state from launch to launch as operand images whose layout depends on the
+    arithmetic (bf16 triples / fp32 fragments), and single launches can be ineligible for the bf16 x 6 kernels - a one-step tail chunk
+    (T % 32 == 1, Tr % 32 == 1), more row groups than compute units in the two-scan launches (B = 1024 without the edge fill: launches 0, 1
+    hold one scan, the others two).  The engine asks for every launch first and runs the WHOLE pipeline on one arithmetic: loss and
+    gradients with set_arith("bf16x6") must agree with the fp32-MFMA step to rounding, never to garbage."""
+    pkg = load_package()
+    from music_fader_nets_amd.synth import synth_batch
+    m = make_model(512, 32, device=DEV)
+    tr = pkg.GMVAETrainer(m, lr=1e-3, beta=0.2)
+    b = synth_batch(np.random.RandomState(3), B, T, Tr)
+    batch = tr.prepare_batch(b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"])
+    torch.manual_seed(7)
+    eps = tr.draw_eps(B, T)
+    out = {}
+    for ar in ("f32", "bf16x6"):
+        m.set_arith(ar)
+        m.engine().fill_edges = fill
+        tup = tr.loss_and_grads(20000, batch, eps)
+        assert not m.engine().ops.gru_sync_error()
+        out[ar] = (tup, {k: tr.flat.G[k].clone() for k in ("grucell_g.weight_hh", "grucell_g_2.weight_hh", "gru_d_r.weight_hh_l0", "gru_r.weight_hh_l0", "linear_out_g.weight")},
+                   m.engine().saved["dec"]["hx1"].clone())
+    np.testing.assert_allclose(out["bf16x6"][0], out["f32"][0], rtol=2e-5)
+    assert float((out["bf16x6"][2] - out["f32"][2]).abs().max()) <= 1e-4 * float(out["f32"][2].abs().max())
+    for k, g32 in out["f32"][1].items():
+        g6 = out["bf16x6"][1][k]
+        assert torch.isfinite(g6).all()
+        assert float((g6 - g32).abs().max()) <= 2e-4 * float(g32.abs().max()), (k, float((g6 - g32).abs().max()), float(g32.abs().max()))
 
 
 def test_time_sum(ops):
@@ -706,12 +780,13 @@ def test_dropin_forward_backward_vs_reference(case, small, c0):
     np.testing.assert_allclose(math.sqrt(sq), gold["gradnorm_unsup_20000"][0], rtol=1e-3)
 
 
+@pytest.mark.parametrize("arith", ["f32", "bf16x6"])
 @pytest.mark.parametrize("case,sup,chunk", [("small", False, 32), ("small", True, 32), ("small", False, 6), ("c0", False, 32), ("c0", False, 24)])
-def test_fused_gradients_vs_reference(case, sup, chunk, small, c0):
+def test_fused_gradients_vs_reference(case, sup, chunk, arith, small, c0):
     gold = small if case == "small" else c0
     H, Z = int(gold["meta_dims"][0]), int(gold["meta_dims"][1])
     pkg = load_package()
-    m = make_model(H, Z, sd_from(gold, "w0/") if case == "small" else None, device=DEV)
+    m = make_model(H, Z, sd_from(gold, "w0/") if case == "small" else None, device=DEV, arith=arith)
     tr = pkg.GMVAETrainer(m, lr=1e-3, beta=0.2)
     m.engine().chunk = chunk                 # decoder-layer pipeline chunk (two HIP streams): results must not depend on it
     b = batch_of(gold)
@@ -734,13 +809,14 @@ def test_fused_gradients_vs_reference(case, sup, chunk, small, c0):
     np.testing.assert_allclose(tr.grad_norm(), gold["gradnorm_%s_20000" % tag][0], rtol=1e-3)
 
 
+@pytest.mark.parametrize("arith", ["f32", "bf16x6"])
 @pytest.mark.parametrize("case", ["small", "c0"])
-def test_three_train_steps_vs_reference_train(case, small, c0):
+def test_three_train_steps_vs_reference_train(case, arith, small, c0):
     """GMVAETrainer.train vs the reference's own train() (trainer_gmm.py:220-258), 3 steps from step 19999."""
     gold = small if case == "small" else c0
     H, Z = int(gold["meta_dims"][0]), int(gold["meta_dims"][1])
     pkg = load_package()
-    m = make_model(H, Z, sd_from(gold, "w0/") if case == "small" else None, device=DEV)
+    m = make_model(H, Z, sd_from(gold, "w0/") if case == "small" else None, device=DEV, arith=arith)
     tr = pkg.GMVAETrainer(m, lr=1e-3, beta=0.2)
     b = batch_of(gold)
     step = 19999
@@ -1098,14 +1174,15 @@ def test_eval_side_callers_vs_reference(tag, H, Z):
 # ----------------------------------------------------------------------------------------------
 # the BENCHMARK configuration against the reference itself (tests/golden/c1.npz: B=256, T=256, Tr=64, hidden 512)
 # ----------------------------------------------------------------------------------------------
-def test_benchmark_config_vs_reference_train():
+@pytest.mark.parametrize("arith", ["f32", "bf16x6"])
+def test_benchmark_config_vs_reference_train(arith):
     """The kernels bench.py times (128-row weight-stationary scans at T=256, K=65536 weight-gradient GEMMs, 65536-row token-segment
     sums) compared with the reference's own forward / backward / train() at that size, on the seeds bench.py uses."""
     pkg = load_package()
     from music_fader_nets_amd.synth import synth_batch
     g = load_golden("c1")
     H, Z, K, B, T, Tr = (int(x) for x in g["meta_dims"])
-    m = make_model(H, Z, device=DEV)
+    m = make_model(H, Z, device=DEV, arith=arith)
     tr = pkg.GMVAETrainer(m, lr=1e-3, beta=0.2)
     b = synth_batch(np.random.RandomState(0), B, T, Tr)
     batch = tr.prepare_batch(b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"])
@@ -1149,46 +1226,36 @@ def test_benchmark_config_vs_reference_train():
 # ----------------------------------------------------------------------------------------------
 # captured graphs vs changing batch shapes / changing weights
 # ----------------------------------------------------------------------------------------------
-def test_benchmark_config_with_bf16x6_vs_reference_train():
-    """the benchmark shape with the opt-in bf16 x 6 arithmetic (HipOps.dw_x6: weight-gradient products AND forward scans): the comparison of
-    test_benchmark_config_vs_reference_train against the reference's own backward / train() at this size (tests/golden/c1.npz) at the SAME
-    tolerances - loss, raw gradient norm, per-parameter |g| and g^2 sums, the train() tuples, the weights after the first step"""
+def test_bf16x6_is_live_at_the_benchmark_shape():
+    """set_arith really switches kernels (and back) on a live model: against the fp32-MFMA gradients of the same step the recurrent weight
+    gradients differ - in their last bits only; the switch survives an engine rebuild (parameters re-homed by a second trainer) and captured
+    steps are keyed by it (the comparison with the reference at this shape runs in test_benchmark_config_vs_reference_train[bf16x6])"""
     pkg = load_package()
     from music_fader_nets_amd.synth import synth_batch
     g = load_golden("c1")
     H, Z, K, B, T, Tr = (int(x) for x in g["meta_dims"])
     m = make_model(H, Z, device=DEV)
     tr = pkg.GMVAETrainer(m, lr=1e-3, beta=0.2)
-    m.engine().ops.dw_x6 = True                             # (after the trainer: it re-homes the parameters and with them the engine / its kernel table)
     b = synth_batch(np.random.RandomState(0), B, T, Tr)
     batch = tr.prepare_batch(b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"])
     torch.manual_seed(99)
     eps = tr.draw_eps(B, T)
-    tup = tr.loss_and_grads(20000, batch, eps)
-    np.testing.assert_allclose(tup[0], g["total_loss_20000"][0], rtol=2e-5)
-    np.testing.assert_allclose(tr.grad_norm(), g["gradnorm_20000"][0], rtol=1e-3)
-    for k in tr.flat.names:
-        gk = tr.flat.G[k].double()
-        ref = g["gradsum/" + k]
-        np.testing.assert_allclose(float(gk.abs().sum()), ref[1], rtol=1e-3, atol=1e-5, err_msg=k)
-        np.testing.assert_allclose(float((gk * gk).sum()), ref[2], rtol=2e-3, atol=1e-9, err_msg=k)
-    # the flag is live: against the default (fp32 MFMA) gradients of the same step the recurrent weight gradients differ in their last bits only
+    m.set_arith("bf16x6")
+    tup6 = tr.loss_and_grads(20000, batch, eps)
+    assert m.engine().ops.dw_x6 and m.engine().whh_f3
     g6 = tr.flat.G["gru_r.weight_hh_l0"].clone()
-    m.engine().ops.dw_x6 = False
-    tr.loss_and_grads(20000, batch, eps)
+    m.set_arith("f32")
+    tup32 = tr.loss_and_grads(20000, batch, eps)
+    assert not m.engine().ops.dw_x6 and not m.engine().whh_f3
     g32 = tr.flat.G["gru_r.weight_hh_l0"]
+    np.testing.assert_allclose(tup6, tup32, rtol=2e-5)
     assert not torch.equal(g6, g32)
     assert float((g6 - g32).abs().max()) <= 1e-5 * float(g32.abs().max())      # fp32 rounding through 256 recurrent steps (forward scans + products differ in their last bits)
-    m.engine().ops.dw_x6 = True
-    step = 20000
-    for it in range(2):
-        step, tup = tr.train(step, None, None, None, b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"], eps=eps)
-        np.testing.assert_allclose(tup, g["train_tuples"][it], rtol=5e-4, err_msg="step %d" % it)
-        if it == 0:
-            for k, v in m.state_dict().items():
-                if k not in NOISE_PARAMS:
-                    vd = v.double()
-                    np.testing.assert_allclose([vd.abs().sum().item(), (vd * vd).sum().item()], g["w1sum/" + k][1:], rtol=2e-5, err_msg=k)
+    m.set_arith("bf16x6")
+    tr2 = pkg.GMVAETrainer(m, lr=1e-3, beta=0.2)            # re-homes the parameters: a new engine and kernel table - the choice lives on the model
+    tr2.loss_and_grads(20000, batch, eps)
+    assert m.engine().ops.dw_x6
+    assert torch.equal(tr2.flat.G["gru_r.weight_hh_l0"], g6)
     assert not m.engine().ops.gru_sync_error()
 
 
@@ -1581,8 +1648,9 @@ def _check_grad_slices(g, pfx, named_grads, tol=5e-4, skip=()):
     return n_rows, n_stride
 
 
+@pytest.mark.parametrize("arith", ["f32", "bf16x6"])
 @pytest.mark.parametrize("pfx,sup", [("c0u/", False), ("c0s/", True), ("c1u/", False)])
-def test_gradient_slices_vs_reference_at_hidden_512(pfx, sup):
+def test_gradient_slices_vs_reference_at_hidden_512(pfx, sup, arith):
     """hidden 512: per-parameter gradient ROWS and a stride-97 sample of every gradient, plus d loss / d (encoder input) at sampled
     (batch, time) positions = both directions' gate-gradient rows of gru_r / gru_n projected through W_ih, against the reference's own
     backward (unsupervised and supervised loss at B=8, the benchmark shape B=256 / T=256: 128-row tiles, K = 65 280 weight-gradient GEMMs)"""
@@ -1590,7 +1658,7 @@ def test_gradient_slices_vs_reference_at_hidden_512(pfx, sup):
     from music_fader_nets_amd.synth import synth_batch
     g = load_golden("slices")
     H, Z, K, B, T, Tr = (int(x) for x in g[pfx + "dims"])
-    m = make_model(H, Z, device=DEV)
+    m = make_model(H, Z, device=DEV, arith=arith)
     tr = pkg.GMVAETrainer(m, lr=1e-3, beta=0.2)
     b = synth_batch(np.random.RandomState(0), B, T, Tr)
     lab = b["a"] if sup else None
@@ -1739,7 +1807,7 @@ def test_entry_driver_v2_runs_an_epoch_from_model_config_v2(family, tmp_path, ca
     T = "112" if family == "glsr" else "48"                     # the GLSR decodes are teacher forced for 100 steps
     argv = ["--config", cfg, "--model", family, "--synthetic", "--synthetic-songs", "320", "--seq-len", T, "--epochs", "1", "--out", str(tmp_path), "--seed", "3"]
     if family == "fader":
-        argv.append("--bf16x6")                                 # the opt-in weight-gradient arithmetic is reachable from the entry driver
+        argv.append("--bf16x6")                                 # the bf16 x 6 arithmetic is reachable from the entry driver (= --arith bf16x6)
     step = main(argv)
     out = capsys.readouterr().out
     assert step == 2                                            # 256 training songs in batches of 128
