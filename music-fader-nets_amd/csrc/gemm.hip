@@ -297,20 +297,24 @@ FN_DEVINL unsigned fn_pack_top16(float a, float b) {          // top 16 bits of 
     return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
 }
 FN_DEVINL float fn_top16(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
-// element `e` of eight float4 vectors (8 consecutive k of one row) -> exact bf16 triple
+// element `e` of eight float4 vectors (8 consecutive k of one row) -> exact bf16 triple.  RN = rounded pieces (fn_rn16: one integer add more per
+// level), else truncated ones.  One ROUNDED operand is enough to make the dropped partial products zero-mean (mid_a lo_b, lo_a mid_b: lo_b and
+// mid_b then carry random signs); with both operands truncated they all have the sign of a b and bias a sum by ~2^-24 sum |a||b| towards zero
+// (tests/test_gpu_parity.py::test_bf16x6_adversarial_operands_vs_float64).  This kernel is bound by these VALU operations: B rounded, A truncated.
+template <bool RN>
 FN_DEVINL void fn_split8(const f32x4 (&v)[8], int e, bf16x8& h, bf16x8& m, bf16x8& l) {
-    float x[8], r1[8], r2[8];
+    float x[8], hi[8], r1[8], mi[8], r2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[j] = v[j][e];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r1[j] = x[j] - fn_top16(x[j]);
+    for (int j = 0; j < 8; ++j) { hi[j] = RN ? fn_rn16(x[j]) : fn_top16(x[j]); r1[j] = x[j] - hi[j]; }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r2[j] = r1[j] - fn_top16(r1[j]);
+    for (int j = 0; j < 8; ++j) { mi[j] = RN ? fn_rn16(r1[j]) : fn_top16(r1[j]); r2[j] = r1[j] - mi[j]; }
     u32x4 H, M, L;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        H[j] = fn_pack_top16(x[2 * j], x[2 * j + 1]);
-        M[j] = fn_pack_top16(r1[2 * j], r1[2 * j + 1]);
+        H[j] = fn_pack_top16(hi[2 * j], hi[2 * j + 1]);
+        M[j] = fn_pack_top16(mi[2 * j], mi[2 * j + 1]);
         L[j] = fn_pack_top16(r2[2 * j], r2[2 * j + 1]);
     }
     h = __builtin_bit_cast(bf16x8, H);
@@ -374,11 +378,11 @@ __global__ __launch_bounds__(NT) void gemm_tn_x6_kernel(int M, int N, int K, flo
             auto mma = [&](int u) {
                 bf16x8 bh[4], bm[4], bl[4];
 #pragma unroll
-                for (int b = 0; b < 4; ++b) fn_split8(fb[u], b, bh[b], bm[b], bl[b]);
+                for (int b = 0; b < 4; ++b) fn_split8<true>(fb[u], b, bh[b], bm[b], bl[b]);
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     bf16x8 ah, am, al;
-                    fn_split8(fa[u], a, ah, am, al);
+                    fn_split8<false>(fa[u], a, ah, am, al);
 #pragma unroll
                     for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[b], acc[a][b], 0, 0, 0);
 #pragma unroll

@@ -429,7 +429,7 @@ __global__ void frag_pack_kernel(const float* __restrict__ src, int rows, int K,
 }
 
 // row-major [rows][K] -> bf16 TRIPLE image for the bf16 x 6 kernels (gru_persist.hip: gru_fwd_x6_kernel): [row tile 16][k block 32][piece 3][64 lanes][8 bf16],
-// lane (i, g) = row 16 t + i, k values 32 b + 8 g .. + 7; piece 0 / 1 / 2 = hi / mid / lo with hi + mid + lo == src exactly (truncation splits);
+// lane (i, g) = row 16 t + i, k values 32 b + 8 g .. + 7; piece 0 / 1 / 2 = hi / mid / lo with hi + mid + lo == src exactly (rounded pieces: fn_rn16);
 // rows padded to a multiple of 16 with zeros.  One thread per (row, 8 k).
 __global__ void frag3_pack_kernel(const float* __restrict__ src, int rows, int K, long ld, unsigned* __restrict__ dst) {
     const int rows16 = (rows + 15) & ~15, nb = K >> 5;
@@ -443,15 +443,17 @@ __global__ void frag3_pack_kernel(const float* __restrict__ src, int rows, int K
         unsigned h[4], m[4], l[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float r1[2], r2[2];
+            float hi[2], mi[2], r1[2], r2[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const float v = x[2 * j + e];
-                r1[e] = v - __uint_as_float(__float_as_uint(v) & 0xffff0000u);
-                r2[e] = r1[e] - __uint_as_float(__float_as_uint(r1[e]) & 0xffff0000u);
+                hi[e] = fn_rn16(v);
+                r1[e] = v - hi[e];
+                mi[e] = fn_rn16(r1[e]);
+                r2[e] = r1[e] - mi[e];
             }
-            h[j] = (__float_as_uint(x[2 * j]) >> 16) | (__float_as_uint(x[2 * j + 1]) & 0xffff0000u);
-            m[j] = (__float_as_uint(r1[0]) >> 16) | (__float_as_uint(r1[1]) & 0xffff0000u);
+            h[j] = (__float_as_uint(hi[0]) >> 16) | (__float_as_uint(hi[1]) & 0xffff0000u);
+            m[j] = (__float_as_uint(mi[0]) >> 16) | (__float_as_uint(mi[1]) & 0xffff0000u);
             l[j] = (__float_as_uint(r2[0]) >> 16) | (__float_as_uint(r2[1]) & 0xffff0000u);
         }
 #pragma unroll

@@ -23,6 +23,7 @@
 #include "gru_layout.h"
 #include "kloop_asm.h"
 #include "kloop2_asm.h"
+#include "kloop3_asm.h"
 
 #ifdef FN_TIMING
 __device__ unsigned long long fn_pdbg[8 * 8];
@@ -379,6 +380,20 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 FN_DEVINL float fn_top16(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
 FN_DEVINL unsigned fn_pack_top16(float a, float b) { return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u); }
+// four fp32 values -> their exact bf16 triples (rounded pieces, fn_rn16), each piece as four packed bf16: what one epilogue item puts on the exchange slab
+FN_DEVINL void fn_split3x4(const f32x4& x, u32x2& th, u32x2& tm, u32x2& tl) {
+    float hi[4], mi[4], lo[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        hi[c] = fn_rn16(x[c]);
+        const float r1 = x[c] - hi[c];
+        mi[c] = fn_rn16(r1);
+        lo[c] = r1 - mi[c];
+    }
+    th = (u32x2){fn_pack_top16(hi[0], hi[1]), fn_pack_top16(hi[2], hi[3])};
+    tm = (u32x2){fn_pack_top16(mi[0], mi[1]), fn_pack_top16(mi[2], mi[3])};
+    tl = (u32x2){fn_pack_top16(lo[0], lo[1]), fn_pack_top16(lo[2], lo[3])};
+}
 FN_DEVINL void gld4u_sc1(u32x4& dst, const u32x4* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory"); }
 FN_DEVINL void stv2_sc1(void* p, const u32x2& v) { asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
 
@@ -571,12 +586,11 @@ __global__ __launch_bounds__(NT) void gru_fwd_x6_kernel(const PArgs args) {
                 o_r[m][c] = r; o_z[m][c] = z; o_n[m][c] = n; o_g[m][c] = gh[2][c];
             }
             if (xout) {                                  // the new state as bf16 triples, straight into the next step's operand layout
-                float r1[4], r2[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { r1[c] = hp[m][c] - fn_top16(hp[m][c]); r2[c] = r1[c] - fn_top16(r1[c]); }
-                stv2_sc1(xout + soff[m], (u32x2){fn_pack_top16(hp[m][0], hp[m][1]), fn_pack_top16(hp[m][2], hp[m][3])});
-                stv2_sc1(xout + soff[m] + 1024, (u32x2){fn_pack_top16(r1[0], r1[1]), fn_pack_top16(r1[2], r1[3])});
-                stv2_sc1(xout + soff[m] + 2048, (u32x2){fn_pack_top16(r2[0], r2[1]), fn_pack_top16(r2[2], r2[3])});
+                u32x2 th, tm, tl;
+                fn_split3x4(hp[m], th, tm, tl);
+                stv2_sc1(xout + soff[m], th);
+                stv2_sc1(xout + soff[m] + 1024, tm);
+                stv2_sc1(xout + soff[m] + 2048, tl);
             }
         }
         // (f) publish: every wave drains its stores, then ONE lane arrives at the group counter
@@ -1165,6 +1179,252 @@ __global__ __launch_bounds__(NT) void gru_fwd_pp_kernel(const PArgs args) {
     flush_stores();                                  // the last epilogue's (no K loop follows)
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Ping-pong forward scan on the bf16 MFMA with exact bf16 triple splits (round 5; kloop3_asm.h / gen_kloop3.py have the protocol): the structure of
+// gru_fwd_pp_kernel - two halves per workgroup, every wave one 16-row tile of each, stores / arrival / counter read of a phase inside the next
+// phase's K loop - with the operands of gru_fwd_x6_kernel: the W_hh slice as bf16 triples in LDS (144 KB), the recurrent state exchanged as
+// triples (rounded pieces, fn_split3x4), 18 v_mfma_f32_16x16x32_bf16 per (row tile, 32 k).  The accumulator tiles in LDS hold ONE half (13 KB):
+// the s_barrier every K loop executes at its arrival point separates a phase's accumulator writes from the previous epilogue's reads.
+// The ring of the next phase is requested by its own statement behind the K loop (fn_x6_fwd_*_pro) once the counter value the loop read
+// near its end says that the other half's inputs are all there (else: poll first).  WK = 1: 128-row groups; WK = 2: 64-row groups, K split
+// over two wave pairs (not the summation order of gru_fwd_x6_kernel's 64-row form, which has no K split).
+// H = 512, full row groups, saved gates, exactly one of gx_table / gx_dense, T >= 2.
+// ---------------------------------------------------------------------------------------------------------------
+template <int WK>
+__global__ __launch_bounds__(NT) void gru_fwd_x6pp_kernel(const PArgs args) {
+    static_assert(WK == 1 || WK == 2, "128-row groups (one wave over all of K) or 64-row groups (K split in two)");
+    constexpr int WM = 4 / WK, EM = 2 * WM;          // wave rows; row tiles per workgroup (one per wave row and half)
+    constexpr int H = 512, NB = 16, nslices = 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    u32x4* wl = reinterpret_cast<u32x4*>(smem);      // [3][NB][3][64] weight triples, B-operand order
+    float* red = smem + 3 * NB * 3 * 64 * 4;         // [WK][WM][3][RT] accumulator exchange of the CURRENT half
+    const unsigned dead = lds_addr(red + WK * WM * 3 * RT);
+
+    const int g = blockIdx.x % args.ngroups, slice = blockIdx.x / args.ngroups;
+    int si = 0;
+#pragma unroll
+    for (int k = 1; k < FN_MAX_SCANS; ++k)
+        if (k < args.n && g >= args.s[k].group0) si = k;
+    const PScan& S = args.s[si];
+    const int B = S.B, T = S.T;
+    const int m0 = (g - S.group0) * (16 * EM), hh0 = slice * 16;
+    const int nrt = B >> 4;
+    const long FSB = (long)nrt * NB * 3 * 1024;      // bytes of one exchange slab
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wk = wave / WM;
+    u32* cnt[2] = {args.sync + (2 * g) * 32, args.sync + (2 * g + 1) * 32};      // one arrival counter per half
+    u32* err = args.err;
+    char* xs = reinterpret_cast<char*>(S.xf);
+    const char* h0f = reinterpret_cast<const char*>(S.h0f);
+
+    if (tid == 0) lds_st(dead, 0);
+#pragma unroll 1
+    for (int q = 0; q < 3; ++q) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(S.w_frag) + (long)(q * nslices + slice) * NB * 3 * 64;
+        u32x4* dst = wl + q * NB * 3 * 64;
+        for (int i = tid; i < NB * 3 * 64; i += NT) dst[i] = src[i];
+    }
+
+    // epilogue item of this thread inside a half: (row, 4 consecutive units); 64-row groups have 128 items per half: lanes 0-31 of every wave
+    const bool has_item = WK == 1 || lane < 32;
+    const int item = WK == 1 ? tid : wave * 32 + (lane & 31);
+    const int rl = item >> 2, th = rl >> 4, u4 = item & 3;
+    const int jj0 = hh0 + 4 * u4;
+    int ib[2];
+    long soff[2];
+    f32x4 bh[3], bi[3], e_rb[2][3], hp[2];
+    const int icoff = (th * 3) * RT + ((rl & 15) >> 2) * 68 + u4 * 16 + (rl & 3);      // tile th of the current half
+#pragma unroll
+    for (int hx = 0; hx < 2; ++hx) {
+        const int tile = 2 * th + hx;
+        ib[hx] = m0 + tile * 16 + (rl & 15);
+        // where this item's four new state values go on the exchange slab: row tile, k block = slice / 2, k group 2 (slice & 1) + u4 / 2, half u4 & 1
+        soff[hx] = ((((long)(ib[hx] >> 4) * NB + (slice >> 1)) * 3) * 64 + (ib[hx] & 15) + 16 * (2 * (slice & 1) + (u4 >> 1))) * 16 + (u4 & 1) * 8;
+        hp[hx] = S.h0 ? ldv4(S.h0 + (long)ib[hx] * H + jj0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            e_rb[hx][q] = S.gx_rowbias ? ldv4(S.gx_rowbias + (long)ib[hx] * 3 * H + q * H + jj0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        bh[q] = ldv4(S.b_hh + q * H + jj0);
+        bi[q] = S.b_ih ? ldv4(S.b_ih + q * H + jj0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    int tokn[2];
+#pragma unroll
+    for (int hx = 0; hx < 2; ++hx) {
+        const int tau0 = (S.reverse ? T - 1 : 0) + S.idx_shift;
+        tokn[hx] = (S.gx_table && tau0 >= 0) ? S.idx[(long)ib[hx] * S.idx_ld + tau0] : S.start_token;
+    }
+    __syncthreads();
+
+    const int c0 = NB * wk / WK;                     // this wave's first K block
+    unsigned vo[2];
+#pragma unroll
+    for (int hx = 0; hx < 2; ++hx) vo[hx] = (unsigned)((((long)(m0 >> 4) + 2 * wm + hx) * NB * 3 * 1024) + lane * 16);
+    const unsigned h_red = lds_addr(red) + ((((wk * WM + wm) * 3) * RT + lane * 4 + (lane >> 4) * 4) * 4);
+    const unsigned lp0 = lds_addr(wl) + c0 * 3072 + lane * 16, lp1 = lp0 + 49152u, lp2 = lp0 + 98304u;
+    const int* legal_i = S.idx ? S.idx : reinterpret_cast<const int*>(S.b_hh);
+
+    // stores of the last epilogue: issued by the NEXT phase's K loop statement (kloop3_asm.h), or by flush_stores() when none follows
+    char* st_a0 = nullptr;
+    float *st_a1 = nullptr, *st_a2 = nullptr;
+    u32x2 st_t[3];
+    f32x4 st_d[5];
+    auto flush_stores = [&]() __attribute__((always_inline)) {
+        if (has_item) {
+            stv2_sc1(st_a0, st_t[0]);
+            stv2_sc1(st_a0 + 1024, st_t[1]);
+            stv2_sc1(st_a0 + 2048, st_t[2]);
+            stv4(st_a1, st_d[0]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) stv4(st_a2 + q * 256, st_d[1 + q]);
+        }
+    };
+    // gate epilogue of half hx at step p: reads the accumulator tiles from LDS, leaves the new state (triples for the exchange slab + h_all) and the
+    // saved gates in st_*: arithmetic and LDS reads only, no vector-memory instruction
+    auto epilogue = [&](auto HX, const int p, const f32x4 (&e_x)[3]) __attribute__((always_inline)) {
+        constexpr int hx = decltype(HX)::value;
+        char* xout = (p + 1 < T || !S.hlf) ? xs + (long)((p + 1) & 1) * FSB : reinterpret_cast<char*>(S.hlf);      // last step: the next launch's hand-over image (or a slab nobody reads)
+        f32x4 gh[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < WK; ++w) a += red[(long)(w * WM * 3 + q) * RT + icoff + c * 4];
+                gh[q][c] = a + bh[q][c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float r, z, n, hn;
+            fn_gru_gate((bi[0][c] + e_x[0][c]) + e_rb[hx][0][c], (bi[1][c] + e_x[1][c]) + e_rb[hx][1][c], (bi[2][c] + e_x[2][c]) + e_rb[hx][2][c],
+                        gh[0][c], gh[1][c], gh[2][c], hp[hx][c], r, z, n, hn);
+            hp[hx][c] = hn;
+            st_d[1][c] = r; st_d[2][c] = z; st_d[3][c] = n; st_d[4][c] = gh[2][c];
+        }
+        st_d[0] = hp[hx];
+        fn_split3x4(hp[hx], st_t[0], st_t[1], st_t[2]);
+        st_a0 = xout + soff[hx];
+        st_a1 = S.h_all + (long)p * B * H + (long)ib[hx] * H + jj0;
+        st_a2 = S.gates + (long)p * 4 * H * nrt * 16 + gate_off(ib[hx], 0, jj0, nrt);
+    };
+    auto next_token = [&](const int hx, const int p, const int loaded) {      // token of step p + 1 (loaded = idx value requested for it)
+        const int tau1 = (S.reverse ? T - 2 - p : p + 1) + S.idx_shift;
+        return tau1 >= 0 ? loaded : S.start_token;
+    };
+    auto token_addr = [&](const int hx, const int p) {                        // where the token of step p + 1 lives (a legal address otherwise)
+        const int tau1 = (S.reverse ? T - 2 - p : p + 1) + S.idx_shift;
+        return (S.gx_table && p + 1 < T && tau1 >= 0) ? S.idx + (long)ib[hx] * S.idx_ld + tau1 : legal_i;
+    };
+    auto request = [&](const char* xin, unsigned v) __attribute__((always_inline)) {
+        if (WK == 1) fn_x6_fwd_k512_pro(xin, v, lp0, lp1, lp2);
+        else fn_x6_fwd_k256_pro(xin, v, lp0, lp1, lp2);
+    };
+
+    int pend = -1;                                   // half whose epilogue stores still await their arrival (made inside the next K loop)
+    int p_first = 0;
+    if (!S.h0) {
+        // ---- step 0 from a zero state: no K loop (gh = b_hh); half A arrives at once, half B's arrival rides in the first K loop --------
+        p_first = 1;
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+            *reinterpret_cast<f32x4*>(red + (long)((wk * WM + wm) * 3 + n) * RT + lane * 4 + (lane >> 4) * 4) = z4;
+        f32x4 e0[2][3];
+        int t1[2];
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                e0[hx][q] = z4;
+                if (S.gx_table) e0[hx][q] = ldv4(S.gx_table + (long)tokn[hx] * 3 * H + jj0 + q * H);
+                if (S.gx_dense) e0[hx][q] += ldv4(S.gx_dense + (long)ib[hx] * 3 * H + jj0 + q * H);
+            }
+            t1[hx] = *token_addr(hx, 0);
+        }
+        __syncthreads();
+        epilogue(std::integral_constant<int, 0>{}, 0, e0[0]);
+        flush_stores();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(cnt[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        epilogue(std::integral_constant<int, 1>{}, 0, e0[1]);
+        flush_stores();
+        pend = 1;
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx)
+            if (S.gx_table) tokn[hx] = next_token(hx, 0, t1[hx]);
+    }
+    // every load the compiler knows about has to be complete HERE (see gru_fwd_pp_kernel)
+#pragma unroll
+    for (int hx = 0; hx < 2; ++hx) {
+        asm volatile("" : "+v"(tokn[hx]));
+        fn_touch(hp[hx]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) fn_touch(e_rb[hx][q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { fn_touch(bh[q]); fn_touch(bi[q]); }
+
+    auto slab_in = [&](const int p) { return ((p == 0 && h0f) ? h0f : xs + (long)(p & 1) * FSB) + (long)c0 * 3072; };
+    // ---- ring of the first K phase (half A of step p_first) ---------------------------------------------------------------------------
+    if (p_first > 0) pp_wait_counter(cnt[0], (u32)nslices * (u32)p_first, err, dead);
+    request(slab_in(p_first), vo[0]);
+    bool first = true;                               // no epilogue stores are waiting to be issued (first K phase of the launch)
+
+    auto phase = [&](auto HX, const int p) __attribute__((always_inline)) -> bool {
+        constexpr int hx = decltype(HX)::value, hy = hx ^ 1;
+        const int f1 = 2 * p + hx + 1, p1 = f1 >> 1;
+        const bool next_k = f1 < 2 * T;
+        const unsigned ptgt = (u32)nslices * (u32)p1;
+        const float* xa = S.gx_table ? S.gx_table + (long)tokn[hx] * 3 * H + jj0 + H : S.gx_dense + ((long)p * B + ib[hx]) * 3 * H + jj0 + H;
+        const int* ta = token_addr(hx, p);
+        f32x4 e_x[3];
+        int tk;
+        unsigned pv;
+        const int arr = pend >= 0 ? (wave == 0 ? 2 : 1) : 0;
+        u32* acnt = cnt[pend > 0 ? 1 : 0];
+        FN_PSTAMP(hx * 4 + 0);
+        if (WK == 1) {
+            if (first) fn_x6_fwd_k512_first(slab_in(p), vo[hx], lp0, lp1, lp2, h_red, arr, acnt, cnt[hy], xa, ta, e_x, tk, pv);
+            else fn_x6_fwd_k512_main(slab_in(p), vo[hx], lp0, lp1, lp2, h_red, arr, acnt, cnt[hy], xa, ta, st_a0, st_a1, st_a2, st_t[0], st_t[1], st_t[2],
+                                     st_d[0], st_d[1], st_d[2], st_d[3], st_d[4], e_x, tk, pv);
+        } else {
+            if (first) fn_x6_fwd_k256_first(slab_in(p), vo[hx], lp0, lp1, lp2, h_red, arr, acnt, cnt[hy], xa, ta, e_x, tk, pv);
+            else fn_x6_fwd_k256_main(slab_in(p), vo[hx], lp0, lp1, lp2, h_red, arr, acnt, cnt[hy], xa, ta, st_a0, st_a1, st_a2, st_t[0], st_t[1], st_t[2],
+                                     st_d[0], st_d[1], st_d[2], st_d[3], st_d[4], e_x, tk, pv);
+        }
+        first = false;
+        FN_PSTAMP(hx * 4 + 1);
+        if (S.gx_table) tokn[hx] = next_token(hx, p, tk);
+        if (next_k) {
+            // the other half's inputs: all published when the loop looked (the usual case), else poll; then its ring, which lands under the epilogue
+            if (p1 > 0 && __builtin_amdgcn_readfirstlane((int)pv) < (int)ptgt) {
+                FN_PCOUNT(0);
+                pp_wait_counter(cnt[hy], ptgt, err, dead);
+            }
+            request(slab_in(p1), vo[hy]);
+        }
+        lds_barrier();
+        FN_PSTAMP(hx * 4 + 2);
+        if (lds_ld(dead)) return false;
+        epilogue(HX, p, e_x);
+        FN_PSTAMP(hx * 4 + 3);
+        pend = p + 1 < T ? hx : -1;                  // the arrival is made inside the next phase's K loop
+        return true;
+    };
+
+#pragma unroll 1
+    for (int p = p_first; p < T; ++p) {
+        if (!phase(std::integral_constant<int, 0>{}, p)) return;
+        if (!phase(std::integral_constant<int, 1>{}, p)) return;
+    }
+    flush_stores();                                  // the last epilogue's (no K loop follows)
+}
+
 // backward scan, ping-pong form with HALF of the W_hh^T slice register-stationary (kloop2_asm.h, GenRS): a workgroup owns 32 dh columns
 // (16 slices) of a 32 TH-row group; column tile 0 of its slice lives in AGPRs (every wave its K quarter), column tile 1 in LDS; every wave
 // multiplies all TH row tiles of the current half over its K quarter, the epilogue adds the four partial sums in wave order.  One operand
@@ -1527,8 +1787,14 @@ int fn_gru_fwd_persist(const FnGruFwd* scans, int n_scans, hipStream_t st) {
             if (me != hipSuccess) return (int)me;
         }
         const size_t lds = (size_t)3 * 16 * 3 * 1024 + (size_t)4 * 3 * RT * 4 + 16;
-        const int rc = mt == 1 ? launch_k<PArgs, gru_fwd_x6_kernel<1>>(a, groups * nslices, lds, cus, st)
-                               : launch_k<PArgs, gru_fwd_x6_kernel<2>>(a, groups * nslices, lds, cus, st);
+        // ping-pong form (kloop3_asm.h): exactly one input source per scan; variant bit 15 keeps the single-group kernel (tests)
+        bool pp = !(scans[0].variant & 0x8000) && 2 * groups <= FN_MAX_GROUPS;
+        for (int s = 0; s < n_scans && pp; ++s) pp = (scans[s].gx_table != nullptr) != (scans[s].gx_dense != nullptr);
+        int rc;
+        if (pp) rc = mt == 1 ? launch_k<PArgs, gru_fwd_x6pp_kernel<2>>(a, groups * nslices, lds, cus, st)
+                             : launch_k<PArgs, gru_fwd_x6pp_kernel<1>>(a, groups * nslices, lds, cus, st);
+        else rc = mt == 1 ? launch_k<PArgs, gru_fwd_x6_kernel<1>>(a, groups * nslices, lds, cus, st)
+                          : launch_k<PArgs, gru_fwd_x6_kernel<2>>(a, groups * nslices, lds, cus, st);
         return rc == FN_PERSIST_NA ? FN_E_UNSUPPORTED : rc;
     }
     // smallest row block whose group count fits on the chip with one workgroup per CU

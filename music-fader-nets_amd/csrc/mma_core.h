@@ -39,6 +39,13 @@ FN_DEVINL void fn_wait_vm() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// bf16 x 6 arithmetic: x rounded to its nearest bf16 value (8 significant bits; ties away from zero: the bit pattern plus half a bf16 ulp,
+// truncated).  Whatever the rounding, x - fn_rn16(x) is exact in fp32, and two levels leave a remainder of <= 8 significant bits: hi + mid + lo == x
+// with all three pieces exact bf16 values.  ROUNDED pieces (instead of truncated ones, whose remainders all carry the sign of x) make the three
+// partial products the arithmetic drops (mid*lo, lo*mid, lo*lo) zero-mean - a truncation split biases every dot product by ~2^-24 sum |a||b|
+// towards zero.  (|x| >= 2^128 (1 - 2^-9) would round to infinity; nothing on this path comes near.)
+FN_DEVINL float fn_rn16(float x) { return __uint_as_float((__float_as_uint(x) + 0x8000u) & 0xffff0000u); }
+
 FN_DEVINL bool fn_aligned16(const void* p, long ld) { return ((((uintptr_t)p) & 15) == 0) && ((ld & 3) == 0); }
 
 // Row maps: local tile row r -> source row.  valid(r) says whether the row exists; clamped(r) is always a legal row
