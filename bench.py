@@ -12,6 +12,11 @@ mode train (default; BASELINE configs[1], configs[2-3] with N>1): a "step" = for
 mode decode (BASELINE configs[4]): a "step" = encode 256 sequences (T=256), 8 fader values each on z_r[:, 0], greedy decode of the
   2048 rows for 300 steps (test_class.py:233-254 batched; replicas only, no collective).
 
+--arith f32 | bf16x6: the arithmetic of the deep MFMA products (music-fader-nets_amd/arith.py; default = the package default).  Both are fp32-class
+(24-bit operands, fp32 accumulation); the line says which one `value` was measured on (`arith`) and carries the other one beside it
+(`fp32_mfma_value` / `bf16x6_value`, timed in a child process on the same seeds).  A bf16 x 6 kernel is rated against the dense bf16 MFMA peak / 6
+(416.7 fp32-equivalent TFLOP/s), an fp32-MFMA kernel against 157.3.
+
 Prints ONE JSON line on rank 0 with the contract fields plus `roofline` (the kernel SYMBOL - template instances merged, as rocprofv3 --stats
 lists them - with the largest time per step), `roofline_by_symbol`, `roofline_scans` (the four scan rows as one time-weighted figure),
 `roofline_all` (split by launch shape), `sustained_ms_per_step` (200 more steps behind the timed region), (N=1) `cpu_baseline`, `decode`
@@ -41,7 +46,9 @@ F_ALG_PER_TOKEN = 37.12e6                              # whole training step, pe
 F_ALG_DECODE_PER_TOKEN = 5.07e6                        # one greedy decode step of one sequence (token projection = row gather)
 DECODE_WEIGHT_BYTES = 10.14e6                          # weights one decode step touches (W_hh_g, W_ih_g2, W_hh_g2, W_out)
 PEAK_F32_MFMA_TFLOPS = 157.3                           # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+PEAK_BF16X6_TFLOPS = 2500.0 / 6.0                      # fp32-equivalent peak of a bf16 x 6 kernel: dense bf16 MFMA peak (2.5 PFLOP/s) / 6 partial products = 416.7
 PEAK_HBM_GBS = 8000.0
+PEAK_OF = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x6": PEAK_BF16X6_TFLOPS}
 
 
 class TimedOps:
@@ -63,12 +70,25 @@ class TimedOps:
             e0.record()
             res = attr(*a, **k)
             e1.record()
-            self.records.append((name, a, k, e0, e1))
+            self.records.append((name, a, k, e0, e1, _x6_of(self._ops, name, a, k)))
             return res
         return call
 
     def __setattr__(self, name, value):
         setattr(self._ops, name, value)
+
+
+def _x6_of(ops, name, a, k):
+    """which arithmetic this op call ran on (mirrors hipops.py's choices)"""
+    if not getattr(ops, "dw_x6", False):
+        return False
+    if name == "gru_seq_fwd":
+        return bool(k.get("x6", None) if k.get("x6", None) is not None else ops.gru_fwd_x6_ok(a[0]))
+    if name == "gru_dwhh":
+        return a[2].shape[0] >= 1024
+    if name == "gemm":
+        return (not k.get("a_k", True)) and (not k.get("b_k", True)) and a[0].shape[0] >= 1024
+    return False
 
 
 def _classify(name, a, k):
@@ -109,15 +129,15 @@ def _classify(name, a, k):
     return None
 
 
-def _symbol(name, a, k):
+def _symbol(name, a, k, x6=False):
     """op call -> (kernel symbol as rocprofv3 prints it without template arguments, bound, work of that launch) for EVERY launch of the heavy
     symbols, whatever its shape (roofline_by_symbol merges what `_classify` splits by launch shape)"""
     if name in ("gru_seq_fwd", "gru_seq_bwd"):
         work = sum(s["B"] * s["T"] for s in a[0]) * FLOP_PER_SAMPLE_STEP
-        return ("gru_fwd_pp_kernel" if name == "gru_seq_fwd" else "gru_bwd_rs_kernel"), "mfma", work
+        return (("gru_fwd_x6pp_kernel" if x6 else "gru_fwd_pp_kernel") if name == "gru_seq_fwd" else "gru_bwd_rs_kernel"), "mfma", work
     if name == "gru_dwhh":
         rows, Hh = a[2].shape
-        return "gemm_tn_kernel", "mfma", 2.0 * rows * 3 * Hh * Hh
+        return ("gemm_tn_x6_kernel" if x6 else "gemm_tn_kernel"), "mfma", 2.0 * rows * 3 * Hh * Hh
     if name == "gemm":
         A, Cm = a[0], a[2]
         M, N = Cm.shape
@@ -125,7 +145,7 @@ def _symbol(name, a, k):
         if k.get("a_k", True) and k.get("b_k", True):
             sym = "gemm_nt_direct_kernel / gemm_kernel"
         else:
-            sym = "gemm_kernel" if k.get("a_k", True) else "gemm_tn_kernel"
+            sym = "gemm_kernel" if k.get("a_k", True) else ("gemm_tn_x6_kernel" if x6 else "gemm_tn_kernel")
         return sym, "mfma", 2.0 * M * N * Kk
     if name == "out_head":
         h, W = a[0], a[1]
@@ -136,12 +156,22 @@ def _symbol(name, a, k):
 
 
 SYMBOL_NOTE = {
+    "gru_fwd_x6pp_kernel": "forward weight-stationary scans on the bf16 MFMA (exact bf16 triple splits, 6 products), ping-pong over two row halves (all launches: encoder 4 x 256 rows x 256 steps, decoder pipeline chunks, attribute decoders); rated against 2.5 PFLOP/s / 6",
+    "gemm_tn_x6_kernel": "weight-gradient products dW = dY^T X on the bf16 MFMA (operands split in the loop; dW_hh of every scan via fn_gru_dwhh_f32, dW of the dense layers); rated against 2.5 PFLOP/s / 6",
     "gru_fwd_pp_kernel": "forward weight-stationary scans, ping-pong over two row halves (all launches: encoder 4 x 256 rows x 256 steps, decoder pipeline chunks, attribute decoders)",
     "gru_bwd_rs_kernel": "backward weight-stationary scans, W_hh^T slice half register-stationary (all launches: encoder, decoder pipeline chunks, attribute decoders)",
     "gemm_tn_kernel": "weight-gradient products dW = dY^T X (dW_hh of every scan via fn_gru_dwhh_f32, dW of the dense layers)",
 }
 
 
+X6_KERNEL = {  # rows whose launches run on the bf16 x 6 kernels when that arithmetic is chosen
+    "enc_fwd_scan": "gru_fwd_x6pp_kernel<1> (4 encoder scans x 256 steps, one launch; bf16 MFMA, exact triple splits)",
+    "dec_fwd_scan_chunk": "gru_fwd_x6pp_kernel<2> (one launch of the decoder pipeline: 2 scans x 256 rows x 32 steps; bf16 MFMA, exact triple splits)",
+    "subdec_fwd_scan": "gru_fwd_x6pp_kernel (both sub-decoders, 64 steps)",
+    "dwhh_gemm_tn": "gemm_tn_x6_kernel via fn_gru_dwhh_f32 (dW_hh of an encoder direction / a decoder layer: [3H x T*B] x [T*B x H], 48 tiles x 16 K ranges; 6 launches per step)",
+    "dwhh_gemm_tn_attr": "gemm_tn_x6_kernel via fn_gru_dwhh_f32 (dW_hh of the attribute decoders, K = Tr*B rows)",
+    "gemm_tn": "gemm_tn_x6_kernel (dW of dense layers)",
+}
 ROW_INFO = {   # row -> (bound, unit of work, kernel, peak share of the chip)
     "enc_fwd_scan": ("mfma", "flop", "gru_fwd_pp_kernel<1> (4 encoder scans x 256 steps, one launch)", 1.0),
     "enc_bwd_scan": ("mfma", "flop", "gru_bwd_rs_kernel<2> (4 encoder scans x 256 steps, one launch)", 1.0),
@@ -160,42 +190,53 @@ ROW_INFO = {   # row -> (bound, unit of work, kernel, peak share of the chip)
 }
 
 
-# HBM bytes per launch from rocprofv3 PMC passes (2 x FETCH_SIZE with the gfx950 correction + WRITE_SIZE, separate passes): bench.py
-# itself cannot run the profiler, so these are the committed measurements of the same launches
-PMC_TRAFFIC = {"enc_fwd_scan": 4.309e9, "enc_bwd_scan": 8.038e9, "dec_fwd_scan_chunk": 0.313e9, "dec_bwd_scan_chunk": 0.585e9, "dwhh_gemm_tn": 0.711e9,
-               "out_head": 0.287e9}
-# symbol -> mean bytes per launch over ALL of its launches in one step (1 encoder + 10 decoder-pipeline launches for the scans): per launch like `achieved`
-PMC_TRAFFIC_SYMBOL = {"gru_fwd_pp_kernel": 0.676e9, "gru_bwd_rs_kernel": 1.262e9, "gemm_tn_kernel": 0.291e9}
-PMC_SOURCE = "profiles/r04_pmc_training_step.txt (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes of the same launches)"
+# HBM bytes per launch come from rocprofv3 --pmc passes of the same launches (2 x FETCH_SIZE with the gfx950 correction + WRITE_SIZE, separate passes;
+# scratch/r5_pmc_step.sh writes the per-row / per-symbol means into profiles/r05_pmc_traffic.json).  bench.py cannot run the profiler around itself,
+# so these are STATIC, committed measurements: the line says so (`traffic_static`) and names the file.
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
+
+
+def pmc_traffic():
+    try:
+        d = json.load(open(PMC_FILE))
+        return d.get("by_row", {}), d.get("by_symbol", {}), "profiles/r05_pmc_traffic.json (%s)" % d.get("how", "rocprofv3 --pmc")
+    except (OSError, ValueError):
+        return {}, {}, None
 
 
 def roofline_rows(records):
     agg = {}
-    for name, a, k, e0, e1 in records:
+    for name, a, k, e0, e1, x6 in records:
         c = _classify(name, a, k)
         if c is None or c[1] is None or c[0] not in ROW_INFO:
             continue
         ms = e0.elapsed_time(e1)
-        ent = agg.setdefault(c[0], [0, 0.0, 0.0])
+        ent = agg.setdefault(c[0], [0, 0.0, 0.0, x6])
         ent[0] += 1
         ent[1] += ms
         ent[2] += c[1]
     rows = {}
-    for row, (cnt, ms, work) in agg.items():
+    for row, (cnt, ms, work, x6) in agg.items():
         bound, unit, kernel, share = ROW_INFO[row]
+        arith = "bf16x6" if x6 else "f32"
         if bound == "mfma":
-            ach, peak, u = work / (ms * 1e-3) / 1e12, PEAK_F32_MFMA_TFLOPS * share, "TFLOP/s"
+            ach, peak, u = work / (ms * 1e-3) / 1e12, PEAK_OF[arith] * share, "TFLOP/s"
+            if x6:
+                kernel = X6_KERNEL.get(row, kernel)
         else:
             ach, peak, u = work / (ms * 1e-3) / 1e9, PEAK_HBM_GBS * share, "GB/s"
         rows[row] = dict(bound=bound, kernel=kernel, launches=cnt, avg_launch_us=round(ms / cnt * 1e3, 1), achieved=round(ach, 2),
-                         peak=peak, unit=u, frac=round(ach / peak, 4), work_per_launch=work / cnt, total_us=ms * 1e3)
+                         peak=round(peak, 1), unit=u, frac=round(ach / peak, 4), work_per_launch=work / cnt, total_us=ms * 1e3)
+        if bound == "mfma":
+            rows[row]["arith"] = arith
+            rows[row]["frac_of_fp32_mfma_peak"] = round(ach / PEAK_F32_MFMA_TFLOPS, 4)
     return rows
 
 
 def symbol_rows(records, reps):
     agg = {}
-    for name, a, k, e0, e1 in records:
-        c = _symbol(name, a, k)
+    for name, a, k, e0, e1, x6 in records:
+        c = _symbol(name, a, k, x6)
         if c is None:
             continue
         ent = agg.setdefault(c[0], [c[1], 0, 0.0, 0.0])
@@ -204,13 +245,17 @@ def symbol_rows(records, reps):
         ent[3] += c[2]
     rows = {}
     for sym, (bound, cnt, ms, work) in agg.items():
+        x6 = "_x6" in sym
         if bound == "mfma":
-            ach, peak, u = work / (ms * 1e-3) / 1e12, PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
+            ach, peak, u = work / (ms * 1e-3) / 1e12, PEAK_OF["bf16x6" if x6 else "f32"], "TFLOP/s"
         else:
             ach, peak, u = work / (ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
         rows[sym] = dict(bound=bound, kernel=sym, note=SYMBOL_NOTE.get(sym), launches_per_step=round(cnt / reps, 1), avg_launch_us=round(ms / cnt * 1e3, 1),
-                         achieved=round(ach, 2), peak=peak, unit=u, frac=round(ach / peak, 4), work_per_launch=work / cnt,
+                         achieved=round(ach, 2), peak=round(peak, 1), unit=u, frac=round(ach / peak, 4), work_per_launch=work / cnt,
                          us_per_step=round(ms * 1e3 / reps, 1))
+        if bound == "mfma":
+            rows[sym]["arith"] = "bf16x6" if x6 else "f32"
+            rows[sym]["frac_of_fp32_mfma_peak"] = round(ach / PEAK_F32_MFMA_TFLOPS, 4)
     return rows
 
 
@@ -225,8 +270,11 @@ def scans_row(rows):
     us = sum(r["us_per_step"] for r in have)
     work = sum(r["work_per_launch"] * r["launches"] for r in have) / max(1, have[0]["_reps"])
     ach = work / (us * 1e-6) / 1e12
-    return dict(bound="mfma", rows=[r for r in SCAN_ROWS if r in rows], us_per_step=round(us, 1), achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS,
-                unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), flop_per_step=work)
+    # time-weighted over rows of possibly different arithmetic: every row's time is set against ITS peak (sum of row time x row fraction / time)
+    frac = sum(r["us_per_step"] * r["frac"] for r in have) / us
+    return dict(bound="mfma", rows=[r for r in SCAN_ROWS if r in rows], us_per_step=round(us, 1), achieved=round(ach, 2), unit="TFLOP/s",
+                frac=round(frac, 4), frac_of_fp32_mfma_peak=round(ach / PEAK_F32_MFMA_TFLOPS, 4), arith={r: rows[r].get("arith") for r in SCAN_ROWS if r in rows},
+                flop_per_step=work)
 
 
 def per_kernel_rooflines(trainer, batch, eps, reps=5):
@@ -300,20 +348,62 @@ def respawn_under_launcher(n):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def bench_train(args, pkg, ctx, local, rank, world, log):
+def make_inputs(trainer, rank, world):
+    """the GLOBAL batch of the job is ONE draw (RandomState(0), B * world rows) and every rank keeps its rows; the noise is drawn for the global batch
+    from one seed on every rank and sliced (GMVAETrainer.draw_eps): an N-rank step IS the single-process step of the global batch (rank 0 of a
+    1-GPU run: the batch of tests/golden/c1.npz)"""
     from music_fader_nets_amd.synth import synth_batch
+    b = synth_batch(np.random.RandomState(0), B * world, T, TR)
+    lo, hi = rank * B, (rank + 1) * B
+    batch = trainer.prepare_batch(b["d"][lo:hi], b["r"][lo:hi], b["n"][lo:hi], b["c"][lo:hi], b["r_density"][lo:hi], b["n_density"][lo:hi])
+    torch.manual_seed(99)
+    eps = trainer.draw_eps(B, T)                            # the reference's draw order; the same eps every step
+    return batch, eps
+
+
+def dp_selfcheck(pkg, ctx, dev, rank, world, log):
+    """N ranks through RCCL == one process on the global batch, at a small size (hidden 64, 8 rows per rank, T = 16): every rank takes one
+    data-parallel step, rank 0 repeats it alone on the concatenated batch; the first-step loss tuples must agree (trainer_gmm.py:249-251: the
+    reduced gradient is what clip + Adam see - compared through the loss of a SECOND step, which depends on the first update)"""
+    from music_fader_nets_amd.synth import synth_batch
+    Hs, Zs, Bs, Ts, Trs = 64, 32, 8, 16, 8
+    b = synth_batch(np.random.RandomState(7), Bs * world, Ts, Trs)
+
+    def run(c, lo, hi, gen_rows):
+        torch.manual_seed(4321)
+        m = pkg.MusicAttrRegGMVAE(342, 3, 16, 24, Hs, Zs, 32, n_component=K).to(dev)
+        tr = pkg.GMVAETrainer(m, lr=1e-3, beta=0.2, dist_ctx=c)
+        tr.use_graph = False
+        batch = tr.prepare_batch(b["d"][lo:hi], b["r"][lo:hi], b["n"][lo:hi], b["c"][lo:hi], b["r_density"][lo:hi], b["n_density"][lo:hi])
+        out = []
+        for it in range(2):
+            torch.manual_seed(55 + it)
+            eps = tr.draw_eps(hi - lo, Ts)
+            beta0, Bg = tr.step_device(20000 + it, batch, eps)
+            out.append(tr._tuple8(beta0, Bg, False))
+        return out
+    dp = run(ctx, rank * Bs, (rank + 1) * Bs, Bs * world)
+    res = None
+    if rank == 0:
+        single = run(None, 0, Bs * world, Bs * world)
+        rel = max(abs(a - b_) / max(1e-12, abs(b_)) for ta, tb in zip(dp, single) for a, b_ in zip(ta, tb))
+        res = dict(loss_dp=[round(t[0], 6) for t in dp], loss_single_process=[round(t[0], 6) for t in single], max_rel_diff_of_the_tuples=float("%.3g" % rel),
+                   shape="hidden 64, %d x %d rows, T = %d, two steps" % (world, Bs, Ts))
+        log("dp self-check: %d RCCL ranks vs one process on the global batch: max rel diff %.3g" % (world, rel))
+        assert rel <= 2e-4, "data-parallel step deviates from the single-process step of the global batch: %r" % (res,)
+    return res
+
+
+def bench_train(args, pkg, ctx, local, rank, world, log):
+    from music_fader_nets_amd import arith as arith_mod
     dev = torch.device("cuda", local)
+    arith = arith_mod.resolve(args.arith)
     torch.manual_seed(1234)                                 # identical weights on every rank
     model = pkg.MusicAttrRegGMVAE(342, 3, 16, 24, H, Z, 32, n_component=K).to(dev)
+    model.set_arith(arith)
     trainer = pkg.GMVAETrainer(model, lr=1e-3, beta=0.2, dist_ctx=ctx)
-    b = synth_batch(np.random.RandomState(rank), B, T, TR)  # each rank its own shard of the global batch (rank 0: the c1 fixture's batch)
-    batch = trainer.prepare_batch(b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"])
-    torch.manual_seed(99 + rank)
-    eps = trainer.draw_eps(B, T)                            # the reference's draw order; the same eps every step
-    log("model + batch ready on %s" % dev)
-    if getattr(args, "x6_only", False):                     # child process of the default run: only the opt-in leg, its dict as the line
-        del trainer
-        return bench_x6_leg(args, pkg, batch, eps, dev, None, log)
+    batch, eps = make_inputs(trainer, rank, world)
+    log("model + batch ready on %s, arithmetic %s" % (dev, arith))
     step = 20000
     first = None
     for i in range(args.warmup):
@@ -341,6 +431,9 @@ def bench_train(args, pkg, ctx, local, rank, world, log):
     assert all(np.isfinite(tup)), tup
     tokens_per_s = world * B * T * args.steps / dt
     log("timed region done: %.3f ms/step (host enqueue %.3f ms/step)" % (dt / args.steps * 1e3, t_host / args.steps * 1e3))
+    if args.leg_only:                                       # child process of the default run: the other arithmetic's timed region, nothing else
+        return dict(arith=arith, ms_per_step=round(dt / args.steps * 1e3, 3), value=round(tokens_per_s, 1), unit="event-tokens/s", steps=args.steps,
+                    first_step_loss=None if first is None else round(first[0], 4), last_loss=round(tup[0], 4))
     # sustained rate: >= 200 more replays right behind the timed region (clock / thermal settle: r03 soak 23.64 ms vs 22.78 in the 20-step bench)
     sustained = None
     if args.sustain > 0:
@@ -363,7 +456,7 @@ def bench_train(args, pkg, ctx, local, rank, world, log):
     out = {
         "metric": "event-tokens/sec GM-VAE train, seq256 b256", "value": round(tokens_per_s, 1), "unit": "event-tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "arith": arith_mod.describe(arith), "data": "synthetic",
         "config": {"workload": "MusicAttrRegGMVAE train step (fwd+losses+bwd+clip+Adam), hidden 512, z 128, K=2, "
                                "B=256/GPU, T=256, Tr=64 (BASELINE configs[1]; N>1: DP, RCCL grad all-reduce)",
                    "global_batch": B * world, "seq_len": T, "parallelism": "dp%d" % world},
@@ -375,27 +468,33 @@ def bench_train(args, pkg, ctx, local, rank, world, log):
         out["sustained_steps"] = args.sustain
     if ctx is not None and getattr(ctx, "rccl", None) is not None:
         comm = comm_times(trainer, ctx, batch, eps, step)
+        comm["rccl_ranks"], comm["rccl_rank"] = ctx.rccl.ranks()      # what RCCL itself says (ncclCommCount / ncclCommUserRank)
+        assert comm["rccl_ranks"] == world, "RCCL reports %r ranks, the launcher %d" % (comm["rccl_ranks"], world)
+        comm["dp_selfcheck"] = _aux(lambda: dp_selfcheck(pkg, ctx, dev, rank, world, log), log, "dp self-check") if world > 1 else None
         if rank == 0:
             out["comm"] = comm
     if rank == 0:
         # `roofline` = the kernel SYMBOL (template instances merged, as rocprofv3 --stats lists them) the step spends most of its time in;
-        # `roofline_all` keeps the split by launch shape, `roofline_scans` the four scan rows as one time-weighted figure
+        # `roofline_all` keeps the split by launch shape, `roofline_scans` the four scan rows as one time-weighted figure.  A bf16 x 6 kernel is
+        # rated against the dense bf16 MFMA peak / 6 = 416.7 fp32-equivalent TFLOP/s, an fp32-MFMA kernel against 157.3.
+        traffic_row, traffic_sym, traffic_src = pmc_traffic()
         scans = scans_row(rows)
         for r in rows.values():
             r.pop("_reps", None)
         dom_sym = max(by_symbol, key=lambda r: by_symbol[r]["us_per_step"])
         dom = dict(by_symbol[dom_sym])
-        dom.update(symbol=dom_sym, traffic=PMC_TRAFFIC_SYMBOL.get(dom_sym), traffic_source=PMC_SOURCE if dom_sym in PMC_TRAFFIC_SYMBOL else None,
+        dom.update(symbol=dom_sym, traffic=traffic_sym.get(dom_sym), traffic_static=True, traffic_source=traffic_src if dom_sym in traffic_sym else None,
                    flop_per_launch=dom.pop("work_per_launch"),
-                   step_frac=round(tokens_per_s / world * F_ALG_PER_TOKEN / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
+                   step_frac=round(tokens_per_s / world * F_ALG_PER_TOKEN / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                   step_frac_note="whole step: 37.12 MFLOP per token x tokens/s against the fp32 MFMA peak (157.3 TFLOP/s), whatever arithmetic the kernels ran on")
         out["roofline"] = dom
         for r in by_symbol.values():
             r.pop("work_per_launch", None)
         out["roofline_by_symbol"] = by_symbol
         out["roofline_scans"] = scans
-        for row, tr_ in PMC_TRAFFIC.items():
+        for row, tr_ in traffic_row.items():
             if row in rows:
-                rows[row]["traffic"], rows[row]["traffic_source"] = tr_, PMC_SOURCE
+                rows[row]["traffic"], rows[row]["traffic_static"], rows[row]["traffic_source"] = tr_, True, traffic_src
         out["roofline_all"] = rows
         out["roofline_worst"] = min(rows, key=lambda r: rows[r]["frac"])
         if first is not None and world == 1:                # same seeds as tests/golden/c1.npz (the reference's own train() at this size)
@@ -405,19 +504,22 @@ def bench_train(args, pkg, ctx, local, rank, world, log):
                 ref = float(np.load(gpath)["train_tuples"][0][0])
                 out["first_step_loss_reference"] = round(ref, 4)
                 assert abs(first[0] - ref) <= 5e-4 * abs(ref), "first optimisation step deviates from the reference: %r vs %r" % (first[0], ref)
-    if world == 1 and not args.no_x6:
-        # OPT-IN arithmetic, reported BESIDE the headline (never inside it): the T*B-deep weight-gradient products and the forward scans on the
-        # bf16 MFMA with every fp32 operand value cut exactly into three bf16 pieces (FN_GEMM_BF16X6, FnGruFwd.variant bit 14; HipOps.dw_x6) -
-        # same seeds, same steps, its own trainer
-        # in a CHILD process: whatever happens to that leg (it runs kernels outside the default path) cannot take the headline line down
-        out["bf16x6_opt_in"] = _aux(lambda: x6_leg_in_child(args, first, log), log, "bf16x6 leg")
+    if world == 1 and not args.no_other_arith:
+        # the OTHER arithmetic beside the headline: same seeds, same steps, its own process (whatever happens to that leg cannot take the
+        # headline line down).  Headline on bf16 x 6 -> `fp32_mfma_value` / `fp32_mfma_ms_per_step`; headline on the fp32 MFMA -> `bf16x6_*`.
+        other = "f32" if arith == "bf16x6" else "bf16x6"
+        leg = _aux(lambda: other_arith_leg(args, other, log), log, "%s leg" % other)
+        pfx = "fp32_mfma" if other == "f32" else "bf16x6"
+        out[pfx + "_leg"] = leg
+        if "error" not in leg:
+            out[pfx + "_value"], out[pfx + "_ms_per_step"] = leg["value"], leg["ms_per_step"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cpu_baseline
         out["cpu_baseline"] = _aux(lambda: cpu_baseline.time_baseline(H, Z, B, T, TR), log, "cpu baseline")
     if world == 1 and not args.no_decode:
         # BASELINE configs[4] rides along in the default line (about 0.3 s of GPU time): 1 warm-up + 3 timed passes
         del trainer
-        dargs = argparse.Namespace(steps=3, warmup=1, no_cpu_baseline=args.no_cpu_baseline, sustain=0, no_x6=True)
+        dargs = argparse.Namespace(steps=3, warmup=1, no_cpu_baseline=args.no_cpu_baseline, sustain=0)
         d = _aux(lambda: bench_decode(dargs, pkg, None, local, rank, world, log), log, "decode leg")
         out["decode"] = d if "error" in d else dict(metric=d["metric"], value=d["value"], unit=d["unit"], ms_per_pass=d["ms_per_step"],
                                                     workload=d["config"]["workload"], roofline=d["roofline"], cpu_baseline=d.get("cpu_baseline"))
@@ -433,61 +535,20 @@ def _aux(fn, log, what):
         return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
 
-def x6_leg_in_child(args, first, log):
-    import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--x6-only", "--steps", str(args.steps), "--warmup", str(max(1, args.warmup)), "--sustain", "0",
-           "--no-cpu-baseline", "--no-decode"]
+def other_arith_leg(args, arith, log):
+    cmd = [sys.executable, os.path.abspath(__file__), "--arith", arith, "--leg-only", "--steps", str(args.steps), "--warmup", str(max(1, args.warmup)),
+           "--sustain", "0", "--no-cpu-baseline", "--no-decode", "--no-other-arith"]
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "FN_FORCE_DIST"):
         env.pop(k, None)
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
     for line in r.stderr.decode(errors="replace").splitlines():
-        if line.startswith("[bench") and "bf16x6" in line:
-            log("(child) " + line.split("] ", 1)[-1])
+        if line.startswith("[bench") and "timed region" in line:
+            log("(%s leg) %s" % (arith, line.split("] ", 1)[-1]))
     lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
     if r.returncode != 0 or not lines:
         raise RuntimeError("child exited with %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-300:]))
-    d = json.loads(lines[-1])
-    if first is not None and "first_step_loss_fp32_path" in d:
-        d["first_step_loss_fp32_path"] = round(first[0], 4)
-    return d
-
-
-def bench_x6_leg(args, pkg, batch, eps, dev, first, log):
-    """the same timed region with HipOps.dw_x6 = True (weight-gradient GEMMs and forward scans: exact bf16 triple splits, 6 of 9 partial products,
-    fp32 accumulation)"""
-    torch.manual_seed(1234)
-    model = pkg.MusicAttrRegGMVAE(342, 3, 16, 24, H, Z, 32, n_component=K).to(dev)
-    trainer = pkg.GMVAETrainer(model, lr=1e-3, beta=0.2)
-    model.engine().ops.dw_x6 = True                         # (after the trainer: it re-homes the parameters and with them the engine / its kernel table)
-    model.weights_changed()                                 # the engine re-derives its weight images, now incl. the bf16 triple images of W_hh
-    step, first6 = 20000, None
-    for i in range(args.warmup):
-        beta0, Bg = trainer.step_device(step, batch, eps)
-        if i == 0:
-            first6 = trainer._tuple8(beta0, Bg, False)
-        step += 1
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        trainer.step_device(step, batch, eps)
-        step += 1
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
-    tup = trainer._tuple8(0.2, B, False)
-    assert all(np.isfinite(tup)), tup
-    log("bf16x6 (weight gradients + forward scans): %.3f ms/step" % (dt * 1e3))
-    out = dict(ms_per_step=round(dt * 1e3, 3), value=round(B * T / dt, 1), unit="event-tokens/s", steps=args.steps, last_loss=round(tup[0], 4),
-               first_step_loss=None if first6 is None else round(first6[0], 4),
-               first_step_loss_fp32_path=None if first is None else round(first[0], 4),
-               note="NOT the headline and not the default: fn_gru_dwhh_f32 / fn_gemm_f32(a_k=0, b_k=0) with FN_GEMM_BF16X6 and the forward weight-stationary scans "
-                    "with FnGruFwd.variant bit 14 (gru_fwd_x6_kernel: weights and exchanged state as bf16 triples) - fp32 values cut EXACTLY into three bf16 pieces, "
-                    "six of the nine exact partial products accumulated in fp32 on v_mfma_f32_16x16x32_bf16 (dropped terms <= 2^-24 |a b|); against float64 as "
-                    "accurate as the fp32 MFMA kernels (tests/test_gpu_parity.py::test_gemm_tn_bf16x6, test_forward_scan_bf16x6, scratch/mfma_bf16x9.hip), the "
-                    "benchmark shape passes the reference comparison at the same tolerances (test_benchmark_config_with_bf16x6_vs_reference_train) and the "
-                    "whole gpu suite passes with the flag forced on (pytest -m gpu --x6); backward scans and every other kernel unchanged")
-    del trainer, model
-    return out
+    return json.loads(lines[-1])
 
 
 def bench_decode(args, pkg, ctx, local, rank, world, log):
@@ -545,8 +606,8 @@ def bench_decode(args, pkg, ctx, local, rank, world, log):
         "config": {"workload": "arousal-transfer / fader-sweep inference (BASELINE configs[4]): 256 sequences x T=256 encoded, 8 values "
                                "of z_r[:,0] each, 2048 rows x 300 greedy steps, hipGraph replay; replicas only for N>1",
                    "global_batch": rows * world, "seq_len": DEC_STEPS, "parallelism": "replicas%d" % world},
-        "roofline": dict(bound="mfma", kernel="greedy decode of 2048 rows x 300 steps (graph of gru_cell_direct_kernel x2 - layer 2 with its input projection - , "
-                                              "out_argmax_lds_kernel (output layer with the argmax in its epilogue) per token)", achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS,
+        "roofline": dict(bound="mfma", kernel="greedy decode of 2048 rows x 300 steps (graph of gru_cell_wlds_ovl_kernel<4, 2, ...> x 2 - the two cells, weight slice in LDS "
+                                              "filled under the K loops, layer 2 with its input projection - and out_argmax_lds8_kernel<4> - output layer with the argmax in its epilogue - per token)", achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS,
                          unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), avg_launch_us=round(ms * 1e3, 1), traffic=None,
                          flop_per_launch=rows * DEC_STEPS * F_ALG_DECODE_PER_TOKEN,
                          weight_stream_GBs=round(DEC_STEPS * DECODE_WEIGHT_BYTES / (ms * 1e-3) / 1e9, 1)),
@@ -564,8 +625,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=("train", "decode"), default="train")
     ap.add_argument("--sustain", type=int, default=200, help="train mode: more steps timed right behind the K timed ones -> sustained_ms_per_step (0 = skip)")
-    ap.add_argument("--no-x6", action="store_true", help="train mode: skip the extra leg with the opt-in bf16 x 6 weight-gradient products")
-    ap.add_argument("--x6-only", action="store_true", help=argparse.SUPPRESS)      # internal: the child process of the default run's opt-in leg
+    ap.add_argument("--arith", choices=("f32", "bf16x6"), default=None,
+                    help="arithmetic of the deep MFMA products (music-fader-nets_amd/arith.py; default: the package default).  Both are fp32-class: f32 = fp32 "
+                         "MFMA chains, bf16x6 = exact bf16 triple splits, six partial products on the bf16 MFMA, fp32 accumulation")
+    ap.add_argument("--no-other-arith", "--no-x6", dest="no_other_arith", action="store_true", help="train mode: skip the leg that times the OTHER arithmetic beside the headline")
+    ap.add_argument("--leg-only", action="store_true", help=argparse.SUPPRESS)      # internal: the child process that times the other arithmetic
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="train mode: leave the configs[4] decode measurement out of the line")
     args = ap.parse_args()

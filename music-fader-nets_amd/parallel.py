@@ -52,6 +52,13 @@ class DirectRccl:
         self._check(self.lib.fn_comm_all_gather(self.handle, C.c_void_p(t.data_ptr()), C.c_void_p(out.data_ptr()), t.numel() * t.element_size(),
                                                 self._st(stream)), "fn_comm_all_gather")
 
+    def ranks(self):
+        """(number of ranks, this rank) as RCCL itself reports them for the communicator (fn_comm_count / fn_comm_rank)"""
+        n, r = C.c_int(-1), C.c_int(-1)
+        self._check(self.lib.fn_comm_count(self.handle, C.byref(n)), "fn_comm_count")
+        self._check(self.lib.fn_comm_rank(self.handle, C.byref(r)), "fn_comm_rank")
+        return int(n.value), int(r.value)
+
     def close(self):
         if self.handle:
             self.lib.fn_comm_destroy(self.handle)
