@@ -84,6 +84,8 @@ def _x6_of(ops, name, a, k):
         return False
     if name == "gru_seq_fwd":
         return bool(k.get("x6", None) if k.get("x6", None) is not None else ops.gru_fwd_x6_ok(a[0]))
+    if name == "gru_seq_bwd":
+        return bool(k.get("x6", None) if k.get("x6", None) is not None else ops.gru_bwd_x6_ok(a[0]))
     if name == "gru_dwhh":
         return a[2].shape[0] >= 1024
     if name == "gemm":
@@ -134,7 +136,7 @@ def _symbol(name, a, k, x6=False):
     symbols, whatever its shape (roofline_by_symbol merges what `_classify` splits by launch shape)"""
     if name in ("gru_seq_fwd", "gru_seq_bwd"):
         work = sum(s["B"] * s["T"] for s in a[0]) * FLOP_PER_SAMPLE_STEP
-        return (("gru_fwd_x6pp_kernel" if x6 else "gru_fwd_pp_kernel") if name == "gru_seq_fwd" else "gru_bwd_rs_kernel"), "mfma", work
+        return (("gru_fwd_x6pp_kernel" if x6 else "gru_fwd_pp_kernel") if name == "gru_seq_fwd" else ("gru_bwd_x6_kernel" if x6 else "gru_bwd_rs_kernel")), "mfma", work
     if name == "gru_dwhh":
         rows, Hh = a[2].shape
         return ("gemm_tn_x6_kernel" if x6 else "gemm_tn_kernel"), "mfma", 2.0 * rows * 3 * Hh * Hh
@@ -157,6 +159,7 @@ def _symbol(name, a, k, x6=False):
 
 SYMBOL_NOTE = {
     "gru_fwd_x6pp_kernel": "forward weight-stationary scans on the bf16 MFMA (exact bf16 triple splits, 6 products), ping-pong over two row halves (all launches: encoder 4 x 256 rows x 256 steps, decoder pipeline chunks, attribute decoders); rated against 2.5 PFLOP/s / 6",
+    "gru_bwd_x6_kernel": "backward weight-stationary scans on the bf16 MFMA (gate gradients exchanged as exact bf16 triples, W_hh^T slice in AGPRs + LDS; all launches: encoder, decoder pipeline chunks, attribute decoders); rated against 2.5 PFLOP/s / 6",
     "gemm_tn_x6_kernel": "weight-gradient products dW = dY^T X on the bf16 MFMA (operands split in the loop; dW_hh of every scan via fn_gru_dwhh_f32, dW of the dense layers); rated against 2.5 PFLOP/s / 6",
     "gru_fwd_pp_kernel": "forward weight-stationary scans, ping-pong over two row halves (all launches: encoder 4 x 256 rows x 256 steps, decoder pipeline chunks, attribute decoders)",
     "gru_bwd_rs_kernel": "backward weight-stationary scans, W_hh^T slice half register-stationary (all launches: encoder, decoder pipeline chunks, attribute decoders)",
@@ -168,6 +171,9 @@ X6_KERNEL = {  # rows whose launches run on the bf16 x 6 kernels when that arith
     "enc_fwd_scan": "gru_fwd_x6pp_kernel<1> (4 encoder scans x 256 steps, one launch; bf16 MFMA, exact triple splits)",
     "dec_fwd_scan_chunk": "gru_fwd_x6pp_kernel<2> (one launch of the decoder pipeline: 2 scans x 256 rows x 32 steps; bf16 MFMA, exact triple splits)",
     "subdec_fwd_scan": "gru_fwd_x6pp_kernel (both sub-decoders, 64 steps)",
+    "enc_bwd_scan": "gru_bwd_x6_kernel<2> (4 encoder scans x 256 steps, one launch; bf16 MFMA, exact triple splits)",
+    "dec_bwd_scan_chunk": "gru_bwd_x6_kernel<1> (one launch of the decoder pipeline: 2 scans x 256 rows x 32 steps; bf16 MFMA, exact triple splits)",
+    "subdec_bwd_scan": "gru_bwd_x6_kernel (both sub-decoders, 64 steps)",
     "dwhh_gemm_tn": "gemm_tn_x6_kernel via fn_gru_dwhh_f32 (dW_hh of an encoder direction / a decoder layer: [3H x T*B] x [T*B x H], 48 tiles x 16 K ranges; 6 launches per step)",
     "dwhh_gemm_tn_attr": "gemm_tn_x6_kernel via fn_gru_dwhh_f32 (dW_hh of the attribute decoders, K = Tr*B rows)",
     "gemm_tn": "gemm_tn_x6_kernel (dW of dense layers)",

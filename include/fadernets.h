@@ -180,11 +180,13 @@ int fn_frag3_pack(const float* src, int rows, int K, int ld, void* dst, void* st
 size_t fn_frag_floats(int rows, int K);
 int fn_frag_pack(const float* src, int rows, int K, int ld, float* dst, void* stream);
 
-/* All weight images of one optimiser step in ONE launch (the refresh after every Adam update: ~40 small matrices).
+/* All weight images of one optimiser step in ONE launch (the refresh after every Adam update: ~40 small matrices, ~56 with the bf16 triple images).
  *   kind 0: dst [cols][rows] = src^T                       (the one-hot column table W_ih[:, :V]^T; src [rows][cols], leading dim ld)
  *   kind 1: dst = fn_frag_pack image of src [rows][K = cols]  (cols % 32 == 0)
  *   kind 2: dst = fn_frag_pack image of src^T, the [cols][K = rows] matrix (rows % 32 == 0): W_hh^T for the backward scans
- * up to 40 jobs; dst of kinds 1 / 2 16-byte aligned with fn_frag_floats(...) floats. */
+ *   kind 3: dst = fn_frag3_pack image (bf16 triples) of src [rows][K = cols]            (bf16 x 6 forward scans, variant bit 14)
+ *   kind 4: dst = fn_frag3_pack image of src^T, the [cols][K = rows] matrix              (bf16 x 6 backward scans: W_hh^T)
+ * up to 56 jobs; dst of kinds 1 / 2 16-byte aligned with fn_frag_floats(...) floats, of kinds 3 / 4 with 3/2 of that. */
 typedef struct FnWeightImage {
     const float* src;
     float* dst;
@@ -284,6 +286,12 @@ typedef struct FnGruBwd {
 } FnGruBwd;
 
 int fn_gru_seq_bwd(const FnGruBwd* scans, int n_scans, void* stream);
+/* variant bit 14 (0x4000), as in FnGruFwd: the backward scan with exact split products on the bf16 MFMA (gru_bwd_x6_kernel).  w_hh_t_frag must then be
+ * the bf16 TRIPLE image of W_hh^T [H][3H] (fn_weight_images kind 4; 3/2 of fn_frag_floats(H, 3H) floats) and frag_ws 3 * fn_frag_floats(B, 3H) floats
+ * (the gate gradients are exchanged as triples).  H = 512, every scan in full groups of 64 (or 32) rows, T >= 2, 9..16 row groups that are all
+ * resident at once (the shapes of the register-stationary fp32 kernel); anything else returns FN_E_UNSUPPORTED.  fn_gru_bwd_x6_ok answers without
+ * enqueuing anything (1 / 0).  Same element-wise gate arithmetic; gradients differ from the default kernels by fp32 rounding only. */
+int fn_gru_bwd_x6_ok(const FnGruBwd* scans, int n_scans);
 
 /* Recurrent weight gradient of one scan from its saved gate gradients (autograd of W_hh in nn.GRU / GRUCell,
  * trainer_gmm.py:249):  dW_hh[3H][H] = beta * dW_hh + [dgx[:, 0:2H] | dghn]^T hprev  over `rows` (time x batch) rows;

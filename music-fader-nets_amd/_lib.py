@@ -99,6 +99,7 @@ SIGNATURES = {
     "fn_out_argmax_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "fn_best_tokens": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     "fn_gru_seq_bwd": (C.c_int, [C.POINTER(FnGruBwd), C.c_int, vp]),
+    "fn_gru_bwd_x6_ok": (C.c_int, [C.POINTER(FnGruBwd), C.c_int]),
     "fn_decode_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "fn_decode_sync_ws_bytes": (C.c_size_t, []),
     "fn_decode_greedy": (C.c_int, [C.POINTER(FnDecode), vp]),

@@ -431,42 +431,47 @@ __global__ void frag_pack_kernel(const float* __restrict__ src, int rows, int K,
 // row-major [rows][K] -> bf16 TRIPLE image for the bf16 x 6 kernels (gru_persist.hip: gru_fwd_x6_kernel): [row tile 16][k block 32][piece 3][64 lanes][8 bf16],
 // lane (i, g) = row 16 t + i, k values 32 b + 8 g .. + 7; piece 0 / 1 / 2 = hi / mid / lo with hi + mid + lo == src exactly (rounded pieces: fn_rn16);
 // rows padded to a multiple of 16 with zeros.  One thread per (row, 8 k).
-__global__ void frag3_pack_kernel(const float* __restrict__ src, int rows, int K, long ld, unsigned* __restrict__ dst) {
-    const int rows16 = (rows + 15) & ~15, nb = K >> 5;
-    const long total = (long)rows16 * (K >> 3);
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int row = (int)(i / (K >> 3)), k8 = (int)(i % (K >> 3));
-        float x[8];
+// item i = (row, 8 k) of the triple image of a [rows][K] matrix whose element (row, k) lives at src[row * sr + k * sk]
+FN_DEVINL void frag3_item(const float* __restrict__ src, int rows, int K, long sr, long sk, unsigned* __restrict__ dst, long i) {
+    const int nb = K >> 5;
+    const int row = (int)(i / (K >> 3)), k8 = (int)(i % (K >> 3));
+    float x[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = row < rows ? src[(long)row * ld + 8 * k8 + j] : 0.f;
-        unsigned* o = dst + ((((long)(row >> 4) * nb + (k8 >> 2)) * 3) * 64 + (row & 15) + 16 * (k8 & 3)) * 4;
-        unsigned h[4], m[4], l[4];
+    for (int j = 0; j < 8; ++j) x[j] = row < rows ? src[(long)row * sr + (long)(8 * k8 + j) * sk] : 0.f;
+    unsigned* o = dst + ((((long)(row >> 4) * nb + (k8 >> 2)) * 3) * 64 + (row & 15) + 16 * (k8 & 3)) * 4;
+    unsigned h[4], m[4], l[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float hi[2], mi[2], r1[2], r2[2];
+    for (int j = 0; j < 4; ++j) {
+        float hi[2], mi[2], r1[2], r2[2];
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const float v = x[2 * j + e];
-                hi[e] = fn_rn16(v);
-                r1[e] = v - hi[e];
-                mi[e] = fn_rn16(r1[e]);
-                r2[e] = r1[e] - mi[e];
-            }
-            h[j] = (__float_as_uint(hi[0]) >> 16) | (__float_as_uint(hi[1]) & 0xffff0000u);
-            m[j] = (__float_as_uint(mi[0]) >> 16) | (__float_as_uint(mi[1]) & 0xffff0000u);
-            l[j] = (__float_as_uint(r2[0]) >> 16) | (__float_as_uint(r2[1]) & 0xffff0000u);
+        for (int e = 0; e < 2; ++e) {
+            const float v = x[2 * j + e];
+            hi[e] = fn_rn16(v);
+            r1[e] = v - hi[e];
+            mi[e] = fn_rn16(r1[e]);
+            r2[e] = r1[e] - mi[e];
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { o[j] = h[j]; o[256 + j] = m[j]; o[512 + j] = l[j]; }
+        h[j] = (__float_as_uint(hi[0]) >> 16) | (__float_as_uint(hi[1]) & 0xffff0000u);
+        m[j] = (__float_as_uint(mi[0]) >> 16) | (__float_as_uint(mi[1]) & 0xffff0000u);
+        l[j] = (__float_as_uint(r2[0]) >> 16) | (__float_as_uint(r2[1]) & 0xffff0000u);
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[j] = h[j]; o[256 + j] = m[j]; o[512 + j] = l[j]; }
+}
+
+__global__ void frag3_pack_kernel(const float* __restrict__ src, int rows, int K, long ld, unsigned* __restrict__ dst) {
+    const long total = (long)((rows + 15) & ~15) * (K >> 3);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) frag3_item(src, rows, K, ld, 1, dst, i);
 }
 
 // ---- all weight images of one optimiser step in ONE launch (fn_weight_images) -------------------------------------------------------
 // job kinds: 0 = dst [C][R] = src^T (src [R][C], leading dimension ld): the one-hot column table W_ih[:, :V]^T
 //            1 = fragment-major image of src [rows = R][K = C]                           (forward scans: W_hh, W_ih2, W_out)
 //            2 = fragment-major image of src^T, i.e. of the [rows = C][K = R] matrix    (backward scans: W_hh^T) - no intermediate
+//            3 = bf16 triple image (fn_frag3_pack layout) of src [rows = R][K = C]       (bf16 x 6 forward scans)
+//            4 = bf16 triple image of src^T, the [rows = C][K = R] matrix                (bf16 x 6 backward scans: W_hh^T)
 // The refresh after every Adam update used to be ~40 dependent launches of a few microseconds of work each (0.5 ms of the step).
-constexpr int WI_MAX_JOBS = 40;
+constexpr int WI_MAX_JOBS = 56;
 struct WiJob {
     const float* src;
     float* dst;
@@ -496,6 +501,13 @@ __global__ __launch_bounds__(256) void weight_images_kernel(const WiArgs a) {
             }
             __syncthreads();
         }
+        return;
+    }
+    if (J.kind >= 3) {
+        const int rows = J.kind == 3 ? J.R : J.C, K = J.kind == 3 ? J.C : J.R;
+        const long total = (long)((rows + 15) & ~15) * (K >> 3);
+        for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L)
+            frag3_item(J.src, rows, K, J.kind == 3 ? (long)J.ld : 1L, J.kind == 3 ? 1L : (long)J.ld, reinterpret_cast<unsigned*>(J.dst), i);
         return;
     }
     const int rows = J.kind == 1 ? J.R : J.C, K = J.kind == 1 ? J.C : J.R;
@@ -1671,9 +1683,9 @@ extern "C" int fn_weight_images(const FnWeightImage* jobs, int n_jobs, void* str
     for (int j = 0; j < n_jobs; ++j) {
         const FnWeightImage& d = jobs[j];
         if (!d.src || !d.dst) return FN_E_NULL;
-        if (d.rows <= 0 || d.cols <= 0 || d.ld < d.cols || d.kind < 0 || d.kind > 2) return FN_E_SHAPE;
-        if (d.kind == 1 && (d.cols % 32)) return FN_E_SHAPE;
-        if (d.kind == 2 && (d.rows % 32)) return FN_E_SHAPE;
+        if (d.rows <= 0 || d.cols <= 0 || d.ld < d.cols || d.kind < 0 || d.kind > 4) return FN_E_SHAPE;
+        if ((d.kind == 1 || d.kind == 3) && (d.cols % 32)) return FN_E_SHAPE;
+        if ((d.kind == 2 || d.kind == 4) && (d.rows % 32)) return FN_E_SHAPE;
         if (d.kind != 0 && (((uintptr_t)d.dst) & 15)) return FN_E_ALIGN;
         a.job[j] = WiJob{d.src, d.dst, d.rows, d.cols, d.ld, d.kind};
     }
@@ -1862,6 +1874,7 @@ int fn_gru_seq_fwd(const FnGruFwd* scans, int n_scans, void* stream) {
     {   // weight-stationary single launch when the configuration fits one workgroup per CU (gru_persist.hip)
         const int rc = fn_gru_fwd_persist(scans, n_scans, st);
         if (rc != FN_PERSIST_NA) return rc;
+        if (scans[0].variant & 0x4000) return FN_E_UNSUPPORTED;      // the per-step kernels below do not read triple images
     }
     for (int s = 0; s < n_scans; ++s)          // initial states -> fragment-major (slot 0 of the ping-pong scratch)
         if (scans[s].h0 && !scans[s].h0_frag) {
@@ -1924,6 +1937,7 @@ int fn_gru_seq_bwd(const FnGruBwd* scans, int n_scans, void* stream) {
     {
         const int rc = fn_gru_bwd_persist(scans, n_scans, st);
         if (rc != FN_PERSIST_NA) return rc;
+        if (scans[0].variant & 0x4000) return FN_E_UNSUPPORTED;      // the per-step kernels below do not read triple images
     }
     for (int it = 0; it <= Tmax; ++it) {
         long big_tiles = 0;

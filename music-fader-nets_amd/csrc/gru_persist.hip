@@ -24,6 +24,7 @@
 #include "kloop_asm.h"
 #include "kloop2_asm.h"
 #include "kloop3_asm.h"
+#include "kloop4_asm.h"
 
 #ifdef FN_TIMING
 __device__ unsigned long long fn_pdbg[8 * 8];
@@ -1655,6 +1656,275 @@ __global__ __launch_bounds__(NT) void gru_bwd_rs_kernel(const QArgs args) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Backward scan on the bf16 MFMA with exact bf16 triple splits (round 5; kloop4_asm.h / gen_kloop4.py have the protocol and the register map): the
+// decomposition of gru_bwd_rs_kernel - 16 slices of 32 dh columns x groups of 32 TH rows, two halves per workgroup, every wave its K quarter of both
+// column tiles - with the gate gradients exchanged as bf16 triples ([row tile][48 K blocks][piece][64 lanes][8 bf16], rounded pieces) and the
+// W_hh^T slice as triples (fn_frag3_pack_t image): column tile 0 of the wave's quarter + block 11 of column tile 1 in AGPRs, blocks 0..10 of
+// column tile 1 in LDS (132 KB).  Accumulator tiles in LDS: one half (the K loops' s_barrier at the arrival point is the fence).  Per phase:
+//   K loop statement (outs of the previous epilogue, arrival, counter read, NEXT phase's epilogue operands requested) -> counter check -> ring
+//   request of the next phase -> barrier -> gate backward (compiler code) -> slab stores (`_pub`) -> next phase's epilogue operands (`_get`).
+// Same arithmetic per element as gru_bwd_rs_kernel (fn_gru_gate_bwd, partial sums added in wave order); the products are exact, their sums
+// run in another order (six partial products per 32 k).
+// ---------------------------------------------------------------------------------------------------------------
+template <int TH>
+__global__ __launch_bounds__(NT) void gru_bwd_x6_kernel(const QArgs args) {
+    static_assert(TH == 1 || TH == 2, "row tiles per half: 32-row or 64-row groups");
+    constexpr int TT = 2 * TH;                       // accumulator tiles per wave and half
+    constexpr int H = 512, NB3 = 48, nslices = 16, QB = 12, LB = 11;      // K blocks per row; per wave quarter; of those in LDS
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    u32x4* wl = reinterpret_cast<u32x4*>(smem);      // [4 quarters][LB blocks][3 pieces][64 lanes] column tile 1, B-operand order
+    float* red = smem + 4 * LB * 3 * 64 * 4;         // [4 waves][TT][RT] partial sums of the CURRENT half
+    const unsigned dead = lds_addr(red + 4 * TT * RT);
+
+    const int g = blockIdx.x % args.ngroups, slice = blockIdx.x / args.ngroups;
+    int si = 0;
+#pragma unroll
+    for (int k = 1; k < FN_MAX_SCANS; ++k)
+        if (k < args.n && g >= args.s[k].group0) si = k;
+    const QScan& S = args.s[si];
+    const int B = S.B, T = S.T;
+    const int m0 = (g - S.group0) * (32 * TH), hh0 = slice * 32;
+    const int nrt = B >> 4;
+    const long FSB = (long)nrt * NB3 * 3 * 1024;     // bytes of one exchange slab
+    const long BH = (long)B * H;
+    const long GS = (long)4 * H * nrt * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u32* cnt[2] = {args.sync + (2 * g) * 32, args.sync + (2 * g + 1) * 32};
+    u32* err = args.err;
+    char* xs = reinterpret_cast<char*>(S.xf);
+    const char* wimg = reinterpret_cast<const char*>(S.wt_frag);          // [32 column tiles][48 K blocks][3][64][16 B]
+
+    if (tid == 0) lds_st(dead, 0);
+    {
+        // column tile 1 (2 slice + 1): blocks 0..10 of every K quarter -> LDS
+        const u32x4* src = reinterpret_cast<const u32x4*>(wimg + (long)(2 * slice + 1) * NB3 * 3072);
+        for (int i = tid; i < 4 * LB * 192; i += NT) {
+            const int qd = i / (LB * 192), r = i % (LB * 192);
+            wl[i] = src[(long)(qd * QB) * 192 + r];
+        }
+    }
+    fn_x6_bwd_wload(wimg + ((long)(2 * slice) * NB3 + wave * QB) * 3072, wimg + ((long)(2 * slice + 1) * NB3 + wave * QB + LB) * 3072, (unsigned)lane * 16u);
+
+    // epilogue item inside a half: (row, 4 consecutive dh columns of the 32); 32-row groups have 128 items per half: lanes 0-31 of every wave
+    const bool has_item = TH == 2 || lane < 32;
+    const int item = TH == 2 ? tid : wave * 32 + (lane & 31);
+    const int rl = item >> 3, u4 = item & 7;
+    const int jj0 = hh0 + 4 * u4;
+    int ib[2];
+    unsigned so[2];
+    f32x4 carry[2], rs[2][3], rsn[2];
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const int icoff = ((rl >> 4) * 2 + (u4 >> 2)) * RT + ((rl & 15) >> 2) * 68 + (u4 & 3) * 16 + (rl & 3);
+#pragma unroll
+    for (int hx = 0; hx < 2; ++hx) {
+        ib[hx] = m0 + (hx * TH + (rl >> 4)) * 16 + (rl & 15);
+        // gate 0 of this item on the slab: row tile, K block = slice (32 columns per block), lane = row + 16 (u4 / 2), half u4 & 1; gates 1, 2: + 16 blocks each
+        so[hx] = (unsigned)(((((long)(ib[hx] >> 4) * NB3 + slice) * 3) * 64 + (ib[hx] & 15) + 16 * (u4 >> 1)) * 16 + (u4 & 1) * 8);
+        carry[hx] = S.dh_last ? ldv4(S.dh_last + (long)ib[hx] * H + jj0) : z4;
+        rsn[hx] = z4;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) rs[hx][q] = z4;
+    }
+    __syncthreads();
+
+    unsigned vo[2];
+#pragma unroll
+    for (int hx = 0; hx < 2; ++hx) vo[hx] = (unsigned)((((long)(m0 >> 4) + hx * TH) * NB3 * 3072) + lane * 16);      // first row tile of the half (the second follows 144 KB on)
+    const unsigned h_red = lds_addr(red) + (((wave * TT) * RT + lane * 4 + (lane >> 4) * 4) * 4);
+    const unsigned lp = lds_addr(wl) + wave * LB * 3072 + lane * 16;
+    const int iters = T + (S.dh0 ? 1 : 0);
+
+    // outputs of the last epilogue: the slab stores leave through `_pub` right behind it, the rest through the NEXT phase's K loop statement, or
+    // flush_stores() when none follows
+    bool st_valid = false;
+    char* st_base = xs;
+    float *st_g = nullptr, *st_n = nullptr;
+    unsigned st_o = 0;
+    f32x4 st_d[4];
+    u32x2 st_t[3][3];
+    auto publish = [&]() __attribute__((always_inline)) {             // exchange-slab stores as ONE counted statement
+        if (TH == 2) fn_x6_bwd_t2_pub(st_base, st_o, st_t[0][0], st_t[0][1], st_t[0][2], st_t[1][0], st_t[1][1], st_t[1][2], st_t[2][0], st_t[2][1], st_t[2][2]);
+        else fn_x6_bwd_t1_pub(st_base, st_o, st_t[0][0], st_t[0][1], st_t[0][2], st_t[1][0], st_t[1][1], st_t[1][2], st_t[2][0], st_t[2][1], st_t[2][2]);
+    };
+    auto flush_outs = [&]() __attribute__((always_inline)) {
+        if (st_valid && has_item) {
+            stv4(st_g - H, st_d[0]);
+            stv4(st_g, st_d[1]);
+            stv4(st_g + H, st_d[2]);
+            stv4(st_n, st_d[3]);
+        }
+        st_valid = false;
+    };
+    // gate backward of half hx at iteration it (step q): arithmetic and LDS reads only; q < 0: only dL/dh0 is left (stored here).  Returns whether
+    // there is something to publish.
+    auto epilogue = [&](auto HX, const int it, const f32x4 (&gt)[4], const f32x4& hpv, const f32x4& ext, const bool hand) __attribute__((always_inline)) -> bool {
+        constexpr int hx = decltype(HX)::value;
+        const int q = T - 1 - it;
+        f32x4 dh;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float a = 0.f;
+            if (hand) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) a += red[(long)(w * TT) * RT + icoff + c * 4];      // the four K quarters, in wave order
+            }
+            dh[c] = (a + carry[hx][c]) + ext[c];
+        }
+        if (q < 0) {
+            if (has_item) stv4(S.dh0 + (long)ib[hx] * H + jj0, dh);
+            st_valid = false;
+            return false;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float dr, dz, dnp, dnr, cy;
+            fn_gru_gate_bwd(dh[c], gt[0][c], gt[1][c], gt[2][c], gt[3][c], hpv[c], dr, dz, dnp, dnr, cy);
+            st_d[0][c] = dr; st_d[1][c] = dz; st_d[2][c] = dnp; st_d[3][c] = dnr; carry[hx][c] = cy;
+        }
+        rs[hx][0] += st_d[0]; rs[hx][1] += st_d[1]; rs[hx][2] += st_d[2]; rsn[hx] += st_d[3];
+        fn_split3x4(st_d[0], st_t[0][0], st_t[0][1], st_t[0][2]);
+        fn_split3x4(st_d[1], st_t[1][0], st_t[1][1], st_t[1][2]);
+        fn_split3x4(st_d[3], st_t[2][0], st_t[2][1], st_t[2][2]);
+        st_base = xs + (long)(it & 1) * FSB;
+        st_o = so[hx];
+        st_g = S.dgx_all + (long)q * 3 * BH + (long)ib[hx] * 3 * H + jj0 + H;
+        st_n = S.dghn_all + (long)q * BH + (long)ib[hx] * H + jj0;
+        st_valid = true;
+        return true;
+    };
+    // addresses of the epilogue operands of (half hx, iteration it); unused values still come from a legal address
+    auto ext_addr = [&](const int hx, const int it, const float*& ga, const float*& ha, const float*& xa) {
+        const int q = T - 1 - it, qc = q > 0 ? q : 0;
+        const long ro = (long)ib[hx] * H + jj0;
+        ga = S.gates + (long)qc * GS + gate_off(ib[hx], 0, jj0, nrt);
+        ha = qc > 0 ? S.h_all + (long)(qc - 1) * BH + ro : (S.h0 ? S.h0 + ro : S.h_all + ro);
+        xa = S.dh_ext ? S.dh_ext + (long)qc * BH + ro : S.h_all + ro;
+    };
+
+    int pend = -1;
+    // ---- iteration 0: no K loop (dh = dh_last + dh_ext[T-1]); half A arrives at once, half B's arrival rides in the first K loop ----------
+    {
+        const int q = T - 1;
+        f32x4 g0[2][4], hp0[2], x0[2];
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) {
+            const float* gq = S.gates + (long)q * GS + gate_off(ib[hx], 0, jj0, nrt);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g0[hx][k] = ldv4(gq + k * 256);
+            hp0[hx] = q > 0 ? ldv4(S.h_all + (long)(q - 1) * BH + (long)ib[hx] * H + jj0) : (S.h0 ? ldv4(S.h0 + (long)ib[hx] * H + jj0) : z4);
+            x0[hx] = S.dh_ext ? ldv4(S.dh_ext + (long)q * BH + (long)ib[hx] * H + jj0) : z4;
+        }
+        const bool pubs = iters > 1;
+        if (epilogue(std::integral_constant<int, 0>{}, 0, g0[0], hp0[0], x0[0], false) && pubs) publish();
+        flush_outs();
+        if (pubs) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(cnt[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (epilogue(std::integral_constant<int, 1>{}, 0, g0[1], hp0[1], x0[1], false) && pubs) publish();
+        flush_outs();
+        pend = pubs ? 1 : -1;
+    }
+    if (iters > 1) {
+        // everything issued so far has to be complete before the statements start counting (half B's slab stores: its arrival in the first K loop
+        // then needs no wait); every load the compiler knows about as well (see gru_fwd_pp_kernel)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) {
+            fn_touch(carry[hx]);
+            fn_touch(rsn[hx]);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) fn_touch(rs[hx][q]);
+        }
+        auto slab_in = [&](const int it) { return xs + (long)((it - 1) & 1) * FSB + (long)(wave * QB) * 3072; };
+        auto request = [&](const char* xin, unsigned v) __attribute__((always_inline)) {
+            if (TH == 2) fn_x6_bwd_t2_pro(xin, v);
+            else fn_x6_bwd_t1_pro(xin, v);
+        };
+        f32x4 gt[4], hp2, xt2;
+        {
+            const float *ga, *ha, *xa;
+            ext_addr(0, 1, ga, ha, xa);
+            pp_wait_counter(cnt[0], (u32)nslices, err, dead);           // compiler code (its own loads and waits): nothing uncounted is in flight behind it
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            fn_x6_bwd_ext(ga, ha, xa);                                 // epilogue operands of the first K phase, then its ring
+            request(slab_in(1), vo[0]);
+            if (TH == 2) fn_x6_bwd_t2_get_first(gt, hp2, xt2);
+            else fn_x6_bwd_t1_get_first(gt, hp2, xt2);
+        }
+        bool first = true;
+
+        auto phase = [&](auto HX, const int it) __attribute__((always_inline)) -> bool {
+            constexpr int hx = decltype(HX)::value, hy = hx ^ 1;
+            const int q = T - 1 - it;
+            const int it1 = it + hx;
+            const int p = it;                             // FN_PSTAMP
+            (void)p;
+            const bool next_k = it1 < iters;
+            const unsigned ptgt = (u32)nslices * (u32)it1;
+            const bool hzero = q < 0 || (q == 0 && !S.h0), xzero = q < 0 || !S.dh_ext;
+            const float *ga, *ha, *xa;
+            ext_addr(hy, next_k ? it1 : it, ga, ha, xa);  // the NEXT phase's epilogue operands (the last phase asks for legal ones nobody reads)
+            unsigned pv;
+            const int arr = pend >= 0 ? (wave == 0 ? 2 : 1) : 0;
+            FN_PSTAMP(hx * 4 + 0);
+            if (TH == 2) {
+                if (first) fn_x6_bwd_t2_first(slab_in(it), vo[hx], lp, h_red, arr, cnt[hy], ga, ha, xa, pv);
+                else fn_x6_bwd_t2_main(slab_in(it), vo[hx], lp, h_red, arr, cnt[hy], ga, ha, xa, st_g, st_n, st_d[0], st_d[1], st_d[2], st_d[3], pv);
+            } else {
+                if (first) fn_x6_bwd_t1_first(slab_in(it), vo[hx], lp, h_red, arr, cnt[hy], ga, ha, xa, pv);
+                else fn_x6_bwd_t1_main(slab_in(it), vo[hx], lp, h_red, arr, cnt[hy], ga, ha, xa, st_g, st_n, st_d[0], st_d[1], st_d[2], st_d[3], pv);
+            }
+            first = false;
+            FN_PSTAMP(hx * 4 + 1);
+            if (next_k && __builtin_amdgcn_readfirstlane((int)pv) < (int)ptgt) {      // rare: the other half's inputs were not all published yet - poll
+                FN_PCOUNT(0);                                                          // (compiler code that drains vmcnt: every wait behind it only gets more patient)
+                pp_wait_counter(cnt[hy], ptgt, err, dead);
+            }
+            // ring of the next phase: lands under the epilogue.  The last phase requests one nobody multiplies: the statements count the same operations.
+            if (next_k) request(slab_in(it1), vo[hy]);
+            else request(slab_in(it), vo[hx]);
+            lds_barrier();
+            FN_PSTAMP(hx * 4 + 2);
+            if (lds_ld(dead)) return false;
+            const bool pub = epilogue(HX, it, gt, hzero ? z4 : hp2, xzero ? z4 : xt2, true);
+            FN_PSTAMP(hx * 4 + 3);
+            const bool more = q > 0 || (q == 0 && S.dh0 != nullptr);
+            pend = more ? hx : -1;
+            // the slab stores (nine per item; a phase with nothing to publish stores its old values again into a slab nobody reads any more: the
+            // K loop statements count nine stores) and the next phase's epilogue operands
+            if (!pub) st_base = xs + (long)(it & 1) * FSB;
+            publish();
+            if (TH == 2) fn_x6_bwd_t2_get(gt, hp2, xt2);
+            else fn_x6_bwd_t1_get(gt, hp2, xt2);
+            return true;
+        };
+
+#pragma unroll 1
+        for (int it = 1; it < iters; ++it) {
+            if (!phase(std::integral_constant<int, 0>{}, it)) return;
+            if (!phase(std::integral_constant<int, 1>{}, it)) return;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        flush_outs();
+    }
+#pragma unroll
+    for (int hx = 0; hx < 2; ++hx) {
+        if (!has_item) continue;
+        if (S.rowsum) {
+            float* p = S.rowsum + (long)ib[hx] * 3 * H + jj0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) stv4(p + q * H, ldv4(p + q * H) + rs[hx][q]);
+        }
+        if (S.rowsum_n) {
+            float* p = S.rowsum_n + (long)ib[hx] * H + jj0;
+            stv4(p, ldv4(p) + rsn[hx]);
+        }
+    }
+}
+
 constexpr int FN_MAX_DEVICES = 32;
 
 int cu_count() {
@@ -1716,6 +1986,23 @@ int x6_row_tiles(const FnGruFwd* scans, int n_scans, int maxgroups) {
     return (d64 && g64 <= maxgroups) ? 1 : ((d128 && g128 <= maxgroups) ? 2 : 0);
 }
 
+
+// bf16 x 6 backward scans: row tiles per half (2 = 64-row groups, 1 = 32-row groups), 0 = not eligible.  The shapes gru_bwd_rs_kernel takes: H = 512,
+// every scan in full row groups, T >= 2, more than half of the chip and at most all of it (16 slices x <= 16 groups, all resident).
+int x6_bwd_tiles(const FnGruBwd* scans, int n_scans, int cus) {
+    if (scans[0].H != 512) return 0;
+    long g64 = 0, g32 = 0;
+    bool d64 = true, d32 = true;
+    for (int s = 0; s < n_scans; ++s) {
+        const FnGruBwd& d = scans[s];
+        if (d.H != 512 || d.T < 2) return 0;
+        g64 += d.B / 64; g32 += d.B / 32;
+        d64 = d64 && d.B % 64 == 0;
+        d32 = d32 && d.B % 32 == 0;
+    }
+    return (d64 && g64 > 8 && g64 <= 16 && g64 * 16 <= cus) ? 2 : (d32 && g32 > 8 && g32 <= 16 && g32 * 16 <= cus) ? 1 : 0;
+}
+
 }  // namespace
 
 extern "C" size_t fn_gru_sync_ws_bytes() { return ((size_t)FN_MAX_GROUPS * 32 + 32) * 4; }
@@ -1728,6 +2015,13 @@ extern "C" int fn_gru_fwd_x6_ok(const FnGruFwd* scans, int n_scans) {
     if (cus < 32) return 0;
     const int maxgroups = cus / 32 < FN_MAX_GROUPS ? cus / 32 : FN_MAX_GROUPS;
     return x6_row_tiles(scans, n_scans, maxgroups) != 0;
+}
+
+extern "C" int fn_gru_bwd_x6_ok(const FnGruBwd* scans, int n_scans) {
+    if (!scans || n_scans < 1 || n_scans > FN_MAX_SCANS) return 0;
+    int cus = cu_count();
+    if (scans[0].cu_budget > 0 && scans[0].cu_budget < cus) cus = scans[0].cu_budget;
+    return x6_bwd_tiles(scans, n_scans, cus) != 0;
 }
 
 int fn_gru_fwd_persist(const FnGruFwd* scans, int n_scans, hipStream_t st) {
@@ -1874,6 +2168,36 @@ int fn_gru_bwd_persist(const FnGruBwd* scans, int n_scans, hipStream_t st) {
     const int nslices = H / 16;
     if (cus <= 0 || nslices > cus) return FN_PERSIST_NA;
     const int force_rows = scans[0].variant & 0xFF;         // tuning / tests: take this row block or none
+    if (scans[0].variant & 0x4000) {
+        // exact split products on the bf16 MFMA (gru_bwd_x6_kernel): w_hh_t_frag = the bf16 triple image of W_hh^T (fn_weight_images kind 4), frag_ws of
+        // 3 * fn_frag_floats(B, 3H) floats (the gate gradients are exchanged as triples).  Eligibility = fn_gru_bwd_x6_ok.
+        const int th = x6_bwd_tiles(scans, n_scans, cus);
+        if (!th) return FN_E_UNSUPPORTED;
+        QArgs a;
+        a.n = n_scans; a.H = H; a.no_hand = 0;
+        a.sync = reinterpret_cast<u32*>(scans[0].sync_ws);
+        int groups = 0;
+        for (int s = 0; s < n_scans; ++s) {
+            const FnGruBwd& d = scans[s];
+            QScan& f = a.s[s];
+            f.wt_frag = d.w_hh_t_frag; f.h0 = d.h0; f.h_all = d.h_all; f.gates = d.gates;
+            f.dh_last = d.dh_last; f.dh_ext = d.dh_ext;
+            f.dgx_all = d.dgx_all; f.dghn_all = d.dghn_all; f.dh0 = d.dh0;
+            f.rowsum = d.dgx_rowsum; f.rowsum_n = d.dghn_rowsum; f.xf = d.frag_ws;
+            f.B = d.B; f.T = d.T;
+            f.group0 = groups;
+            groups += d.B / (32 * th);
+        }
+        a.ngroups = groups;
+        a.err = scans[0].err_ws ? reinterpret_cast<u32*>(scans[0].err_ws) : a.sync + FN_MAX_GROUPS * 32;
+        if (!(scans[0].variant & 0x200)) {
+            hipError_t me = hipMemsetAsync(a.sync, 0, (size_t)FN_MAX_GROUPS * 32 * 4, st);
+            if (me != hipSuccess) return (int)me;
+        }
+        const size_t lds = (size_t)4 * 11 * 3072 + (size_t)4 * (2 * th) * RT * 4 + 16;
+        const int rc = th == 2 ? launch_k<QArgs, gru_bwd_x6_kernel<2>>(a, groups * 16, lds, cus, st) : launch_k<QArgs, gru_bwd_x6_kernel<1>>(a, groups * 16, lds, cus, st);
+        return rc == FN_PERSIST_NA ? FN_E_UNSUPPORTED : rc;
+    }
     // Register-stationary ping-pong form (gru_bwd_rs_kernel): H = 512, 16 slices of 32 columns x up to 16 groups of 64 (or 32) rows, every group
     // full, more than half of the chip used (smaller problems keep the 32-slice kernels).  Variant bits 10 / 11 / 13 select the older loops.
     if (H == 512 && !(scans[0].variant & 0x2C00) && !force_rows) {

@@ -33,13 +33,13 @@ def greedy_decode(model, z, steps, want_logp=True, use_graph=None):
     if not use_graph:
         return _decode_body(eng, z, steps, want_logp, None, None)
     cache = eng.__dict__.setdefault("_decode_graphs", {})
-    key = (z.shape[0], steps, bool(want_logp), z.shape[0] >= eng.cell_decode_rows)     # the captured launches depend on the path taken
+    key = (z.shape[0], steps, bool(want_logp), z.shape[0] >= eng.cell_decode_rows, bool(getattr(eng, "fused_argmax", True)))     # the captured launches depend on the path taken
     ent = cache.get(key)
     if ent is None:
         zs = z.clone()
         tokens = torch.zeros(z.shape[0], steps, dtype=torch.int32, device=z.device)
         logp = torch.empty(z.shape[0], steps, E_VOCAB, device=z.device) if want_logp else None
-        _decode_body(eng, zs, min(steps, 2), want_logp, logp, tokens)                # warm-up: allocates every buffer
+        _decode_body(eng, zs, min(steps, 2), want_logp, logp, tokens, alloc_steps=steps)      # warm-up: allocates every buffer at its FINAL size (nothing is allocated inside the capture)
         g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
         getattr(eng.ops, "begin_capture", lambda: None)()
@@ -82,7 +82,7 @@ def _decode_single_launch(eng, z, steps, want_logp):
     return logp, tokens
 
 
-def _decode_body(eng, z, steps, want_logp, logp, tokens):
+def _decode_body(eng, z, steps, want_logp, logp, tokens, alloc_steps=None):
     ops, P, H = eng.ops, eng.p, eng.H
     Bi = z.shape[0]
     dev = z.device
@@ -109,7 +109,7 @@ def _decode_body(eng, z, steps, want_logp, logp, tokens):
         # words by 64-bit atomic max, no logits, no argmax launch) and the next layer-1 cell reads its token from the packed word -
         # 3 launches per token; the int32 tokens are unpacked once at the end
         fused = not want_logp and getattr(eng, "fused_argmax", True) and hasattr(ops, "out_argmax")
-        best = eng.buf("dec_best", (steps, Bi), dtype=torch.int64) if fused else None
+        best = eng.buf("dec_best", (max(steps, alloc_steps or 0), Bi), dtype=torch.int64)[:steps] if fused else None
         if fused:
             best.zero_()
         for i in range(steps):

@@ -38,8 +38,9 @@ class Engine:
         self._bufs = {}
         self.tab = {}                   # transposed one-hot columns of W_ih:  key -> [V][3H]
         self.whh_f = {}                 # W_hh in the kernels' fragment-major operand layout (forward scans)
-        self.whh_f3 = {}                # ... as bf16 triple images (opt-in bf16 x 6 forward scans, HipOps.dw_x6)
+        self.whh_f3 = {}                # ... as bf16 triple images (bf16 x 6 forward scans: model.set_arith("bf16x6") -> HipOps.dw_x6)
         self.whh_t = {}                 # W_hh^T, fragment-major (backward scans)
+        self.whh_t3 = {}                # ... as bf16 triple images (bf16 x 6 backward scans)
         self.packs = {}                 # fragment-major W_ih2 / W_out (single-launch greedy decode)
         self.saved = None
         self.chunk = 32                 # time steps per pipeline chunk of the two decoder layers (layer 2 lags layer 1 by two chunks)
@@ -241,16 +242,21 @@ class Engine:
             if w2 is not None:
                 self.wih2_t = self.buf("wih2_t", (w2.shape[1], w2.shape[0]))
                 jobs.append(("transpose", w2, self.wih2_t))
+        if getattr(self.ops, "dw_x6", False) and H == 512:
+            # bf16 x 6 arithmetic: bf16 triple images of the recurrent matrices (forward scans) and of their transposes (backward scans)
+            for key, (pfx, sfx, V) in self._gru_sets().items():
+                w_hh = self.p[pfx + "weight_hh" + sfx]
+                self.whh_f3[key] = self.buf("whhf3_" + key, (self.ops.frag_floats(3 * H, H) * 3 // 2,))
+                jobs.append(("frag3", w_hh, self.whh_f3[key]))
+                if need_backward:
+                    self.whh_t3[key] = self.buf("whht3_" + key, (self.ops.frag_floats(H, 3 * H) * 3 // 2,))
+                    jobs.append(("frag3_t", w_hh, self.whh_t3[key]))
+        else:
+            self.whh_f3.clear()
+            self.whh_t3.clear()
         self.ops.weight_images(jobs)
         if need_backward:
             self.ops.transpose(self.p["linear_out_g.weight"], self.wout_t[:, :E_VOCAB])
-        if getattr(self.ops, "dw_x6", False) and hasattr(self.ops, "frag3_pack") and H == 512:
-            # OPT-IN arithmetic (HipOps.dw_x6): bf16 triple images of the recurrent matrices for the forward scans on the bf16 MFMA
-            for key, (pfx, sfx, V) in self._gru_sets().items():
-                self.whh_f3[key] = self.buf("whhf3_" + key, (self.ops.frag_floats(3 * H, H) * 3 // 2,))
-                self.ops.frag3_pack(self.p[pfx + "weight_hh" + sfx], self.whh_f3[key])
-        else:
-            self.whh_f3.clear()
 
     # ------------------------------------------------------------------------------------------
     # forward
@@ -528,9 +534,9 @@ class Engine:
         # per-sequence sums over time of the gate gradients (bias / z-projection gradients) are accumulated by the scans
         rs2, rsn2 = self.zbuf("g_rs2", (B, 3 * H)), self.zbuf("g_rsn2", (B, H))
         drb_g, rsn_g = self.zbuf("g_drb", (B, 3 * H)), self.zbuf("g_rsn1", (B, H))
-        l2 = dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t["g2"], h0=dec["hx0"][0], h_all=dec["hx1"], gates=dec["g2"], dh_ext=dhx1,
+        l2 = dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t["g2"], w_hh_t_frag3=self.whh_t3.get("g2"), h0=dec["hx0"][0], h_all=dec["hx1"], gates=dec["g2"], dh_ext=dhx1,
                   dgx_all=dgx2, dghn_all=dghn2, scratch=self.buf("g_scr2", (B, H)), dgx_rowsum=rs2, dghn_rowsum=rsn2, tag="dec_l2")
-        l1 = dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t["g"], h0=dec["h0g"], h_all=dec["hx0"], gates=dec["g1"], dh_ext=dhx0,
+        l1 = dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t["g"], w_hh_t_frag3=self.whh_t3.get("g"), h0=dec["h0g"], h_all=dec["hx0"], gates=dec["g1"], dh_ext=dhx0,
                   dgx_all=dgx1, dghn_all=dghn1, scratch=self.buf("g_scr1", (B, H)), dgx_rowsum=drb_g, dghn_rowsum=rsn_g, tag="dec_l1")
         CH = self.chunk
         carry = {k: [self.buf("carry_%s_%d" % (k, i), (B, H)) for i in range(2)] for k in ("l2", "l1")}
@@ -703,7 +709,7 @@ class Engine:
             ops.gemm(dl, P["linear_out_%s.weight" % e], dh_sd[e].view(Tr * B, H), a_k=True, b_k=False)
             sdb[e] = dict(dgx=self.buf("sd_dgx_" + e, (Tr, B, 3 * H)), dghn=self.buf("sd_dghn_" + e, (Tr, B, H)),
                           drb=self.zbuf("sd_drb_" + e, (B, 3 * H)), rsn=self.zbuf("sd_rsn_" + e, (B, H)), dh0=self.buf("sd_dh0_" + e, (B, H)))
-            sds[e] = dict(B=B, T=Tr, H=H, w_hh_t_frag=self.whh_t["d_" + e], h0=sd[e]["h0"], h_all=sd[e]["h_all"], gates=sd[e]["gates"],
+            sds[e] = dict(B=B, T=Tr, H=H, w_hh_t_frag=self.whh_t["d_" + e], w_hh_t_frag3=self.whh_t3.get("d_" + e), h0=sd[e]["h0"], h_all=sd[e]["h_all"], gates=sd[e]["gates"],
                           dh_ext=dh_sd[e], dgx_all=sdb[e]["dgx"], dghn_all=sdb[e]["dghn"], scratch=self.buf("sd_scr_" + e, (B, H)),
                           dgx_rowsum=sdb[e]["drb"], dghn_rowsum=sdb[e]["rsn"], tag="sd_" + e)
         if defer:                                                # the scans are left to _bwd_global_decoder_scans(fill=...)
@@ -762,7 +768,7 @@ class Engine:
             for key, dh in ((e, dhf), (e + "_reverse", dhb)):
                 encb[key] = dict(dgx=self.buf("enc_dgx_" + key, (T, B, 3 * H)), dghn=self.buf("enc_dghn_" + key, (T, B, H)),
                                  rs=self.zbuf("enc_rs_" + key, (B, 3 * H)), rsn=self.zbuf("enc_rsn_" + key, (B, H)))
-                scans.append(dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t[key], h0=None, h_all=pre["h_all"][key],
+                scans.append(dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t[key], w_hh_t_frag3=self.whh_t3.get(key), h0=None, h_all=pre["h_all"][key],
                                   gates=pre["gates"][key], dh_last=dh, dgx_all=encb[key]["dgx"], dghn_all=encb[key]["dghn"],
                                   scratch=self.buf("enc_scr_" + key, (B, H)), dgx_rowsum=encb[key]["rs"], dghn_rowsum=encb[key]["rsn"]))
         if before_scans is not None:

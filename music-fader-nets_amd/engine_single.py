@@ -41,7 +41,7 @@ class SingleEncEngine(Engine):
             if self.enc_extra:
                 rb = self.buf("enc_rb_" + key, (B, 3 * H))
                 ops.gemm(extra, P[self.gru + "weight_ih" + sfx][:, E_VOCAB:], rb)
-            scans.append(dict(B=B, T=T, H=H, reverse=rev, w_hh_frag=self.whh_f[key], b_hh=P[self.gru + "bias_hh" + sfx],
+            scans.append(dict(B=B, T=T, H=H, reverse=rev, w_hh_frag=self.whh_f[key], w_hh_frag3=self.whh_f3.get(key), b_hh=P[self.gru + "bias_hh" + sfx],
                               b_ih=P[self.gru + "bias_ih" + sfx], gx_table=self.tab[key], idx=d, idx_shift=0, gx_rowbias=rb,
                               h_all=hall[key], gates=gates[key]))
         ops.gru_seq_fwd(scans)
@@ -119,7 +119,7 @@ class SingleEncEngine(Engine):
         for key, dh in (("e", dhf), ("e_reverse", dhb)):
             encb[key] = dict(dgx=self.buf("enc_dgx_" + key, (T, B, 3 * H)), dghn=self.buf("enc_dghn_" + key, (T, B, H)),
                              rs=self.zbuf("enc_rs_" + key, (B, 3 * H)), rsn=self.zbuf("enc_rsn_" + key, (B, H)))
-            scans.append(dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t[key], h0=None, h_all=enc["h_all"][key], gates=enc["gates"][key],
+            scans.append(dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t[key], w_hh_t_frag3=self.whh_t3.get(key), h0=None, h_all=enc["h_all"][key], gates=enc["gates"][key],
                               dh_last=dh, dgx_all=encb[key]["dgx"], dghn_all=encb[key]["dghn"], scratch=self.buf("enc_scr_" + key, (B, H)),
                               dgx_rowsum=encb[key]["rs"], dghn_rowsum=encb[key]["rsn"]))
         ops.gru_seq_bwd(scans)

@@ -26,7 +26,12 @@ def cpu_state_dict(model):
 def _count(dl, seen):
     """divisor of the per-epoch means: the reference divides by ``len(dl)``; a rank shard that had to skip batches smaller than the world
     (train.py: RankShard) yields fewer than it announces - then the batches actually seen count"""
-    return seen if getattr(dl, "may_skip", False) else len(dl)
+    if getattr(dl, "may_skip", False):
+        if seen == 0:
+            raise RuntimeError("a data-parallel shard yielded no batch at all: every batch of this loader is smaller than the world size "
+                               "(%d batches announced) - use a batch size of at least one row per rank" % len(dl))
+        return seen
+    return len(dl)
 
 
 def _run_half(trainer, step, train_dl, val_dl, supervised, log):

@@ -55,6 +55,7 @@ class HipOps:
         self._retired = []
         self.cell_variant = 0     # FnGruCell.variant (tuning / tests)
         self.dw_x6 = False        # arithmetic of the deep products (set by the model: arith.py): True = exact bf16 triple splits on the bf16 MFMA (FN_GEMM_BF16X6, FnGruFwd.variant bit 14), False = fp32 MFMA
+        self.bwd_x6 = True        # with dw_x6: the backward scans on the bf16 x 6 kernel too (False: fp32 MFMA backward scans; A/B measurements, tests)
         self.variant = 0          # FnGruFwd.variant of every scan launch (tuning / tests only; results do not depend on it)
         self.lane = ""            # scratch namespace: kernels enqueued on different streams must not share workspaces
 
@@ -176,16 +177,17 @@ class HipOps:
         _lib.check(self.lib.fn_frag_pack(ps, rows, K, ld, _p(dst), self.stream()), "fn_frag_pack")
 
     def weight_images(self, jobs):
-        """jobs: (kind, src 2-D view, dst) with kind "transpose" (dst [C][R] contiguous), "frag" (fragment-major image of src) or
-        "frag_t" (fragment-major image of src^T) - all in ONE launch (fn_weight_images)"""
-        kinds = {"transpose": 0, "frag": 1, "frag_t": 2}
-        for i0 in range(0, len(jobs), 40):
-            part = jobs[i0:i0 + 40]
+        """jobs: (kind, src 2-D view, dst) with kind "transpose" (dst [C][R] contiguous), "frag" (fragment-major image of src), "frag_t"
+        (fragment-major image of src^T), "frag3" / "frag3_t" (the same two as bf16 triple images) - all in ONE launch (fn_weight_images)"""
+        kinds = {"transpose": 0, "frag": 1, "frag_t": 2, "frag3": 3, "frag3_t": 4}
+        for i0 in range(0, len(jobs), 56):
+            part = jobs[i0:i0 + 56]
             arr = (_lib.FnWeightImage * len(part))()
             for d, (kind, src, dst) in zip(arr, part):
                 ps, R, Cc, ld = _mat(src, "src")
                 _dense(dst, name="dst")
-                need = R * Cc if kind == "transpose" else (self.frag_floats(R, Cc) if kind == "frag" else self.frag_floats(Cc, R))
+                need = {"transpose": lambda: R * Cc, "frag": lambda: self.frag_floats(R, Cc), "frag_t": lambda: self.frag_floats(Cc, R),
+                        "frag3": lambda: self.frag_floats(R, Cc) * 3 // 2, "frag3_t": lambda: self.frag_floats(Cc, R) * 3 // 2}[kind]()
                 if dst.numel() < need:
                     raise RuntimeError("weight_images: dst too small for %s of %s" % (kind, tuple(src.shape)))
                 d.src, d.dst, d.rows, d.cols, d.ld, d.kind = ps, _p(dst), R, Cc, ld, kinds[kind]
@@ -350,22 +352,39 @@ class HipOps:
             raise RuntimeError("best_tokens: tokens%s does not take %d x %d words" % (tuple(tokens.shape), steps, B))
         _lib.check(self.lib.fn_best_tokens(best.data_ptr(), steps, B, int(V), tokens.data_ptr(), tokens.stride(0), self.stream()), "fn_best_tokens")
 
-    def gru_seq_bwd(self, scans, persistent=True, cu_budget=0, variant=None):
+    def _bwd_descriptors(self, scans, cu_budget=0):
         arr = (_lib.FnGruBwd * len(scans))()
-        variant = self.variant if variant is None else variant
-        sync = self._sync_region() if persistent else None
-        for i, (d, s) in enumerate(zip(arr, scans)):
+        for d, s in zip(arr, scans):
             for k in ("w_hh_t_frag", "h0", "h_all", "gates", "dh_last", "dh_ext", "dgx_all", "dghn_all", "dh0", "dgx_rowsum", "dghn_rowsum", "scratch"):
                 _dense(s.get(k), name=k)
-            d.frag_ws = _p(self._frag_ws("fragb", i, 2 * self.frag_floats(s["B"], 3 * s["H"])))
-            d.sync_ws, d.err_ws, d.variant = (_p(sync[0]), _p(sync[1]), int(variant) | sync[2]) if persistent else (None, None, int(variant))
             d.cu_budget = int(cu_budget)
             d.B, d.T, d.H = s["B"], s["T"], s["H"]
             d.w_hh_t_frag, d.h0, d.h_all, d.gates = _p(s["w_hh_t_frag"]), _p(s.get("h0")), _p(s["h_all"]), _p(s["gates"])
             d.dh_last, d.dh_ext = _p(s.get("dh_last")), _p(s.get("dh_ext"))
             d.dgx_all, d.dghn_all, d.dh0 = _p(s["dgx_all"]), _p(s["dghn_all"]), _p(s.get("dh0"))
             d.dgx_rowsum, d.dghn_rowsum, d.scratch = _p(s.get("dgx_rowsum")), _p(s.get("dghn_rowsum")), _p(s["scratch"])
-        _lib.check(self.lib.fn_gru_seq_bwd(arr, len(scans), self.stream()), "fn_gru_seq_bwd")
+        return arr
+
+    def gru_bwd_x6_ok(self, scans, cu_budget=0):
+        """would gru_seq_bwd run this launch on the bf16 x 6 kernel (fn_gru_bwd_x6_ok)?"""
+        if not (self.dw_x6 and self.bwd_x6 and all(s.get("w_hh_t_frag3") is not None for s in scans)):
+            return False
+        return bool(self.lib.fn_gru_bwd_x6_ok(self._bwd_descriptors(scans, cu_budget), len(scans)))
+
+    def gru_seq_bwd(self, scans, persistent=True, cu_budget=0, variant=None, x6=None):
+        """x6: None = bf16 x 6 where the launch is eligible (a backward launch hands nothing but fp32 tensors to the next one: every launch decides for
+        itself), True / False = forced"""
+        arr = self._bwd_descriptors(scans, cu_budget)
+        variant = self.variant if variant is None else variant
+        sync = self._sync_region() if persistent else None
+        if x6 is None:
+            x6 = persistent and self.gru_bwd_x6_ok(scans, cu_budget)
+        for i, (d, s) in enumerate(zip(arr, scans)):
+            d.frag_ws = _p(self._frag_ws("fragb", i, 3 * self.frag_floats(s["B"], 3 * s["H"])))      # 2 slabs of fp32 fragments, or 2 of bf16 triples (x6)
+            d.sync_ws, d.err_ws, d.variant = (_p(sync[0]), _p(sync[1]), int(variant) | sync[2]) if persistent else (None, None, int(variant))
+            if x6:
+                d.w_hh_t_frag, d.variant = _p(s["w_hh_t_frag3"]), d.variant | 0x4000
+        _lib.check(self.lib.fn_gru_seq_bwd(arr, len(scans), self.stream()), "fn_gru_seq_bwd (bf16 x 6)" if x6 else "fn_gru_seq_bwd")
 
     def gru_dwhh(self, dgx, dghn, hprev, dW, beta=0.0, splitk=1, lean=False):
         """dW [3H][H] = beta*dW + [dgx[:, :2H] | dghn]^T hprev  (dgx [rows][3H], dghn / hprev [rows][H])."""

@@ -492,6 +492,68 @@ def test_forward_scan_bf16x6(ops, n, B, T):
         ops.dw_x6, ops.variant = False, 0
 
 
+@pytest.mark.parametrize("n,B,Ts", [(4, 256, (7, 7, 7, 7)), (4, 256, (2, 9, 5, 3)), (2, 256, (6, 4)), (3, 128, (5, 8, 3)), (2, 512, (4, 4))])
+def test_backward_scan_bf16x6(ops, n, B, Ts):
+    """the backward scan with exact split products on the bf16 MFMA (FnGruBwd.variant bit 14: gate gradients exchanged as bf16 triples, W_hh^T as a
+    triple image, gru_bwd_x6_kernel) against the default register-stationary fp32 kernel on the SAME saved activations at H = 512: gate gradients,
+    dL/dh0 and the per-sequence row sums agree to fp32 rounding (exact products, another summation order); 64-row groups (4 x 256 rows: 16
+    groups) and 32-row groups (2 x 256, 3 x 128, 2 x 512 rows), scans of different lengths in one launch, with / without dh_last, dh_ext, h0, dh0;
+    repeated launches on warm slabs are bit-identical; the sync-error word stays clear"""
+    H, V = 512, 57
+    torch.manual_seed(n * 1000 + B)
+    fwd, bwd = [], []
+    for s_ in range(n):
+        T = Ts[s_]
+        w = (torch.randn(3 * H, H, device=DEV) / (H ** 0.5)).contiguous()
+        wf = torch.zeros(ops.frag_floats(3 * H, H), device=DEV); ops.frag_pack(w, wf)
+        wt = torch.zeros(ops.frag_floats(H, 3 * H), device=DEV)
+        wt3 = torch.zeros(ops.frag_floats(H, 3 * H) * 3 // 2, device=DEV)
+        ops.weight_images([("frag_t", w, wt), ("frag3_t", w, wt3)])
+        wt3_ref = torch.zeros_like(wt3)
+        ops.frag3_pack(w.t().contiguous(), wt3_ref)                  # the transposing job == the plain pack of the transposed matrix
+        assert torch.equal(wt3, wt3_ref)
+        h0 = torch.randn(B, H, device=DEV) * 0.3 if s_ % 2 == 0 else None
+        f = dict(B=B, T=T, H=H, w_hh_frag=wf, b_hh=torch.randn(3 * H, device=DEV) * 0.1, b_ih=torch.randn(3 * H, device=DEV) * 0.1, h0=h0,
+                 gx_dense=torch.randn(T, B, 3 * H, device=DEV) * 0.5, h_all=torch.zeros(T, B, H, device=DEV), gates=torch.zeros(T, ops.gates_floats(B, H), device=DEV))
+        fwd.append(f)
+        bwd.append(dict(B=B, T=T, H=H, w_hh_t_frag=wt, w_hh_t_frag3=wt3, h0=h0, h_all=f["h_all"], gates=f["gates"],
+                        dh_last=torch.randn(B, H, device=DEV) if s_ != 1 else None, dh_ext=torch.randn(T, B, H, device=DEV) * 0.5 if s_ != 0 else None,
+                        dgx_all=torch.zeros(T, B, 3 * H, device=DEV), dghn_all=torch.zeros(T, B, H, device=DEV),
+                        dh0=torch.zeros(B, H, device=DEV) if s_ != 2 else None, dgx_rowsum=torch.zeros(B, 3 * H, device=DEV),
+                        dghn_rowsum=torch.zeros(B, H, device=DEV) if s_ != 3 else None, scratch=torch.zeros(B, H, device=DEV)))
+    ops.gru_seq_fwd(fwd)
+    keys = ("dgx_all", "dghn_all", "dh0", "dgx_rowsum", "dghn_rowsum")
+
+    def run(x6):
+        ops.dw_x6 = x6
+        for b in bwd:
+            for k in keys:
+                if b[k] is not None:
+                    b[k].zero_() if "rowsum" in k else b[k].fill_(float("nan"))
+        if x6:
+            assert ops.gru_bwd_x6_ok(bwd)
+        ops.gru_seq_bwd(bwd)
+        torch.cuda.synchronize()
+        return [[None if b[k] is None else b[k].clone() for k in keys] for b in bwd]
+    try:
+        ref = run(False)
+        got = run(True)
+        again = run(True)
+        assert not ops.gru_sync_error()
+        differs = False
+        for i, (rs_, gs_, as_) in enumerate(zip(ref, got, again)):
+            for k, a, b, c in zip(keys, rs_, gs_, as_):
+                if a is None:
+                    continue
+                assert not torch.isnan(b).any(), (i, k)
+                assert torch.equal(b, c), (i, k)
+                differs |= not torch.equal(a, b)
+                assert float((a - b).abs().max()) <= 5e-5 * float(a.abs().max()), (i, k, float((a - b).abs().max()), float(a.abs().max()))
+        assert differs                                     # the x6 kernel really ran
+    finally:
+        ops.dw_x6 = False
+
+
 @pytest.mark.parametrize("lo,hi", [(-100, 60), (-120, -90), (-30, 30)])
 @pytest.mark.parametrize("K,splitk", [(65536, 16), (4096, 4)])
 def test_bf16x6_adversarial_operands_vs_float64(ops, lo, hi, K, splitk):
@@ -904,6 +966,33 @@ def test_greedy_decode_tokens(case, small, c0):
     tk, _ = pkg.fader_sweep(m, d, c, [0.75, -0.5], steps=steps, which="r", eps=eps)
     from helpers import tokens_match_upto_near_tie
     assert tokens_match_upto_near_tie(tk[:, 0].cpu().numpy(), ref, gap) >= 0.9 * ref.size      # full length, not a prefix
+
+
+@pytest.mark.parametrize("path", ["pipeline", "cells"])
+def test_batched_fader_sweep_vs_reference_decoder(path):
+    """tests/golden/sweep.npz: the REFERENCE's eval-mode global_decoder (gmm_model.py:119-149, 73-80) on the (64, 280) batch that 8 samples x the 8
+    fader values of test_class.py:84-85 make, hidden 512, 100 greedy steps - against the one-launch block pipeline (64 rows = two 32-row
+    blocks) and against the per-token cells (fn_gru_cell_f32 + fn_out_argmax_f32, the path of thousands of rows): tokens bit-exact in every
+    row up to the first position where the reference's own top-2 gap is below 1e-4, first-step log-probabilities to 1e-4"""
+    g = load_golden("sweep")
+    H, Z, K, NS, NV, steps = (int(x) for x in g["dims"])
+    m = make_model(H, Z, device=DEV)
+    for k, v in m.state_dict().items():                      # the seeded init IS the reference's (checksums of every tensor)
+        vd = v.double()
+        np.testing.assert_allclose([vd.sum().item(), vd.abs().sum().item(), (vd * vd).sum().item()], g["w0sum/" + k], rtol=1e-9, atol=1e-9, err_msg=k)
+    m.eval()
+    eng = m.engine()
+    if path == "cells":
+        eng.single_launch_decode, eng.cell_decode_rows = False, 1
+    pkg = load_package()
+    z = torch.from_numpy(g["z"]).to(DEV)
+    lp, tok = pkg.greedy_decode(m, z, steps, want_logp=True)
+    np.testing.assert_allclose(lp[:, 0].cpu().numpy(), g["logp_first"], rtol=1e-4, atol=1e-4)
+    _, tok_only = pkg.greedy_decode(m, z, steps, want_logp=False)          # the tokens-only form (argmax in the output layer's epilogue on the cells path)
+    from helpers import tokens_match_upto_near_tie
+    for t in (tok, tok_only):
+        assert tokens_match_upto_near_tie(t.cpu().numpy(), g["tokens"], g["gap"]) >= 0.9 * g["tokens"].size
+    assert not eng.ops.gru_sync_error()
 
 
 # ----------------------------------------------------------------------------------------------

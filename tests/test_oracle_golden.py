@@ -189,6 +189,17 @@ def test_greedy_decode_tokens_bit_exact(case, small, c0):
     assert np.array_equal(tok.numpy(), g["dec_tokens"])
 
 
+def test_batched_sweep_oracle_vs_reference_decoder(golden_dir):
+    """tests/golden/sweep.npz (the reference's eval-mode global_decoder on the 64-row batch of 8 samples x 8 fader values, hidden 512, 100 steps):
+    the oracle's greedy decode reproduces the reference's tokens row by row up to the reference's own first near-tie"""
+    from helpers import tokens_match_upto_near_tie
+    g = np.load(os.path.join(golden_dir, "sweep.npz"))
+    sd = orc.init_state_dict(512, 128)
+    lp, tok = orc.greedy_decode(sd, torch.from_numpy(g["z"]), int(g["dims"][5]))
+    np.testing.assert_allclose(lp[:, 0].numpy(), g["logp_first"], rtol=1e-5, atol=1e-5)
+    assert tokens_match_upto_near_tie(tok.numpy(), g["tokens"], g["gap"]) >= 0.9 * g["tokens"].size
+
+
 def test_cpu_baseline_model_matches_reference_train(c0):
     """oracle/cpu_baseline.py (the timed torch.nn restatement of the reference's CPU path) reproduces the
     reference's own train() numbers on BASELINE config 0 (B=8, T=64, hidden 512)."""
