@@ -41,7 +41,7 @@ extern "C" {
 
 #define FN_MAX_SCANS 8
 
-int fn_version(void);                 /* ABI version, currently 4 */
+int fn_version(void);                 /* ABI version, currently 5 (round 5: fn_gru_fwd_x6_ok, fn_gru_bwd_x6_ok, fn_comm_count / fn_comm_rank, fn_weight_images kinds 3 / 4, FnGruBwd.variant bit 14) */
 const char* fn_strerror(int code);    /* static string for FN_E_* / hipError_t */
 
 /* ------------------------------------------------------------------------------------------
@@ -288,8 +288,9 @@ typedef struct FnGruBwd {
 int fn_gru_seq_bwd(const FnGruBwd* scans, int n_scans, void* stream);
 /* variant bit 14 (0x4000), as in FnGruFwd: the backward scan with exact split products on the bf16 MFMA (gru_bwd_x6_kernel).  w_hh_t_frag must then be
  * the bf16 TRIPLE image of W_hh^T [H][3H] (fn_weight_images kind 4; 3/2 of fn_frag_floats(H, 3H) floats) and frag_ws 3 * fn_frag_floats(B, 3H) floats
- * (the gate gradients are exchanged as triples).  H = 512, every scan in full groups of 64 (or 32) rows, T >= 2, 9..16 row groups that are all
- * resident at once (the shapes of the register-stationary fp32 kernel); anything else returns FN_E_UNSUPPORTED.  fn_gru_bwd_x6_ok answers without
+ * (the gate gradients are exchanged as triples).  H = 512, every scan in full groups of 64 rows (with variant bit 15 also: of 32 rows - that form
+ * measured slower than the fp32 kernel and is not chosen on its own), T >= 2, 9..16 row groups that are all resident at once (the shapes of the
+ * register-stationary fp32 kernel); anything else returns FN_E_UNSUPPORTED.  fn_gru_bwd_x6_ok answers without
  * enqueuing anything (1 / 0).  Same element-wise gate arithmetic; gradients differ from the default kernels by fp32 rounding only. */
 int fn_gru_bwd_x6_ok(const FnGruBwd* scans, int n_scans);
 

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfadernets_hip.so")
 
 FN_MAX_SCANS = 8
-ABI_VERSION = 4
+ABI_VERSION = 5
 GEMM_LEAN = 0x10000          # FN_GEMM_LEAN
 GEMM_BF16X6 = 0x20000        # FN_GEMM_BF16X6 (opt-in: exact bf16 triple split on the bf16 MFMA)
 FN_E_NULL, FN_E_SHAPE, FN_E_ALIGN, FN_E_WORKSPACE, FN_E_COUNT = -1, -2, -3, -4, -5

@@ -16,11 +16,14 @@ partial sums meet in LDS.  What the triple arithmetic changes:
     live in VGPRs that only exist inside a statement (v208..v255: clobbered, nothing crosses a statement in them);
   * the epilogue operands (saved gates, previous state, external gradient: 6 HBM reads per item) are requested ONE PHASE AHEAD into AGPRs
     behind the last refill of the loop and are NOT waited for at its end (vmcnt retires in order: they stand in front of nothing but the next
-    phase's ring, which is needed a whole epilogue later); a statement of their own (`_get`, 24 scalar outputs: inline asm takes 30 operands and
-    cannot name a component of a 128-bit one) hands them to the compiler behind the epilogue, in front of the next K loop;
-  * the exchange-slab stores of an epilogue (9 x 8 bytes per item) are a statement of their own right behind it (`*_pub`: the split into
-    triples is compiler code, the statement only issues the stores so that they enter the vmcnt arithmetic); the K loop carries the four
-    16-byte stores nobody waits for and the arrival;
+    phase's ring, which is needed a whole epilogue later); the NEXT K loop statement hands them to the compiler: behind its arrival barrier the
+    wave's own accumulator tiles in LDS are free until the end of the loop, so the 128-bit values bounce through them (ds_write_b128 from the
+    AGPRs, ds_read_b128 into the output operands - inline asm cannot name a component of a 128-bit operand, v_accvgpr_read would need 24
+    scalar outputs and the statement is limited to 30 operands);
+  * the exchange-slab stores of an epilogue (9 x 8 bytes per item, write-through: ~30 cycles of the CU's address path each - 1.2 k cycles per phase
+    when the four waves issue them back to back, measured) ride in the NEXT K loop, three per unit in front of the arrival; the four 16-byte
+    stores nobody waits for (dgx, dghn) are a small statement of their own right behind the epilogue (`*_out`: counted, so that they enter the
+    vmcnt arithmetic) - with both store sets the K loop statement would need 33 operands (inline asm takes 30);
   * counter of the other half: loaded near the end of the loop, looked at behind it; the ring request is a statement of its own (as kloop3_asm.h).
 
 State that crosses statements: W (a0..a155), the ring (RU - 1 units in flight), the next phase's epilogue operands (in flight), the slab stores,
@@ -41,6 +44,7 @@ VACC, VWF, VO2 = 208, 224, 255
 NBLK = 12
 NEXT = 6             # epilogue-operand loads per phase
 NSLAB = 9            # exchange-slab stores per item (3 gates x 3 pieces)
+NOUT = 4             # dgx r / z / n and dghn stores per item
 
 
 class GenX6B:
@@ -101,19 +105,19 @@ class GenX6B:
         return ["s_mov_b64 s[%d:%d], exec" % (SB + 2, SB + 3), "s_mov_b64 exec, 0xffffffff"] + ins + ["s_mov_b64 exec, s[%d:%d]" % (SB + 2, SB + 3)]
 
     def arrive_block(self):
-        """every wave's exchange-slab stores (issued by the `_pub` statement in front of this one: the youngest operations in flight when it starts)
-        have completed -> barrier (also the fence between the previous epilogue's reads of the accumulator tiles and this phase's writes) -> one
+        """every wave's exchange-slab stores (issued by this statement's first units) have completed -> barrier (also the fence between the previous epilogue's reads of the accumulator tiles and this phase's writes) -> one
         arrival (arr: 0 = none due, 1 = due, 2 = due and this wave issues it).  `_first`: the stores it would wait for were drained by the caller."""
-        L = ["s_waitcnt vmcnt(%d)" % (len(self.vmops) - self.n0)] if self.stores else []
+        slab = [i for i, o in enumerate(self.vmops) if o == ("store", "slab")]
+        L = ["s_waitcnt vmcnt(%d)" % (len(self.vmops) - 1 - max(slab))] if slab else []
         return L + ["s_barrier", "s_cmp_lt_u32 %[arr], 2", "s_cbranch_scc1 .Lnoarr_%=",
                     "s_mov_b64 s[%d:%d], exec" % (SB + 2, SB + 3), "s_mov_b64 exec, 1", "v_mov_b32 %[pv], 1",
                     "global_atomic_add %[pcnt], %[pv], off", "s_mov_b64 exec, s[%d:%d]" % (SB + 2, SB + 3), ".Lnoarr_%=:"]
 
     def body(self):
         RU, units, TH = self.RU, self.units, self.TH
-        # in flight when the statement starts, oldest first: the ring request (`_pro`), the previous epilogue's slab stores (`_pub`); this phase's
-        # epilogue operands have been taken out of their AGPRs (`_get`, which waited for them)
-        self.vmops = [("ring", u) for u in range(RU - 1) for _ in range(3)] + ([("store", "slab")] * NSLAB if self.stores else [])
+        # in flight when the statement starts, oldest first: this phase's epilogue operands (requested by the previous statement, or `_ext`), the ring
+        # request (`_pro`), the previous epilogue's dgx / dghn stores (`_out`)
+        self.vmops = [("ext", 0)] * NEXT + [("ring", u) for u in range(RU - 1) for _ in range(3)] + ([("store", "out")] * NOUT if self.stores else [])
         self.n0 = len(self.vmops)
         L = []
         if TH == 2:
@@ -123,10 +127,13 @@ class GenX6B:
         L += self.wread(0)
         for c in range(4 * self.nacc):
             L.append("v_mov_b32 v%d, 0" % (VACC + c))
-        outs = []
-        if self.stores:      # previous epilogue: dgx r / z / n (2 KB apart around the middle one), dghn
-            outs = ["global_store_dwordx4 %[sg], %[d0], off offset:-2048", "global_store_dwordx4 %[sg], %[d1], off",
-                    "global_store_dwordx4 %[sg], %[d2], off offset:2048", "global_store_dwordx4 %[sn], %[d3], off"]
+        slabs = []
+        if self.stores:      # previous epilogue's gate gradients as triples: gate g at byte offset 0xC000 g (16 K blocks), piece p 1 KB further
+            for g in range(3):
+                for pc in range(3):
+                    pre = ["v_add_u32 v%d, 0x%x, %%[so0]" % (VO2 - 1, 0xC000 * g)] if (g and pc == 0) else []
+                    slabs.append(pre + ["global_store_dwordx2 %s, %%[t%d%d], %%[sbase] offset:%d sc1" % ("%[so0]" if g == 0 else "v%d" % (VO2 - 1), g, pc, pc * 1024)])
+        ext_out = ["gt0", "gt1", "gt2", "gt3", "hp", "xt"]
         ext_in = ["global_load_dwordx4 a[%d:%d], %%[ga], off offset:%d" % (EXT0 + 4 * q, EXT0 + 4 * q + 3, q * 1024) for q in range(4)]
         ext_in += ["global_load_dwordx4 a[%d:%d], %%[ha], off" % (EXT0 + 16, EXT0 + 19), "global_load_dwordx4 a[%d:%d], %%[xa], off" % (EXT0 + 20, EXT0 + 23)]
         done_arr = False
@@ -146,10 +153,20 @@ class GenX6B:
             if m == TH - 1 and blk + 1 < NBLK - 1:       # last unit of a K block: the LDS half of the next block's weights
                 for i, ins in enumerate(self.wread(blk + 1)):
                     comp[4 + i].append(ins)
-            if outs and 1 <= u < 1 + len(outs):
-                ins = outs[u - 1]
-                comp[7] += self.masked_ins([ins])
-                vm[7].append(("store", "out"))
+            # hand-over of this phase's epilogue operands (they landed long ago: older than unit 0's ring loads): AGPRs -> own accumulator tiles in LDS ->
+            # output operands, nacc vectors per unit, in the units behind the arrival barrier (a wave's LDS operations execute in order, every lane
+            # reads back its own 16 bytes: no wait in between)
+            rounds = [list(range(i, min(i + self.nacc, NEXT))) for i in range(0, NEXT, self.nacc)]
+            if self.u_arr < u <= self.u_arr + len(rounds):
+                js = rounds[u - self.u_arr - 1]
+                for i, j in enumerate(js):
+                    comp[i].append("ds_write_b128 %%[red], a[%d:%d] offset:%d" % (EXT0 + 4 * j, EXT0 + 4 * j + 3, i * 1088))
+                for i, j in enumerate(js):
+                    comp[6 + i].append("ds_read_b128 %%[%s], %%[red] offset:%d" % (ext_out[j], i * 1088))
+            if slabs and u < 3:                          # three slab stores per unit in units 0..2 (gate u)
+                for i in range(3):
+                    comp[5 + 2 * i] += self.masked_ins(slabs[3 * u + i])
+                    vm[5 + 2 * i].append(("store", "slab"))
             if u == self.poll_unit:
                 comp[8].append("global_load_dword %[pv], %[pcnt], off sc1")
                 vm[8].append(("poll", 0))
@@ -170,14 +187,14 @@ class GenX6B:
         assert done_arr
         # the counter value and everything older have landed; the next phase's epilogue operands may still be in flight
         assert self.vmops[-NEXT:] == [("next_ext", 0)] * NEXT
-        L += ["s_waitcnt vmcnt(%d)" % NEXT, "s_nop 7"]
+        L += ["s_waitcnt vmcnt(%d)" % NEXT, "s_waitcnt lgkmcnt(0)", "s_nop 7"]
         L += ["ds_write_b128 %%[red], v[%d:%d] offset:%d" % (VACC + 4 * j, VACC + 4 * j + 3, j * 1088) for j in range(self.nacc)]
         L.append("s_waitcnt lgkmcnt(0)")
         return L
 
     def clobbers(self, ring_only=False):
         regs = ['"a%d"' % i for i in range(RING0, EXT0 + 24)]
-        regs += ['"v%d"' % i for i in range(VACC, VACC + 4 * self.nacc)] + ['"v%d"' % i for i in range(VWF, VWF + 24)] + ['"v%d"' % VO2]
+        regs += ['"v%d"' % i for i in range(VACC, VACC + 4 * self.nacc)] + ['"v%d"' % i for i in range(VWF, VWF + 24)] + ['"v%d"' % VO2, '"v%d"' % (VO2 - 1)]
         return ", ".join(regs)
 
     def emit_main(self):
@@ -186,19 +203,20 @@ class GenX6B:
         sig = ("const void* xin_, unsigned vo, unsigned lp, unsigned red, int arr, u32* pcnt,\n"
                "        const float* ga, const float* ha, const float* xa")
         ins = '[ga] "v"(ga), [ha] "v"(ha), [xa] "v"(xa)'
-        if self.stores:
-            sig += ",\n        float* sg, float* sn, const f32x4& d0, const f32x4& d1, const f32x4& d2, const f32x4& d3"
-            ins += ', [sg] "v"(sg), [sn] "v"(sn), [d0] "v"(d0), [d1] "v"(d1), [d2] "v"(d2), [d3] "v"(d3)'
-        sig += ",\n        unsigned& pv"
-        outs = '[pv] "=&v"(pv)'
         decl = post = ""
+        if self.stores:
+            sig += ",\n        void* sbase_, unsigned so0, " + ", ".join("const u32x2& t%d%d" % (g, pc) for g in range(3) for pc in range(3))
+            ins += ', [sbase] "s"(sbase), [so0] "v"(so0), ' + ", ".join('[t%d%d] "v"(t%d%d)' % (g, pc, g, pc) for g in range(3) for pc in range(3))
+            decl = "    void* sbase = const_cast<float*>(fn_uniform_ptr(reinterpret_cast<const float*>(sbase_)));\n"
+        sig += ",\n        f32x4 (&gt)[4], f32x4& hp, f32x4& xt, unsigned& pv"
+        outs = ", ".join(['[gt%d] "=&v"(gt[%d])' % (q, q) for q in range(4)] + ['[hp] "=&v"(hp)', '[xt] "=&v"(xt)', '[pv] "=&v"(pv)'])
         return """
 // %s: K loop of one backward phase on the bf16 MFMA (%d row tile(s) x 2 column tiles, %d units = this wave's K quarter, ring of %d, 12 MFMAs per unit; %s).
 // xin = this wave's first K block of THIS phase's operand slab (uniform), vo = byte offset of the half's first row tile (+ lane * 16); lp = LDS byte
-// address of this wave's first weight block of column tile 1.  In flight at the start, oldest first: the ring (`_pro`)%s.
+// address of this wave's first weight block of column tile 1.  In flight at the start, oldest first: this phase's epilogue operands, the ring (`_pro`)%s.
 // arr / pcnt: arrival for the previous phase's epilogue (0 none, 1 due, 2 due and this wave issues it) - its half is the half of the NEXT phase, whose
 // counter pcnt also is: the value the loop loads near its end is returned in pv.  ga / ha / xa: epilogue operands of the NEXT phase (saved gates, previous
-// state, external gradient): requested here into a[%d:%d], still in flight at the end, taken out by `fn_x6_bwd_get`.%s
+// state, external gradient): requested here into a[%d:%d], still in flight at the end, handed over by the NEXT statement; gt / hp / xt: those of THIS phase.%s
 FN_DEVINL void %s(%s) {
     const void* xin = fn_uniform_ptr(reinterpret_cast<const float*>(xin_));
     arr = __builtin_amdgcn_readfirstlane(arr);
@@ -208,10 +226,10 @@ FN_DEVINL void %s(%s) {
         : [xin] "s"(xin), [vo] "v"(vo), [red] "v"(red), [lp] "v"(lp), [arr] "s"(arr), [pcnt] "v"(pcnt), %s
         : "memory", "scc", "vcc", "s%d", "s%d", "s%d", "s%d", %s);
 %s}
-""" % (self.name, self.TH, self.units, self.RU, "issues the previous epilogue's 16-byte stores" if self.stores else "no stores to issue",
-       ", the previous epilogue's slab stores (`_pub`)" if self.stores else "",
+""" % (self.name, self.TH, self.units, self.RU, "issues the previous epilogue's exchange-slab stores" if self.stores else "no stores to issue",
+       ", the previous epilogue's dgx / dghn stores (`_out`)" if self.stores else "",
        EXT0, EXT0 + 23,
-       "\n// sg / sn: dgx (middle gate) and dghn addresses of the previous epilogue, d0..d3 = dr', dz', dn', dn' r" if self.stores else "",
+       "\n// sbase + so0: exchange slab of the previous epilogue (uniform) and this lane's byte offset of gate 0 in it; t<gate><piece>: its gate gradients dr', dz', dn' r as bf16 triples" if self.stores else "",
        self.name, sig, decl, body, outs, ins, SB, SB + 1, SB + 2, SB + 3, self.clobbers(), post)
 
     def emit_pro(self, name):
@@ -256,35 +274,30 @@ FN_DEVINL void %s(const float* ga, const float* ha, const float* xa) {
 """ % (EXT0, EXT0 + 23, name, body, clob)
 
 
-def emit_get(name, younger):
-    """the epilogue operands of the phase about to run: a[EXT0 ..] -> 24 scalar outputs, behind a wait that leaves the `younger` operations issued after
-    their loads in flight"""
-    names = ["gt0", "gt1", "gt2", "gt3", "hp", "xt"]
-    L = ["s_waitcnt vmcnt(%d)" % younger]
-    for j, nm in enumerate(names):
-        for c in range(4):
-            L.append("v_accvgpr_read_b32 %%[%s%d], a%d" % (nm, c, EXT0 + 4 * j + c))
+def emit_out(name, masked):
+    L = ["global_store_dwordx4 %[sg], %[d0], off offset:-2048", "global_store_dwordx4 %[sg], %[d1], off",
+         "global_store_dwordx4 %[sg], %[d2], off offset:2048", "global_store_dwordx4 %[sn], %[d3], off"]
+    if masked:
+        L = ["s_mov_b64 s[%d:%d], exec" % (SB + 2, SB + 3), "s_mov_b64 exec, 0xffffffff"] + L + ["s_mov_b64 exec, s[%d:%d]" % (SB + 2, SB + 3)]
     body = "\n".join('        "%s\\n\\t"' % l for l in L)
-    decl = "    float " + ", ".join("%s%d" % (n, c) for n in names for c in range(4)) + ";\n"
-    outs = ", ".join('[%s%d] "=&v"(%s%d)' % (n, c, n, c) for n in names for c in range(4))
-    post = "".join("    gt[%d] = (f32x4){gt%d0, gt%d1, gt%d2, gt%d3};\n" % (q, q, q, q, q) for q in range(4))
-    post += "    hp = (f32x4){hp0, hp1, hp2, hp3};\n    xt = (f32x4){xt0, xt1, xt2, xt3};\n"
     return """
-// hands the epilogue operands of the coming phase (saved gates r, z, n, hn; previous state; external gradient) from a[%d:%d] to the compiler; the %d
-// operations issued behind their loads (ring request%s) stay in flight
-FN_DEVINL void %s(f32x4 (&gt)[4], f32x4& hp, f32x4& xt) {
-%s    asm volatile(
+// the stores of an epilogue item%s nobody in the launch waits for: dgx r / z / n (sg = the middle gate, 2 KB apart) and dghn (sn); d0..d3 = dr', dz', dn', dn' r.
+// Counted by the next K loop statement (four operations behind the ring request).
+FN_DEVINL void %s(float* sg, float* sn, const f32x4& d0, const f32x4& d1, const f32x4& d2, const f32x4& d3) {
+    asm volatile(
 %s
-        : %s
         :
-        : "memory");
-%s}
-""" % (EXT0, EXT0 + 23, younger, ", slab stores" if younger > 20 else "", name, decl, body, outs, post)
+        : [sg] "v"(sg), [sn] "v"(sn), [d0] "v"(d0), [d1] "v"(d1), [d2] "v"(d2), [d3] "v"(d3)
+        : "memory", "s%d", "s%d");
+}
+""" % (" (lanes 0-31)" if masked else "", name, body, SB + 2, SB + 3)
 
 
 def emit_pub(name, masked):
     """the 9 exchange-slab stores of an epilogue item: gate g at byte offset 0xC000 g (16 K blocks), piece p 1 KB further"""
-    L = []
+    # sbase reaches the statement through v_readfirstlane: a VALU-written SGPR needs 5 wait states before a vector-memory instruction may use it as its
+    # scalar base, and the compiler inserts none in front of inline asm (found the hard way: the first store went to {high word, 0} + offset)
+    L = ["s_nop 4"]
     for g in range(3):
         if g:
             L.append("v_add_u32 v%d, 0x%x, %%[so0]" % (VO2, 0xC000 * g))
@@ -296,8 +309,8 @@ def emit_pub(name, masked):
     sig = ", ".join("const u32x2& t%d%d" % (g, pc) for g in range(3) for pc in range(3))
     ins = ", ".join('[t%d%d] "v"(t%d%d)' % (g, pc, g, pc) for g in range(3) for pc in range(3))
     return """
-// publication of an epilogue item%s: its gate gradients dr', dz', dn' r as bf16 triples (t<gate><piece>, four packed values each) on the exchange slab
-// sbase (uniform) at this lane's byte offset so0 - write-through; the next K loop statement counts these nine stores and makes the arrival
+// publication of an epilogue item%s outside of a K loop (iteration 0 of a launch): its gate gradients dr', dz', dn' r as bf16 triples (t<gate><piece>, four
+// packed values each) on the exchange slab sbase (uniform) at this lane's byte offset so0 - write-through
 FN_DEVINL void %s(void* sbase_, unsigned so0, %s) {
     void* sbase = const_cast<float*>(fn_uniform_ptr(reinterpret_cast<const float*>(sbase_)));
     asm volatile(
@@ -346,7 +359,7 @@ HEAD = """// GENERATED by gen_kloop4.py - do not edit.  K loops of the ping-pong
 """
 
 # TH -> (ring depth, unit of the arrival, unit whose MFMAs load the other half's counter)
-CONFIG = {"t2": (2, 6, 5, 21), "t1": (1, 6, 5, 9)}
+CONFIG = {"t2": (2, 6, 6, 21), "t1": (1, 6, 6, 10)}
 
 
 def main(path, overrides=()):
@@ -361,8 +374,7 @@ def main(path, overrides=()):
             out.append(GenX6B("fn_x6_bwd_%s_%s" % (tag, "main" if stores else "first"), TH, RU, stores, u_arr, poll).emit_main())
         out.append(GenX6B("x", TH, RU, 0, u_arr, poll).emit_pro("fn_x6_bwd_%s_pro" % tag))
         out.append(emit_pub("fn_x6_bwd_%s_pub" % tag, TH == 1))
-        out.append(emit_get("fn_x6_bwd_%s_get" % tag, 3 * (RU - 1) + NSLAB))
-        out.append(emit_get("fn_x6_bwd_%s_get_first" % tag, 3 * (RU - 1)))
+        out.append(emit_out("fn_x6_bwd_%s_out" % tag, TH == 1))
     out.append(emit_ext("fn_x6_bwd_ext"))
     out.append(emit_wload("fn_x6_bwd_wload"))
     open(path, "w").write("\n".join(out))

@@ -1554,6 +1554,10 @@ __global__ __launch_bounds__(NT) void gru_cell_wlds_ovl_kernel(const CellArgs a)
 #pragma unroll
             for (int j = 0; j < NF; ++j) fv[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(f_base(W, ldw, 0, j)) + f_off(ldw));
         }
+        // Not the first phase: this half was requested by asm loads during the previous phase's last steps, and its LAST load was issued behind the ring
+        // loads of that phase's final steps - no ring wait covered it.  Everything but the PF ring requests just issued has to have landed before the
+        // registers go to LDS (round 5: found by a soak - 1 launch in ~30 suites wrote a stale register: a wrong weight row for one (gate, unit)).
+        if (!first) fn_wait_vm_n(PF * RT);
         fill_store(0);                               // (every reader of these steps' fragments passed the previous phase's half barrier)
         __syncthreads();
         f32x4 bq[2][3];
@@ -1593,7 +1597,10 @@ __global__ __launch_bounds__(NT) void gru_cell_wlds_ovl_kernel(const CellArgs a)
         };
 #pragma unroll
         for (int u = 0; u < HALF; ++u) step(u);
-        // second half of the slice: requested during steps 0 .. NF - 1, complete behind step HALF - 1's wait
+        // second half of the slice ...
+        // ... requested during steps 0 .. NF - 1; the last of them was issued BEHIND the ring loads of step NF - 1 (for step NF - 1 + PF), so the ring
+        // waits of the steps up to HALF - 1 do not cover it: wait until only the ring requests issued behind it (steps NF .. HALF - 1) are in flight
+        fn_wait_vm_n((HALF - NF) * RT);
 #pragma unroll
         for (int j = 0; j < NF; ++j) fn_keep(fv[j]);
         fill_store(1);

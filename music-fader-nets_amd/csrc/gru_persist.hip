@@ -1662,8 +1662,8 @@ __global__ __launch_bounds__(NT) void gru_bwd_rs_kernel(const QArgs args) {
 // column tiles - with the gate gradients exchanged as bf16 triples ([row tile][48 K blocks][piece][64 lanes][8 bf16], rounded pieces) and the
 // W_hh^T slice as triples (fn_frag3_pack_t image): column tile 0 of the wave's quarter + block 11 of column tile 1 in AGPRs, blocks 0..10 of
 // column tile 1 in LDS (132 KB).  Accumulator tiles in LDS: one half (the K loops' s_barrier at the arrival point is the fence).  Per phase:
-//   K loop statement (outs of the previous epilogue, arrival, counter read, NEXT phase's epilogue operands requested) -> counter check -> ring
-//   request of the next phase -> barrier -> gate backward (compiler code) -> slab stores (`_pub`) -> next phase's epilogue operands (`_get`).
+//   K loop statement (exchange-slab stores of the previous epilogue, arrival, this phase's epilogue operands handed over, counter read, NEXT phase's
+//   epilogue operands requested) -> counter check -> ring request of the next phase -> barrier -> gate backward (compiler code) -> dgx / dghn stores (`_out`).
 // Same arithmetic per element as gru_bwd_rs_kernel (fn_gru_gate_bwd, partial sums added in wave order); the products are exact, their sums
 // run in another order (six partial products per 32 k).
 // ---------------------------------------------------------------------------------------------------------------
@@ -1735,8 +1735,7 @@ __global__ __launch_bounds__(NT) void gru_bwd_x6_kernel(const QArgs args) {
     const unsigned lp = lds_addr(wl) + wave * LB * 3072 + lane * 16;
     const int iters = T + (S.dh0 ? 1 : 0);
 
-    // outputs of the last epilogue: the slab stores leave through `_pub` right behind it, the rest through the NEXT phase's K loop statement, or
-    // flush_stores() when none follows
+    // outputs of the last epilogue: dgx / dghn leave through `_out` right behind it, the exchange-slab stores through the NEXT phase's K loop statement
     bool st_valid = false;
     char* st_base = xs;
     float *st_g = nullptr, *st_n = nullptr;
@@ -1851,8 +1850,6 @@ __global__ __launch_bounds__(NT) void gru_bwd_x6_kernel(const QArgs args) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             fn_x6_bwd_ext(ga, ha, xa);                                 // epilogue operands of the first K phase, then its ring
             request(slab_in(1), vo[0]);
-            if (TH == 2) fn_x6_bwd_t2_get_first(gt, hp2, xt2);
-            else fn_x6_bwd_t1_get_first(gt, hp2, xt2);
         }
         bool first = true;
 
@@ -1871,11 +1868,13 @@ __global__ __launch_bounds__(NT) void gru_bwd_x6_kernel(const QArgs args) {
             const int arr = pend >= 0 ? (wave == 0 ? 2 : 1) : 0;
             FN_PSTAMP(hx * 4 + 0);
             if (TH == 2) {
-                if (first) fn_x6_bwd_t2_first(slab_in(it), vo[hx], lp, h_red, arr, cnt[hy], ga, ha, xa, pv);
-                else fn_x6_bwd_t2_main(slab_in(it), vo[hx], lp, h_red, arr, cnt[hy], ga, ha, xa, st_g, st_n, st_d[0], st_d[1], st_d[2], st_d[3], pv);
+                if (first) fn_x6_bwd_t2_first(slab_in(it), vo[hx], lp, h_red, arr, cnt[hy], ga, ha, xa, gt, hp2, xt2, pv);
+                else fn_x6_bwd_t2_main(slab_in(it), vo[hx], lp, h_red, arr, cnt[hy], ga, ha, xa, st_base, st_o, st_t[0][0], st_t[0][1], st_t[0][2], st_t[1][0], st_t[1][1],
+                                       st_t[1][2], st_t[2][0], st_t[2][1], st_t[2][2], gt, hp2, xt2, pv);
             } else {
-                if (first) fn_x6_bwd_t1_first(slab_in(it), vo[hx], lp, h_red, arr, cnt[hy], ga, ha, xa, pv);
-                else fn_x6_bwd_t1_main(slab_in(it), vo[hx], lp, h_red, arr, cnt[hy], ga, ha, xa, st_g, st_n, st_d[0], st_d[1], st_d[2], st_d[3], pv);
+                if (first) fn_x6_bwd_t1_first(slab_in(it), vo[hx], lp, h_red, arr, cnt[hy], ga, ha, xa, gt, hp2, xt2, pv);
+                else fn_x6_bwd_t1_main(slab_in(it), vo[hx], lp, h_red, arr, cnt[hy], ga, ha, xa, st_base, st_o, st_t[0][0], st_t[0][1], st_t[0][2], st_t[1][0], st_t[1][1],
+                                       st_t[1][2], st_t[2][0], st_t[2][1], st_t[2][2], gt, hp2, xt2, pv);
             }
             first = false;
             FN_PSTAMP(hx * 4 + 1);
@@ -1893,12 +1892,11 @@ __global__ __launch_bounds__(NT) void gru_bwd_x6_kernel(const QArgs args) {
             FN_PSTAMP(hx * 4 + 3);
             const bool more = q > 0 || (q == 0 && S.dh0 != nullptr);
             pend = more ? hx : -1;
-            // the slab stores (nine per item; a phase with nothing to publish stores its old values again into a slab nobody reads any more: the
-            // K loop statements count nine stores) and the next phase's epilogue operands
+            // the exchange-slab stores of this epilogue ride in the next phase's K loop (nine per item; a phase with nothing to publish lets it store
+            // its old values again, into a slab nobody reads any more: the K loop statements count nine stores); dgx / dghn leave here
             if (!pub) st_base = xs + (long)(it & 1) * FSB;
-            publish();
-            if (TH == 2) fn_x6_bwd_t2_get(gt, hp2, xt2);
-            else fn_x6_bwd_t1_get(gt, hp2, xt2);
+            if (TH == 2) fn_x6_bwd_t2_out(st_g, st_n, st_d[0], st_d[1], st_d[2], st_d[3]);
+            else fn_x6_bwd_t1_out(st_g, st_n, st_d[0], st_d[1], st_d[2], st_d[3]);
             return true;
         };
 
@@ -1908,7 +1906,6 @@ __global__ __launch_bounds__(NT) void gru_bwd_x6_kernel(const QArgs args) {
             if (!phase(std::integral_constant<int, 1>{}, it)) return;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        flush_outs();
     }
 #pragma unroll
     for (int hx = 0; hx < 2; ++hx) {
@@ -2000,7 +1997,11 @@ int x6_bwd_tiles(const FnGruBwd* scans, int n_scans, int cus) {
         d64 = d64 && d.B % 64 == 0;
         d32 = d32 && d.B % 32 == 0;
     }
-    return (d64 && g64 > 8 && g64 <= 16 && g64 * 16 <= cus) ? 2 : (d32 && g32 > 8 && g32 <= 16 && g32 * 16 <= cus) ? 1 : 0;
+    // 64-row groups (the encoder shape: 4 scans x 256 rows): 3.05 ms against 3.5 ms on the fp32 MFMA.  32-row groups (a decoder-pipeline launch: 2 scans x
+    // 256 rows x 32 steps) measured SLOWER than the fp32 kernel (353 against 322-337 us: both are bound by the exchange stream through the XCD's L2, which
+    // the triples make 1.5 x wider, and the 12-unit K loops are too short for the store -> arrival -> counter chain): only on request (variant bit 15)
+    const bool th1_ok = (scans[0].variant & 0x8000) != 0;
+    return (d64 && g64 > 8 && g64 <= 16 && g64 * 16 <= cus) ? 2 : (th1_ok && d32 && g32 > 8 && g32 <= 16 && g32 * 16 <= cus) ? 1 : 0;
 }
 
 }  // namespace

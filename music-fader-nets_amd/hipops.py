@@ -369,7 +369,9 @@ class HipOps:
         """would gru_seq_bwd run this launch on the bf16 x 6 kernel (fn_gru_bwd_x6_ok)?"""
         if not (self.dw_x6 and self.bwd_x6 and all(s.get("w_hh_t_frag3") is not None for s in scans)):
             return False
-        return bool(self.lib.fn_gru_bwd_x6_ok(self._bwd_descriptors(scans, cu_budget), len(scans)))
+        arr = self._bwd_descriptors(scans, cu_budget)
+        arr[0].variant = int(self.variant)
+        return bool(self.lib.fn_gru_bwd_x6_ok(arr, len(scans)))
 
     def gru_seq_bwd(self, scans, persistent=True, cu_budget=0, variant=None, x6=None):
         """x6: None = bf16 x 6 where the launch is eligible (a backward launch hands nothing but fp32 tensors to the next one: every launch decides for

@@ -9,6 +9,8 @@ from music_fader_nets_amd.synth import synth_batch
 dev = torch.device("cuda:0")
 torch.manual_seed(1234)
 m = pkg.MusicAttrRegGMVAE(342, 3, 16, 24, 512, 128, 32, n_component=2).to(dev)
+if len(sys.argv) > 2:                      # arithmetic of the deep MFMA products: f32 / bf16x6 (default: the package default)
+    m.set_arith(sys.argv[2])
 tr = pkg.GMVAETrainer(m, lr=1e-3, beta=0.2)
 tr.use_graph = False
 b = synth_batch(np.random.RandomState(0), 256, 256, 64)
