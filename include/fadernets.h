@@ -62,11 +62,12 @@ const char* fn_strerror(int code);    /* static string for FN_E_* / hipError_t *
  * wavefront of the decoder pipeline's forward scans) - same results as the full instance.
  * ------------------------------------------------------------------------------------------ */
 #define FN_GEMM_LEAN 0x10000
-/* splitk | FN_GEMM_BF16X6 (weight-gradient form a_k=0,b_k=0 and fn_gru_dwhh_f32; OPT-IN, never set by default): the products run on the
- * bf16 MFMA with every fp32 operand value cut EXACTLY into three bf16 pieces (x = hi + mid + lo) and six of the nine exact partial
- * products accumulated in fp32, smallest first (the three dropped ones are <= 2^-24 of |a b|).  Against float64 the result is as
- * accurate as the fp32 MFMA chain (scratch/mfma_bf16x9.hip, tests/test_gpu_parity.py::test_gemm_tn_bf16x6); it is a different
- * summation, so results differ from the default kernel in the last bits.  K tails below 32 run on the fp32 MFMA. */
+/* splitk | FN_GEMM_BF16X6 (weight-gradient form a_k=0,b_k=0 and fn_gru_dwhh_f32): the products run on the bf16 MFMA with every fp32
+ * operand value cut EXACTLY into three bf16 pieces (x = hi + mid + lo) and six of the nine exact partial products accumulated in
+ * fp32, smallest first (the three dropped ones are <= 2^-24 of |a b| and, with B's pieces rounded, zero-mean).  Against float64 the
+ * result is as accurate as the fp32 MFMA chain (tests/test_gpu_parity.py::test_gemm_tn_bf16x6, ::test_bf16x6_adversarial_operands_vs_float64);
+ * it is a different summation, so results differ from the fp32-MFMA kernel in the last bits.  Split-K ranges are whole 32-k blocks; a K
+ * tail below 32 (unsplit products, the last range) runs on the fp32 MFMA. */
 #define FN_GEMM_BF16X6 0x20000
 size_t fn_gemm_ws_bytes(int M, int N, int splitk);
 int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha,

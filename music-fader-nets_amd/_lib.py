@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libfadernets_hip.so")
 FN_MAX_SCANS = 8
 ABI_VERSION = 5
 GEMM_LEAN = 0x10000          # FN_GEMM_LEAN
-GEMM_BF16X6 = 0x20000        # FN_GEMM_BF16X6 (opt-in: exact bf16 triple split on the bf16 MFMA)
+GEMM_BF16X6 = 0x20000        # FN_GEMM_BF16X6 (exact bf16 triple split on the bf16 MFMA)
 FN_E_NULL, FN_E_SHAPE, FN_E_ALIGN, FN_E_WORKSPACE, FN_E_COUNT = -1, -2, -3, -4, -5
 FN_E_UNSUPPORTED = -6
 FN_E_COMM = -7

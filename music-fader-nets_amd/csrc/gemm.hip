@@ -971,7 +971,9 @@ int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha, co
         (((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0)) {
         int klen = K;
         if (splitk > 1) {
-            klen = ((K + splitk - 1) / splitk + 3) / 4 * 4;
+            // K ranges of whole 32-k blocks for the bf16 x 6 kernel (no fp32-MFMA tail inside a range), of 4 rows otherwise
+            const int gran = x6 ? 32 : 4;
+            klen = ((K + splitk - 1) / splitk + gran - 1) / gran * gran;
             splitk = (K + klen - 1) / klen;
         }
         const int ntm = (M + 127) / 128, ntn = (N + 127) / 128;
@@ -1039,7 +1041,8 @@ int fn_gru_dwhh_f32(const float* dgx, const float* dghn, const float* hprev, int
     hipStream_t st = (hipStream_t)stream;
     int klen = K;
     if (splitk > 1) {
-        klen = ((K + splitk - 1) / splitk + 3) / 4 * 4;
+        const int gran = x6 ? 32 : 4;
+        klen = ((K + splitk - 1) / splitk + gran - 1) / gran * gran;
         splitk = (K + klen - 1) / klen;
     }
     const int ntm = (M + 127) / 128, ntn = (N + 127) / 128;
