@@ -301,6 +301,9 @@ FN_DEVINL float fn_top16(float x) { return __uint_as_float(__float_as_uint(x) & 
 // level), else truncated ones.  One ROUNDED operand is enough to make the dropped partial products zero-mean (mid_a lo_b, lo_a mid_b: lo_b and
 // mid_b then carry random signs); with both operands truncated they all have the sign of a b and bias a sum by ~2^-24 sum |a||b| towards zero
 // (tests/test_gpu_parity.py::test_bf16x6_adversarial_operands_vs_float64).  This kernel is bound by these VALU operations: B rounded, A truncated.
+// Two cheaper-on-paper forms measured SLOWER in one session (round 5, dW_hh product 1536 x 512 x 65280 at 16 / 32 K ranges; this form 698-736 / 603-610 us):
+// v_cvt_pk_bf16_f32 for every piece (both halves of a dword rounded to nearest even by one instruction, 4.5 operations per value: 740 / 665 us) and
+// two-element vector arithmetic that makes the remainders packed subtractions (v_pk_add_f32; 882 / 846 us: the compiler shuffles registers around them).
 template <bool RN>
 FN_DEVINL void fn_split8(const f32x4 (&v)[8], int e, bf16x8& h, bf16x8& m, bf16x8& l) {
     float x[8], hi[8], r1[8], mi[8], r2[8];

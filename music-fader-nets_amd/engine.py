@@ -43,6 +43,7 @@ class Engine:
         self.whh_t3 = {}                # ... as bf16 triple images (bf16 x 6 backward scans)
         self.packs = {}                 # fragment-major W_ih2 / W_out (single-launch greedy decode)
         self.saved = None
+        self.splitk_big = 16            # K ranges of the T*B-deep weight-gradient products (see _splitk)
         self.chunk = 32                 # time steps per pipeline chunk of the two decoder layers (layer 2 lags layer 1 by two chunks)
         self.persist_dec = True         # decoder scans as weight-stationary launches (False: per-step kernels; debug / tests)
         self.fill_edges = True          # the attribute decoders' chunks ride in the half-empty head / tail launches of the global decoder's
@@ -510,11 +511,10 @@ class Engine:
         self.colsum(rs[:, : 2 * H], db[: 2 * H])
         self.colsum(rsn, db[2 * H:])
 
-    @staticmethod
-    def _splitk(rows):
+    def _splitk(self, rows):
         # 48 tiles x split depth workgroups at two per CU: 8 ranges = 384 workgroups leave half of the second round empty (rows = 16384: 264 us = 0.62 of the MFMA
         # peak against 210 us = 0.78 with 16; scratch/sweep_dwhh_splitk.py)
-        return 16 if rows >= 8192 else (8 if rows >= 4096 else (4 if rows >= 1024 else 1))
+        return self.splitk_big if rows >= 8192 else (8 if rows >= 4096 else (4 if rows >= 1024 else 1))
 
     def _bwd_global_decoder_scans(self, S, fill=None):
         """Backward of global_decoder_tf up to the gate gradients (dlogits must already be in S['dec']['logits'], in place):

@@ -5,6 +5,9 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert
 import numpy as np, torch
 from mfn_import import load_package
 pkg = load_package()
+if os.environ.get("FN_LIB"):
+    from music_fader_nets_amd import _lib
+    _lib.LIB_PATH = os.path.join(R, "scratch", os.environ["FN_LIB"]); print("library:", _lib.LIB_PATH)
 from music_fader_nets_amd.synth import synth_batch
 dev = torch.device("cuda:0")
 REPS = int(os.environ.get("AB_REPS", "3"))
@@ -14,10 +17,15 @@ for rep in range(REPS):
         torch.manual_seed(1234)
         m = pkg.MusicAttrRegGMVAE(342, 3, 16, 24, 512, 128, 32, n_component=2).to(dev)
         tr = pkg.GMVAETrainer(m, lr=1e-3, beta=0.2)
+        if os.environ.get("AB_ARITH"):
+            m.set_arith(os.environ["AB_ARITH"])
         eng = m.engine()
         for kv in [x for x in spec.split(",") if x]:
             k, v = kv.split("=", 1)
-            setattr(eng, k, eval(v))
+            if k.startswith("ops."):
+                setattr(eng.ops, k[4:], eval(v))
+            else:
+                setattr(eng, k, eval(v))
         b = synth_batch(np.random.RandomState(0), 256, 256, 64)
         batch = tr.prepare_batch(b["d"], b["r"], b["n"], b["c"], b["r_density"], b["n_density"])
         torch.manual_seed(99); eps = tr.draw_eps(256, 256)

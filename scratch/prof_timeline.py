@@ -5,7 +5,7 @@ rows = list(cur.execute("select start, end, name, stream_id from kernels order b
 def short(n):
     n = re.sub(r"\(anonymous namespace\)::", "", n); n = re.sub(r"^void ", "", n)
     return n.split("(")[0][:44]
-starts = [r[0] for r in rows if "gru_fwd_pp_kernel<1>" in r[2] or "gru_fwd_persist_kernel<4, 1, 2" in r[2]]      # the encoder forward scan opens a step
+starts = [r[0] for r in rows if "gru_fwd_pp_kernel<1>" in r[2] or "gru_fwd_x6pp_kernel<1>" in r[2] or "gru_fwd_persist_kernel<4, 1, 2" in r[2]]      # the encoder forward scan opens a step
 t0 = starts[int(sys.argv[3]) if len(sys.argv) > 3 else -1]
 t_end = starts[(int(sys.argv[3]) if len(sys.argv) > 3 else -1) + 1] if len(sys.argv) > 3 else 1 << 62
 rows = [r for r in rows if t0 <= r[0] < t_end]

@@ -5,6 +5,9 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert
 import torch
 from mfn_import import load_package
 load_package()
+from music_fader_nets_amd import _lib
+if os.environ.get("FN_LIB"):
+    _lib.LIB_PATH = os.path.join(R, "scratch", os.environ["FN_LIB"]); print("library:", _lib.LIB_PATH)
 from music_fader_nets_amd.hipops import HipOps
 dev = torch.device("cuda:0"); ops = HipOps(dev)
 H = 512
