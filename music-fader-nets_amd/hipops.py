@@ -9,7 +9,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib
+from . import _lib, arith
 
 
 def _p(t):
@@ -54,7 +54,7 @@ class HipOps:
         self._ws = {}
         self._retired = []
         self.cell_variant = 0     # FnGruCell.variant (tuning / tests)
-        self.dw_x6 = False        # arithmetic of the deep products (set by the model: arith.py): True = exact bf16 triple splits on the bf16 MFMA (FN_GEMM_BF16X6, FnGruFwd.variant bit 14), False = fp32 MFMA
+        self.dw_x6 = arith.default() == arith.BF16X6        # arithmetic of the deep products (the package default; a model sets its own choice: arith.py): True = exact bf16 triple splits on the bf16 MFMA (FN_GEMM_BF16X6, FnGruFwd.variant bit 14), False = fp32 MFMA
         self.bwd_x6 = True        # with dw_x6: the backward scans on the bf16 x 6 kernel too (False: fp32 MFMA backward scans; A/B measurements, tests)
         self.variant = 0          # FnGruFwd.variant of every scan launch (tuning / tests only; results do not depend on it)
         self.lane = ""            # scratch namespace: kernels enqueued on different streams must not share workspaces

@@ -19,29 +19,24 @@ def golden_dir():
 
 
 def pytest_addoption(parser):
-    parser.addoption("--x6", action="store_true", default=False,
-                     help="run the gpu suite with the bf16 x 6 arithmetic as the package default (arith.set_default) and in every bare kernel table: "
-                          "evidence that every parity test holds with that arithmetic at the same tolerances (the end-to-end parity tests are "
-                          "parametrised over both arithmetics anyway)")
+    parser.addoption("--f32", action="store_true", default=False,
+                     help="run the suite with the fp32 MFMA as the package default arithmetic (arith.set_default) - models and bare kernel tables alike; "
+                          "the package default is bf16 x 6 since round 5.  The end-to-end parity tests are parametrised over both arithmetics anyway")
+    parser.addoption("--x6", action="store_true", default=False, help="the bf16 x 6 arithmetic as the package default (what it is anyway; kept from round 4)")
 
 
 @pytest.fixture(scope="session", autouse=True)
-def _x6_everywhere(request):
-    if not request.config.getoption("--x6"):
+def _default_arithmetic(request):
+    f32, x6 = request.config.getoption("--f32"), request.config.getoption("--x6")
+    if not (f32 or x6):
         yield
         return
+    assert not (f32 and x6), "--f32 and --x6 exclude each other"
     from mfn_import import load_package
     load_package()
-    from music_fader_nets_amd import arith, hipops
-    init = hipops.HipOps.__init__
-    prev = arith.set_default(arith.BF16X6)          # models follow the package default; bare HipOps tables (the `ops` fixtures) are patched below
-
-    def patched(self, *a, **k):
-        init(self, *a, **k)
-        self.dw_x6 = True
-    hipops.HipOps.__init__ = patched
+    from music_fader_nets_amd import arith
+    prev = arith.set_default(arith.F32 if f32 else arith.BF16X6)      # models AND bare HipOps tables (the `ops` fixtures) start from the package default
     try:
         yield
     finally:
-        hipops.HipOps.__init__ = init
         arith.set_default(prev)

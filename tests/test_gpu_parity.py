@@ -42,6 +42,12 @@ def g(t):
     return None if t is None else t.to(DEV)
 
 
+def _x6_default():
+    """what a kernel table starts with (tests that switch ops.dw_x6 put it back): the package default arithmetic"""
+    from music_fader_nets_amd import arith
+    return arith.default() == arith.BF16X6
+
+
 def close(a, b, tol=2e-5, msg=""):
     e = relerr(a.detach().cpu().numpy() if torch.is_tensor(a) else a, b.detach().cpu().numpy() if torch.is_tensor(b) else b)
     assert e < tol, "%s rel err %.3e" % (msg, e)
@@ -156,7 +162,7 @@ def test_gemm_tn_column_view_at_the_end_of_its_allocation(ops):
         close(dW[:, :H], want.float(), 2e-5)
         close(dW[:, H:], want.float(), 2e-5)
         assert bool((canary == 7.0).all())
-    ops.dw_x6 = False
+    ops.dw_x6 = _x6_default()
 
 
 def test_gemm_is_transpose_detecting(ops):
@@ -370,7 +376,7 @@ def test_gemm_tn_bf16x6(ops, M, N, K, splitk):
         C = torch.full((M, N), float("nan"), device=DEV)
         ops.gemm(A, B, C, a_k=False, b_k=False, splitk=splitk)
         out[x6] = float((C.double() - ref).abs().max()) / scale
-    ops.dw_x6 = False
+    ops.dw_x6 = _x6_default()
     assert out[True] < 2e-6 and out[True] <= 2.0 * out[False] + 1e-9, out
     if M == 1536:                                          # the one-launch [dr' dz' | dn' r]^T h form (A2 second source)
         H = 512
@@ -383,7 +389,7 @@ def test_gemm_tn_bf16x6(ops, M, N, K, splitk):
             dW = torch.zeros(3 * H, H, device=DEV)
             ops.gru_dwhh(dgx, dghn, hp, dW, splitk=splitk)
             err[x6] = float((dW.double() - want).abs().max()) / sc
-        ops.dw_x6 = False
+        ops.dw_x6 = _x6_default()
         assert err[True] < 2e-6 and err[True] <= 2.0 * err[False] + 1e-9, err
 
 
@@ -482,14 +488,14 @@ def test_forward_scan_bf16x6(ops, n, B, T):
                     i = scans.index(d)
                     assert torch.equal(d["h_all"], got[i]) and torch.equal(d["gates"], got[len(scans) + i])      # chunked == one launch, bit for bit
         scans[0]["gates"] = None                               # not eligible (no saved gates): falls back to the default kernels, bit for bit
-        ops.dw_x6 = False
+        ops.dw_x6 = _x6_default()
         ops.gru_seq_fwd(scans); torch.cuda.synchronize()
         ref = [d["h_all"].clone() for d in scans]
         ops.dw_x6 = True
         ops.gru_seq_fwd(scans); torch.cuda.synchronize()
         assert all(torch.equal(a, d["h_all"]) for a, d in zip(ref, scans))
     finally:
-        ops.dw_x6, ops.variant = False, 0
+        ops.dw_x6, ops.variant = _x6_default(), 0
 
 
 @pytest.mark.parametrize("n,B,Ts", [(4, 256, (7, 7, 7, 7)), (4, 256, (2, 9, 5, 3)), (2, 256, (6, 4)), (3, 128, (5, 8, 3)), (2, 512, (4, 4))])
@@ -553,7 +559,7 @@ def test_backward_scan_bf16x6(ops, n, B, Ts):
                 assert float((a - b).abs().max()) <= 5e-5 * float(a.abs().max()), (i, k, float((a - b).abs().max()), float(a.abs().max()))
         assert differs                                     # the x6 kernel really ran
     finally:
-        ops.dw_x6, ops.variant = False, 0
+        ops.dw_x6, ops.variant = _x6_default(), 0
 
 
 @pytest.mark.parametrize("lo,hi", [(-100, 60), (-120, -90), (-30, 30)])
@@ -594,7 +600,7 @@ def test_bf16x6_adversarial_operands_vs_float64(ops, lo, hi, K, splitk):
             e = (C.double() - ref).abs() / scale
             err[x6], rms[x6] = float(e.max()), float((e * e).mean().sqrt())
     finally:
-        ops.dw_x6 = False
+        ops.dw_x6 = _x6_default()
     print("bf16x6 adversarial 2^%d..2^%d K=%d: max err / sum|a||b| fp32 %.3e x6 %.3e (x %.2f), rms fp32 %.3e x6 %.3e (x %.2f)"
           % (lo, hi, K, err[False], err[True], err[True] / err[False], rms[False], rms[True], rms[True] / rms[False]))
     # Measured (round 5, profiles/r05_bf16x6_adversarial.txt): the bf16 x 6 error is 1.0 - 1.45 x the fp32-MFMA kernel's in this setting (both are
