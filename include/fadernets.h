@@ -165,6 +165,8 @@ typedef struct FnGruFwd {
                               /* alternative wave tiling of the 64-row configuration.  Results never depend on it.               */
                               /* bit 9: sync_ws counters are ALREADY zero (the caller zero-fills a pool of regions once and gives  */
                               /* every launch its own region: saves one memset node per launch)                                  */
+                              /* bit 12 (tests): the workgroups of every row group are spread over all XCDs instead of sharing    */
+                              /* one (the default placement is speed only; tests/test_gpu_parity.py runs both and compares)       */
     void* err_ws;             /* optional: sticky error word outside sync_ws (>= 4 bytes, scans[0]'s is used); NULL = the last     */
                               /* 128 bytes of sync_ws                                                                            */
 } FnGruFwd;

@@ -77,10 +77,18 @@ struct PArgs {
     PScan s[FN_MAX_SCANS];
     int n, ngroups, H;
     int no_hand;          // tuning / tests: the compiler-scheduled K loop instead of kloop_asm.h
+    int spread;           // tests: deal the block ids so that every row group is spread over all XCDs (variant bit 12; see block_group)
     u32* sync;            // [ngroups * 32] arrival counters (one per 128-byte line), zero at launch
     u32* err;             // sticky error word
 };
 constexpr int FN_MAX_GROUPS = 64;
+
+// Which (row group, slice) a workgroup is.  Default: group = id mod groups - with 8 (or 16) groups every row group sits on ONE XCD (workgroups are
+// dealt to the XCDs round robin by id), its exchange slab then lives in that XCD's L2.  That is speed only: the hand-over protocol is agent-scope
+// (sc1 stores and loads, agent-scope counters).  spread (FnGruFwd / FnGruBwd.variant bit 12) deals consecutive ids to the slices of one group, so
+// that every group is spread over all XCDs: the test that correctness does not depend on the placement.
+FN_DEVINL int block_group(int ngroups, int spread) { return spread ? (int)blockIdx.x / ((int)gridDim.x / ngroups) : (int)blockIdx.x % ngroups; }
+FN_DEVINL int block_slice(int ngroups, int spread) { return spread ? (int)blockIdx.x % ((int)gridDim.x / ngroups) : (int)blockIdx.x / ngroups; }
 
 
 // waves = WM (row blocks of MT tiles) x WK (K split); rows per workgroup RPW = 16 * WM * MT
@@ -94,7 +102,7 @@ __global__ __launch_bounds__(NT) void gru_fwd_persist_kernel(const PArgs args) {
     float* red = smem + 3 * H * 16;                  // [WK][EM][3][RT]    accumulator exchange
     volatile int& dead = *reinterpret_cast<volatile int*>(red + WK * EM * 3 * RT);   // all LDS is dynamic (16-byte aligned base)
 
-    const int g = blockIdx.x % args.ngroups, slice = blockIdx.x / args.ngroups;
+    const int g = block_group(args.ngroups, args.spread), slice = block_slice(args.ngroups, args.spread);
     int si = 0;
 #pragma unroll
     for (int k = 1; k < FN_MAX_SCANS; ++k)
@@ -406,7 +414,7 @@ __global__ __launch_bounds__(NT) void gru_fwd_x6_kernel(const PArgs args) {
     float* red = smem + 3 * NB * 3 * 64 * 4;                                 // [4 waves][3][RT] one accumulator tile per wave
     volatile int& dead = *reinterpret_cast<volatile int*>(red + 4 * 3 * RT);
 
-    const int g = blockIdx.x % args.ngroups, slice = blockIdx.x / args.ngroups;
+    const int g = block_group(args.ngroups, args.spread), slice = block_slice(args.ngroups, args.spread);
     int si = 0;
 #pragma unroll
     for (int k = 1; k < FN_MAX_SCANS; ++k)
@@ -637,6 +645,7 @@ struct QArgs {
     QScan s[FN_MAX_SCANS];
     int n, ngroups, H;
     int no_hand;
+    int spread;           // as in PArgs
     u32* sync;
     u32* err;
 };
@@ -651,7 +660,7 @@ __global__ __launch_bounds__(NT) void gru_bwd_persist_kernel(const QArgs args) {
     float* red = smem + 3 * H * 16;                  // [2][WK][EM][RT]  (second plane: the hand-placed K loop's odd-k accumulators)
     volatile int& dead = *reinterpret_cast<volatile int*>(red + 2 * WK * EM * RT);
 
-    const int g = blockIdx.x % args.ngroups, slice = blockIdx.x / args.ngroups;
+    const int g = block_group(args.ngroups, args.spread), slice = block_slice(args.ngroups, args.spread);
     int si = 0;
 #pragma unroll
     for (int k = 1; k < FN_MAX_SCANS; ++k)
@@ -957,7 +966,7 @@ __global__ __launch_bounds__(NT) void gru_fwd_pp_kernel(const PArgs args) {
     // object it is reached through FLAT instructions, which count on vmcnt: the compiler then drains the ring in flight)
     const unsigned dead = lds_addr(red + WK * EM * 3 * RT);
 
-    const int g = blockIdx.x % args.ngroups, slice = blockIdx.x / args.ngroups;
+    const int g = block_group(args.ngroups, args.spread), slice = block_slice(args.ngroups, args.spread);
     int si = 0;
 #pragma unroll
     for (int k = 1; k < FN_MAX_SCANS; ++k)
@@ -1201,7 +1210,7 @@ __global__ __launch_bounds__(NT) void gru_fwd_x6pp_kernel(const PArgs args) {
     float* red = smem + 3 * NB * 3 * 64 * 4;         // [WK][WM][3][RT] accumulator exchange of the CURRENT half
     const unsigned dead = lds_addr(red + WK * WM * 3 * RT);
 
-    const int g = blockIdx.x % args.ngroups, slice = blockIdx.x / args.ngroups;
+    const int g = block_group(args.ngroups, args.spread), slice = block_slice(args.ngroups, args.spread);
     int si = 0;
 #pragma unroll
     for (int k = 1; k < FN_MAX_SCANS; ++k)
@@ -1441,7 +1450,7 @@ __global__ __launch_bounds__(NT) void gru_bwd_rs_kernel(const QArgs args) {
     float* red = smem + 3 * H * 16;                  // [2 halves][4 waves][TT][RT]
     const unsigned dead = lds_addr(red + 2 * 4 * TT * RT);
 
-    const int g = blockIdx.x % args.ngroups, slice = blockIdx.x / args.ngroups;
+    const int g = block_group(args.ngroups, args.spread), slice = block_slice(args.ngroups, args.spread);
     int si = 0;
 #pragma unroll
     for (int k = 1; k < FN_MAX_SCANS; ++k)
@@ -1677,7 +1686,7 @@ __global__ __launch_bounds__(NT) void gru_bwd_x6_kernel(const QArgs args) {
     float* red = smem + 4 * LB * 3 * 64 * 4;         // [4 waves][TT][RT] partial sums of the CURRENT half
     const unsigned dead = lds_addr(red + 4 * TT * RT);
 
-    const int g = blockIdx.x % args.ngroups, slice = blockIdx.x / args.ngroups;
+    const int g = block_group(args.ngroups, args.spread), slice = block_slice(args.ngroups, args.spread);
     int si = 0;
 #pragma unroll
     for (int k = 1; k < FN_MAX_SCANS; ++k)
@@ -2057,7 +2066,7 @@ int fn_gru_fwd_persist(const FnGruFwd* scans, int n_scans, hipStream_t st) {
         const int mt = x6_row_tiles(scans, n_scans, maxgroups);
         if (!mt) return FN_E_UNSUPPORTED;
         PArgs a;
-        a.n = n_scans; a.H = H; a.no_hand = 0;
+        a.n = n_scans; a.H = H; a.no_hand = 0; a.spread = (scans[0].variant & 0x1000) ? 1 : 0;
         a.sync = reinterpret_cast<u32*>(scans[0].sync_ws);
         int groups = 0;
         for (int s = 0; s < n_scans; ++s) {
@@ -2108,6 +2117,7 @@ int fn_gru_fwd_persist(const FnGruFwd* scans, int n_scans, hipStream_t st) {
     a.n = n_scans;
     a.H = H;
     a.no_hand = (scans[0].variant & 0x400) ? 1 : 0;
+    a.spread = (scans[0].variant & 0x1000) ? 1 : 0;
     a.sync = reinterpret_cast<u32*>(scans[0].sync_ws);
     int groups = 0;
     for (int s = 0; s < n_scans; ++s) {
@@ -2175,7 +2185,7 @@ int fn_gru_bwd_persist(const FnGruBwd* scans, int n_scans, hipStream_t st) {
         const int th = x6_bwd_tiles(scans, n_scans, cus);
         if (!th) return FN_E_UNSUPPORTED;
         QArgs a;
-        a.n = n_scans; a.H = H; a.no_hand = 0;
+        a.n = n_scans; a.H = H; a.no_hand = 0; a.spread = (scans[0].variant & 0x1000) ? 1 : 0;
         a.sync = reinterpret_cast<u32*>(scans[0].sync_ws);
         int groups = 0;
         for (int s = 0; s < n_scans; ++s) {
@@ -2213,7 +2223,7 @@ int fn_gru_bwd_persist(const FnGruBwd* scans, int n_scans, hipStream_t st) {
         const int th = (d64 && g64 > 8 && g64 <= 16 && g64 * 16 <= cus) ? 2 : (d32 && g32 > 8 && g32 <= 16 && g32 * 16 <= cus) ? 1 : 0;
         if (th) {
             QArgs a;
-            a.n = n_scans; a.H = H; a.no_hand = 0;
+            a.n = n_scans; a.H = H; a.no_hand = 0; a.spread = (scans[0].variant & 0x1000) ? 1 : 0;
             a.sync = reinterpret_cast<u32*>(scans[0].sync_ws);
             int groups = 0;
             for (int s = 0; s < n_scans; ++s) {
@@ -2253,6 +2263,7 @@ int fn_gru_bwd_persist(const FnGruBwd* scans, int n_scans, hipStream_t st) {
     a.n = n_scans;
     a.H = H;
     a.no_hand = (scans[0].variant & 0x400) ? 1 : 0;
+    a.spread = (scans[0].variant & 0x1000) ? 1 : 0;
     a.sync = reinterpret_cast<u32*>(scans[0].sync_ws);
     int groups = 0;
     for (int s = 0; s < n_scans; ++s) {

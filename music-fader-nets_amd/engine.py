@@ -61,6 +61,7 @@ class Engine:
         self.losses_on_side = True      # trainer: the small loss-term launches run on the side lane beside the decoder backward's first launches
         self.buf_ns = ""                # namespace of buf(): a second decoder pass (GLSR) must not overwrite the saved activations of the first
         self.serialize_lanes = False    # True: every lane runs on the caller's stream (per-kernel measurements: each kernel alone)
+        self.eager_safe_bwd = True      # decoder backward pipeline, eager launches beside a live aux lane: the 32-slice loops (see _bwd_global_decoder_scans)
         if hidden % 32 != 0:
             raise ValueError("hidden_dims must be a multiple of 32 (K chunks of the MFMA step kernels)")
         if n_component > 8:
@@ -562,6 +563,15 @@ class Engine:
         # gate gradients of chunk js[k] into layer 1's incoming state gradient: dhx0[chunk] = dgx2[chunk] W_ih2 (one GEMM)
         js = list(reversed(range(0, T, CH)))
         nch = len(js)
+        # EAGER launches beside a live aux lane take the 32-slice loops of round 3 (FnGruBwd.variant bit 13) instead of the register-stationary form:
+        # once in ~2500 eager steps one workgroup of a gru_bwd_rs_kernel<1> launch that runs beside the aux lane's projection GEMM came out with a
+        # perturbed 16 x 32 patch of one step (relative 3e-3; any arithmetic; round-4 code too), never in 13 000 replayed captured steps, never with
+        # the lanes serialised, never with these loops (12 000 steps each) - cause not found (profiles/r05_x6_suite_soak.txt lists what was excluded).
+        # Eager steps are bound by the host's ~2400 launches, not by these kernels; captured steps (the product path) keep the fast form.
+        bkw = {}
+        if (self.eager_safe_bwd and self.dev.type == "cuda" and not self.serialize_lanes and not torch.cuda.is_current_stream_capturing()
+                and hasattr(ops, "variant")):
+            bkw = {"variant": int(ops.variant) | 0x2000}
         for k in range(nch + 2):
             part = []
             if k < nch:
@@ -574,7 +584,7 @@ class Engine:
             if k >= nch and "r" in fch and k - nch < len(fch["r"]):
                 part.append(fch["r"][k - nch])
             if part:
-                ops.gru_seq_bwd(part, persistent=pd)
+                ops.gru_seq_bwd(part, persistent=pd, **bkw)
             if k < nch:
                 t0, t1 = js[k], min(T, js[k] + CH)
                 lane = "auxb%d" % (k & 1)

@@ -562,6 +562,55 @@ def test_backward_scan_bf16x6(ops, n, B, Ts):
         ops.dw_x6, ops.variant = _x6_default(), 0
 
 
+@pytest.mark.parametrize("x6", [False, True])
+@pytest.mark.parametrize("n,B,T", [(2, 256, 12), (4, 256, 9)])
+def test_scan_results_do_not_depend_on_the_xcd_placement(ops, n, B, T, x6):
+    """the weight-stationary scans deal their workgroups so that a row group (its exchange slab, its arrival counters) sits on ONE XCD - speed
+    only: with FnGruFwd / FnGruBwd.variant bit 12 the slices of every row group are spread over all 8 XCDs and every hand-over crosses
+    XCDs; forward states, saved gates, gate gradients and row sums must come out bit-identical (ping-pong forward on both arithmetics,
+    register-stationary backward with 32- and 64-row groups, the bf16 x 6 backward), the sync-error word clear"""
+    H = 512
+    torch.manual_seed(77 + n)
+    fwd, bwd = [], []
+    for s_ in range(n):
+        w = (torch.randn(3 * H, H, device=DEV) / (H ** 0.5)).contiguous()
+        wf = torch.zeros(ops.frag_floats(3 * H, H), device=DEV)
+        wf3 = torch.zeros(ops.frag_floats(3 * H, H) * 3 // 2, device=DEV)
+        wt = torch.zeros(ops.frag_floats(H, 3 * H), device=DEV)
+        wt3 = torch.zeros(ops.frag_floats(H, 3 * H) * 3 // 2, device=DEV)
+        ops.weight_images([("frag", w, wf), ("frag3", w, wf3), ("frag_t", w, wt), ("frag3_t", w, wt3)])
+        h0 = torch.randn(B, H, device=DEV) * 0.3
+        f = dict(B=B, T=T, H=H, w_hh_frag=wf, w_hh_frag3=wf3, b_hh=torch.randn(3 * H, device=DEV) * 0.1, b_ih=torch.randn(3 * H, device=DEV) * 0.1, h0=h0,
+                 gx_dense=torch.randn(T, B, 3 * H, device=DEV) * 0.5, h_all=torch.zeros(T, B, H, device=DEV), gates=torch.zeros(T, ops.gates_floats(B, H), device=DEV))
+        fwd.append(f)
+        bwd.append(dict(B=B, T=T, H=H, w_hh_t_frag=wt, w_hh_t_frag3=wt3, h0=h0, h_all=f["h_all"], gates=f["gates"], dh_last=torch.randn(B, H, device=DEV),
+                        dh_ext=torch.randn(T, B, H, device=DEV) * 0.5, dgx_all=torch.zeros(T, B, 3 * H, device=DEV), dghn_all=torch.zeros(T, B, H, device=DEV),
+                        dh0=torch.zeros(B, H, device=DEV), dgx_rowsum=torch.zeros(B, 3 * H, device=DEV), dghn_rowsum=torch.zeros(B, H, device=DEV),
+                        scratch=torch.zeros(B, H, device=DEV)))
+    fk, bk = ("h_all", "gates"), ("dgx_all", "dghn_all", "dh0", "dgx_rowsum", "dghn_rowsum")
+
+    def run(variant):
+        ops.dw_x6, ops.variant = x6, variant
+        for f in fwd:
+            f["h_all"].fill_(float("nan"))
+        ops.gru_seq_fwd(fwd)
+        out = [f[k].clone() for f in fwd for k in fk]
+        for b in bwd:
+            for k in bk:
+                b[k].zero_() if "rowsum" in k else b[k].fill_(float("nan"))
+        ops.gru_seq_bwd(bwd)
+        torch.cuda.synchronize()
+        return out + [b[k].clone() for b in bwd for k in bk]
+    try:
+        ref, spread = run(0), run(0x1000)
+        assert not ops.gru_sync_error()
+        for i, (a, b) in enumerate(zip(ref, spread)):
+            assert not torch.isnan(b).any(), i
+            assert torch.equal(a, b), i
+    finally:
+        ops.dw_x6, ops.variant = _x6_default(), 0
+
+
 @pytest.mark.parametrize("lo,hi", [(-100, 60), (-120, -90), (-30, 30)])
 @pytest.mark.parametrize("K,splitk", [(65536, 16), (4096, 4)])
 def test_bf16x6_adversarial_operands_vs_float64(ops, lo, hi, K, splitk):
