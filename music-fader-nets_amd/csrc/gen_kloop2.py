@@ -29,6 +29,7 @@ Pipeline unit = 16 K values of ONE row tile: 1 operand load (1 KB), NB weight-fr
 Register maps (a = AGPR):  acc a[0..nacc), ring[slot] a[nacc + 4 slot ..], wfrag[bs][n] a[w0 + 4 (NB bs + n) ..].  Scalars s84..s87,
 temporaries v200, v201 (backward).
 """
+import os
 import sys
 
 SB = 84          # s84:85 = running operand base, s86:87 = saved exec / scratch
@@ -133,6 +134,16 @@ class Gen:
         last = max(i for i, o in enumerate(self.vmops) if o == ("ring", unit_abs))
         n = len(self.vmops) - 1 - last
         assert n < 60, n
+        if os.environ.get("KLOOP2_RING0") == "1":        # experiment (round 5): every ring wait drains the counter
+            n = 0
+        if os.environ.get("KLOOP2_RING0_RANGE"):         # experiment: only the waits of units lo..hi (inside this wave's K range) drain it
+            lo, hi = (int(x) for x in os.environ["KLOOP2_RING0_RANGE"].split("-"))
+            if lo <= unit_abs <= hi:
+                n = 0
+        if os.environ.get("KLOOP2_NOSTORE") == "1":      # experiment (round 5): younger STORES are not assumed to stay behind the ring load (loads only)
+            n = sum(1 for o in self.vmops[last + 1:] if o[0] != "store")
+        if os.environ.get("KLOOP2_NOEXTRA") == "1":      # experiment (round 5): neither are the plain (non-sc1) loads of the epilogue operands
+            n = sum(1 for o in self.vmops[last + 1:] if o[0] != "extra")
         return "s_waitcnt vmcnt(%d)" % n
 
     def arrive_block(self):
@@ -140,6 +151,8 @@ class Gen:
         wave -> one arrival (arr: 0 = none due, 1 = due, 2 = due and this wave issues it)"""
         slab = [i for i, o in enumerate(self.vmops) if o == ("store", "slab")]
         n = (len(self.vmops) - 1 - max(slab)) if slab else (len(self.vmops) - self.n0)
+        if os.environ.get("KLOOP2_ARR0") == "1":         # experiment (round 5): the arrival waits for everything in flight
+            n = 0
         return ["s_cmp_eq_u32 %[arr], 0", "s_cbranch_scc1 .Lnoarr_%=", "s_waitcnt vmcnt(%d)" % n, "s_barrier",
                 "s_cmp_lt_u32 %[arr], 2", "s_cbranch_scc1 .Lnoarr_%=",
                 "s_mov_b64 s[%d:%d], exec" % (SB + 2, SB + 3), "s_mov_b64 exec, 1", "v_mov_b32 %[pv], 1",
@@ -186,18 +199,24 @@ class Gen:
             wnext = (not final) or k < RU - 1
             if path is None:
                 out.append(self.wait_unit(u))
+                if os.environ.get("KLOOP2_NOP"):             # experiment (round 5): wait states between the counted wait and the first MFMA that reads the ring slot
+                    out.append("s_nop %d" % (int(os.environ["KLOOP2_NOP"]) - 1))
             out.append("s_waitcnt lgkmcnt(0)")
             comp = [[] for _ in range(self.nmf)]
+            issued = []            # (MFMA slot, order inside the slot, what) of this unit's memory operations: self.vmops must list them in ISSUE order -
+            # an epilogue-operand load sits in an earlier slot than the store of the same unit, and the arrival's wait counts the operations BEHIND
+            # the last slab store (round 5: listed in append order, that wait of fn_rs_bwd_t1_main / fn_pp_bwd_k768_main was one too lenient - the
+            # last slab store could still be in flight when the arrival was posted)
             if refill:
                 imm = (k + RU - 1) * 1024 - self.s_rel
                 assert 0 <= imm <= 4095
                 for t_, ins_ in self.refill_ins((k - 1) % RU, imm):
                     comp[t_].append(ins_)
-                    self.vmops.append(("ring", u + RU - 1))
+                    issued.append((t_, len(issued), ("ring", u + RU - 1)))
             if final and k == 0:
                 # the last refill is out: the counter of the NEXT phase's half, looked at KC units later
                 comp[1].append("global_load_dword %[pv], %[pcnt], off sc1")
-                self.vmops.append(("poll", 0))
+                issued.append((1, len(issued), ("poll", 0)))
             if path == "R":
                 # ring of the next phase: slot s is free once unit u0 + s has been multiplied.  Unit KC + 1 requests slots 0 .. KC, every later one its predecessor's
                 slots = list(range(0, KC + 1)) if k == KC + 1 else [k - 1]
@@ -213,13 +232,13 @@ class Gen:
             if stores and path is None and not final:                 # one store of the previous epilogue per unit, the exchange slab first
                 kind, ins = stores.pop(0)
                 comp[t_store] += self.store_ins(ins)
-                self.vmops.append(("store", kind))
+                issued.append((t_store, len(issued), ("store", kind)))
             if wnext:
                 for n, t in enumerate(wslots):
                     comp[t].append(self.wread_at((k + 1) & 1, n, u + 1))
             if u in extra_units:
                 comp[t_extra].append(pending.pop(0))
-                self.vmops.append(("extra", 0))
+                issued.append((t_extra, len(issued), ("extra", 0)))
             tail = []
             if (not final) and k + 1 < RU:
                 tail += self.advance_to((k + 1 + RU - 1) * 1024)
@@ -235,6 +254,7 @@ class Gen:
                     if tail and tail[0].startswith("s_addc"):
                         out.append(tail.pop(0))
             out += tail
+            self.vmops += [e for _, _, e in sorted(issued)]
             if u == u_arr:
                 out += self.arrive_block()
             return out

@@ -33,8 +33,10 @@ AGPR map: W0[blk][piece] a[12 blk + 4 piece ..] (blk 0..11), W1[11][piece] a[144
 ext[j] a[228 + 4 j ..] (j = 0..3 saved gates r, z, n, hn; 4 previous state; 5 external gradient).
 VGPR temporaries: acc[m][ct] v[208 + 4 (2 m + ct) ..], wfrag[bs][piece] v[224 + 12 bs + 4 piece ..], v255 = offset of the second row tile.  Scalars s84..s87.
 """
+import os
 import sys
 
+NT = " nt" if os.environ.get("KLOOP4_NT") == "1" else ""      # experiment: streaming hint for read-once / write-once traffic
 SB = 84
 UB = 3072
 TILE = 48 * UB       # bytes of one row tile on the exchange slab
@@ -134,8 +136,8 @@ class GenX6B:
                     pre = ["v_add_u32 v%d, 0x%x, %%[so0]" % (VO2 - 1, 0xC000 * g)] if (g and pc == 0) else []
                     slabs.append(pre + ["global_store_dwordx2 %s, %%[t%d%d], %%[sbase] offset:%d sc1" % ("%[so0]" if g == 0 else "v%d" % (VO2 - 1), g, pc, pc * 1024)])
         ext_out = ["gt0", "gt1", "gt2", "gt3", "hp", "xt"]
-        ext_in = ["global_load_dwordx4 a[%d:%d], %%[ga], off offset:%d" % (EXT0 + 4 * q, EXT0 + 4 * q + 3, q * 1024) for q in range(4)]
-        ext_in += ["global_load_dwordx4 a[%d:%d], %%[ha], off" % (EXT0 + 16, EXT0 + 19), "global_load_dwordx4 a[%d:%d], %%[xa], off" % (EXT0 + 20, EXT0 + 23)]
+        ext_in = ["global_load_dwordx4 a[%d:%d], %%[ga], off offset:%d" % (EXT0 + 4 * q, EXT0 + 4 * q + 3, q * 1024) + NT for q in range(4)]
+        ext_in += ["global_load_dwordx4 a[%d:%d], %%[ha], off" % (EXT0 + 16, EXT0 + 19) + NT, "global_load_dwordx4 a[%d:%d], %%[xa], off" % (EXT0 + 20, EXT0 + 23) + NT]
         done_arr = False
         for u in range(units):
             blk, m = self.blk_m(u)
@@ -257,8 +259,8 @@ FN_DEVINL void %s(const void* xin_, unsigned vo) {
 
 
 def emit_ext(name):
-    L = ["global_load_dwordx4 a[%d:%d], %%[ga], off offset:%d" % (EXT0 + 4 * q, EXT0 + 4 * q + 3, q * 1024) for q in range(4)]
-    L += ["global_load_dwordx4 a[%d:%d], %%[ha], off" % (EXT0 + 16, EXT0 + 19), "global_load_dwordx4 a[%d:%d], %%[xa], off" % (EXT0 + 20, EXT0 + 23)]
+    L = ["global_load_dwordx4 a[%d:%d], %%[ga], off offset:%d" % (EXT0 + 4 * q, EXT0 + 4 * q + 3, q * 1024) + NT for q in range(4)]
+    L += ["global_load_dwordx4 a[%d:%d], %%[ha], off" % (EXT0 + 16, EXT0 + 19) + NT, "global_load_dwordx4 a[%d:%d], %%[xa], off" % (EXT0 + 20, EXT0 + 23) + NT]
     body = "\n".join('        "%s\\n\\t"' % l for l in L)
     clob = ", ".join('"a%d"' % i for i in range(EXT0, EXT0 + 24))
     return """
@@ -275,8 +277,8 @@ FN_DEVINL void %s(const float* ga, const float* ha, const float* xa) {
 
 
 def emit_out(name, masked):
-    L = ["global_store_dwordx4 %[sg], %[d0], off offset:-2048", "global_store_dwordx4 %[sg], %[d1], off",
-         "global_store_dwordx4 %[sg], %[d2], off offset:2048", "global_store_dwordx4 %[sn], %[d3], off"]
+    L = ["global_store_dwordx4 %[sg], %[d0], off offset:-2048" + NT, "global_store_dwordx4 %[sg], %[d1], off" + NT,
+         "global_store_dwordx4 %[sg], %[d2], off offset:2048" + NT, "global_store_dwordx4 %[sg], %[d3], off".replace("%[sg], %[d3]", "%[sn], %[d3]") + NT]
     if masked:
         L = ["s_mov_b64 s[%d:%d], exec" % (SB + 2, SB + 3), "s_mov_b64 exec, 0xffffffff"] + L + ["s_mov_b64 exec, s[%d:%d]" % (SB + 2, SB + 3)]
     body = "\n".join('        "%s\\n\\t"' % l for l in L)

@@ -1455,7 +1455,18 @@ __global__ __launch_bounds__(NT) void gru_bwd_rs_kernel(const QArgs args) {
 #pragma unroll
     for (int k = 1; k < FN_MAX_SCANS; ++k)
         if (k < args.n && g >= args.s[k].group0) si = k;
+#ifdef FN_PIN_ARGS
+    // experiment (round 5): every field of the scan descriptor read from the kernarg segment ONCE and pinned in SGPRs (the compiler otherwise re-loads
+    // them from the kernarg segment wherever it is short of SGPRs - 40 scalar loads inside the phase loop)
+    QScan S = args.s[si];
+    {
+        auto pin = [](auto& p) __attribute__((always_inline)) { asm volatile("" : "+s"(p)); };
+        pin(S.wt_frag); pin(S.h0); pin(S.h_all); pin(S.gates); pin(S.dh_last); pin(S.dh_ext); pin(S.dgx_all); pin(S.dghn_all); pin(S.dh0);
+        pin(S.rowsum); pin(S.rowsum_n); pin(S.xf); pin(S.B); pin(S.T); pin(S.group0);
+    }
+#else
     const QScan& S = args.s[si];
+#endif
     const int B = S.B, T = S.T;
     const int m0 = (g - S.group0) * (32 * TH), hh0 = slice * 32;
     const int nrt = B >> 4;

@@ -22,6 +22,10 @@ os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29633", RANK="0", WORLD_
 from helpers import make_model  # noqa: E402
 from mfn_import import load_package  # noqa: E402
 pkg = load_package()
+if os.environ.get("FN_LIB"):                     # A/B of library builds (scratch/r5_build_variant*.sh)
+    from music_fader_nets_amd import _lib
+    _lib.LIB_PATH = os.path.join(ROOT, "scratch", os.environ["FN_LIB"])
+    print("library:", _lib.LIB_PATH, flush=True)
 from music_fader_nets_amd import parallel  # noqa: E402
 from music_fader_nets_amd.synth import synth_batch  # noqa: E402
 
@@ -44,6 +48,8 @@ for rep in range(REPS):
         m.engine().serialize_lanes = True
     if os.environ.get("DIAG_VARIANT"):
         ops.variant = int(os.environ["DIAG_VARIANT"], 0)
+    if os.environ.get("DIAG_NOSAFE") == "1":       # the register-stationary backward in eager launches too (what Engine.eager_safe_bwd avoids)
+        m.engine().eager_safe_bwd = False
     if os.environ.get("DIAG_NOFILL") == "1":
         m.engine().fill_edges = False
     plain_finish = type(ctx).finish_buckets if ctx is not None else None

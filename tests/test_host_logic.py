@@ -333,3 +333,18 @@ def test_sibling_forward_has_autograd(kind):
     H, Z = int(g["dims"][0]), int(g["dims"][1])
     m = make_sibling(kind, H, Z, ops=FakeOps())
     check_sibling_autograd(pkg, kind, m, g, "cpu", tol_grad=2e-4)
+
+
+def test_generated_k_loops_wait_counts():
+    """the hand-counted `s_waitcnt vmcnt(n)` of the generated K-loop statements against the issue order of their memory operations (csrc/check_kloops.py):
+    no arrival may be posted while an exchange-slab store of the statement can still be in flight, no MFMA may read a register a load is still allowed
+    to be writing.  Round 5: the arrival wait of fn_rs_bwd_t1_main was one operation too lenient (a wrong 16 x 32 patch once in ~2500 eager steps)."""
+    import importlib.util
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "music-fader-nets_amd", "csrc")
+    spec = importlib.util.spec_from_file_location("check_kloops", os.path.join(csrc, "check_kloops.py"))
+    ck = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ck)
+    heads = [os.path.join(csrc, h) for h in ("kloop2_asm.h", "kloop3_asm.h", "kloop4_asm.h")]
+    for h in heads:
+        assert os.path.exists(h), "%s missing: run __graft_entry__.build()" % h
+    assert ck.main(heads) == 0
