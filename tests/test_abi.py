@@ -43,3 +43,10 @@ def test_argument_errors_without_gpu():
     assert lib.fn_colsum_multi((_lib.FnColsumJob * 1)(), 65, None) == -5
     assert lib.fn_occupy_cus(0, 1024, 10, None) == -2
     assert lib.fn_strerror(-7).startswith(b"librccl")
+
+
+def test_build_entry_checks_the_current_abi_version():
+    """__graft_entry__.build() must compare the library with _lib.ABI_VERSION, not with a literal (round 5: it still asked for 4 after the ABI went to 5)"""
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "__graft_entry__.py")).read()
+    assert "lib.fn_version() == _lib.ABI_VERSION" in src and not re.search(r"fn_version\(\) == \d", src)
