@@ -1442,6 +1442,9 @@ __global__ __launch_bounds__(NT) void gru_fwd_x6pp_kernel(const PArgs args) {
 // NOT bit-identical to the kernels above (another summation order over K).
 template <int TH>
 __global__ __launch_bounds__(NT) void gru_bwd_rs_kernel(const QArgs args) {
+#ifdef FN_WHOLE_RF
+    asm volatile("" ::: "v255", "a255");             // experiment (round 5): the kernel claims the whole register file - no wave of another kernel beside it on a SIMD
+#endif
     static_assert(TH == 1 || TH == 2, "row tiles per half: 32-row or 64-row groups");
     constexpr int TT = 2 * TH;                       // accumulator tiles per wave and half
     constexpr int H = 512, nk3 = 48, nslices = 16;
