@@ -286,7 +286,7 @@ class Gen:
         L += [".Ldone_%=:"]
         for n in range(self.NB):          # weight fragments of the next phase's unit 0 (the same slice for both halves)
             L.append(self.wread_at(0, n, 0))
-        L += ["s_nop 15"]
+        L += ["s_nop 15"] * int(os.environ.get("KLOOP2_ENDNOP", "1"))      # (experiment switch, round 5: more wait states in front of the accumulator hand-over)
         # accumulators -> LDS (padded MFMA C layout); an MFMA result needs 12 wait states before anything but an accumulating MFMA reads it
         L += self.acc_writes()
         L.append("s_waitcnt lgkmcnt(0)")
