@@ -56,7 +56,8 @@ def test_dropin_forward_and_autograd(small):
     got = dict(out=out, r_out=r_out, n_out=n_out, mu_r=dis_r.mean, sigma_r=dis_r.stddev, mu_n=dis_n.mean, sigma_n=dis_n.stddev,
                z_r=z_r, z_n=z_n, ll_r=ll_r, ll_n=ll_n, qy_r=qy_r, qy_n=qy_n)
     for k, v in got.items():
-        np.testing.assert_allclose(v.detach().numpy(), small["fw_" + k], rtol=2e-5, atol=2e-5, err_msg=k)
+        tol = 1e-4 if k.startswith("qy_") else 2e-5          # q(y|x) = softmax of differences of ~1e3 log-likelihoods: fp32-ill-conditioned (tests/helpers.py)
+        np.testing.assert_allclose(v.detach().numpy(), small["fw_" + k], rtol=tol, atol=tol, err_msg=k)
     assert np.array_equal(y_r.numpy(), small["fw_y_r"]) and np.array_equal(y_n.numpy(), small["fw_y_n"])
     # reference-style loss in torch on OUR outputs (what trainer_gmm.py would do after `from gmm_model import *`)
     sd = {k: p for k, p in m.named_parameters()}
