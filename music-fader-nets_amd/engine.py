@@ -568,10 +568,7 @@ class Engine:
         # perturbed 16 x 32 patch of one step (relative 3e-3; any arithmetic; round-4 code too), never in 13 000 replayed captured steps, never with
         # the lanes serialised, never with these loops (12 000 steps each) - cause not found (profiles/r05_x6_suite_soak.txt lists what was excluded).
         # Eager steps are bound by the host's ~2400 launches, not by these kernels; captured steps (the product path) keep the fast form.
-        bkw = {}
-        if (self.eager_safe_bwd and self.dev.type == "cuda" and not self.serialize_lanes and not torch.cuda.is_current_stream_capturing()
-                and hasattr(ops, "variant")):
-            bkw = {"variant": int(ops.variant) | 0x2000}
+        bkw = self._eager_bwd_kw()
         for k in range(nch + 2):
             part = []
             if k < nch:
@@ -594,6 +591,15 @@ class Engine:
                     if t0 == 0:
                         ops.axpy(1.0, carry["l2"][0], dhx0[0])          # hx1 was initialised with hx0[0]: dL/dh_init of layer 2
         return dict(dgx1=dgx1, dghn1=dghn1, dgx2=dgx2, dghn2=dghn2, rs2=rs2, rsn2=rsn2, drb_g=drb_g, rsn_g=rsn_g, dh0_g=carry["l1"][0])
+
+    def _eager_bwd_kw(self):
+        """extra arguments of ops.gru_seq_bwd for a launch that may run beside another lane's kernels: EAGER launches take the 32-slice loops
+        (FnGruBwd.variant bit 13, see _bwd_global_decoder_scans); captured launches and serialised lanes keep the default choice"""
+        ops = self.ops
+        if (self.eager_safe_bwd and self.dev.type == "cuda" and not self.serialize_lanes and not torch.cuda.is_current_stream_capturing()
+                and hasattr(ops, "variant")):
+            return {"variant": int(ops.variant) | 0x2000}
+        return {}
 
     def _bwd_global_decoder_params(self, G, S, gd, flush=True):
         """parameter gradients of the global decoder (linear_out_g, grucell_g_2, grucell_g, linear_init_global) from the gate gradients;
@@ -783,7 +789,7 @@ class Engine:
                                   scratch=self.buf("enc_scr_" + key, (B, H)), dgx_rowsum=encb[key]["rs"], dghn_rowsum=encb[key]["rsn"]))
         if before_scans is not None:
             before_scans()
-        ops.gru_seq_bwd(scans)        # 4 concurrent reverse scans, one weight-stationary launch
+        ops.gru_seq_bwd(scans, **self._eager_bwd_kw())        # 4 concurrent reverse scans, one weight-stationary launch (the side lane's GEMMs run beside it)
         enc_keys = [(e, "gru_%s." % e, key, sfx, rev) for e in ("r", "n") for key, sfx, rev in ((e, "_l0", 0), (e + "_reverse", "_l0_reverse", 1))]
         # one-hot columns of the four W_ih: token-segment sums of the gate gradients (ONE launch pair, the batch's token sort is shared)
         ops.embed_grad_sorted(S["sort"]["d"], [dict(dgx=encb[key]["dgx"], out=G[pfx + "weight_ih" + sfx], transposed=True, reverse=rev)
