@@ -66,9 +66,14 @@ const char* fn_strerror(int code);    /* static string for FN_E_* / hipError_t *
  * operand value cut EXACTLY into three bf16 pieces (x = hi + mid + lo) and six of the nine exact partial products accumulated in
  * fp32, smallest first (the three dropped ones are <= 2^-24 of |a b| and, with B's pieces rounded, zero-mean).  Against float64 the
  * result is as accurate as the fp32 MFMA chain (tests/test_gpu_parity.py::test_gemm_tn_bf16x6, ::test_bf16x6_adversarial_operands_vs_float64);
- * it is a different summation, so results differ from the fp32-MFMA kernel in the last bits.  Split-K ranges are whole 32-k blocks; a K
- * tail below 32 (unsplit products, the last range) runs on the fp32 MFMA. */
+ * it is a different summation, so results differ from the fp32-MFMA kernel in the last bits.  Split-K ranges are whole 32-k blocks; the
+ * rows of a K tail below 32 (unsplit products, the last range) are multiplied in a zero-padded block. */
 #define FN_GEMM_BF16X6 0x20000
+/* ... | FN_GEMM_X6_PERWAVE (only with FN_GEMM_BF16X6; tests / A-B measurements): the round-5 kernel in which every wavefront splits its own operands.
+ * The default bf16 x 6 kernel has producer wavefronts that split every operand value once per workgroup and consumer wavefronts that only multiply
+ * (gemm.hip: gemm_tn_x6w_kernel); both accumulate the same products in the same order, so on K ranges of whole 32-k blocks their results are
+ * bit-identical. */
+#define FN_GEMM_X6_PERWAVE 0x40000
 size_t fn_gemm_ws_bytes(int M, int N, int splitk);
 int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha,
                 const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc,

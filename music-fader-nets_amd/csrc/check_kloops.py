@@ -9,7 +9,9 @@ the statement's memory operations (vector memory operations retire in order on t
      ring request), in that order - for the bf16 x 6 backward followed by the `*_out` stores of the last epilogue; both paths behind the counter check are walked.
 
 Round 5: check 1 found fn_rs_bwd_t1_main and fn_pp_bwd_k768_main one operation too lenient (the generator listed a unit's operations in the order it
-appended them, not in the order of their MFMA slots) - the cause of a rare wrong 16 x 32 patch in eager training steps (profiles/r05_eager_nondeterminism.txt).
+appended them, not in the order of their MFMA slots).  A real defect, fixed in the generator - but NOT the cause of the rare wrong 16 x 32 patch of eager
+training steps that was being hunted then (the rate was unchanged with the fix: profiles/r05_eager_nondeterminism.txt; that one is handled by
+gru_bwd_rs_kernel claiming the whole register file, gru_persist.hip).
 
 usage: check_kloops.py kloop2_asm.h [...]     exit status 1 on a finding
 """

@@ -2,6 +2,8 @@
 // Replaces nn.Linear forward / backward of the reference (gmm_model.py:86,91,108,113,123,137 and their
 // autograd), see include/fadernets.h.
 #include <atomic>
+#include <type_traits>
+#include <utility>
 
 #include "common.h"
 #include "mma_core.h"
@@ -280,12 +282,14 @@ FN_DEVINL void gemm_tn_body(int M, int N, int K, float alpha, const float* __res
 
 // ---------------------------------------------------------------------------------------------------------
 // The same "TN" product with EXACT fp32 products on the bf16 MFMA (v_mfma_f32_16x16x32_bf16: 16 x the fp32 MFMA rate) - "bf16 x 6":
-//   every fp32 operand value is cut into three bf16 pieces, x = hi + mid + lo EXACTLY (truncation splits: hi = the top 16 bits of x,
-//   mid = the top 16 bits of x - hi, lo = the rest; each remainder is computed without rounding and the last one has <= 8 significant bits),
+//   every fp32 operand value is cut into three bf16 pieces, x = hi + mid + lo EXACTLY (B: rounded pieces, fn_rn16; A: truncated ones, hi = the top
+//   16 bits of x, mid = the top 16 bits of x - hi, lo = the rest; each remainder is computed without rounding and the last one has <= 8 significant bits),
 //   a b = sum_ij a_i b_j: nine partial products, each exact in the MFMA's fp32 accumulation.  The three smallest (lo x lo, lo x mid,
 //   mid x lo: <= 2^-24 |a b|, below the rounding of the fp32 sum itself) are dropped; the other six are accumulated smallest first.
 // Measured against float64 the result is as accurate as the fp32 MFMA chain (scratch/mfma_bf16x9.hip: max error 1.06e-7 vs 0.77e-7 of
-// sum |a||b| at K = 4096, 1.37e-7 vs 1.91e-7 at K = 65536).  OPT-IN (FN_GEMM_BF16X6): the default path multiplies on the fp32 MFMA.
+// sum |a||b| at K = 4096, 1.37e-7 vs 1.91e-7 at K = 65536).  Chosen with FN_GEMM_BF16X6 (the package's default arithmetic "bf16x6" sets it, arith.py).
+// THIS kernel (every wavefront splits its own operands) is the round-5 form, kept for A/B measurements and as the bit-identity reference of the
+// producer / consumer kernel below (FN_GEMM_X6_PERWAVE).
 // Layout: a 16x16x32 MFMA takes 8 consecutive k per lane, so lane (i, g) loads the float4 A[k0 + 8 g + j][m0 + 4 i ..] for j = 0..7 (the
 // same 256-byte runs as the fp32 kernel, 8 loads per operand and 32-k block), element a of those eight vectors = the 8 k values of row
 // 4 i + a of MFMA tile a; they are split in registers (5.5 VALU operations per value - what bounds this kernel: 1.38 x the fp32 rate
@@ -425,6 +429,292 @@ __global__ __launch_bounds__(NT) void gemm_tn_x6_kernel(int M, int N, int K, flo
                 for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(va, a), f4c(vb, b), acc[a][b], 0, 0, 0);
         }
     }
+    const int colb = n0 + 4 * li;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + 4 * (lg * 4 + r) + a;
+            if (row >= M) continue;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int col = colb + b;
+                if (col >= N) continue;
+                const float v = acc[a][b][r];
+                if (slabs) {
+                    slabs[((long)zk * M + row) * N + col] = v;
+                } else {
+                    float o = alpha * v;
+                    if (bias) o += bias[col];
+                    if (beta != 0.f) o += beta * C[(long)row * ldc + col];
+                    C[(long)row * ldc + col] = o;
+                }
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The bf16 x 6 "TN" product with PRODUCER and CONSUMER wavefronts (round 6).  gemm_tn_x6_kernel above is bound by its VALU splits: every wave cuts its
+// own 64 + 64 operand columns of a 32-k block into triples (~416 VALU instructions) beside 96 MFMAs, a wave's VALU work does not run in the shadow
+// of its own MFMAs, and the two waves that share an operand both split it.  Sharing the split through LDS with four waves that all consume, then all
+// split, then meet at a barrier was slower still (round 5, scratch/gemm_tn_x6_lds_shared_experiment.hip.txt): the phases run one after the other.
+// Here a workgroup is EIGHT waves, two per SIMD: waves 0-3 only multiply (64 x 64 outputs each of the 128 x 128 tile: 24 ds_read_b128 + 96 MFMAs per
+// block), waves 4-7 only produce (each loads one quarter of the block's operand values - 64 columns of A or of B x 32 k, 8 loads of 16 bytes per lane -
+// cuts them into triples and writes them to LDS in MFMA operand order: ~208 VALU + 12 ds_write_b128).  The matrix pipe and the VALU are separate
+// pipes of a SIMD: the producer's splits of block t + 1 run WHILE its SIMD neighbour multiplies block t.  Every operand value is split once per
+// workgroup (half the VALU work of the kernel above) and loaded once (half the vector-memory traffic of the CU).  LDS: [stage 2][set 4][tile 4]
+// [piece 3][64 lanes][8 bf16] = 96 KB, one workgroup per CU; ONE barrier per block (s_barrier behind lgkmcnt(0) only: the producers' global loads of
+// block t + 2 stay in flight across it).  Same products in the same order per accumulator as gemm_tn_x6_kernel (lo*hi, hi*lo, mid*mid, mid*hi,
+// hi*mid, hi*hi per 32 k; B pieces rounded, A pieces truncated): bit-identical results on K ranges of whole 32-k blocks; rows beyond the last row
+// of the matrix count as zeros (the kernel above runs them on the fp32 MFMA).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int X6W_NT = 512;
+// experiment switches of scratch/r6_build_gemm_variant.sh (never defined in the product build)
+#ifndef X6W_PRIO_P
+#define X6W_PRIO_P 0
+#endif
+#ifndef X6W_PRIO_C
+#define X6W_PRIO_C 0
+#endif
+#ifndef X6W_SWAP
+#define X6W_SWAP 0
+#endif
+constexpr int X6W_SET = 4 * 3 * 64;              // u32x4 vectors of one set (64 operand columns x 32 k as triples: 12 KB)
+constexpr int X6W_STAGE = 4 * X6W_SET;           // ... of one stage (48 KB)
+constexpr int X6W_STAGES = 3;
+// producers: every ds_write of the block has to be in LDS before the barrier; consumers: a bare s_barrier (their reads of the block the barrier
+// retires were consumed by MFMAs long before; the reads in flight belong to the NEXT block, whose stage nobody writes for two more blocks)
+FN_DEVINL void x6w_barrier_p() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+FN_DEVINL void x6w_barrier_c() {
+    asm volatile("s_barrier" ::: "memory");
+}
+
+// Producer wavefront of gemm_tn_x6w_kernel: operand columns [pcol, pcol + 4) of rows kbeg + 32 blk + 8 lg + j (j = 0..7) of P, block after block.
+// Loads are asm statements whose completion WE count (mma_core.h): 8 per block into register set blk % NS.  In trip t the loads of block t + NS + 1
+// are requested, vmcnt(8 (NS - 1)) then says "block t + 2 has landed" (NS - 1 blocks stay in flight: the loads are bound by the bytes a CU keeps in
+// flight against ~2 us of latency under load, not by any bandwidth - measured), block t + 2 is cut into LDS stage (t + 2) % 3, barrier.
+// The consumers multiply block t meanwhile and read block t + 1 ahead.
+#ifndef X6W_NS
+#define X6W_NS 3
+#endif
+template <int I>
+using x6w_ic = std::integral_constant<int, I>;
+template <int... I, class F>
+FN_DEVINL void x6w_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(x6w_ic<I>{}), ...); }
+template <int N, class F>
+FN_DEVINL void x6w_for(F&& f) { x6w_for_impl(std::make_integer_sequence<int, N>{}, f); }      // f(integral_constant<0>) .. f(integral_constant<N - 1>), unrolled
+template <bool RN>
+FN_DEVINL void x6w_produce(u32x4* __restrict__ lds, const float* __restrict__ P, long pld, long pcol, int ps, int lane, int kbeg, int kend, int nblk) {
+    constexpr int NS = X6W_NS;
+    const int lg = lane >> 4;
+    f32x4 fa[NS][8];
+    const bool partial = ((kend - kbeg) & 31) != 0;      // only the last block of the matrix can be
+    auto gload = [&](auto SET, int blk) __attribute__((always_inline)) {
+#ifndef X6W_EXP_NOLOAD
+        constexpr int set = decltype(SET)::value;
+        const long k0 = (long)kbeg + 32 * blk + 8 * lg;
+        if (partial && blk == nblk - 1) {                // rows beyond the matrix are read from its last row (and zeroed in cut)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fn_gld4_asm(fa[set][j], P + min(k0 + j, (long)kend - 1) * pld + pcol);
+        } else {
+            const float* p0 = P + k0 * pld + pcol;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fn_gld4_asm(fa[set][j], p0 + j * pld);
+        }
+#endif
+    };
+    auto cut = [&](auto SET, int blk, int stage) __attribute__((always_inline)) {      // block blk: register set blk % NS -> LDS stage blk % 3
+        constexpr int set = decltype(SET)::value;
+        if (partial && blk == nblk - 1) {
+            const long k0 = (long)kbeg + 32 * blk + 8 * lg;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (k0 + j >= kend) fa[set][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        u32x4* dst = lds + stage * X6W_STAGE + ps * X6W_SET + lane;
+#ifdef X6W_EXP_NOCUT
+        if (blk > 1) return;
+#endif
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            bf16x8 h, m, l;
+            fn_split8<RN>(fa[set], a, h, m, l);
+            dst[(a * 3 + 0) * 64] = __builtin_bit_cast(u32x4, h);
+            dst[(a * 3 + 1) * 64] = __builtin_bit_cast(u32x4, m);
+            dst[(a * 3 + 2) * 64] = __builtin_bit_cast(u32x4, l);
+        }
+    };
+    // prologue: blocks 0 and 1 cut, blocks 2 .. NS requested
+    x6w_for<NS>([&](auto I) __attribute__((always_inline)) {
+        if (decltype(I)::value < nblk) gload(I, decltype(I)::value);
+    });
+    fn_wait_vm<0>();
+    cut(x6w_ic<0>{}, 0, 0);
+    if (nblk > 1) cut(x6w_ic<1>{}, 1, 1);
+    if (nblk > NS) gload(x6w_ic<0>{}, NS);
+    x6w_barrier_p();
+    // trip t (t % NS == R): request block t + NS + 1 -> set (R + 1) % NS | block t + 2 has landed | cut it (set (R + 2) % NS, stage (t + 2) % 3) | barrier
+    int stage = 2;
+    auto trip = [&](auto R, int t) __attribute__((always_inline)) {
+        constexpr int r = decltype(R)::value;
+        if (t + NS + 1 < nblk) {
+            gload(x6w_ic<(r + 1) % NS>{}, t + NS + 1);
+            fn_wait_vm<8 * (NS - 1)>();
+            cut(x6w_ic<(r + 2) % NS>{}, t + 2, stage);
+        } else {                                         // the last trips: nothing left to request, no counting
+            fn_wait_vm<0>();
+            if (t + 2 < nblk) cut(x6w_ic<(r + 2) % NS>{}, t + 2, stage);
+        }
+        stage = stage == 2 ? 0 : stage + 1;
+        x6w_barrier_p();
+    };
+    int t = 0;
+#pragma unroll 1
+    for (; t + NS - 1 < nblk; t += NS) {
+        x6w_for<NS>([&](auto I) __attribute__((always_inline)) { trip(I, t + decltype(I)::value); });
+    }
+    x6w_for<NS - 1>([&](auto I) __attribute__((always_inline)) {
+        if (t + decltype(I)::value < nblk) trip(I, t + decltype(I)::value);
+    });
+#pragma unroll
+    for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fn_keep(fa[q][j]);
+}
+
+__global__ __launch_bounds__(X6W_NT) void gemm_tn_x6w_kernel(int M, int N, int K, float alpha, const float* __restrict__ A, long lda,
+                                                              const float* __restrict__ B, long ldb, float beta, float* __restrict__ C, long ldc,
+                                                              const float* __restrict__ bias, int ksplit_len, float* __restrict__ slabs,
+                                                              const float* __restrict__ A2, long lda2, int msplit) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 x6w_lds[];      // [3 stages][4 sets][4 tiles][3 pieces][64 lanes]
+    const int ntn = (N + 127) / 128, ntm = (M + 127) / 128;
+    int tile, zk;
+    if (gridDim.z == 1 && slabs != nullptr) {            // K ranges dealt to the XCDs (see gemm_tn_body)
+        const int S = (K + ksplit_len - 1) / ksplit_len, c = blockIdx.x & 7, q = blockIdx.x >> 3;
+        zk = c * (S >> 3) + q / (ntn * ntm);
+        tile = q % (ntn * ntm);
+    } else {
+        tile = fn_xcd_remap(blockIdx.x, ntn * ntm);
+        zk = blockIdx.z;
+    }
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mb = (tile / ntn) * 128, nb = (tile % ntn) * 128;          // the workgroup's output tile
+    const int li = lane & 15, lg = lane >> 4;
+    const int kbeg = zk * ksplit_len, kend = min(K, kbeg + ksplit_len);
+    const int nblk = (kend - kbeg + 31) >> 5;
+    if (nblk <= 0) return;                               // (the host never launches an empty K range)
+
+    if (X6W_SWAP ? wave < 4 : wave >= 4) {
+        if (X6W_PRIO_P) __builtin_amdgcn_s_setprio(X6W_PRIO_P);
+        // ---- producer: set ps = 64 operand columns (sets 0, 1: A columns mb + 64 ps; sets 2, 3: B columns nb + 64 (ps - 2)) ----
+        const int ps = wave & 3;
+        const bool pa = ps < 2;
+        const float* P = pa ? A : B;
+        long pld = pa ? lda : ldb;
+        // column offset of this lane's 16-byte loads, kept inside the columns the operand REALLY has (see gemm_tn_body)
+        const int pc0 = pa ? mb + 64 * ps : nb + 64 * (ps - 2);
+        long ncols = pa ? (long)M : (long)N, rel = pc0;
+        if (pa && A2 != nullptr) {
+            if (pc0 >= msplit) { P = A2; pld = lda2; ncols = (long)M - msplit; rel = pc0 - msplit; }
+            else ncols = msplit;
+        }
+        long pcol = min(rel + 4 * li, ((ncols - 1) >> 2) << 2);
+        if (rel >= ncols) pcol = ((ncols - 1) >> 2) << 2;                // a set entirely beyond the matrix: any legal column (never stored)
+        if (pa) x6w_produce<false>(x6w_lds, P, pld, pcol, ps, lane, kbeg, kend, nblk);
+        else x6w_produce<true>(x6w_lds, P, pld, pcol, ps, lane, kbeg, kend, nblk);
+        return;
+    }
+
+    // ---- consumer: wave (wm, wn) multiplies sets wm (A) and 2 + wn (B).  Operand registers: A triples of the current block and of the next one
+    //      (two banks, block parity), B triples of output columns 0, 1 (first half of a block) and 2, 3 (second half).  While the first half of
+    //      block t runs, B[2..3] of block t and A[0..1] of block t + 1 are read; during the second half A[2..3] and B[0..1] of block t + 1: no
+    //      LDS latency is ever exposed, and no read of block t is in flight at the barrier that hands its stage back to the producers ----
+    if (X6W_PRIO_C) __builtin_amdgcn_s_setprio(X6W_PRIO_C);
+    const int wm = (wave >> 1) & 1, wn = wave & 1;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 Af[2][4][3], Bf[4][3];
+    const u32x4* lA = x6w_lds + wm * X6W_SET + lane;
+    const u32x4* lB = x6w_lds + (2 + wn) * X6W_SET + lane;
+    auto rdA = [&](auto BANK, int stage, int a) __attribute__((always_inline)) {
+        constexpr int bank = decltype(BANK)::value;
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) Af[bank][a][pc] = __builtin_bit_cast(bf16x8, lA[stage * X6W_STAGE + (a * 3 + pc) * 64]);
+    };
+    auto rdB = [&](int stage, int b) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) Bf[b][pc] = __builtin_bit_cast(bf16x8, lB[stage * X6W_STAGE + (b * 3 + pc) * 64]);
+    };
+    // the six products of a 32-k block, smallest first (piece 0 = hi, 1 = mid, 2 = lo): lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    auto half = [&](auto BANK, auto B0) __attribute__((always_inline)) {      // 48 MFMAs: output columns b0, b0 + 1 of all four row tiles
+        constexpr int bank = decltype(BANK)::value, b0 = decltype(B0)::value;
+#ifdef X6W_EXP_NOMMA
+        return;
+#endif
+#pragma unroll
+        for (int ap = 0; ap < 2; ++ap)                   // row tiles 0, 1 first (their A triples were read half a block earlier than those of 2, 3)
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+#pragma unroll
+                for (int a = 2 * ap; a < 2 * ap + 2; ++a)
+#pragma unroll
+                    for (int b = b0; b < b0 + 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af[bank][a][PA[c]], Bf[b][PB[c]], acc[a][b], 0, 0, 0);
+    };
+    // block t (stage st), reading ahead in block t + 1 (stage st1).  The reads are unconditional - straight-line code, so that the compiler can
+    // spread them between the MFMAs (sched_group_barrier) and count its LDS waits exactly; behind the last block they fetch a stage nobody uses
+    auto step = [&](auto BANK, int st, int st1) __attribute__((always_inline)) {
+        constexpr int bank = decltype(BANK)::value;
+        const std::integral_constant<int, bank ^ 1> NB;
+        rdB(st, 2);
+        rdB(st, 3);
+        rdA(NB, st1, 0);
+        rdA(NB, st1, 1);
+        half(BANK, std::integral_constant<int, 0>{});
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {                   // 3 MFMAs : 1 read, the last 12 MFMAs of the half without (the reads land before the next half needs them)
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        rdB(st1, 0);
+        rdB(st1, 1);
+        rdA(NB, st1, 2);
+        rdA(NB, st1, 3);
+        half(BANK, std::integral_constant<int, 2>{});
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {                   // 3 MFMAs : 1 read, the last 12 MFMAs of the half without (the reads land before the next half needs them)
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        x6w_barrier_c();
+    };
+    const std::integral_constant<int, 0> K0;
+    const std::integral_constant<int, 1> K1;
+    x6w_barrier_c();                                     // stages 0 and 1 hold blocks 0 and 1
+    rdA(K0, 0, 0);                                       // (same order as the read-ahead of a step: the loop's wait counts hold for the first trip)
+    rdA(K0, 0, 1);
+    rdB(0, 0);
+    rdB(0, 1);
+    rdA(K0, 0, 2);
+    rdA(K0, 0, 3);
+    int st = 0;
+#pragma unroll 1
+    for (int t = 0; t < nblk; t += 2) {                  // one barrier per block, as many as the producers execute: 1 + nblk
+        const int s1 = st == 2 ? 0 : st + 1, s2 = s1 == 2 ? 0 : s1 + 1;
+        step(K0, st, s1);
+        if (t + 1 < nblk) step(K1, s1, s2);
+        st = s2;
+    }
+    const int m0 = mb + 64 * wm, n0 = nb + 64 * wn;
     const int colb = n0 + 4 * li;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -959,6 +1249,26 @@ static dim3 tn_grid(int tiles, int splitk) {
     return splitk > 1 && (splitk & 7) == 0 ? dim3(tiles * splitk, 1, 1) : dim3(tiles, 1, splitk > 1 ? splitk : 1);
 }
 
+// the bf16 x 6 weight-gradient product: producer / consumer kernel (512 threads, 96 KB of LDS), or the per-wave kernel of round 5 on request
+static int launch_tn_x6(bool perwave, int tiles, int splitk, hipStream_t st, int M, int N, int K, float alpha, const float* A, long lda, const float* B, long ldb,
+                        float beta, float* C, long ldc, const float* bias, int klen, float* slabs, const float* A2, long lda2, int msplit) {
+    if (perwave) {
+        hipLaunchKernelGGL(gemm_tn_x6_kernel, tn_grid(tiles, splitk), dim3(NT), 0, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, klen, slabs, A2, lda2, msplit);
+        return FN_OK;
+    }
+    const size_t lds = (size_t)X6W_STAGES * X6W_STAGE * 16;
+    static std::atomic<bool> attr_set[32];         // write-once per device; setting the attribute twice is harmless
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return FN_E_SHAPE;
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_x6w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set[dev].store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(gemm_tn_x6w_kernel, tn_grid(tiles, splitk), dim3(X6W_NT), lds, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, klen, slabs, A2, lda2, msplit);
+    return FN_OK;
+}
+
 size_t fn_gemm_ws_bytes(int M, int N, int splitk) { return splitk > 1 ? (size_t)splitk * M * N * sizeof(float) : 0; }
 
 int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb,
@@ -966,8 +1276,8 @@ int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha, co
     if (!A || !B || !C) return FN_E_NULL;
     if (M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return FN_E_SHAPE;
     const bool lean = (splitk & FN_GEMM_LEAN) != 0;
-    const bool x6 = (splitk & FN_GEMM_BF16X6) != 0;
-    splitk &= ~(FN_GEMM_LEAN | FN_GEMM_BF16X6);
+    const bool x6 = (splitk & FN_GEMM_BF16X6) != 0, x6_perwave = (splitk & FN_GEMM_X6_PERWAVE) != 0;
+    splitk &= ~(FN_GEMM_LEAN | FN_GEMM_BF16X6 | FN_GEMM_X6_PERWAVE);
     if (splitk > 1 && (!ws || ws_bytes < fn_gemm_ws_bytes(M, N, splitk))) return FN_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (!a_kmajor && !b_kmajor && (lda % 4) == 0 && (ldb % 4) == 0 && lda >= 4 && ldb >= 4 &&
@@ -981,8 +1291,14 @@ int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha, co
         }
         const int ntm = (M + 127) / 128, ntn = (N + 127) / 128;
         float* slabs = splitk > 1 ? ws : nullptr;
-        hipLaunchKernelGGL(x6 ? gemm_tn_x6_kernel : (lean ? gemm_tn_lean_kernel : gemm_tn_kernel), tn_grid(ntm * ntn, splitk), dim3(NT), 0, st, M, N, K, alpha, A,
-                           (long)lda, B, (long)ldb, beta, C, (long)ldc, bias, klen, slabs, (const float*)nullptr, 0L, 0);
+        if (x6) {
+            const int rc = launch_tn_x6(x6_perwave, ntm * ntn, splitk, st, M, N, K, alpha, A, (long)lda, B, (long)ldb, beta, C, (long)ldc, bias, klen, slabs,
+                                        (const float*)nullptr, 0L, 0);
+            if (rc != FN_OK) return rc;
+        } else {
+            hipLaunchKernelGGL(lean ? gemm_tn_lean_kernel : gemm_tn_kernel, tn_grid(ntm * ntn, splitk), dim3(NT), 0, st, M, N, K, alpha, A,
+                               (long)lda, B, (long)ldb, beta, C, (long)ldc, bias, klen, slabs, (const float*)nullptr, 0L, 0);
+        }
         FN_CHECK_LAUNCH();
         if (splitk > 1) {
             const long total = (long)M * N;
@@ -1030,13 +1346,14 @@ int fn_gru_dwhh_f32(const float* dgx, const float* dghn, const float* hprev, int
     if (!dgx || !dghn || !hprev || !dW) return FN_E_NULL;
     if (rows <= 0 || rows > 0x7fffffff || H <= 0) return FN_E_SHAPE;
     const bool lean = (splitk & FN_GEMM_LEAN) != 0;
-    const bool x6 = (splitk & FN_GEMM_BF16X6) != 0;
-    splitk &= ~(FN_GEMM_LEAN | FN_GEMM_BF16X6);
+    const bool x6 = (splitk & FN_GEMM_BF16X6) != 0, x6_perwave = (splitk & FN_GEMM_X6_PERWAVE) != 0;
+    const int xflags = splitk & (FN_GEMM_BF16X6 | FN_GEMM_X6_PERWAVE);
+    splitk &= ~(FN_GEMM_LEAN | FN_GEMM_BF16X6 | FN_GEMM_X6_PERWAVE);
     if (splitk > 1 && (!ws || ws_bytes < fn_gru_dwhh_ws_bytes(H, splitk))) return FN_E_WORKSPACE;
     const int M = 3 * H, N = H, K = (int)rows;
     const bool one_launch = (2 * H) % 128 == 0 && (H % 4) == 0 && (((((uintptr_t)dgx) | ((uintptr_t)dghn) | ((uintptr_t)hprev)) & 15) == 0);
     if (!one_launch) {          // two products: rows [0, 2H) from dgx, rows [2H, 3H) from dghn
-        const int fl = splitk | (x6 ? FN_GEMM_BF16X6 : 0);
+        const int fl = splitk | xflags;
         int rc = fn_gemm_f32(0, 0, 2 * H, N, K, 1.0f, dgx, 3 * H, hprev, H, beta, dW, H, nullptr, fl, ws, ws_bytes, stream);
         if (rc != FN_OK) return rc;
         return fn_gemm_f32(0, 0, H, N, K, 1.0f, dghn, H, hprev, H, beta, dW + (size_t)2 * H * H, H, nullptr, fl, ws, ws_bytes, stream);
@@ -1050,8 +1367,14 @@ int fn_gru_dwhh_f32(const float* dgx, const float* dghn, const float* hprev, int
     }
     const int ntm = (M + 127) / 128, ntn = (N + 127) / 128;
     float* slabs = splitk > 1 ? ws : nullptr;
-    hipLaunchKernelGGL(x6 ? gemm_tn_x6_kernel : (lean ? gemm_tn_lean_kernel : gemm_tn_kernel), tn_grid(ntm * ntn, splitk), dim3(NT), 0, st, M, N, K, 1.0f, dgx,
-                       (long)3 * H, hprev, (long)H, beta, dW, (long)H, (const float*)nullptr, klen, slabs, dghn, (long)H, 2 * H);
+    if (x6) {
+        const int rc = launch_tn_x6(x6_perwave, ntm * ntn, splitk, st, M, N, K, 1.0f, dgx, (long)3 * H, hprev, (long)H, beta, dW, (long)H, (const float*)nullptr, klen,
+                                    slabs, dghn, (long)H, 2 * H);
+        if (rc != FN_OK) return rc;
+    } else {
+        hipLaunchKernelGGL(lean ? gemm_tn_lean_kernel : gemm_tn_kernel, tn_grid(ntm * ntn, splitk), dim3(NT), 0, st, M, N, K, 1.0f, dgx,
+                           (long)3 * H, hprev, (long)H, beta, dW, (long)H, (const float*)nullptr, klen, slabs, dghn, (long)H, 2 * H);
+    }
     FN_CHECK_LAUNCH();
     if (splitk > 1) {
         const long total = (long)M * N;

@@ -32,6 +32,12 @@ temporaries v200, v201 (backward).
 import os
 import sys
 
+# Experiment switches (KLOOP2_* environment variables, used by scratch/ variant scripts only) change wait counts / hints of the generated statements: a
+# production build must not pick up a stray one.  They are honoured only when KLOOP_EXPERIMENT=1 is set with them; otherwise the generator refuses.
+_stray = sorted(k for k in os.environ if k.startswith("KLOOP2_"))
+if _stray and os.environ.get("KLOOP_EXPERIMENT") != "1":
+    sys.exit("gen_kloop2.py: experiment switches %s are set without KLOOP_EXPERIMENT=1 - refusing to generate a production header" % ", ".join(_stray))
+
 SB = 84          # s84:85 = running operand base, s86:87 = saved exec / scratch
 TV = 200         # v200, v201: address temporaries of the backward slab stores
 

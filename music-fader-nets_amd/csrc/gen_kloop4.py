@@ -36,6 +36,12 @@ VGPR temporaries: acc[m][ct] v[208 + 4 (2 m + ct) ..], wfrag[bs][piece] v[224 + 
 import os
 import sys
 
+# Experiment switches (KLOOP4_* environment variables, used by scratch/ variant scripts only) change wait counts / hints of the generated statements: a
+# production build must not pick up a stray one.  They are honoured only when KLOOP_EXPERIMENT=1 is set with them; otherwise the generator refuses.
+_stray = sorted(k for k in os.environ if k.startswith("KLOOP4_"))
+if _stray and os.environ.get("KLOOP_EXPERIMENT") != "1":
+    sys.exit("gen_kloop4.py: experiment switches %s are set without KLOOP_EXPERIMENT=1 - refusing to generate a production header" % ", ".join(_stray))
+
 NT = " nt" if os.environ.get("KLOOP4_NT") == "1" else ""      # experiment: streaming hint for read-once / write-once traffic
 SB = 84
 UB = 3072

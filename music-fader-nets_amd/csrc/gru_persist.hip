@@ -1442,9 +1442,12 @@ __global__ __launch_bounds__(NT) void gru_fwd_x6pp_kernel(const PArgs args) {
 // NOT bit-identical to the kernels above (another summation order over K).
 template <int TH>
 __global__ __launch_bounds__(NT) void gru_bwd_rs_kernel(const QArgs args) {
-#ifdef FN_WHOLE_RF
-    asm volatile("" ::: "v255", "a255");             // experiment (round 5): the kernel claims the whole register file - no wave of another kernel beside it on a SIMD
-#endif
+    // The kernel claims the WHOLE register file (512 registers per lane; it needs 372): no wave of another kernel can sit on a SIMD beside a scan
+    // wave.  With a co-resident wave (the <= 128-register projection GEMM of the aux lane) one workgroup of a <1> launch came out with a perturbed
+    // 16 x 32 patch about once in 2500 eager steps (profiles/r05_eager_nondeterminism.txt: cause not found, narrowed down to "a foreign wave on the
+    // same SIMD"; never seen with this claim: profiles/r06_whole_rf_soak.txt).  Cost: the co-running GEMM runs behind the scan instead of beside it,
+    // < 0.1 % of the step.
+    asm volatile("" ::: "v255", "a255");
     static_assert(TH == 1 || TH == 2, "row tiles per half: 32-row or 64-row groups");
     constexpr int TT = 2 * TH;                       // accumulator tiles per wave and half
     constexpr int H = 512, nk3 = 48, nslices = 16;

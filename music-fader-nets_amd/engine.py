@@ -61,7 +61,6 @@ class Engine:
         self.losses_on_side = True      # trainer: the small loss-term launches run on the side lane beside the decoder backward's first launches
         self.buf_ns = ""                # namespace of buf(): a second decoder pass (GLSR) must not overwrite the saved activations of the first
         self.serialize_lanes = False    # True: every lane runs on the caller's stream (per-kernel measurements: each kernel alone)
-        self.eager_safe_bwd = True      # decoder backward pipeline, eager launches beside a live aux lane: the 32-slice loops (see _bwd_global_decoder_scans)
         if hidden % 32 != 0:
             raise ValueError("hidden_dims must be a multiple of 32 (K chunks of the MFMA step kernels)")
         if n_component > 8:
@@ -563,12 +562,8 @@ class Engine:
         # gate gradients of chunk js[k] into layer 1's incoming state gradient: dhx0[chunk] = dgx2[chunk] W_ih2 (one GEMM)
         js = list(reversed(range(0, T, CH)))
         nch = len(js)
-        # EAGER launches beside a live aux lane take the 32-slice loops of round 3 (FnGruBwd.variant bit 13) instead of the register-stationary form:
-        # once in ~2500 eager steps one workgroup of a gru_bwd_rs_kernel<1> launch that runs beside the aux lane's projection GEMM came out with a
-        # perturbed 16 x 32 patch of one step (relative 3e-3; any arithmetic; round-4 code too), never in 13 000 replayed captured steps, never with
-        # the lanes serialised, never with these loops (12 000 steps each) - cause not found (profiles/r05_x6_suite_soak.txt lists what was excluded).
-        # Eager steps are bound by the host's ~2400 launches, not by these kernels; captured steps (the product path) keep the fast form.
-        bkw = self._eager_bwd_kw()
+        # (gru_bwd_rs_kernel claims the whole register file: the aux lane's projection GEMM runs in the gaps of these launches, never on a SIMD
+        # beside a scan wave - gru_persist.hip, profiles/r05_eager_nondeterminism.txt; eager and captured launches take the same kernel)
         for k in range(nch + 2):
             part = []
             if k < nch:
@@ -581,7 +576,7 @@ class Engine:
             if k >= nch and "r" in fch and k - nch < len(fch["r"]):
                 part.append(fch["r"][k - nch])
             if part:
-                ops.gru_seq_bwd(part, persistent=pd, **bkw)
+                ops.gru_seq_bwd(part, persistent=pd)
             if k < nch:
                 t0, t1 = js[k], min(T, js[k] + CH)
                 lane = "auxb%d" % (k & 1)
@@ -591,15 +586,6 @@ class Engine:
                     if t0 == 0:
                         ops.axpy(1.0, carry["l2"][0], dhx0[0])          # hx1 was initialised with hx0[0]: dL/dh_init of layer 2
         return dict(dgx1=dgx1, dghn1=dghn1, dgx2=dgx2, dghn2=dghn2, rs2=rs2, rsn2=rsn2, drb_g=drb_g, rsn_g=rsn_g, dh0_g=carry["l1"][0])
-
-    def _eager_bwd_kw(self):
-        """extra arguments of ops.gru_seq_bwd for a launch that may run beside another lane's kernels: EAGER launches take the 32-slice loops
-        (FnGruBwd.variant bit 13, see _bwd_global_decoder_scans); captured launches and serialised lanes keep the default choice"""
-        ops = self.ops
-        if (self.eager_safe_bwd and self.dev.type == "cuda" and not self.serialize_lanes and not torch.cuda.is_current_stream_capturing()
-                and hasattr(ops, "variant")):
-            return {"variant": int(ops.variant) | 0x2000}
-        return {}
 
     def _bwd_global_decoder_params(self, G, S, gd, flush=True):
         """parameter gradients of the global decoder (linear_out_g, grucell_g_2, grucell_g, linear_init_global) from the gate gradients;
@@ -789,7 +775,7 @@ class Engine:
                                   scratch=self.buf("enc_scr_" + key, (B, H)), dgx_rowsum=encb[key]["rs"], dghn_rowsum=encb[key]["rsn"]))
         if before_scans is not None:
             before_scans()
-        ops.gru_seq_bwd(scans, **self._eager_bwd_kw())        # 4 concurrent reverse scans, one weight-stationary launch (the side lane's GEMMs run beside it)
+        ops.gru_seq_bwd(scans)        # 4 concurrent reverse scans, one weight-stationary launch (the side lane's GEMMs run beside it)
         enc_keys = [(e, "gru_%s." % e, key, sfx, rev) for e in ("r", "n") for key, sfx, rev in ((e, "_l0", 0), (e + "_reverse", "_l0_reverse", 1))]
         # one-hot columns of the four W_ih: token-segment sums of the gate gradients (ONE launch pair, the batch's token sort is shared)
         ops.embed_grad_sorted(S["sort"]["d"], [dict(dgx=encb[key]["dgx"], out=G[pfx + "weight_ih" + sfx], transposed=True, reverse=rev)

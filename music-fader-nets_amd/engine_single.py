@@ -122,7 +122,7 @@ class SingleEncEngine(Engine):
             scans.append(dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t[key], w_hh_t_frag3=self.whh_t3.get(key), h0=None, h_all=enc["h_all"][key], gates=enc["gates"][key],
                               dh_last=dh, dgx_all=encb[key]["dgx"], dghn_all=encb[key]["dghn"], scratch=self.buf("enc_scr_" + key, (B, H)),
                               dgx_rowsum=encb[key]["rs"], dghn_rowsum=encb[key]["rsn"]))
-        ops.gru_seq_bwd(scans, **self._eager_bwd_kw())          # the side lane's parameter-gradient GEMMs run beside it
+        ops.gru_seq_bwd(scans)          # the side lane's parameter-gradient GEMMs run beside it
         keys = (("e", "_l0", 0), ("e_reverse", "_l0_reverse", 1))
         ops.embed_grad_sorted(S["sort"]["d"], [dict(dgx=encb[key]["dgx"], out=G[self.gru + "weight_ih" + sfx][:, :E_VOCAB], transposed=True,
                                                     reverse=rev) for key, sfx, rev in keys])

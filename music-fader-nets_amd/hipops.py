@@ -55,6 +55,7 @@ class HipOps:
         self._retired = []
         self.cell_variant = 0     # FnGruCell.variant (tuning / tests)
         self.dw_x6 = arith.default() == arith.BF16X6        # arithmetic of the deep products (the package default; a model sets its own choice: arith.py): True = exact bf16 triple splits on the bf16 MFMA (FN_GEMM_BF16X6, FnGruFwd.variant bit 14), False = fp32 MFMA
+        self.x6_perwave = False   # with dw_x6: the round-5 weight-gradient kernel in which every wavefront splits its own operands (FN_GEMM_X6_PERWAVE; A/B measurements, tests)
         self.bwd_x6 = True        # with dw_x6: the backward scans on the bf16 x 6 kernel too (False: fp32 MFMA backward scans; A/B measurements, tests)
         self.variant = 0          # FnGruFwd.variant of every scan launch (tuning / tests only; results do not depend on it)
         self.lane = ""            # scratch namespace: kernels enqueued on different streams must not share workspaces
@@ -90,6 +91,8 @@ class HipOps:
             wsb = self.lib.fn_gemm_ws_bytes(M, N, splitk & 0xffff)
             ws = self.workspace(wsb, "gemm")
         x6 = _lib.GEMM_BF16X6 if (self.dw_x6 and not a_k and not b_k and K >= 1024) else 0
+        if x6 and self.x6_perwave:
+            x6 |= _lib.GEMM_X6_PERWAVE
         _lib.check(self.lib.fn_gemm_f32(int(a_k), int(b_k), M, N, K, alpha, pa, lda, pb, ldb, beta, pc, ldc, _p(bias),
                                         splitk | (_lib.GEMM_LEAN if lean else 0) | x6,
                                         _p(ws), wsb, self.stream()), "fn_gemm_f32")
@@ -253,8 +256,8 @@ class HipOps:
         for i, (d, s) in enumerate(zip(arr, scans)):
             for k in ("w_hh_frag", "b_hh", "b_ih", "h0", "gx_dense", "gx_table", "gx_rowbias", "h_all", "gates", "h0_frag", "h_last_frag"):
                 _dense(s.get(k), name=k)
-            for k in ("h0_frag", "h_last_frag"):
-                if s.get(k) is not None and s[k].numel() < self.frag_floats(s["B"], s["H"]):
+            for k in ("h0_frag", "h_last_frag"):       # (the size the launch's arithmetic needs is checked in gru_seq_fwd, once x6 is decided)
+                if s.get(k) is not None and s[k].numel() * s[k].element_size() < self.frag_floats(s["B"], s["H"]) * 4:
                     raise RuntimeError("%s needs frag_floats(B, H) floats" % k)
             d.cu_budget = int(cu_budget)
             _dense(s.get("idx"), torch.int32, "idx")
@@ -288,6 +291,10 @@ class HipOps:
         if x6 and not persistent:
             raise RuntimeError("gru_seq_fwd: the bf16 x 6 scans are weight-stationary launches")
         for i, (d, s) in enumerate(zip(arr, scans)):
+            if x6:                               # hand-over images of a bf16 x 6 launch are triples: 6 bytes per value (an fp32-sized buffer would be overrun)
+                for k in ("h0_frag", "h_last_frag"):
+                    if s.get(k) is not None and s[k].numel() * s[k].element_size() < self.frag_floats(s["B"], s["H"]) * 6:
+                        raise RuntimeError("%s of a bf16 x 6 launch needs 3/2 * frag_floats(B, H) floats (bf16 triples)" % k)
             d.frag_ws = _p(self._frag_ws("fragf", i, 3 * self.frag_floats(s["B"], s["H"])))      # 2 slabs of fp32 fragments, or 2 of bf16 triples (x6)
             d.sync_ws, d.err_ws, d.variant = (_p(sync[0]), _p(sync[1]), int(variant) | sync[2]) if persistent else (None, None, int(variant))
             if x6:
@@ -379,14 +386,23 @@ class HipOps:
         arr = self._bwd_descriptors(scans, cu_budget)
         variant = self.variant if variant is None else variant
         sync = self._sync_region() if persistent else None
-        if x6 is None:
+        auto = x6 is None
+        if auto:
             x6 = persistent and self.gru_bwd_x6_ok(scans, cu_budget)
         for i, (d, s) in enumerate(zip(arr, scans)):
             d.frag_ws = _p(self._frag_ws("fragb", i, 3 * self.frag_floats(s["B"], 3 * s["H"])))      # 2 slabs of fp32 fragments, or 2 of bf16 triples (x6)
             d.sync_ws, d.err_ws, d.variant = (_p(sync[0]), _p(sync[1]), int(variant) | sync[2]) if persistent else (None, None, int(variant))
             if x6:
                 d.w_hh_t_frag, d.variant = _p(s["w_hh_t_frag3"]), d.variant | 0x4000
-        _lib.check(self.lib.fn_gru_seq_bwd(arr, len(scans), self.stream()), "fn_gru_seq_bwd (bf16 x 6)" if x6 else "fn_gru_seq_bwd")
+        rc = self.lib.fn_gru_seq_bwd(arr, len(scans), self.stream())
+        if rc == _lib.FN_E_UNSUPPORTED and x6 and auto:
+            # the shape predicate said yes, a launch-time check (alignment, occupancy) said no: nothing was launched, and a backward launch hands only
+            # fp32 tensors on - the fp32 kernels take it (a FORCED x6=True still raises)
+            for d, s in zip(arr, scans):
+                d.w_hh_t_frag, d.variant = _p(s["w_hh_t_frag"]), d.variant & ~0x4000
+            x6 = False
+            rc = self.lib.fn_gru_seq_bwd(arr, len(scans), self.stream())
+        _lib.check(rc, "fn_gru_seq_bwd (bf16 x 6)" if x6 else "fn_gru_seq_bwd")
 
     def gru_dwhh(self, dgx, dghn, hprev, dW, beta=0.0, splitk=1, lean=False):
         """dW [3H][H] = beta*dW + [dgx[:, :2H] | dghn]^T hprev  (dgx [rows][3H], dghn / hprev [rows][H])."""
@@ -398,6 +414,8 @@ class HipOps:
         wsb = int(self.lib.fn_gru_dwhh_ws_bytes(H, splitk))
         ws = self.workspace(wsb, "gemm") if wsb else None
         x6 = _lib.GEMM_BF16X6 if (self.dw_x6 and rows >= 1024) else 0
+        if x6 and self.x6_perwave:
+            x6 |= _lib.GEMM_X6_PERWAVE
         _lib.check(self.lib.fn_gru_dwhh_f32(_p(dgx), _p(dghn), _p(hprev), rows, H, beta, _p(dW), splitk | (_lib.GEMM_LEAN if lean else 0) | x6,
                                             _p(ws), wsb, self.stream()), "fn_gru_dwhh_f32")
 

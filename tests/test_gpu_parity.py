@@ -393,6 +393,67 @@ def test_gemm_tn_bf16x6(ops, M, N, K, splitk):
         assert err[True] < 2e-6 and err[True] <= 2.0 * err[False] + 1e-9, err
 
 
+@pytest.mark.parametrize("M,N,K,splitk", [(1536, 512, 1024, 32), (1536, 512, 2048, 32), (342, 512, 3072, 32), (256, 384, 4096, 32), (130, 70, 5120, 32),
+                                          (1536, 512, 65280, 16), (342, 512, 65536, 42), (128, 128, 1024, 1), (200, 130, 1031, 1), (1536, 512, 4100, 16),
+                                          (64, 48, 1056, 3)])
+def test_gemm_tn_x6_producer_consumer_vs_per_wave_kernel(ops, M, N, K, splitk):
+    """gemm_tn_x6w_kernel (round 6: producer wavefronts split every operand value once per workgroup, consumer wavefronts only multiply) against the
+    round-5 kernel in which every wavefront splits its own operands (FN_GEMM_X6_PERWAVE): the same products in the same order per accumulator, so
+    on K ranges of whole 32-k blocks the results are BIT-IDENTICAL (1 .. 5 blocks per range: every prologue / tail path of the two loops; ragged
+    tiles; 1-D and 3-D grids; the two-source form of fn_gru_dwhh_f32); with a K tail (which the per-wave kernel runs on the fp32 MFMA and this one
+    as a zero-padded block) both stay within the fp32 kernel's error bound against float64.  beta / bias / alpha on an unsplit product."""
+    torch.manual_seed(M * 7 + K)
+    A = torch.randn(K, M, device=DEV)
+    B = torch.randn(K, N, device=DEV) * 0.3
+    ref = (A.double().t() @ B.double())
+    scale = float((A.double().abs().t() @ B.double().abs()).max())
+    out = {}
+    ops.dw_x6 = True
+    try:
+        for pw in (True, False):
+            ops.x6_perwave = pw
+            C = torch.full((M, N), float("nan"), device=DEV)
+            ops.gemm(A, B, C, a_k=False, b_k=False, splitk=splitk)
+            out[pw] = C
+        klen = K if splitk <= 1 else ((K + splitk - 1) // splitk + 31) // 32 * 32
+        whole = all(min(K, k0 + klen) % 32 == 0 for k0 in range(0, K, klen))
+        for pw in (True, False):
+            assert float((out[pw].double() - ref).abs().max()) / scale < 2e-6, pw
+        if whole:
+            assert torch.equal(out[True], out[False])
+        if splitk <= 1:                                   # epilogue without slabs: alpha, beta, bias
+            bias = torch.randn(N, device=DEV)
+            C0 = torch.randn(M, N, device=DEV)
+            res = {}
+            for pw in (True, False):
+                ops.x6_perwave = pw
+                C = C0.clone()
+                ops.gemm(A, B, C, a_k=False, b_k=False, alpha=0.5, beta=2.0, bias=bias)
+                res[pw] = C
+            want = 0.5 * ref + 2.0 * C0.double() + bias.double()
+            for pw in (True, False):
+                assert float((res[pw].double() - want).abs().max()) / (scale + float(C0.abs().max()) * 2) < 2e-6, pw
+            if whole:
+                assert torch.equal(res[True], res[False])
+        if M == 1536:                                     # the one-launch [dr' dz' | dn' r]^T h form (A2 second source)
+            H = 512
+            dgx, dghn, hp = A, torch.randn(K, H, device=DEV), B
+            dws = {}
+            for pw in (True, False):
+                ops.x6_perwave = pw
+                dW = torch.zeros(3 * H, H, device=DEV)
+                ops.gru_dwhh(dgx, dghn, hp, dW, splitk=splitk)
+                dws[pw] = dW
+            want = torch.cat([dgx[:, :2 * H], dghn], 1).double().t() @ hp.double()
+            sc = float((torch.cat([dgx[:, :2 * H], dghn], 1).double().abs().t() @ hp.double().abs()).max())
+            for pw in (True, False):
+                assert float((dws[pw].double() - want).abs().max()) / sc < 2e-6, pw
+            if whole:
+                assert torch.equal(dws[True], dws[False])
+    finally:
+        ops.dw_x6, ops.x6_perwave = _x6_default(), False
+
+
 @pytest.mark.parametrize("n,B,T", [(4, 256, 14), (2, 256, 9), (1, 128, 6), (3, 64, 5)])
 def test_forward_scan_bf16x6(ops, n, B, T):
     """the opt-in forward scan with exact split products on the bf16 MFMA (FnGruFwd.variant bit 14: weights and exchanged state as bf16 triples,

@@ -339,7 +339,8 @@ def test_sibling_forward_has_autograd(kind):
 def test_generated_k_loops_wait_counts():
     """the hand-counted `s_waitcnt vmcnt(n)` of the generated K-loop statements against the issue order of their memory operations (csrc/check_kloops.py):
     no arrival may be posted while an exchange-slab store of the statement can still be in flight, no MFMA may read a register a load is still allowed
-    to be writing.  Round 5: the arrival wait of fn_rs_bwd_t1_main was one operation too lenient (a wrong 16 x 32 patch once in ~2500 eager steps)."""
+    to be writing.  Round 5: the arrival wait of fn_rs_bwd_t1_main was one operation too lenient - a real defect, unrelated to the rare eager-step
+    nondeterminism of profiles/r05_eager_nondeterminism.txt (its rate did not change with the fix).  Also: the committed headers equal a clean regeneration."""
     import importlib.util
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "music-fader-nets_amd", "csrc")
     spec = importlib.util.spec_from_file_location("check_kloops", os.path.join(csrc, "check_kloops.py"))
@@ -349,3 +350,17 @@ def test_generated_k_loops_wait_counts():
     for h in heads:
         assert os.path.exists(h), "%s missing: run __graft_entry__.build()" % h
     assert ck.main(heads) == 0
+    # the headers the library was built from are what the generators produce in a clean environment (no stray experiment switch: ADVICE r5)
+    import subprocess
+    import sys
+    import tempfile
+    env = {k: v for k, v in os.environ.items() if not k.startswith("KLOOP")}
+    with tempfile.TemporaryDirectory() as td:
+        for gen, head in (("gen_kloop.py", "kloop_asm.h"), ("gen_kloop2.py", "kloop2_asm.h"), ("gen_kloop3.py", "kloop3_asm.h"), ("gen_kloop4.py", "kloop4_asm.h")):
+            out = os.path.join(td, head)
+            subprocess.run([sys.executable, os.path.join(csrc, gen), out], check=True, env=env, cwd=csrc)
+            assert open(out).read() == open(os.path.join(csrc, head)).read(), "%s differs from a clean regeneration by %s" % (head, gen)
+        # and a stray switch is refused
+        r = subprocess.run([sys.executable, os.path.join(csrc, "gen_kloop2.py"), os.path.join(td, "x.h")], env=dict(env, KLOOP2_ARR0="1"), cwd=csrc,
+                           capture_output=True)
+        assert r.returncode != 0 and not os.path.exists(os.path.join(td, "x.h"))
