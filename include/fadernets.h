@@ -74,6 +74,11 @@ const char* fn_strerror(int code);    /* static string for FN_E_* / hipError_t *
  * (gemm.hip: gemm_tn_x6w_kernel); both accumulate the same products in the same order, so on K ranges of whole 32-k blocks their results are
  * bit-identical. */
 #define FN_GEMM_X6_PERWAVE 0x40000
+/* ... | FN_GEMM_X6_WIDE (only with FN_GEMM_BF16X6): 128 x 256 output tiles per workgroup (gemm.hip: gemm_tn_x6v_kernel) instead of 128 x 128: a CU's
+ * operand loads, which bound the 128 x 128 kernel, drop from 21 to 16 bytes per MFMA clock.  The caller wants twice the K ranges it would use with
+ * 128 x 128 tiles (the same number of workgroups).  Same products in the same order per accumulator: bit-identical to the other two kernels on the
+ * same K ranges. */
+#define FN_GEMM_X6_WIDE 0x80000
 size_t fn_gemm_ws_bytes(int M, int N, int splitk);
 int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha,
                 const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc,

@@ -740,6 +740,329 @@ __global__ __launch_bounds__(X6W_NT) void gemm_tn_x6w_kernel(int M, int N, int K
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The producer / consumer bf16 x 6 product on 128 x 256 output tiles (round 6).  Measured on gemm_tn_x6w_kernel (profiles/r06_gemm_tn_x6_*.txt): its
+// consumers alone run at 0.88 of the MFMA peak and the producers' VALU work costs next to nothing beside them, but the producers' LOADS do not
+// arrive faster than ~14.5 bytes per clock and CU (25 M 128-byte requests per dW_hh product at ~400 cycles each against what a CU's L1 keeps in
+// flight: 419 us with the MFMAs switched off, whatever the prefetch depth) - a 128 x 128 tile needs 32 KB per 1536 MFMA cycles = 21 bytes per clock.
+// A 128 x 256 tile needs (128 + 256) x 32 x 4 = 48 KB per 3072 MFMA cycles = 16 bytes per clock.
+//   workgroup = 8 waves; LDS = [2 stages][6 sets: A columns mb + 64 s (s = 0, 1), B columns nb + 64 (s - 2) (s = 2..5)][4 tiles][3 pieces][64 lanes]
+//   [8 bf16] = 144 KB.  Producer wave p cuts set p (8 loads of 16 bytes per lane and block) and one k half of set 4 + (p >> 1) (4 loads: lane (i, lg)
+//   takes rows 8 (2 (p & 1) + (lg >> 1)) + 4 (lg & 1) + j of its column quad, two lanes fill one 16-byte operand slot with ds_write_b64).
+//   Consumer wave (wm, wn) = 64 rows x 128 columns: 4 x 8 accumulator tiles (128 registers), the A triples of its 4 row tiles resident (48
+//   registers), the B triples of one column tile per buffer, 4 buffers.  Column tiles 0..5 run "c-major" (24 MFMAs each, B[b + 2] read meanwhile);
+//   then every read of the stage has landed -> BARRIER (the producers arrive with the next block cut) -> column tiles 6, 7 run "a-major" and behind
+//   the last MFMA of a row tile its A triples of the NEXT block are read into the same registers, B[0], B[1] of the next block beside them: no LDS
+//   latency is exposed, one barrier per block, and neither side waits at it unless the other one is late.
+// Same products in the same order per accumulator as gemm_tn_x6_kernel: bit-identical on K ranges of whole 32-k blocks.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int X6V_STAGE = 6 * X6W_SET;           // u32x4 vectors per stage (72 KB)
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+// element e of four float4 vectors (4 consecutive k of one column) -> the three pieces as 4 bf16 each
+template <bool RN>
+FN_DEVINL void fn_split4(const f32x4 (&v)[4], int e, u32x2& h, u32x2& m, u32x2& l) {
+    float x[4], hi[4], r1[4], mi[4], r2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = v[j][e];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { hi[j] = RN ? fn_rn16(x[j]) : fn_top16(x[j]); r1[j] = x[j] - hi[j]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { mi[j] = RN ? fn_rn16(r1[j]) : fn_top16(r1[j]); r2[j] = r1[j] - mi[j]; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        h[j] = fn_pack_top16(hi[2 * j], hi[2 * j + 1]);
+        m[j] = fn_pack_top16(mi[2 * j], mi[2 * j + 1]);
+        l[j] = fn_pack_top16(r2[2 * j], r2[2 * j + 1]);
+    }
+}
+
+#ifndef X6V_NS
+#define X6V_NS 2
+#endif
+// producer wave: full set `fs` from (Pf, ldf, colf) [RNF = rounded pieces], k half `kh` of set `hs` from (Ph, ldh, colh) [always B: rounded]
+template <bool RNF>
+FN_DEVINL void x6v_produce(u32x4* __restrict__ lds, const float* __restrict__ Pf, long ldf, long colf, int fs, const float* __restrict__ Ph, long ldh,
+                           long colh, int hs, int kh, int lane, int kbeg, int kend, int nblk) {
+    constexpr int NS = X6V_NS;
+    const int lg = lane >> 4, li = lane & 15;
+    f32x4 fa[NS][8], fh[NS][4];
+    const bool partial = ((kend - kbeg) & 31) != 0;      // only the last block of the matrix can be
+    const int hrow = 8 * (2 * kh + (lg >> 1)) + 4 * (lg & 1);      // first row (inside a block) of this lane's four half-set rows
+    auto gload = [&](auto SET, int blk) __attribute__((always_inline)) {
+#ifndef X6W_EXP_NOLOAD
+        constexpr int set = decltype(SET)::value;
+        const long k0 = (long)kbeg + 32 * blk + 8 * lg, k1 = (long)kbeg + 32 * blk + hrow;
+        if (partial && blk == nblk - 1) {                // rows beyond the matrix are read from its last row (and zeroed in cut)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fn_gld4_asm(fa[set][j], Pf + min(k0 + j, (long)kend - 1) * ldf + colf);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fn_gld4_asm(fh[set][j], Ph + min(k1 + j, (long)kend - 1) * ldh + colh);
+        } else {
+#ifdef X6W_EXP_CONTIG
+            // timing experiment only (wrong data): the same bytes of the same tile, but every wave load = 1 KB of one row (B) or 2 x 512 B of two rows (A)
+            const long kb = (long)kbeg + 32 * blk;
+            if (fs < 2) {
+                const float* p0 = Pf + (kb + 16 * fs + (lane >> 5)) * ldf + (colf - 4 * li - 64 * fs) + 4 * (lane & 31);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) fn_gld4_asm(fa[set][j], p0 + 2 * j * ldf);
+            } else {
+                const float* p0 = Pf + (kb + 8 * (fs - 2)) * ldf + (colf - 4 * li - 64 * (fs - 2)) + 4 * lane;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) fn_gld4_asm(fa[set][j], p0 + j * ldf);
+            }
+            const float* p1 = Ph + (kb + 16 + 4 * (2 * (hs - 4) + kh)) * ldh + (colh - 4 * li - 128 - 64 * (hs - 4)) + 4 * lane;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fn_gld4_asm(fh[set][j], p1 + j * ldh);
+#else
+            const float* p0 = Pf + k0 * ldf + colf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fn_gld4_asm(fa[set][j], p0 + j * ldf);
+            const float* p1 = Ph + k1 * ldh + colh;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fn_gld4_asm(fh[set][j], p1 + j * ldh);
+#endif
+        }
+#endif
+    };
+    auto cut = [&](auto SET, int blk, int stage) __attribute__((always_inline)) {
+        constexpr int set = decltype(SET)::value;
+        if (partial && blk == nblk - 1) {
+            const long k0 = (long)kbeg + 32 * blk + 8 * lg, k1 = (long)kbeg + 32 * blk + hrow;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (k0 + j >= kend) fa[set][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (k1 + j >= kend) fh[set][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#ifdef X6W_EXP_NOCUT
+        if (blk > 0) return;
+#endif
+        u32x4* dst = lds + stage * X6V_STAGE + fs * X6W_SET + lane;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            bf16x8 h, m, l;
+            fn_split8<RNF>(fa[set], a, h, m, l);
+            dst[(a * 3 + 0) * 64] = __builtin_bit_cast(u32x4, h);
+            dst[(a * 3 + 1) * 64] = __builtin_bit_cast(u32x4, m);
+            dst[(a * 3 + 2) * 64] = __builtin_bit_cast(u32x4, l);
+        }
+        // half set: operand slot of MFMA lane (i = li, g = 2 kh + (lg >> 1)), its low or high 8 bytes (k 8 g + 4 (lg & 1) ..)
+        u32x2* dh = reinterpret_cast<u32x2*>(lds + stage * X6V_STAGE + hs * X6W_SET + li + 16 * (2 * kh + (lg >> 1))) + (lg & 1);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            u32x2 h, m, l;
+            fn_split4<true>(fh[set], a, h, m, l);
+            dh[((a * 3 + 0) * 64) * 2] = h;
+            dh[((a * 3 + 1) * 64) * 2] = m;
+            dh[((a * 3 + 2) * 64) * 2] = l;
+        }
+    };
+    // prologue: block 0 cut into stage 0, blocks 1 .. NS - 1 requested
+    x6w_for<NS>([&](auto I) __attribute__((always_inline)) {
+        if (decltype(I)::value < nblk) gload(I, decltype(I)::value);
+    });
+    fn_wait_vm<0>();
+    cut(x6w_ic<0>{}, 0, 0);
+    x6w_barrier_p();
+    // trip t (t % NS == R): request block t + NS -> set R | block t + 1 has landed | cut it (set (R + 1) % NS, stage (t + 1) & 1) | barrier
+    auto trip = [&](auto R, int t) __attribute__((always_inline)) {
+        constexpr int r = decltype(R)::value;
+        if (t + NS < nblk) {
+            gload(R, t + NS);
+            fn_wait_vm<12 * (NS - 1)>();
+            cut(x6w_ic<(r + 1) % NS>{}, t + 1, (t + 1) & 1);
+        } else {                                         // the last trips: nothing left to request, no counting
+            fn_wait_vm<0>();
+            if (t + 1 < nblk) cut(x6w_ic<(r + 1) % NS>{}, t + 1, (t + 1) & 1);
+        }
+        x6w_barrier_p();
+    };
+    int t = 0;
+#pragma unroll 1
+    for (; t + NS - 1 < nblk; t += NS) x6w_for<NS>([&](auto I) __attribute__((always_inline)) { trip(I, t + decltype(I)::value); });
+    x6w_for<NS - 1>([&](auto I) __attribute__((always_inline)) {
+        if (t + decltype(I)::value < nblk) trip(I, t + decltype(I)::value);
+    });
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fn_keep(fa[q][j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fn_keep(fh[q][j]);
+    }
+}
+
+__global__ __launch_bounds__(X6W_NT) void gemm_tn_x6v_kernel(int M, int N, int K, float alpha, const float* __restrict__ A, long lda,
+                                                              const float* __restrict__ B, long ldb, float beta, float* __restrict__ C, long ldc,
+                                                              const float* __restrict__ bias, int ksplit_len, float* __restrict__ slabs,
+                                                              const float* __restrict__ A2, long lda2, int msplit) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 x6v_lds[];      // [2 stages][6 sets][4 tiles][3 pieces][64 lanes]
+    const int ntn = (N + 255) / 256, ntm = (M + 127) / 128;
+    int tile, zk;
+    if (gridDim.z == 1 && slabs != nullptr) {            // K ranges dealt to the XCDs (see gemm_tn_body)
+        const int S = (K + ksplit_len - 1) / ksplit_len, c = blockIdx.x & 7, q = blockIdx.x >> 3;
+        zk = c * (S >> 3) + q / (ntn * ntm);
+        tile = q % (ntn * ntm);
+    } else {
+        tile = fn_xcd_remap(blockIdx.x, ntn * ntm);
+        zk = blockIdx.z;
+    }
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mb = (tile / ntn) * 128, nb = (tile % ntn) * 256;          // the workgroup's output tile
+    const int li = lane & 15, lg = lane >> 4;
+    const int kbeg = zk * ksplit_len, kend = min(K, kbeg + ksplit_len);
+    const int nblk = (kend - kbeg + 31) >> 5;
+    if (nblk <= 0) return;                               // (the host never launches an empty K range)
+
+    if (wave >= 4) {
+        // ---- producer p: set p (p < 2: A columns mb + 64 p; else B columns nb + 64 (p - 2)) and k half p & 1 of set 4 + (p >> 1) (B columns nb + 128 + 64 (p >> 1)) ----
+        const int p = wave & 3;
+        const bool pa = p < 2;
+        const float* P = pa ? A : B;
+        long pld = pa ? lda : ldb;
+        // column offsets of this lane's 16-byte loads, kept inside the columns the operand REALLY has (see gemm_tn_body)
+        const int pc0 = pa ? mb + 64 * p : nb + 64 * (p - 2);
+        long ncols = pa ? (long)M : (long)N, rel = pc0;
+        if (pa && A2 != nullptr) {
+            if (pc0 >= msplit) { P = A2; pld = lda2; ncols = (long)M - msplit; rel = pc0 - msplit; }
+            else ncols = msplit;
+        }
+        long pcol = min(rel + 4 * li, ((ncols - 1) >> 2) << 2);
+        if (rel >= ncols) pcol = ((ncols - 1) >> 2) << 2;                // a set entirely beyond the matrix: any legal column (never stored)
+        const long hrel = (long)nb + 128 + 64 * (p >> 1);
+        long hcol = min(hrel + 4 * li, (((long)N - 1) >> 2) << 2);
+        if (hrel >= N) hcol = (((long)N - 1) >> 2) << 2;
+        if (pa) x6v_produce<false>(x6v_lds, P, pld, pcol, p, B, ldb, hcol, 4 + (p >> 1), p & 1, lane, kbeg, kend, nblk);
+        else x6v_produce<true>(x6v_lds, P, pld, pcol, p, B, ldb, hcol, 4 + (p >> 1), p & 1, lane, kbeg, kend, nblk);
+        return;
+    }
+
+    // ---- consumer (wm, wn): rows mb + 64 wm (set wm), columns nb + 128 wn (sets 2 + 2 wn, 3 + 2 wn) ----
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 Af[4][3], Bf[4][3];
+    const u32x4* lA = x6v_lds + wm * X6W_SET + lane;
+    const u32x4* lB = x6v_lds + (2 + 2 * wn) * X6W_SET + lane;        // column tile b = tile b & 3 of set 2 + 2 wn + (b >> 2): (b * 3 + piece) * 64 vectors on
+    auto rdA = [&](int stage, int a) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) Af[a][pc] = __builtin_bit_cast(bf16x8, lA[stage * X6V_STAGE + (a * 3 + pc) * 64]);
+    };
+    auto rdB = [&](int stage, int b) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) Bf[b & 3][pc] = __builtin_bit_cast(bf16x8, lB[stage * X6V_STAGE + (b * 3 + pc) * 64]);
+    };
+    // the six products of a 32-k block, smallest first (piece 0 = hi, 1 = mid, 2 = lo): lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    x6w_barrier_p();                                     // stage 0 holds block 0
+    rdB(0, 0);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) rdA(0, a);
+    rdB(0, 1);
+#pragma unroll 1
+    for (int t = 0; t < nblk; ++t) {
+        const int st = t & 1, sn = st ^ 1;
+        // column tiles 0..5, c-major: 24 MFMAs each, the B triples of column tile b + 2 read meanwhile (sched_barrier: nothing migrates between the
+        // phases - left alone the compiler collects the reads of several phases in one place and waits for all of them)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            rdB(st, b + 2);
+#ifndef X6W_EXP_NOMMA
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af[a][PA[c]], Bf[b & 3][PB[c]], acc[a][b], 0, 0, 0);
+#endif
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // every read of this stage has landed; the producers arrive with the next block cut into the other stage
+        x6w_barrier_p();
+        // column tiles 6, 7, a-major; behind a row tile's last MFMA its A triples of the NEXT block are read, B[0], B[1] of the next block beside them
+        // (behind the last block: reads of a stage nobody uses)
+        auto joint = [&](auto AA) __attribute__((always_inline)) {
+            constexpr int a = decltype(AA)::value;
+#ifndef X6W_EXP_NOMMA
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+#pragma unroll
+                for (int b = 6; b < 8; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af[a][PA[c]], Bf[b & 3][PB[c]], acc[a][b], 0, 0, 0);
+#endif
+        };
+        rdB(sn, 0);
+        joint(x6w_ic<0>{});
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        rdA(sn, 0);
+        joint(x6w_ic<1>{});
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        rdA(sn, 1);
+        rdB(sn, 1);
+        joint(x6w_ic<2>{});
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        rdA(sn, 2);
+        joint(x6w_ic<3>{});
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        rdA(sn, 3);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const int m0 = mb + 64 * wm, n0 = nb + 128 * wn;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + 4 * (lg * 4 + r) + a;
+            if (row >= M) continue;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int col = n0 + 64 * (b >> 2) + 4 * li + (b & 3);
+                if (col >= N) continue;
+                const float v = acc[a][b][r];
+                if (slabs) {
+                    slabs[((long)zk * M + row) * N + col] = v;
+                } else {
+                    float o = alpha * v;
+                    if (bias) o += bias[col];
+                    if (beta != 0.f) o += beta * C[(long)row * ldc + col];
+                    C[(long)row * ldc + col] = o;
+                }
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // "NT" GEMM without LDS for the short-K products beside the decoder scans (layer-2 input projection gx2 = hx0 W_ih2^T and the input
 // gradient dhx0 = dgx2 W_ih2 through the transposed weight image): C[M][N] = alpha * sum_k A[m][k] B[n][k] (+ bias, + beta C), both
 // operands K-contiguous.  The LDS-staged kernel spends its 16 K tiles of a K = 512 product on prologue / barrier / epilogue (MFMA pipe
@@ -1250,22 +1573,30 @@ static dim3 tn_grid(int tiles, int splitk) {
 }
 
 // the bf16 x 6 weight-gradient product: producer / consumer kernel (512 threads, 96 KB of LDS), or the per-wave kernel of round 5 on request
-static int launch_tn_x6(bool perwave, int tiles, int splitk, hipStream_t st, int M, int N, int K, float alpha, const float* A, long lda, const float* B, long ldb,
+static int launch_tn_x6(int mode, int tiles, int splitk, hipStream_t st, int M, int N, int K, float alpha, const float* A, long lda, const float* B, long ldb,
                         float beta, float* C, long ldc, const float* bias, int klen, float* slabs, const float* A2, long lda2, int msplit) {
-    if (perwave) {
+    // mode: FN_GEMM_X6_PERWAVE = the round-5 kernel, FN_GEMM_X6_WIDE = 128 x 256 tiles, 0 = 128 x 128 tiles (producer / consumer kernels)
+    if (mode & FN_GEMM_X6_PERWAVE) {
         hipLaunchKernelGGL(gemm_tn_x6_kernel, tn_grid(tiles, splitk), dim3(NT), 0, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, klen, slabs, A2, lda2, msplit);
         return FN_OK;
     }
-    const size_t lds = (size_t)X6W_STAGES * X6W_STAGE * 16;
-    static std::atomic<bool> attr_set[32];         // write-once per device; setting the attribute twice is harmless
+    const bool wide = (mode & FN_GEMM_X6_WIDE) != 0;
+    const size_t lds = wide ? (size_t)2 * X6V_STAGE * 16 : (size_t)X6W_STAGES * X6W_STAGE * 16;
+    const void* fn = wide ? reinterpret_cast<const void*>(gemm_tn_x6v_kernel) : reinterpret_cast<const void*>(gemm_tn_x6w_kernel);
+    static std::atomic<bool> attr_set[2][32];      // write-once per device and kernel; setting the attribute twice is harmless
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return FN_E_SHAPE;
-    if (!attr_set[dev].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_x6w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (!attr_set[wide][dev].load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr_set[dev].store(true, std::memory_order_release);
+        attr_set[wide][dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL(gemm_tn_x6w_kernel, tn_grid(tiles, splitk), dim3(X6W_NT), lds, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, klen, slabs, A2, lda2, msplit);
+    if (wide) {
+        const int wtiles = ((M + 127) / 128) * ((N + 255) / 256);
+        hipLaunchKernelGGL(gemm_tn_x6v_kernel, tn_grid(wtiles, splitk), dim3(X6W_NT), lds, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, klen, slabs, A2, lda2, msplit);
+    } else {
+        hipLaunchKernelGGL(gemm_tn_x6w_kernel, tn_grid(tiles, splitk), dim3(X6W_NT), lds, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, klen, slabs, A2, lda2, msplit);
+    }
     return FN_OK;
 }
 
@@ -1276,8 +1607,9 @@ int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha, co
     if (!A || !B || !C) return FN_E_NULL;
     if (M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return FN_E_SHAPE;
     const bool lean = (splitk & FN_GEMM_LEAN) != 0;
-    const bool x6 = (splitk & FN_GEMM_BF16X6) != 0, x6_perwave = (splitk & FN_GEMM_X6_PERWAVE) != 0;
-    splitk &= ~(FN_GEMM_LEAN | FN_GEMM_BF16X6 | FN_GEMM_X6_PERWAVE);
+    const bool x6 = (splitk & FN_GEMM_BF16X6) != 0;
+    const int x6_mode = splitk & (FN_GEMM_X6_PERWAVE | FN_GEMM_X6_WIDE);
+    splitk &= ~(FN_GEMM_LEAN | FN_GEMM_BF16X6 | FN_GEMM_X6_PERWAVE | FN_GEMM_X6_WIDE);
     if (splitk > 1 && (!ws || ws_bytes < fn_gemm_ws_bytes(M, N, splitk))) return FN_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (!a_kmajor && !b_kmajor && (lda % 4) == 0 && (ldb % 4) == 0 && lda >= 4 && ldb >= 4 &&
@@ -1292,7 +1624,7 @@ int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha, co
         const int ntm = (M + 127) / 128, ntn = (N + 127) / 128;
         float* slabs = splitk > 1 ? ws : nullptr;
         if (x6) {
-            const int rc = launch_tn_x6(x6_perwave, ntm * ntn, splitk, st, M, N, K, alpha, A, (long)lda, B, (long)ldb, beta, C, (long)ldc, bias, klen, slabs,
+            const int rc = launch_tn_x6(x6_mode, ntm * ntn, splitk, st, M, N, K, alpha, A, (long)lda, B, (long)ldb, beta, C, (long)ldc, bias, klen, slabs,
                                         (const float*)nullptr, 0L, 0);
             if (rc != FN_OK) return rc;
         } else {
@@ -1346,9 +1678,10 @@ int fn_gru_dwhh_f32(const float* dgx, const float* dghn, const float* hprev, int
     if (!dgx || !dghn || !hprev || !dW) return FN_E_NULL;
     if (rows <= 0 || rows > 0x7fffffff || H <= 0) return FN_E_SHAPE;
     const bool lean = (splitk & FN_GEMM_LEAN) != 0;
-    const bool x6 = (splitk & FN_GEMM_BF16X6) != 0, x6_perwave = (splitk & FN_GEMM_X6_PERWAVE) != 0;
-    const int xflags = splitk & (FN_GEMM_BF16X6 | FN_GEMM_X6_PERWAVE);
-    splitk &= ~(FN_GEMM_LEAN | FN_GEMM_BF16X6 | FN_GEMM_X6_PERWAVE);
+    const bool x6 = (splitk & FN_GEMM_BF16X6) != 0;
+    const int x6_mode = splitk & (FN_GEMM_X6_PERWAVE | FN_GEMM_X6_WIDE);
+    const int xflags = splitk & (FN_GEMM_BF16X6 | FN_GEMM_X6_PERWAVE | FN_GEMM_X6_WIDE);
+    splitk &= ~(FN_GEMM_LEAN | FN_GEMM_BF16X6 | FN_GEMM_X6_PERWAVE | FN_GEMM_X6_WIDE);
     if (splitk > 1 && (!ws || ws_bytes < fn_gru_dwhh_ws_bytes(H, splitk))) return FN_E_WORKSPACE;
     const int M = 3 * H, N = H, K = (int)rows;
     const bool one_launch = (2 * H) % 128 == 0 && (H % 4) == 0 && (((((uintptr_t)dgx) | ((uintptr_t)dghn) | ((uintptr_t)hprev)) & 15) == 0);
@@ -1368,7 +1701,7 @@ int fn_gru_dwhh_f32(const float* dgx, const float* dghn, const float* hprev, int
     const int ntm = (M + 127) / 128, ntn = (N + 127) / 128;
     float* slabs = splitk > 1 ? ws : nullptr;
     if (x6) {
-        const int rc = launch_tn_x6(x6_perwave, ntm * ntn, splitk, st, M, N, K, 1.0f, dgx, (long)3 * H, hprev, (long)H, beta, dW, (long)H, (const float*)nullptr, klen,
+        const int rc = launch_tn_x6(x6_mode, ntm * ntn, splitk, st, M, N, K, 1.0f, dgx, (long)3 * H, hprev, (long)H, beta, dW, (long)H, (const float*)nullptr, klen,
                                     slabs, dghn, (long)H, 2 * H);
         if (rc != FN_OK) return rc;
     } else {

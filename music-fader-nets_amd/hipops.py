@@ -55,6 +55,7 @@ class HipOps:
         self._retired = []
         self.cell_variant = 0     # FnGruCell.variant (tuning / tests)
         self.dw_x6 = arith.default() == arith.BF16X6        # arithmetic of the deep products (the package default; a model sets its own choice: arith.py): True = exact bf16 triple splits on the bf16 MFMA (FN_GEMM_BF16X6, FnGruFwd.variant bit 14), False = fp32 MFMA
+        self.x6_wide = True       # with dw_x6: 128 x 256 output tiles (FN_GEMM_X6_WIDE) where the product has >= 256 columns - with TWICE the K ranges the caller asked for (the same number of workgroups); False: 128 x 128 tiles
         self.x6_perwave = False   # with dw_x6: the round-5 weight-gradient kernel in which every wavefront splits its own operands (FN_GEMM_X6_PERWAVE; A/B measurements, tests)
         self.bwd_x6 = True        # with dw_x6: the backward scans on the bf16 x 6 kernel too (False: fp32 MFMA backward scans; A/B measurements, tests)
         self.variant = 0          # FnGruFwd.variant of every scan launch (tuning / tests only; results do not depend on it)
@@ -87,15 +88,29 @@ class HipOps:
             raise RuntimeError("gemm shape mismatch A%s B%s C%s a_k=%s b_k=%s" % (tuple(A.shape), tuple(B.shape), tuple(Cm.shape), a_k, b_k))
         _chk(bias, name="bias")
         ws, wsb = None, 0
+        x6 = _lib.GEMM_BF16X6 if (self.dw_x6 and not a_k and not b_k and K >= 1024) else 0
+        if x6:
+            splitk, x6 = self._x6_mode(splitk, N, K, x6)
         if splitk > 1:
             wsb = self.lib.fn_gemm_ws_bytes(M, N, splitk & 0xffff)
             ws = self.workspace(wsb, "gemm")
-        x6 = _lib.GEMM_BF16X6 if (self.dw_x6 and not a_k and not b_k and K >= 1024) else 0
-        if x6 and self.x6_perwave:
-            x6 |= _lib.GEMM_X6_PERWAVE
         _lib.check(self.lib.fn_gemm_f32(int(a_k), int(b_k), M, N, K, alpha, pa, lda, pb, ldb, beta, pc, ldc, _p(bias),
                                         splitk | (_lib.GEMM_LEAN if lean else 0) | x6,
                                         _p(ws), wsb, self.stream()), "fn_gemm_f32")
+
+    def _x6_mode(self, splitk, N, K, x6):
+        """kernel choice of a bf16 x 6 weight-gradient product: (K ranges, flags).  Wide (128 x 256) tiles halve the number of output tiles: twice the K
+        ranges keep the number of workgroups (whole 32-k blocks per range permitting).  The per-wave kernel (tests, A/B) runs on the same K ranges."""
+        if self.x6_wide == "force":                       # tests: the wide kernel on whatever shape and split, K ranges as given
+            if not self.x6_perwave:
+                x6 |= _lib.GEMM_X6_WIDE
+        elif self.x6_wide and N >= 256 and splitk > 1 and K >= 32768:      # (K = 16384, the attribute decoders: 162 us on 128 x 128 tiles / 16 ranges, 172 on wide / 32)
+            splitk *= 2
+            if not self.x6_perwave:
+                x6 |= _lib.GEMM_X6_WIDE
+        if self.x6_perwave:
+            x6 |= _lib.GEMM_X6_PERWAVE
+        return splitk, x6
 
     def gemm_multi(self, jobs, a_k=True, b_k=True):
         """jobs: dicts(C=2-D view, segs=[(A, B), ...] (<= 4 products summed), beta=0.0, bias=None) - independent GEMMs of one
@@ -411,11 +426,11 @@ class HipOps:
         rows, H = hprev.shape
         if tuple(dgx.shape) != (rows, 3 * H) or tuple(dghn.shape) != (rows, H) or tuple(dW.shape) != (3 * H, H):
             raise RuntimeError("gru_dwhh shape mismatch")
+        x6 = _lib.GEMM_BF16X6 if (self.dw_x6 and rows >= 1024) else 0
+        if x6:
+            splitk, x6 = self._x6_mode(splitk, H, rows, x6)
         wsb = int(self.lib.fn_gru_dwhh_ws_bytes(H, splitk))
         ws = self.workspace(wsb, "gemm") if wsb else None
-        x6 = _lib.GEMM_BF16X6 if (self.dw_x6 and rows >= 1024) else 0
-        if x6 and self.x6_perwave:
-            x6 |= _lib.GEMM_X6_PERWAVE
         _lib.check(self.lib.fn_gru_dwhh_f32(_p(dgx), _p(dghn), _p(hprev), rows, H, beta, _p(dW), splitk | (_lib.GEMM_LEAN if lean else 0) | x6,
                                             _p(ws), wsb, self.stream()), "fn_gru_dwhh_f32")
 

@@ -13,8 +13,8 @@ torch.manual_seed(0)
 rows = int(os.environ.get("ROWS", "65536"))
 dgx, dghn, hp = torch.randn(rows, 3 * H, device=dev), torch.randn(rows, H, device=dev), torch.randn(rows, H, device=dev) * 0.3
 dW = torch.zeros(3 * H, H, device=dev)
-ops.dw_x6 = True
-for sk in (16, 32):
+ops.dw_x6 = True; ops.x6_wide = "force" if os.environ.get("WIDE", "1") == "1" else False
+for sk in ((32,) if os.environ.get("WIDE", "1") == "1" else (16,)):
     ms = []
     for _ in range(12):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

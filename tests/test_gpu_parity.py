@@ -397,61 +397,81 @@ def test_gemm_tn_bf16x6(ops, M, N, K, splitk):
                                           (1536, 512, 65280, 16), (342, 512, 65536, 42), (128, 128, 1024, 1), (200, 130, 1031, 1), (1536, 512, 4100, 16),
                                           (64, 48, 1056, 3)])
 def test_gemm_tn_x6_producer_consumer_vs_per_wave_kernel(ops, M, N, K, splitk):
-    """gemm_tn_x6w_kernel (round 6: producer wavefronts split every operand value once per workgroup, consumer wavefronts only multiply) against the
-    round-5 kernel in which every wavefront splits its own operands (FN_GEMM_X6_PERWAVE): the same products in the same order per accumulator, so
-    on K ranges of whole 32-k blocks the results are BIT-IDENTICAL (1 .. 5 blocks per range: every prologue / tail path of the two loops; ragged
-    tiles; 1-D and 3-D grids; the two-source form of fn_gru_dwhh_f32); with a K tail (which the per-wave kernel runs on the fp32 MFMA and this one
-    as a zero-padded block) both stay within the fp32 kernel's error bound against float64.  beta / bias / alpha on an unsplit product."""
+    """gemm_tn_x6w_kernel / gemm_tn_x6v_kernel (round 6: producer wavefronts split every operand value once per workgroup, consumer wavefronts only
+    multiply; 128 x 128 and 128 x 256 output tiles) against the round-5 kernel in which every wavefront splits its own operands (FN_GEMM_X6_PERWAVE):
+    the same products in the same order per accumulator, so on K ranges of whole 32-k blocks the results are BIT-IDENTICAL (1 .. 5 blocks per range:
+    every prologue / tail path of the loops; ragged tiles; 1-D and 3-D grids; the two-source form of fn_gru_dwhh_f32); with a K tail (which the
+    per-wave kernel runs on the fp32 MFMA and these as a zero-padded block) all stay within the fp32 kernel's error bound against float64.
+    beta / bias / alpha on an unsplit product."""
     torch.manual_seed(M * 7 + K)
     A = torch.randn(K, M, device=DEV)
     B = torch.randn(K, N, device=DEV) * 0.3
     ref = (A.double().t() @ B.double())
     scale = float((A.double().abs().t() @ B.double().abs()).max())
-    out = {}
+    MODES = (("perwave", False, True), ("tile128", False, False), ("tile256", "force", False))
     ops.dw_x6 = True
+
+    def run(fn):
+        out = {}
+        for name, wide, pw in MODES:
+            ops.x6_wide, ops.x6_perwave = wide, pw
+            out[name] = fn()
+        return out
     try:
-        for pw in (True, False):
-            ops.x6_perwave = pw
+        def plain():
             C = torch.full((M, N), float("nan"), device=DEV)
             ops.gemm(A, B, C, a_k=False, b_k=False, splitk=splitk)
-            out[pw] = C
+            return C
+        out = run(plain)
         klen = K if splitk <= 1 else ((K + splitk - 1) // splitk + 31) // 32 * 32
         whole = all(min(K, k0 + klen) % 32 == 0 for k0 in range(0, K, klen))
-        for pw in (True, False):
-            assert float((out[pw].double() - ref).abs().max()) / scale < 2e-6, pw
+        for name in out:
+            assert float((out[name].double() - ref).abs().max()) / scale < 2e-6, name
         if whole:
-            assert torch.equal(out[True], out[False])
+            assert torch.equal(out["perwave"], out["tile128"]) and torch.equal(out["perwave"], out["tile256"])
+        else:
+            assert torch.equal(out["tile128"], out["tile256"])      # both multiply the K tail as a zero-padded block
         if splitk <= 1:                                   # epilogue without slabs: alpha, beta, bias
             bias = torch.randn(N, device=DEV)
             C0 = torch.randn(M, N, device=DEV)
-            res = {}
-            for pw in (True, False):
-                ops.x6_perwave = pw
+
+            def full():
                 C = C0.clone()
                 ops.gemm(A, B, C, a_k=False, b_k=False, alpha=0.5, beta=2.0, bias=bias)
-                res[pw] = C
+                return C
+            res = run(full)
             want = 0.5 * ref + 2.0 * C0.double() + bias.double()
-            for pw in (True, False):
-                assert float((res[pw].double() - want).abs().max()) / (scale + float(C0.abs().max()) * 2) < 2e-6, pw
+            for name in res:
+                assert float((res[name].double() - want).abs().max()) / (scale + float(C0.abs().max()) * 2) < 2e-6, name
             if whole:
-                assert torch.equal(res[True], res[False])
+                assert torch.equal(res["perwave"], res["tile128"]) and torch.equal(res["perwave"], res["tile256"])
         if M == 1536:                                     # the one-launch [dr' dz' | dn' r]^T h form (A2 second source)
             H = 512
             dgx, dghn, hp = A, torch.randn(K, H, device=DEV), B
-            dws = {}
-            for pw in (True, False):
-                ops.x6_perwave = pw
+
+            def dwhh():
                 dW = torch.zeros(3 * H, H, device=DEV)
                 ops.gru_dwhh(dgx, dghn, hp, dW, splitk=splitk)
-                dws[pw] = dW
+                return dW
+            dws = run(dwhh)
             want = torch.cat([dgx[:, :2 * H], dghn], 1).double().t() @ hp.double()
             sc = float((torch.cat([dgx[:, :2 * H], dghn], 1).double().abs().t() @ hp.double().abs()).max())
-            for pw in (True, False):
-                assert float((dws[pw].double() - want).abs().max()) / sc < 2e-6, pw
+            for name in dws:
+                assert float((dws[name].double() - want).abs().max()) / sc < 2e-6, name
             if whole:
-                assert torch.equal(dws[True], dws[False])
+                assert torch.equal(dws["perwave"], dws["tile128"]) and torch.equal(dws["perwave"], dws["tile256"])
+            # the automatic choice (twice the K ranges with the wide tiles) against the per-wave kernel on the same ranges
+            ops.x6_wide = True
+            auto = {}
+            for pw in (True, False):
+                ops.x6_perwave = pw
+                auto[pw] = dwhh()
+            for pw in auto:
+                assert float((auto[pw].double() - want).abs().max()) / sc < 2e-6, pw
+            if K % 32 == 0 and splitk > 1 and (K // (2 * splitk)) % 32 == 0:
+                assert torch.equal(auto[True], auto[False])
     finally:
-        ops.dw_x6, ops.x6_perwave = _x6_default(), False
+        ops.dw_x6, ops.x6_perwave, ops.x6_wide = _x6_default(), False, True
 
 
 @pytest.mark.parametrize("n,B,T", [(4, 256, 14), (2, 256, 9), (1, 128, 6), (3, 64, 5)])
