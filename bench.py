@@ -86,11 +86,15 @@ def _x6_of(ops, name, a, k):
         return bool(k.get("x6", None) if k.get("x6", None) is not None else ops.gru_fwd_x6_ok(a[0]))
     if name == "gru_seq_bwd":
         return bool(k.get("x6", None) if k.get("x6", None) is not None else ops.gru_bwd_x6_ok(a[0]))
-    if name == "gru_dwhh":
-        return a[2].shape[0] >= 1024
-    if name == "gemm":
-        return (not k.get("a_k", True)) and (not k.get("b_k", True)) and a[0].shape[0] >= 1024
-    return False
+    # weight-gradient products: which of the bf16 x 6 kernels (hipops._x6_mode: 128 x 256 tiles for the T*B-deep products, 128 x 128 otherwise)
+    from music_fader_nets_amd import _lib
+    if name == "gru_dwhh" and a[2].shape[0] >= 1024:
+        fl = ops._x6_mode(k.get("splitk", 1), a[2].shape[1], a[2].shape[0], _lib.GEMM_BF16X6)[1]
+    elif name == "gemm" and (not k.get("a_k", True)) and (not k.get("b_k", True)) and a[0].shape[0] >= 1024:
+        fl = ops._x6_mode(k.get("splitk", 1), a[2].shape[1], a[0].shape[0], _lib.GEMM_BF16X6)[1]
+    else:
+        return False
+    return "gemm_tn_x6_kernel" if fl & _lib.GEMM_X6_PERWAVE else ("gemm_tn_x6v_kernel" if fl & _lib.GEMM_X6_WIDE else "gemm_tn_x6w_kernel")
 
 
 def _classify(name, a, k):
@@ -139,7 +143,7 @@ def _symbol(name, a, k, x6=False):
         return (("gru_fwd_x6pp_kernel" if x6 else "gru_fwd_pp_kernel") if name == "gru_seq_fwd" else ("gru_bwd_x6_kernel" if x6 else "gru_bwd_rs_kernel")), "mfma", work
     if name == "gru_dwhh":
         rows, Hh = a[2].shape
-        return ("gemm_tn_x6_kernel" if x6 else "gemm_tn_kernel"), "mfma", 2.0 * rows * 3 * Hh * Hh
+        return (x6 if x6 else "gemm_tn_kernel"), "mfma", 2.0 * rows * 3 * Hh * Hh
     if name == "gemm":
         A, Cm = a[0], a[2]
         M, N = Cm.shape
@@ -147,7 +151,7 @@ def _symbol(name, a, k, x6=False):
         if k.get("a_k", True) and k.get("b_k", True):
             sym = "gemm_nt_direct_kernel / gemm_kernel"
         else:
-            sym = "gemm_kernel" if k.get("a_k", True) else ("gemm_tn_x6_kernel" if x6 else "gemm_tn_kernel")
+            sym = "gemm_kernel" if k.get("a_k", True) else (x6 if x6 else "gemm_tn_kernel")
         return sym, "mfma", 2.0 * M * N * Kk
     if name == "out_head":
         h, W = a[0], a[1]
@@ -159,10 +163,12 @@ def _symbol(name, a, k, x6=False):
 
 SYMBOL_NOTE = {
     "gru_fwd_x6pp_kernel": "forward weight-stationary scans on the bf16 MFMA (exact bf16 triple splits, 6 products), ping-pong over two row halves (all launches: encoder 4 x 256 rows x 256 steps, decoder pipeline chunks, attribute decoders); rated against 2.5 PFLOP/s / 6",
-    "gru_bwd_x6_kernel": "backward weight-stationary scans on the bf16 MFMA (gate gradients exchanged as exact bf16 triples, W_hh^T slice in AGPRs + LDS; all launches: encoder, decoder pipeline chunks, attribute decoders); rated against 2.5 PFLOP/s / 6",
-    "gemm_tn_x6_kernel": "weight-gradient products dW = dY^T X on the bf16 MFMA (operands split in the loop; dW_hh of every scan via fn_gru_dwhh_f32, dW of the dense layers); rated against 2.5 PFLOP/s / 6",
+    "gru_bwd_x6_kernel": "backward weight-stationary scans on the bf16 MFMA (gate gradients exchanged as exact bf16 triples, W_hh^T slice in AGPRs + LDS; the ENCODER launch only - the 32-row groups of the decoder pipeline / attribute decoders stay on gru_bwd_rs_kernel<1>); rated against 2.5 PFLOP/s / 6",
+    "gemm_tn_x6v_kernel": "weight-gradient products dW = dY^T X on the bf16 MFMA, 128 x 256 output tiles: producer wavefronts split every operand value once per workgroup into LDS, consumer wavefronts only multiply (the T*B-deep products: dW_hh of the encoder directions / decoder layers via fn_gru_dwhh_f32, W_ih2, output layer); rated against 2.5 PFLOP/s / 6",
+    "gemm_tn_x6w_kernel": "the same on 128 x 128 output tiles (the products over Tr*B rows: attribute decoders); rated against 2.5 PFLOP/s / 6",
+    "gemm_tn_x6_kernel": "the round-5 kernel (every wavefront splits its own operands; only with HipOps.x6_perwave)",
     "gru_fwd_pp_kernel": "forward weight-stationary scans, ping-pong over two row halves (all launches: encoder 4 x 256 rows x 256 steps, decoder pipeline chunks, attribute decoders)",
-    "gru_bwd_rs_kernel": "backward weight-stationary scans, W_hh^T slice half register-stationary (all launches: encoder, decoder pipeline chunks, attribute decoders)",
+    "gru_bwd_rs_kernel": "backward weight-stationary scans on the fp32 MFMA, W_hh^T slice half register-stationary (arithmetic f32: all launches; bf16x6: the decoder pipeline chunks and attribute decoders)",
     "gemm_tn_kernel": "weight-gradient products dW = dY^T X (dW_hh of every scan via fn_gru_dwhh_f32, dW of the dense layers)",
 }
 
@@ -172,11 +178,9 @@ X6_KERNEL = {  # rows whose launches run on the bf16 x 6 kernels when that arith
     "dec_fwd_scan_chunk": "gru_fwd_x6pp_kernel<2> (one launch of the decoder pipeline: 2 scans x 256 rows x 32 steps; bf16 MFMA, exact triple splits)",
     "subdec_fwd_scan": "gru_fwd_x6pp_kernel (both sub-decoders, 64 steps)",
     "enc_bwd_scan": "gru_bwd_x6_kernel<2> (4 encoder scans x 256 steps, one launch; bf16 MFMA, exact triple splits)",
-    "dec_bwd_scan_chunk": "gru_bwd_x6_kernel<1> (one launch of the decoder pipeline: 2 scans x 256 rows x 32 steps; bf16 MFMA, exact triple splits)",
-    "subdec_bwd_scan": "gru_bwd_x6_kernel (both sub-decoders, 64 steps)",
-    "dwhh_gemm_tn": "gemm_tn_x6_kernel via fn_gru_dwhh_f32 (dW_hh of an encoder direction / a decoder layer: [3H x T*B] x [T*B x H], 48 tiles x 16 K ranges; 6 launches per step)",
-    "dwhh_gemm_tn_attr": "gemm_tn_x6_kernel via fn_gru_dwhh_f32 (dW_hh of the attribute decoders, K = Tr*B rows)",
-    "gemm_tn": "gemm_tn_x6_kernel (dW of dense layers)",
+    "dwhh_gemm_tn": "gemm_tn_x6v_kernel via fn_gru_dwhh_f32 (dW_hh of an encoder direction / a decoder layer: [3H x T*B] x [T*B x H], 24 tiles of 128 x 256 x 32 K ranges; 6 launches per step)",
+    "dwhh_gemm_tn_attr": "gemm_tn_x6w_kernel via fn_gru_dwhh_f32 (dW_hh of the attribute decoders, K = Tr*B rows, 48 tiles of 128 x 128 x 16 K ranges)",
+    "gemm_tn": "gemm_tn_x6v_kernel (dW of dense layers: W_ih2, output layer)",
 }
 ROW_INFO = {   # row -> (bound, unit of work, kernel, peak share of the chip)
     "enc_fwd_scan": ("mfma", "flop", "gru_fwd_pp_kernel<1> (4 encoder scans x 256 steps, one launch)", 1.0),
@@ -199,43 +203,48 @@ ROW_INFO = {   # row -> (bound, unit of work, kernel, peak share of the chip)
 # HBM bytes per launch come from rocprofv3 --pmc passes of the same launches (2 x FETCH_SIZE with the gfx950 correction + WRITE_SIZE, separate passes;
 # scratch/r5_pmc_step.sh writes the per-row / per-symbol means into profiles/r05_pmc_traffic.json).  bench.py cannot run the profiler around itself,
 # so these are STATIC, committed measurements: the line says so (`traffic_static`) and names the file.
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
+PMC_FILE = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r06_pmc_traffic.json", "r05_pmc_traffic.json")) if os.path.exists(f)),
+                os.path.join(ROOT, "profiles", "r05_pmc_traffic.json"))
 
 
 def pmc_traffic():
     try:
         d = json.load(open(PMC_FILE))
-        return d.get("by_row", {}), d.get("by_symbol", {}), "profiles/r05_pmc_traffic.json (%s)" % d.get("how", "rocprofv3 --pmc")
+        return d.get("by_row", {}), d.get("by_symbol", {}), "profiles/%s (%s)" % (os.path.basename(PMC_FILE), d.get("how", "rocprofv3 --pmc"))
     except (OSError, ValueError):
         return {}, {}, None
 
 
 def roofline_rows(records):
+    """rows of `roofline_all`: one per (launch shape, arithmetic) - a row whose launches ran on both arithmetics is split into `row` (the arithmetic
+    of most of its time) and `row[other]`, never mislabelled"""
     agg = {}
     for name, a, k, e0, e1, x6 in records:
         c = _classify(name, a, k)
         if c is None or c[1] is None or c[0] not in ROW_INFO:
             continue
         ms = e0.elapsed_time(e1)
-        ent = agg.setdefault(c[0], [0, 0.0, 0.0, x6])
+        ent = agg.setdefault((c[0], bool(x6)), [0, 0.0, 0.0])
         ent[0] += 1
         ent[1] += ms
         ent[2] += c[1]
     rows = {}
-    for row, (cnt, ms, work, x6) in agg.items():
+    for (row, x6), (cnt, ms, work) in agg.items():
         bound, unit, kernel, share = ROW_INFO[row]
         arith = "bf16x6" if x6 else "f32"
+        other = agg.get((row, not x6))
+        key = row if other is None or other[1] < ms else "%s[%s]" % (row, arith)
         if bound == "mfma":
             ach, peak, u = work / (ms * 1e-3) / 1e12, PEAK_OF[arith] * share, "TFLOP/s"
             if x6:
-                kernel = X6_KERNEL.get(row, kernel)
+                kernel = X6_KERNEL.get(row, kernel + " [launches that ran on the bf16 x 6 kernels]")
         else:
             ach, peak, u = work / (ms * 1e-3) / 1e9, PEAK_HBM_GBS * share, "GB/s"
-        rows[row] = dict(bound=bound, kernel=kernel, launches=cnt, avg_launch_us=round(ms / cnt * 1e3, 1), achieved=round(ach, 2),
+        rows[key] = dict(bound=bound, kernel=kernel, launches=cnt, avg_launch_us=round(ms / cnt * 1e3, 1), achieved=round(ach, 2),
                          peak=round(peak, 1), unit=u, frac=round(ach / peak, 4), work_per_launch=work / cnt, total_us=ms * 1e3)
         if bound == "mfma":
-            rows[row]["arith"] = arith
-            rows[row]["frac_of_fp32_mfma_peak"] = round(ach / PEAK_F32_MFMA_TFLOPS, 4)
+            rows[key]["arith"] = arith
+            rows[key]["frac_of_fp32_mfma_peak"] = round(ach / PEAK_F32_MFMA_TFLOPS, 4)
     return rows
 
 
@@ -462,7 +471,9 @@ def bench_train(args, pkg, ctx, local, rank, world, log):
     out = {
         "metric": "event-tokens/sec GM-VAE train, seq256 b256", "value": round(tokens_per_s, 1), "unit": "event-tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "arith": arith_mod.describe(arith), "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        # the arithmetic the path computes in: fp32 operands and fp32 accumulation in both cases; "f32/bf16x6" = every fp32 product formed exactly from bf16 pieces
+        "dtype": "f32" if arith_mod.resolve(arith) == arith_mod.F32 else "f32/bf16x6", "arith": arith_mod.describe(arith), "data": "synthetic",
         "config": {"workload": "MusicAttrRegGMVAE train step (fwd+losses+bwd+clip+Adam), hidden 512, z 128, K=2, "
                                "B=256/GPU, T=256, Tr=64 (BASELINE configs[1]; N>1: DP, RCCL grad all-reduce)",
                    "global_batch": B * world, "seq_len": T, "parallelism": "dp%d" % world},

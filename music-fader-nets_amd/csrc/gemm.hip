@@ -492,11 +492,15 @@ FN_DEVINL void x6w_barrier_c() {
     asm volatile("s_barrier" ::: "memory");
 }
 
-// Producer wavefront of gemm_tn_x6w_kernel: operand columns [pcol, pcol + 4) of rows kbeg + 32 blk + 8 lg + j (j = 0..7) of P, block after block.
-// Loads are asm statements whose completion WE count (mma_core.h): 8 per block into register set blk % NS.  In trip t the loads of block t + NS + 1
-// are requested, vmcnt(8 (NS - 1)) then says "block t + 2 has landed" (NS - 1 blocks stay in flight: the loads are bound by the bytes a CU keeps in
-// flight against ~2 us of latency under load, not by any bandwidth - measured), block t + 2 is cut into LDS stage (t + 2) % 3, barrier.
-// The consumers multiply block t meanwhile and read block t + 1 ahead.
+// Producer wavefront of gemm_tn_x6w_kernel: operand columns [pcol, pcol + 4) of rows kbeg + 32 blk + 8 lg + j (j = 0..7) of P, block after block,
+// 8 loads per block into register set blk % NS.  In trip t the loads of block t + NS + 1 are requested, then block t + 2 (requested NS - 1 trips
+// ago) is cut into LDS stage (t + 2) % 3, barrier; the consumers multiply block t meanwhile and read block t + 1 ahead.
+// PLAIN loads, the compiler counts vmcnt: the steady-state trips are straight-line code (whole blocks only, no clamping, no branch between a request
+// and its use), for which hipcc emits exactly `s_waitcnt vmcnt(8 (NS - 1))` in front of the cut (checked in the ISA; Makefile target isa.checked
+// re-checks every build: csrc/check_isa_waits.py).  A first version with asm-statement loads and hand-counted waits passed every test, but its ISA
+// showed whole register sets copied (`v_mov_b64`) at the control-flow merges of the partial-block / tail paths while asm loads into them could be in
+// flight - the compiler cannot know: the hazard class of profiles/r05_x6_suite_soak.txt.  The last 2 NS + 1 blocks (the only ones that can be
+// partial) run through guarded code with clamped row addresses and zero-filled rows.
 #ifndef X6W_NS
 #define X6W_NS 3
 #endif
@@ -506,33 +510,39 @@ template <int... I, class F>
 FN_DEVINL void x6w_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(x6w_ic<I>{}), ...); }
 template <int N, class F>
 FN_DEVINL void x6w_for(F&& f) { x6w_for_impl(std::make_integer_sequence<int, N>{}, f); }      // f(integral_constant<0>) .. f(integral_constant<N - 1>), unrolled
+FN_DEVINL f32x4 x6w_ld(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
 template <bool RN>
 FN_DEVINL void x6w_produce(u32x4* __restrict__ lds, const float* __restrict__ P, long pld, long pcol, int ps, int lane, int kbeg, int kend, int nblk) {
     constexpr int NS = X6W_NS;
     const int lg = lane >> 4;
     f32x4 fa[NS][8];
-    const bool partial = ((kend - kbeg) & 31) != 0;      // only the last block of the matrix can be
-    auto gload = [&](auto SET, int blk) __attribute__((always_inline)) {
+    auto gload = [&](auto SET, int blk) __attribute__((always_inline)) {              // a whole block inside the matrix
+#ifndef X6W_EXP_NOLOAD
+        constexpr int set = decltype(SET)::value;
+        const float* p0 = P + ((long)kbeg + 32 * blk + 8 * lg) * pld + pcol;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fa[set][j] = x6w_ld(p0 + j * pld);
+#endif
+    };
+    auto gload_safe = [&](auto SET, int blk) __attribute__((always_inline)) {         // any block: rows beyond the matrix are read from its last row
 #ifndef X6W_EXP_NOLOAD
         constexpr int set = decltype(SET)::value;
         const long k0 = (long)kbeg + 32 * blk + 8 * lg;
-        if (partial && blk == nblk - 1) {                // rows beyond the matrix are read from its last row (and zeroed in cut)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) fn_gld4_asm(fa[set][j], P + min(k0 + j, (long)kend - 1) * pld + pcol);
-        } else {
-            const float* p0 = P + k0 * pld + pcol;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) fn_gld4_asm(fa[set][j], p0 + j * pld);
-        }
+        for (int j = 0; j < 8; ++j) fa[set][j] = x6w_ld(P + min(k0 + j, (long)kend - 1) * pld + pcol);
 #endif
     };
-    auto cut = [&](auto SET, int blk, int stage) __attribute__((always_inline)) {      // block blk: register set blk % NS -> LDS stage blk % 3
+    auto cut = [&](auto SET, int blk, int stage, bool zero_tail) __attribute__((always_inline)) {      // block blk: register set blk % NS -> LDS stage blk % 3
         constexpr int set = decltype(SET)::value;
-        if (partial && blk == nblk - 1) {
+        if (zero_tail) {                                 // rows beyond the matrix count as zeros (selects, no branch)
             const long k0 = (long)kbeg + 32 * blk + 8 * lg;
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (k0 + j >= kend) fa[set][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 8; ++j) {
+                const bool in = k0 + j < kend;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) fa[set][j][e] = in ? fa[set][j][e] : 0.f;
+            }
         }
         u32x4* dst = lds + stage * X6W_STAGE + ps * X6W_SET + lane;
 #ifdef X6W_EXP_NOCUT
@@ -549,40 +559,35 @@ FN_DEVINL void x6w_produce(u32x4* __restrict__ lds, const float* __restrict__ P,
     };
     // prologue: blocks 0 and 1 cut, blocks 2 .. NS requested
     x6w_for<NS>([&](auto I) __attribute__((always_inline)) {
-        if (decltype(I)::value < nblk) gload(I, decltype(I)::value);
+        if (decltype(I)::value < nblk) gload_safe(I, decltype(I)::value);
     });
-    fn_wait_vm<0>();
-    cut(x6w_ic<0>{}, 0, 0);
-    if (nblk > 1) cut(x6w_ic<1>{}, 1, 1);
-    if (nblk > NS) gload(x6w_ic<0>{}, NS);
+    cut(x6w_ic<0>{}, 0, 0, true);
+    if (nblk > 1) cut(x6w_ic<1>{}, 1, 1, true);
+    if (nblk > NS) gload_safe(x6w_ic<0>{}, NS);
     x6w_barrier_p();
-    // trip t (t % NS == R): request block t + NS + 1 -> set (R + 1) % NS | block t + 2 has landed | cut it (set (R + 2) % NS, stage (t + 2) % 3) | barrier
-    int stage = 2;
-    auto trip = [&](auto R, int t) __attribute__((always_inline)) {
-        constexpr int r = decltype(R)::value;
-        if (t + NS + 1 < nblk) {
-            gload(x6w_ic<(r + 1) % NS>{}, t + NS + 1);
-            fn_wait_vm<8 * (NS - 1)>();
-            cut(x6w_ic<(r + 2) % NS>{}, t + 2, stage);
-        } else {                                         // the last trips: nothing left to request, no counting
-            fn_wait_vm<0>();
-            if (t + 2 < nblk) cut(x6w_ic<(r + 2) % NS>{}, t + 2, stage);
-        }
-        stage = stage == 2 ? 0 : stage + 1;
-        x6w_barrier_p();
-    };
-    int t = 0;
+    int stage = 2, t = 0;
+    // steady state, NS trips per pass (static register sets): trip t (t % NS == r) requests block t + NS + 1 -> set (r + 1) % NS and cuts block
+    // t + 2 (set (r + 2) % NS, stage (t + 2) % 3).  Only whole blocks: t + NS + 1 <= nblk - 2 for every trip of the pass.
 #pragma unroll 1
-    for (; t + NS - 1 < nblk; t += NS) {
-        x6w_for<NS>([&](auto I) __attribute__((always_inline)) { trip(I, t + decltype(I)::value); });
+    for (; t + 2 * NS + 1 < nblk; t += NS) {
+        x6w_for<NS>([&](auto R) __attribute__((always_inline)) {
+            constexpr int r = decltype(R)::value;
+            gload(x6w_ic<(r + 1) % NS>{}, t + r + NS + 1);
+            cut(x6w_ic<(r + 2) % NS>{}, t + r + 2, stage, false);
+            stage = stage == 2 ? 0 : stage + 1;
+            x6w_barrier_p();
+        });
     }
-    x6w_for<NS - 1>([&](auto I) __attribute__((always_inline)) {
-        if (t + decltype(I)::value < nblk) trip(I, t + decltype(I)::value);
+    // the last <= 2 NS + 1 trips (t is a multiple of NS here: the register sets stay static)
+    x6w_for<2 * NS + 1>([&](auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value, r = i % NS;
+        if (t + i < nblk) {
+            if (t + i + NS + 1 < nblk) gload_safe(x6w_ic<(r + 1) % NS>{}, t + i + NS + 1);
+            if (t + i + 2 < nblk) cut(x6w_ic<(r + 2) % NS>{}, t + i + 2, stage, true);
+            stage = stage == 2 ? 0 : stage + 1;
+            x6w_barrier_p();
+        }
     });
-#pragma unroll
-    for (int q = 0; q < NS; ++q)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) fn_keep(fa[q][j]);
 }
 
 __global__ __launch_bounds__(X6W_NT) void gemm_tn_x6w_kernel(int M, int N, int K, float alpha, const float* __restrict__ A, long lda,
@@ -778,61 +783,53 @@ FN_DEVINL void fn_split4(const f32x4 (&v)[4], int e, u32x2& h, u32x2& m, u32x2& 
 #ifndef X6V_NS
 #define X6V_NS 2
 #endif
-// producer wave: full set `fs` from (Pf, ldf, colf) [RNF = rounded pieces], k half `kh` of set `hs` from (Ph, ldh, colh) [always B: rounded]
+// producer wave: full set `fs` from (Pf, ldf, colf) [RNF = rounded pieces], k half `kh` of set `hs` from (Ph, ldh, colh) [always B: rounded].
+// Plain loads counted by the compiler, steady-state trips straight-line (see x6w_produce): 12 loads per block, `s_waitcnt vmcnt(12 (NS - 1))`.
 template <bool RNF>
 FN_DEVINL void x6v_produce(u32x4* __restrict__ lds, const float* __restrict__ Pf, long ldf, long colf, int fs, const float* __restrict__ Ph, long ldh,
                            long colh, int hs, int kh, int lane, int kbeg, int kend, int nblk) {
     constexpr int NS = X6V_NS;
     const int lg = lane >> 4, li = lane & 15;
     f32x4 fa[NS][8], fh[NS][4];
-    const bool partial = ((kend - kbeg) & 31) != 0;      // only the last block of the matrix can be
     const int hrow = 8 * (2 * kh + (lg >> 1)) + 4 * (lg & 1);      // first row (inside a block) of this lane's four half-set rows
-    auto gload = [&](auto SET, int blk) __attribute__((always_inline)) {
+    auto gload = [&](auto SET, int blk) __attribute__((always_inline)) {              // a whole block inside the matrix
+#ifndef X6W_EXP_NOLOAD
+        constexpr int set = decltype(SET)::value;
+        const long kb = (long)kbeg + 32 * blk;
+        const float* p0 = Pf + (kb + 8 * lg) * ldf + colf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fa[set][j] = x6w_ld(p0 + j * ldf);
+        const float* p1 = Ph + (kb + hrow) * ldh + colh;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fh[set][j] = x6w_ld(p1 + j * ldh);
+#endif
+    };
+    auto gload_safe = [&](auto SET, int blk) __attribute__((always_inline)) {         // any block: rows beyond the matrix are read from its last row
 #ifndef X6W_EXP_NOLOAD
         constexpr int set = decltype(SET)::value;
         const long k0 = (long)kbeg + 32 * blk + 8 * lg, k1 = (long)kbeg + 32 * blk + hrow;
-        if (partial && blk == nblk - 1) {                // rows beyond the matrix are read from its last row (and zeroed in cut)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) fn_gld4_asm(fa[set][j], Pf + min(k0 + j, (long)kend - 1) * ldf + colf);
+        for (int j = 0; j < 8; ++j) fa[set][j] = x6w_ld(Pf + min(k0 + j, (long)kend - 1) * ldf + colf);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fn_gld4_asm(fh[set][j], Ph + min(k1 + j, (long)kend - 1) * ldh + colh);
-        } else {
-#ifdef X6W_EXP_CONTIG
-            // timing experiment only (wrong data): the same bytes of the same tile, but every wave load = 1 KB of one row (B) or 2 x 512 B of two rows (A)
-            const long kb = (long)kbeg + 32 * blk;
-            if (fs < 2) {
-                const float* p0 = Pf + (kb + 16 * fs + (lane >> 5)) * ldf + (colf - 4 * li - 64 * fs) + 4 * (lane & 31);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) fn_gld4_asm(fa[set][j], p0 + 2 * j * ldf);
-            } else {
-                const float* p0 = Pf + (kb + 8 * (fs - 2)) * ldf + (colf - 4 * li - 64 * (fs - 2)) + 4 * lane;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) fn_gld4_asm(fa[set][j], p0 + j * ldf);
-            }
-            const float* p1 = Ph + (kb + 16 + 4 * (2 * (hs - 4) + kh)) * ldh + (colh - 4 * li - 128 - 64 * (hs - 4)) + 4 * lane;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fn_gld4_asm(fh[set][j], p1 + j * ldh);
-#else
-            const float* p0 = Pf + k0 * ldf + colf;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) fn_gld4_asm(fa[set][j], p0 + j * ldf);
-            const float* p1 = Ph + k1 * ldh + colh;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fn_gld4_asm(fh[set][j], p1 + j * ldh);
-#endif
-        }
+        for (int j = 0; j < 4; ++j) fh[set][j] = x6w_ld(Ph + min(k1 + j, (long)kend - 1) * ldh + colh);
 #endif
     };
-    auto cut = [&](auto SET, int blk, int stage) __attribute__((always_inline)) {
+    auto cut = [&](auto SET, int blk, int stage, bool zero_tail) __attribute__((always_inline)) {
         constexpr int set = decltype(SET)::value;
-        if (partial && blk == nblk - 1) {
+        if (zero_tail) {                                 // rows beyond the matrix count as zeros (selects, no branch)
             const long k0 = (long)kbeg + 32 * blk + 8 * lg, k1 = (long)kbeg + 32 * blk + hrow;
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (k0 + j >= kend) fa[set][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 8; ++j) {
+                const bool in = k0 + j < kend;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (k1 + j >= kend) fh[set][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int e = 0; e < 4; ++e) fa[set][j][e] = in ? fa[set][j][e] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool in = k1 + j < kend;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) fh[set][j][e] = in ? fh[set][j][e] : 0.f;
+            }
         }
 #ifdef X6W_EXP_NOCUT
         if (blk > 0) return;
@@ -859,37 +856,30 @@ FN_DEVINL void x6v_produce(u32x4* __restrict__ lds, const float* __restrict__ Pf
     };
     // prologue: block 0 cut into stage 0, blocks 1 .. NS - 1 requested
     x6w_for<NS>([&](auto I) __attribute__((always_inline)) {
-        if (decltype(I)::value < nblk) gload(I, decltype(I)::value);
+        if (decltype(I)::value < nblk) gload_safe(I, decltype(I)::value);
     });
-    fn_wait_vm<0>();
-    cut(x6w_ic<0>{}, 0, 0);
+    cut(x6w_ic<0>{}, 0, 0, true);
     x6w_barrier_p();
-    // trip t (t % NS == R): request block t + NS -> set R | block t + 1 has landed | cut it (set (R + 1) % NS, stage (t + 1) & 1) | barrier
-    auto trip = [&](auto R, int t) __attribute__((always_inline)) {
-        constexpr int r = decltype(R)::value;
-        if (t + NS < nblk) {
-            gload(R, t + NS);
-            fn_wait_vm<12 * (NS - 1)>();
-            cut(x6w_ic<(r + 1) % NS>{}, t + 1, (t + 1) & 1);
-        } else {                                         // the last trips: nothing left to request, no counting
-            fn_wait_vm<0>();
-            if (t + 1 < nblk) cut(x6w_ic<(r + 1) % NS>{}, t + 1, (t + 1) & 1);
-        }
-        x6w_barrier_p();
-    };
     int t = 0;
+    // steady state: trip t (t % NS == r) requests block t + NS -> set r and cuts block t + 1 (set (r + 1) % NS, stage (t + 1) & 1); whole blocks only
 #pragma unroll 1
-    for (; t + NS - 1 < nblk; t += NS) x6w_for<NS>([&](auto I) __attribute__((always_inline)) { trip(I, t + decltype(I)::value); });
-    x6w_for<NS - 1>([&](auto I) __attribute__((always_inline)) {
-        if (t + decltype(I)::value < nblk) trip(I, t + decltype(I)::value);
-    });
-#pragma unroll
-    for (int q = 0; q < NS; ++q) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) fn_keep(fa[q][j]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fn_keep(fh[q][j]);
+    for (; t + 2 * NS < nblk; t += NS) {
+        x6w_for<NS>([&](auto R) __attribute__((always_inline)) {
+            constexpr int r = decltype(R)::value;
+            gload(R, t + r + NS);
+            cut(x6w_ic<(r + 1) % NS>{}, t + r + 1, (t + r + 1) & 1, false);
+            x6w_barrier_p();
+        });
     }
+    // the last <= 2 NS trips (t is a multiple of NS here)
+    x6w_for<2 * NS>([&](auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value, r = i % NS;
+        if (t + i < nblk) {
+            if (t + i + NS < nblk) gload_safe(x6w_ic<r>{}, t + i + NS);
+            if (t + i + 1 < nblk) cut(x6w_ic<(r + 1) % NS>{}, t + i + 1, (t + i + 1) & 1, true);
+            x6w_barrier_p();
+        }
+    });
 }
 
 __global__ __launch_bounds__(X6W_NT) void gemm_tn_x6v_kernel(int M, int N, int K, float alpha, const float* __restrict__ A, long lda,

@@ -364,3 +364,37 @@ def test_generated_k_loops_wait_counts():
         r = subprocess.run([sys.executable, os.path.join(csrc, "gen_kloop2.py"), os.path.join(td, "x.h")], env=dict(env, KLOOP2_ARR0="1"), cwd=csrc,
                            capture_output=True)
         assert r.returncode != 0 and not os.path.exists(os.path.join(td, "x.h"))
+
+
+def test_isa_wait_checker_finds_an_uncovered_asm_load(tmp_path):
+    """csrc/check_isa_waits.py (run by the Makefile on the compiled kernels): a register that an asm-issued load may still be writing must not be touched
+    before a vmcnt wait has covered the load - across loop back-edges too.  Synthetic instruction streams: the round-5 decode race (a fill load issued
+    behind the ring loads, used after a wait that only covers the ring) is a finding, the fixed order is not; a software-pipelined ring is followed
+    around its loop; a load overwriting an older pending load's destination is ordered behind it."""
+    import importlib.util
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "music-fader-nets_amd", "csrc")
+    spec = importlib.util.spec_from_file_location("check_isa_waits", os.path.join(csrc, "check_isa_waits.py"))
+    ck = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ck)
+
+    def run(body):
+        f = tmp_path / "k.s"
+        f.write_text("_Z4testv:\n" + body + "\ts_endpgm\n.Lfunc_end0:\n")
+        return ck.main([str(f)], jobs=1)
+    asm = lambda ins: "\t;;#ASMSTART\n\t%s\n\t;;#ASMEND\n" % ins
+    ring = asm("global_load_dwordx4 v[0:3], v[40:41], off") + asm("global_load_dwordx4 v[4:7], v[40:41], off")
+    fill = asm("global_load_dwordx4 v[8:11], v[42:43], off")
+    # the fill load is the YOUNGEST operation: vmcnt(1) covers the two ring loads only
+    assert run(ring + fill + "\ts_waitcnt vmcnt(1)\n\tv_mfma_f32_16x16x4_f32 v[20:23], v0, v4, v[20:23]\n\tds_write_b128 v30, v[8:11]\n\ts_waitcnt vmcnt(0)\n") == 1
+    assert run(ring + fill + "\ts_waitcnt vmcnt(1)\n\tv_mfma_f32_16x16x4_f32 v[20:23], v0, v4, v[20:23]\n\ts_waitcnt vmcnt(0)\n\tds_write_b128 v30, v[8:11]\n") == 0
+    # a two-slot ring around a loop: slot 0 is used one trip after its request, behind vmcnt(1) - correct; with vmcnt(2) the use races the load
+    loop = (asm("global_load_dwordx4 v[0:3], v[40:41], off") + ".LBB0_1:\n" + asm("global_load_dwordx4 v[4:7], v[40:41], off") + "\ts_waitcnt vmcnt(%d)\n"
+            "\tv_add_f32 v20, v0, v20\n" + asm("global_load_dwordx4 v[0:3], v[40:41], off") + "\ts_waitcnt vmcnt(%d)\n\tv_add_f32 v20, v4, v20\n"
+            "\ts_cbranch_scc1 .LBB0_1\n\ts_waitcnt vmcnt(0)\n")
+    assert run(loop % (1, 1)) == 0
+    assert run(loop % (2, 1)) == 1
+    # load -> load on the same destination is ordered; a VALU write of a pending destination is not
+    assert run(asm("global_load_dwordx4 v[0:3], v[40:41], off") + asm("global_load_dwordx4 v[0:3], v[42:43], off") + "\ts_waitcnt vmcnt(0)\n\tv_mov_b32 v9, v0\n") == 0
+    assert run(asm("global_load_dwordx4 v[0:3], v[40:41], off") + "\tv_mov_b64 v[2:3], v[8:9]\n\ts_waitcnt vmcnt(0)\n") == 1
+    # the build ran it on the real kernels
+    assert os.path.exists(os.path.join(csrc, "isa.checked")), "run __graft_entry__.build(): csrc/Makefile checks the compiled kernels (isa.checked)"
