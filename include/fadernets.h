@@ -69,6 +69,8 @@ const char* fn_strerror(int code);    /* static string for FN_E_* / hipError_t *
  * it is a different summation, so results differ from the fp32-MFMA kernel in the last bits.  Split-K ranges are whole 32-k blocks; the
  * rows of a K tail below 32 (unsplit products, the last range) are multiplied in a zero-padded block. */
 #define FN_GEMM_BF16X6 0x20000
+/* FN_GEMM_BF16X6 on the Linear-forward form (a_k=1,b_k=1; whole 128 x 128 tiles - at least 128 of them -, K % 32 == 0, 16-byte aligned operands, no
+ * split): the same arithmetic through gemm_nt_x6w_kernel (gemm.hip); other shapes of that form ignore the flag and run on the fp32 MFMA. */
 /* ... | FN_GEMM_X6_PERWAVE (only with FN_GEMM_BF16X6; tests / A-B measurements): the round-5 kernel in which every wavefront splits its own operands.
  * The default bf16 x 6 kernel has producer wavefronts that split every operand value once per workgroup and consumer wavefronts that only multiply
  * (gemm.hip: gemm_tn_x6w_kernel); both accumulate the same products in the same order, so on K ranges of whole 32-k blocks their results are

@@ -590,60 +590,12 @@ FN_DEVINL void x6w_produce(u32x4* __restrict__ lds, const float* __restrict__ P,
     });
 }
 
-__global__ __launch_bounds__(X6W_NT) void gemm_tn_x6w_kernel(int M, int N, int K, float alpha, const float* __restrict__ A, long lda,
-                                                              const float* __restrict__ B, long ldb, float beta, float* __restrict__ C, long ldc,
-                                                              const float* __restrict__ bias, int ksplit_len, float* __restrict__ slabs,
-                                                              const float* __restrict__ A2, long lda2, int msplit) {
-    extern __shared__ __attribute__((aligned(16))) u32x4 x6w_lds[];      // [3 stages][4 sets][4 tiles][3 pieces][64 lanes]
-    const int ntn = (N + 127) / 128, ntm = (M + 127) / 128;
-    int tile, zk;
-    if (gridDim.z == 1 && slabs != nullptr) {            // K ranges dealt to the XCDs (see gemm_tn_body)
-        const int S = (K + ksplit_len - 1) / ksplit_len, c = blockIdx.x & 7, q = blockIdx.x >> 3;
-        zk = c * (S >> 3) + q / (ntn * ntm);
-        tile = q % (ntn * ntm);
-    } else {
-        tile = fn_xcd_remap(blockIdx.x, ntn * ntm);
-        zk = blockIdx.z;
-    }
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int mb = (tile / ntn) * 128, nb = (tile % ntn) * 128;          // the workgroup's output tile
-    const int li = lane & 15, lg = lane >> 4;
-    const int kbeg = zk * ksplit_len, kend = min(K, kbeg + ksplit_len);
-    const int nblk = (kend - kbeg + 31) >> 5;
-    if (nblk <= 0) return;                               // (the host never launches an empty K range)
-
-    if (X6W_SWAP ? wave < 4 : wave >= 4) {
-        if (X6W_PRIO_P) __builtin_amdgcn_s_setprio(X6W_PRIO_P);
-        // ---- producer: set ps = 64 operand columns (sets 0, 1: A columns mb + 64 ps; sets 2, 3: B columns nb + 64 (ps - 2)) ----
-        const int ps = wave & 3;
-        const bool pa = ps < 2;
-        const float* P = pa ? A : B;
-        long pld = pa ? lda : ldb;
-        // column offset of this lane's 16-byte loads, kept inside the columns the operand REALLY has (see gemm_tn_body)
-        const int pc0 = pa ? mb + 64 * ps : nb + 64 * (ps - 2);
-        long ncols = pa ? (long)M : (long)N, rel = pc0;
-        if (pa && A2 != nullptr) {
-            if (pc0 >= msplit) { P = A2; pld = lda2; ncols = (long)M - msplit; rel = pc0 - msplit; }
-            else ncols = msplit;
-        }
-        long pcol = min(rel + 4 * li, ((ncols - 1) >> 2) << 2);
-        if (rel >= ncols) pcol = ((ncols - 1) >> 2) << 2;                // a set entirely beyond the matrix: any legal column (never stored)
-        if (pa) x6w_produce<false>(x6w_lds, P, pld, pcol, ps, lane, kbeg, kend, nblk);
-        else x6w_produce<true>(x6w_lds, P, pld, pcol, ps, lane, kbeg, kend, nblk);
-        return;
-    }
-
-    // ---- consumer: wave (wm, wn) multiplies sets wm (A) and 2 + wn (B).  Operand registers: A triples of the current block and of the next one
-    //      (two banks, block parity), B triples of output columns 0, 1 (first half of a block) and 2, 3 (second half).  While the first half of
-    //      block t runs, B[2..3] of block t and A[0..1] of block t + 1 are read; during the second half A[2..3] and B[0..1] of block t + 1: no
-    //      LDS latency is ever exposed, and no read of block t is in flight at the barrier that hands its stage back to the producers ----
-    if (X6W_PRIO_C) __builtin_amdgcn_s_setprio(X6W_PRIO_C);
-    const int wm = (wave >> 1) & 1, wn = wave & 1;
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+// Consumer wavefront of gemm_tn_x6w_kernel / gemm_nt_x6w_kernel: wave (wm, wn) multiplies sets wm (A) and 2 + wn (B) of every block into its 4 x 4
+// accumulator tiles.  Operand registers: A triples of the current block and of the next one (two banks, block parity), B triples of output columns
+// 0, 1 (first half of a block) and 2, 3 (second half).  While the first half of block t runs, B[2..3] of block t and A[0..1] of block t + 1 are
+// read; during the second half A[2..3] and B[0..1] of block t + 1: no LDS latency is ever exposed, and no read of block t is in flight at the
+// barrier that hands its stage back to the producers.
+FN_DEVINL void x6w_consume(const u32x4* __restrict__ x6w_lds, int wm, int wn, int lane, int nblk, f32x4 (&acc)[4][4]) {
     bf16x8 Af[2][4][3], Bf[4][3];
     const u32x4* lA = x6w_lds + wm * X6W_SET + lane;
     const u32x4* lB = x6w_lds + (2 + wn) * X6W_SET + lane;
@@ -719,6 +671,60 @@ __global__ __launch_bounds__(X6W_NT) void gemm_tn_x6w_kernel(int M, int N, int K
         if (t + 1 < nblk) step(K1, s1, s2);
         st = s2;
     }
+}
+
+__global__ __launch_bounds__(X6W_NT) void gemm_tn_x6w_kernel(int M, int N, int K, float alpha, const float* __restrict__ A, long lda,
+                                                              const float* __restrict__ B, long ldb, float beta, float* __restrict__ C, long ldc,
+                                                              const float* __restrict__ bias, int ksplit_len, float* __restrict__ slabs,
+                                                              const float* __restrict__ A2, long lda2, int msplit) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 x6w_lds[];      // [3 stages][4 sets][4 tiles][3 pieces][64 lanes]
+    const int ntn = (N + 127) / 128, ntm = (M + 127) / 128;
+    int tile, zk;
+    if (gridDim.z == 1 && slabs != nullptr) {            // K ranges dealt to the XCDs (see gemm_tn_body)
+        const int S = (K + ksplit_len - 1) / ksplit_len, c = blockIdx.x & 7, q = blockIdx.x >> 3;
+        zk = c * (S >> 3) + q / (ntn * ntm);
+        tile = q % (ntn * ntm);
+    } else {
+        tile = fn_xcd_remap(blockIdx.x, ntn * ntm);
+        zk = blockIdx.z;
+    }
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mb = (tile / ntn) * 128, nb = (tile % ntn) * 128;          // the workgroup's output tile
+    const int li = lane & 15, lg = lane >> 4;
+    const int kbeg = zk * ksplit_len, kend = min(K, kbeg + ksplit_len);
+    const int nblk = (kend - kbeg + 31) >> 5;
+    if (nblk <= 0) return;                               // (the host never launches an empty K range)
+
+    if (X6W_SWAP ? wave < 4 : wave >= 4) {
+        if (X6W_PRIO_P) __builtin_amdgcn_s_setprio(X6W_PRIO_P);
+        // ---- producer: set ps = 64 operand columns (sets 0, 1: A columns mb + 64 ps; sets 2, 3: B columns nb + 64 (ps - 2)) ----
+        const int ps = wave & 3;
+        const bool pa = ps < 2;
+        const float* P = pa ? A : B;
+        long pld = pa ? lda : ldb;
+        // column offset of this lane's 16-byte loads, kept inside the columns the operand REALLY has (see gemm_tn_body)
+        const int pc0 = pa ? mb + 64 * ps : nb + 64 * (ps - 2);
+        long ncols = pa ? (long)M : (long)N, rel = pc0;
+        if (pa && A2 != nullptr) {
+            if (pc0 >= msplit) { P = A2; pld = lda2; ncols = (long)M - msplit; rel = pc0 - msplit; }
+            else ncols = msplit;
+        }
+        long pcol = min(rel + 4 * li, ((ncols - 1) >> 2) << 2);
+        if (rel >= ncols) pcol = ((ncols - 1) >> 2) << 2;                // a set entirely beyond the matrix: any legal column (never stored)
+        if (pa) x6w_produce<false>(x6w_lds, P, pld, pcol, ps, lane, kbeg, kend, nblk);
+        else x6w_produce<true>(x6w_lds, P, pld, pcol, ps, lane, kbeg, kend, nblk);
+        return;
+    }
+
+    // ---- consumer ----
+    if (X6W_PRIO_C) __builtin_amdgcn_s_setprio(X6W_PRIO_C);
+    const int wm = (wave >> 1) & 1, wn = wave & 1;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    x6w_consume(x6w_lds, wm, wn, lane, nblk, acc);
     const int m0 = mb + 64 * wm, n0 = nb + 64 * wn;
     const int colb = n0 + 4 * li;
 #pragma unroll
@@ -741,6 +747,130 @@ __global__ __launch_bounds__(X6W_NT) void gemm_tn_x6w_kernel(int M, int N, int K
                     C[(long)row * ldc + col] = o;
                 }
             }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The "NT" product C[M][N] = alpha sum_k A[m][k] B[n][k] (+ bias, + beta C) - nn.Linear forward / dX through a transposed weight image - on the
+// bf16 MFMA with exact triple splits, producer / consumer form (round 6): the consumers are those of gemm_tn_x6w_kernel; a producer wave owns
+// 64 rows of A or of B: lane (r = lane >> 2, q = lane & 3) loads k = 8 q .. 8 q + 7 (two 16-byte loads, 32 consecutive bytes) of row 4 r + e for
+// e = 0..3 - the 8 consecutive k of MFMA operand lane (i = r, g = q) of tile e (tile e = rows 4 i + e: a consumer lane's four column tiles are four
+// consecutive output columns, one 16-byte store).  Both operands K-contiguous with K % 32 == 0, M, N multiples of 128.  A: truncated pieces,
+// B: rounded ones, six products smallest first, as everywhere.  Runs where the decoder pipeline turns layer-1 states into layer-2 gate inputs
+// (gx2 = hx0 W_ih2^T per 32-step chunk) and gate gradients into state gradients (dhx0 = dgx2 W_ih2): 116 / 102 us per launch on the fp32 MFMA.
+// ---------------------------------------------------------------------------------------------------------
+template <bool RN>
+FN_DEVINL void x6w_produce_nt(u32x4* __restrict__ lds, const float* __restrict__ P, long pld, int ps, int lane, int nblk) {
+    constexpr int NS = X6W_NS;
+    const int r = lane >> 2, q = lane & 3;
+    f32x4 fa[NS][8];                                     // [set][2 e + j]: row 4 r + e, k = 8 q + 4 j ..
+    const float* base = P + (long)(4 * r) * pld + 8 * q;
+    auto gload = [&](auto SET, int blk) __attribute__((always_inline)) {
+        constexpr int set = decltype(SET)::value;
+        const float* p0 = base + 32 * blk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            fa[set][2 * e] = x6w_ld(p0 + e * pld);
+            fa[set][2 * e + 1] = x6w_ld(p0 + e * pld + 4);
+        }
+    };
+    auto cut = [&](auto SET, int stage) __attribute__((always_inline)) {
+        constexpr int set = decltype(SET)::value;
+        u32x4* dst = lds + stage * X6W_STAGE + ps * X6W_SET + r + 16 * q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x[8], hi[8], r1[8], mi[8], r2[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = fa[set][2 * e + (j >> 2)][j & 3];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { hi[j] = RN ? fn_rn16(x[j]) : fn_top16(x[j]); r1[j] = x[j] - hi[j]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { mi[j] = RN ? fn_rn16(r1[j]) : fn_top16(r1[j]); r2[j] = r1[j] - mi[j]; }
+            u32x4 Hh, Mm, Ll;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                Hh[j] = fn_pack_top16(hi[2 * j], hi[2 * j + 1]);
+                Mm[j] = fn_pack_top16(mi[2 * j], mi[2 * j + 1]);
+                Ll[j] = fn_pack_top16(r2[2 * j], r2[2 * j + 1]);
+            }
+            dst[(e * 3 + 0) * 64] = Hh;
+            dst[(e * 3 + 1) * 64] = Mm;
+            dst[(e * 3 + 2) * 64] = Ll;
+        }
+    };
+    // same trip structure as x6w_produce (whole blocks only here: K % 32 == 0): blocks 0, 1 cut and 2 .. NS requested, then per trip
+    // request t + NS + 1 | cut t + 2 | barrier
+    x6w_for<NS>([&](auto I) __attribute__((always_inline)) {
+        if (decltype(I)::value < nblk) gload(I, decltype(I)::value);
+    });
+    cut(x6w_ic<0>{}, 0);
+    if (nblk > 1) cut(x6w_ic<1>{}, 1);
+    if (nblk > NS) gload(x6w_ic<0>{}, NS);
+    x6w_barrier_p();
+    int stage = 2, t = 0;
+#pragma unroll 1
+    for (; t + 2 * NS < nblk; t += NS) {
+        x6w_for<NS>([&](auto R) __attribute__((always_inline)) {
+            constexpr int rr = decltype(R)::value;
+            gload(x6w_ic<(rr + 1) % NS>{}, t + rr + NS + 1);
+            cut(x6w_ic<(rr + 2) % NS>{}, stage);
+            stage = stage == 2 ? 0 : stage + 1;
+            x6w_barrier_p();
+        });
+    }
+    x6w_for<2 * NS>([&](auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value, rr = i % NS;
+        if (t + i < nblk) {
+            if (t + i + NS + 1 < nblk) gload(x6w_ic<(rr + 1) % NS>{}, t + i + NS + 1);
+            if (t + i + 2 < nblk) cut(x6w_ic<(rr + 2) % NS>{}, stage);
+            stage = stage == 2 ? 0 : stage + 1;
+            x6w_barrier_p();
+        }
+    });
+}
+
+__global__ __launch_bounds__(X6W_NT) void gemm_nt_x6w_kernel(int M, int N, int K, float alpha, const float* __restrict__ A, long lda,
+                                                              const float* __restrict__ B, long ldb, float beta, float* __restrict__ C, long ldc,
+                                                              const float* __restrict__ bias) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 x6w_lds[];      // [3 stages][4 sets][4 tiles][3 pieces][64 lanes]
+    const int ntn = N >> 7;
+    const int tile = fn_xcd_remap(blockIdx.x, ntn * (M >> 7));           // consecutive tiles (same rows of A) on one XCD
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mb = (tile / ntn) * 128, nb = (tile % ntn) * 128;
+    const int nblk = K >> 5;
+    if (wave >= 4) {
+        const int ps = wave & 3;
+        if (ps < 2) x6w_produce_nt<false>(x6w_lds, A + (long)(mb + 64 * ps) * lda, lda, ps, lane, nblk);
+        else x6w_produce_nt<true>(x6w_lds, B + (long)(nb + 64 * (ps - 2)) * ldb, ldb, ps, lane, nblk);
+        return;
+    }
+    const int wm = (wave >> 1) & 1, wn = wave & 1;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    x6w_consume(x6w_lds, wm, wn, lane, nblk, acc);
+    // D[(l >> 4) * 4 + rr][l & 15] of tile (a, b) = row mb + 64 wm + 4 ((l >> 4) * 4 + rr) + a, column nb + 64 wn + 4 (l & 15) + b
+    const int li = lane & 15, lg = lane >> 4;
+    const int col = nb + 64 * wn + 4 * li;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + col);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = mb + 64 * wm + 4 * (lg * 4 + rr) + a;
+            float* cp = C + (long)row * ldc + col;
+            f32x4 o;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) o[b] = alpha * acc[a][b][rr] + bv[b];
+            if (beta != 0.f) {
+                const f32x4 old = *reinterpret_cast<const f32x4*>(cp);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) o[b] += beta * old[b];
+            }
+            *reinterpret_cast<f32x4*>(cp) = o;
         }
 }
 
@@ -1628,6 +1758,22 @@ int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha, co
             hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, slabs, splitk, M, N, alpha, beta, C, (long)ldc, bias);
             FN_CHECK_LAUNCH();
         }
+        return FN_OK;
+    }
+    // bf16 x 6, K-contiguous operands, whole 128 x 128 tiles and 32-k blocks, no split: the producer / consumer kernel
+    if (x6 && a_kmajor && b_kmajor && splitk <= 1 && (M % 128) == 0 && (N % 128) == 0 && (K % 32) == 0 && K >= 128 && (lda % 4) == 0 && (ldb % 4) == 0 &&
+        (ldc % 4) == 0 && (((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C) | ((uintptr_t)bias)) & 15) == 0) && (long)(M / 128) * (N / 128) >= 128) {
+        const size_t lds = (size_t)X6W_STAGES * X6W_STAGE * 16;
+        static std::atomic<bool> attr_set[32];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return FN_E_SHAPE;
+        if (!attr_set[dev].load(std::memory_order_acquire)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_x6w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+            attr_set[dev].store(true, std::memory_order_release);
+        }
+        hipLaunchKernelGGL(gemm_nt_x6w_kernel, dim3((M / 128) * (N / 128)), dim3(X6W_NT), lds, st, M, N, K, alpha, A, (long)lda, B, (long)ldb, beta, C, (long)ldc, bias);
+        FN_CHECK_LAUNCH();
         return FN_OK;
     }
     // K-contiguous operands, whole 128 x 128 tiles that fill the chip, short K, no split: the LDS-free kernel

@@ -56,6 +56,7 @@ class HipOps:
         self.cell_variant = 0     # FnGruCell.variant (tuning / tests)
         self.dw_x6 = arith.default() == arith.BF16X6        # arithmetic of the deep products (the package default; a model sets its own choice: arith.py): True = exact bf16 triple splits on the bf16 MFMA (FN_GEMM_BF16X6, FnGruFwd.variant bit 14), False = fp32 MFMA
         self.x6_wide = True       # with dw_x6: 128 x 256 output tiles (FN_GEMM_X6_WIDE) where the product has >= 256 columns - with TWICE the K ranges the caller asked for (the same number of workgroups); False: 128 x 128 tiles
+        self.nt_x6 = True         # with dw_x6: the big Linear-forward / dX products (whole 128 x 128 tiles, K % 32 == 0) on the bf16 x 6 kernel too; False: fp32 MFMA (A/B measurements)
         self.x6_perwave = False   # with dw_x6: the round-5 weight-gradient kernel in which every wavefront splits its own operands (FN_GEMM_X6_PERWAVE; A/B measurements, tests)
         self.bwd_x6 = True        # with dw_x6: the backward scans on the bf16 x 6 kernel too (False: fp32 MFMA backward scans; A/B measurements, tests)
         self.variant = 0          # FnGruFwd.variant of every scan launch (tuning / tests only; results do not depend on it)
@@ -91,6 +92,8 @@ class HipOps:
         x6 = _lib.GEMM_BF16X6 if (self.dw_x6 and not a_k and not b_k and K >= 1024) else 0
         if x6:
             splitk, x6 = self._x6_mode(splitk, N, K, x6)
+        elif self.dw_x6 and self.nt_x6 and a_k and b_k and splitk <= 1 and M % 128 == 0 and N % 128 == 0 and K % 32 == 0 and K >= 128 and (M // 128) * (N // 128) >= 128:
+            x6 = _lib.GEMM_BF16X6                  # Linear forward / dX of the decoder pipeline on the bf16 MFMA (gemm_nt_x6w_kernel; the lean instance is then moot)
         if splitk > 1:
             wsb = self.lib.fn_gemm_ws_bytes(M, N, splitk & 0xffff)
             ws = self.workspace(wsb, "gemm")

@@ -474,6 +474,40 @@ def test_gemm_tn_x6_producer_consumer_vs_per_wave_kernel(ops, M, N, K, splitk):
         ops.dw_x6, ops.x6_perwave, ops.x6_wide = _x6_default(), False, True
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 1536, 512), (8192, 512, 1536), (65536, 512, 352), (2048, 1024, 128), (2048, 1024, 160), (4096, 512, 32 * 7)])
+def test_gemm_nt_bf16x6(ops, M, N, K):
+    """gemm_nt_x6w_kernel (round 6): the Linear-forward form C = alpha A B^T + bias + beta C with both operands K-contiguous, exact bf16 triple splits
+    on the bf16 MFMA - the decoder pipeline's layer-2 input projection and the state-gradient products.  Against float64 it is as accurate as the fp32
+    MFMA kernels (error bound of the fp32 tests, within 2 x of the fp32 kernel's own error); 4 .. 48 blocks of 32 k (every prologue / tail path of the
+    producer loop), alpha / beta / bias; repeated launches are bit-identical."""
+    torch.manual_seed(M + N + K)
+    A = torch.randn(M, K, device=DEV)
+    W = torch.randn(N, K, device=DEV) * 0.2
+    bias = torch.randn(N, device=DEV)
+    C0 = torch.randn(M, N, device=DEV)
+    ref = A.double() @ W.double().t()
+    scale = float((A.double().abs() @ W.double().abs().t()).max())
+    err, outs = {}, {}
+    try:
+        for x6 in (False, True):
+            ops.dw_x6, ops.nt_x6 = x6, x6
+            C = torch.full((M, N), float("nan"), device=DEV)
+            ops.gemm(A, W, C, a_k=True, b_k=True)
+            err[x6] = float((C.double() - ref).abs().max()) / scale
+            C2 = C0.clone()
+            ops.gemm(A, W, C2, a_k=True, b_k=True, alpha=0.5, beta=2.0, bias=bias)
+            want = 0.5 * ref + 2.0 * C0.double() + bias.double()
+            assert float((C2.double() - want).abs().max()) / (scale + 2 * float(C0.abs().max())) < 2e-6, x6
+            outs[x6] = C
+        assert err[True] < 2e-6 and err[True] <= 2.0 * err[False] + 1e-9, err
+        ops.dw_x6, ops.nt_x6 = True, True
+        C = torch.empty(M, N, device=DEV)
+        ops.gemm(A, W, C, a_k=True, b_k=True)
+        assert torch.equal(C, outs[True])
+    finally:
+        ops.dw_x6, ops.nt_x6 = _x6_default(), True
+
+
 @pytest.mark.parametrize("n,B,T", [(4, 256, 14), (2, 256, 9), (1, 128, 6), (3, 64, 5)])
 def test_forward_scan_bf16x6(ops, n, B, T):
     """the opt-in forward scan with exact split products on the bf16 MFMA (FnGruFwd.variant bit 14: weights and exchanged state as bf16 triples,
