@@ -92,6 +92,11 @@ def _x6_of(ops, name, a, k):
         fl = ops._x6_mode(k.get("splitk", 1), a[2].shape[1], a[2].shape[0], _lib.GEMM_BF16X6)[1]
     elif name == "gemm" and (not k.get("a_k", True)) and (not k.get("b_k", True)) and a[0].shape[0] >= 1024:
         fl = ops._x6_mode(k.get("splitk", 1), a[2].shape[1], a[0].shape[0], _lib.GEMM_BF16X6)[1]
+    elif name == "gemm" and k.get("a_k", True) and k.get("b_k", True):
+        M, N = a[2].shape
+        Kk = a[0].shape[1]
+        ok = (getattr(ops, "nt_x6", False) and k.get("splitk", 1) <= 1 and M % 128 == 0 and N % 128 == 0 and Kk % 32 == 0 and Kk >= 128 and (M // 128) * (N // 128) >= 128)
+        return "gemm_nt_x6w_kernel" if ok else False
     else:
         return False
     return "gemm_tn_x6_kernel" if fl & _lib.GEMM_X6_PERWAVE else ("gemm_tn_x6v_kernel" if fl & _lib.GEMM_X6_WIDE else "gemm_tn_x6w_kernel")
@@ -149,7 +154,7 @@ def _symbol(name, a, k, x6=False):
         M, N = Cm.shape
         Kk = A.shape[1] if k.get("a_k", True) else A.shape[0]
         if k.get("a_k", True) and k.get("b_k", True):
-            sym = "gemm_nt_direct_kernel / gemm_kernel"
+            sym = x6 if x6 else "gemm_nt_direct_kernel / gemm_kernel"
         else:
             sym = "gemm_kernel" if k.get("a_k", True) else (x6 if x6 else "gemm_tn_kernel")
         return sym, "mfma", 2.0 * M * N * Kk
@@ -166,6 +171,7 @@ SYMBOL_NOTE = {
     "gru_bwd_x6_kernel": "backward weight-stationary scans on the bf16 MFMA (gate gradients exchanged as exact bf16 triples, W_hh^T slice in AGPRs + LDS; the ENCODER launch only - the 32-row groups of the decoder pipeline / attribute decoders stay on gru_bwd_rs_kernel<1>); rated against 2.5 PFLOP/s / 6",
     "gemm_tn_x6v_kernel": "weight-gradient products dW = dY^T X on the bf16 MFMA, 128 x 256 output tiles: producer wavefronts split every operand value once per workgroup into LDS, consumer wavefronts only multiply (the T*B-deep products: dW_hh of the encoder directions / decoder layers via fn_gru_dwhh_f32, W_ih2, output layer); rated against 2.5 PFLOP/s / 6",
     "gemm_tn_x6w_kernel": "the same on 128 x 128 output tiles (the products over Tr*B rows: attribute decoders); rated against 2.5 PFLOP/s / 6",
+    "gemm_nt_x6w_kernel": "Linear-forward / dX products of the decoder pipeline on the bf16 MFMA (gx2 = hx0 W_ih2^T and dhx0 = dgx2 W_ih2 per 32-step chunk, dhx1 = dlogits W_out), producer / consumer form; rated against 2.5 PFLOP/s / 6",
     "gemm_tn_x6_kernel": "the round-5 kernel (every wavefront splits its own operands; only with HipOps.x6_perwave)",
     "gru_fwd_pp_kernel": "forward weight-stationary scans, ping-pong over two row halves (all launches: encoder 4 x 256 rows x 256 steps, decoder pipeline chunks, attribute decoders)",
     "gru_bwd_rs_kernel": "backward weight-stationary scans on the fp32 MFMA, W_hh^T slice half register-stationary (arithmetic f32: all launches; bf16x6: the decoder pipeline chunks and attribute decoders)",
@@ -181,6 +187,7 @@ X6_KERNEL = {  # rows whose launches run on the bf16 x 6 kernels when that arith
     "dwhh_gemm_tn": "gemm_tn_x6v_kernel via fn_gru_dwhh_f32 (dW_hh of an encoder direction / a decoder layer: [3H x T*B] x [T*B x H], 24 tiles of 128 x 256 x 32 K ranges; 6 launches per step)",
     "dwhh_gemm_tn_attr": "gemm_tn_x6w_kernel via fn_gru_dwhh_f32 (dW_hh of the attribute decoders, K = Tr*B rows, 48 tiles of 128 x 128 x 16 K ranges)",
     "gemm_tn": "gemm_tn_x6v_kernel (dW of dense layers: W_ih2, output layer)",
+    "gemm_nt": "gemm_nt_x6w_kernel (dhx1 = dlogits W_out through the transposed weight image)",
 }
 ROW_INFO = {   # row -> (bound, unit of work, kernel, peak share of the chip)
     "enc_fwd_scan": ("mfma", "flop", "gru_fwd_pp_kernel<1> (4 encoder scans x 256 steps, one launch)", 1.0),

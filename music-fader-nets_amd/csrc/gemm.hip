@@ -727,6 +727,18 @@ __global__ __launch_bounds__(X6W_NT) void gemm_tn_x6w_kernel(int M, int N, int K
     x6w_consume(x6w_lds, wm, wn, lane, nblk, acc);
     const int m0 = mb + 64 * wm, n0 = nb + 64 * wn;
     const int colb = n0 + 4 * li;
+    if (slabs != nullptr && (N & 3) == 0) {              // split-K slabs: 16-byte stores
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + 4 * (lg * 4 + r) + a;
+                if (row >= M || colb >= N) continue;
+                const f32x4 v = {acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
+                *reinterpret_cast<f32x4*>(slabs + ((long)zk * M + row) * N + colb) = v;
+            }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -1159,6 +1171,23 @@ __global__ __launch_bounds__(X6W_NT) void gemm_tn_x6v_kernel(int M, int N, int K
         __builtin_amdgcn_sched_barrier(0);
     }
     const int m0 = mb + 64 * wm, n0 = nb + 128 * wn;
+    if (slabs != nullptr && (N & 3) == 0) {              // split-K slabs: a lane's four column tiles of a set are four consecutive columns - 16-byte stores
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + 4 * (lg * 4 + r) + a;
+                if (row >= M) continue;
+#pragma unroll
+                for (int bs = 0; bs < 2; ++bs) {
+                    const int col = n0 + 64 * bs + 4 * li;
+                    if (col >= N) continue;
+                    const f32x4 v = {acc[a][4 * bs][r], acc[a][4 * bs + 1][r], acc[a][4 * bs + 2][r], acc[a][4 * bs + 3][r]};
+                    *reinterpret_cast<f32x4*>(slabs + ((long)zk * M + row) * N + col) = v;
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -1506,6 +1535,41 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, int S, int M
     }
 }
 
+// the same for N % 4 == 0, 16-byte aligned slabs / C / bias: four columns per thread, eight slab loads in flight (same summation order per element: slab 0, 1, ...)
+__global__ void slab_reduce4_kernel(const float* __restrict__ slabs, int S, int M, int N, float alpha, float beta,
+                                    float* __restrict__ C, long ldc, const float* __restrict__ bias) {
+    const long total4 = (long)M * N / 4, total = (long)M * N;
+    const int n4 = N / 4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        const float* p = slabs + 4 * i;
+        int k = 0;
+        for (; k + 8 <= S; k += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (long)(k + u) * total);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < S; ++k) s += *reinterpret_cast<const f32x4*>(p + (long)k * total);
+        const int row = (int)(i / n4), col = (int)(i % n4) * 4;
+        f32x4 o = alpha * s;
+        if (bias) o += *reinterpret_cast<const f32x4*>(bias + col);
+        float* cp = C + (long)row * ldc + col;
+        if (beta != 0.f) o += beta * *reinterpret_cast<const f32x4*>(cp);
+        *reinterpret_cast<f32x4*>(cp) = o;
+    }
+}
+
+// split-K slabs -> C (the float4 form where everything is 16-byte aligned; same summation order per element)
+static void launch_slab_reduce(hipStream_t st, const float* slabs, int S, int M, int N, float alpha, float beta, float* C, long ldc, const float* bias) {
+    const bool v4 = (N & 3) == 0 && (ldc & 3) == 0 && (((((uintptr_t)slabs) | ((uintptr_t)C) | ((uintptr_t)bias)) & 15) == 0);
+    const long total = v4 ? (long)M * N / 4 : (long)M * N;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    if (v4) hipLaunchKernelGGL(slab_reduce4_kernel, dim3(blocks), dim3(256), 0, st, slabs, S, M, N, alpha, beta, C, ldc, bias);
+    else hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, slabs, S, M, N, alpha, beta, C, ldc, bias);
+}
+
 __global__ void transpose_kernel(const float* __restrict__ src, int R, int Cc, long src_ld, float* __restrict__ dst, long dst_ld) {
     __shared__ float t[32][33];
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
@@ -1616,9 +1680,7 @@ int launch_gemm(int ak, int bk, int M, int N, int K, float alpha, const float* A
 #undef FN_GEMM_LAUNCH
     FN_CHECK_LAUNCH();
     if (splitk > 1) {
-        const long total = (long)M * N;
-        const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, slabs, splitk, M, N, alpha, beta, C, (long)ldc, bias);
+        launch_slab_reduce(st, slabs, splitk, M, N, alpha, beta, C, (long)ldc, bias);
         FN_CHECK_LAUNCH();
     }
     return FN_OK;
@@ -1753,9 +1815,7 @@ int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha, co
         }
         FN_CHECK_LAUNCH();
         if (splitk > 1) {
-            const long total = (long)M * N;
-            const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-            hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, slabs, splitk, M, N, alpha, beta, C, (long)ldc, bias);
+            launch_slab_reduce(st, slabs, splitk, M, N, alpha, beta, C, (long)ldc, bias);
             FN_CHECK_LAUNCH();
         }
         return FN_OK;
@@ -1846,9 +1906,7 @@ int fn_gru_dwhh_f32(const float* dgx, const float* dghn, const float* hprev, int
     }
     FN_CHECK_LAUNCH();
     if (splitk > 1) {
-        const long total = (long)M * N;
-        const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, slabs, splitk, M, N, 1.0f, beta, dW, (long)H, (const float*)nullptr);
+        launch_slab_reduce(st, slabs, splitk, M, N, 1.0f, beta, dW, (long)H, (const float*)nullptr);
         FN_CHECK_LAUNCH();
     }
     return FN_OK;

@@ -220,7 +220,7 @@ def test_bench_launches_its_own_ranks(n):
     assert 0 < out["roofline"]["frac"] < 1 and out["roofline_all"]
     assert out["roofline"]["symbol"] in out["roofline_by_symbol"] and 0 < out["roofline_scans"]["frac"] < 1
     assert out["sustained_steps"] == 20 and out["sustained_ms_per_step"] > 0
-    assert out["dtype"] == "f32" and out["arith"]
+    assert out["dtype"] in ("f32", "f32/bf16x6") and out["arith"]
     assert out["comm"]["rccl_ranks"] == n and out["comm"]["rccl_rank"] == 0     # what RCCL itself reports (fn_comm_count / fn_comm_rank)
     if n == 1:
         leg = out.get("bf16x6_leg") or out.get("fp32_mfma_leg")     # the OTHER arithmetic rides beside the headline, timed in its own process
