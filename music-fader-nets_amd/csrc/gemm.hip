@@ -479,6 +479,9 @@ constexpr int X6W_NT = 512;
 #ifndef X6W_SWAP
 #define X6W_SWAP 0
 #endif
+#ifndef X6W_INTERLEAVE
+#define X6W_INTERLEAVE 1         // 0 (A/B builds): a block's loads as one burst in front of the cut
+#endif
 constexpr int X6W_SET = 4 * 3 * 64;              // u32x4 vectors of one set (64 operand columns x 32 k as triples: 12 KB)
 constexpr int X6W_STAGE = 4 * X6W_SET;           // ... of one stage (48 KB)
 constexpr int X6W_STAGES = 3;
@@ -568,12 +571,37 @@ FN_DEVINL void x6w_produce(u32x4* __restrict__ lds, const float* __restrict__ P,
     int stage = 2, t = 0;
     // steady state, NS trips per pass (static register sets): trip t (t % NS == r) requests block t + NS + 1 -> set (r + 1) % NS and cuts block
     // t + 2 (set (r + 2) % NS, stage (t + 2) % 3).  Only whole blocks: t + NS + 1 <= nblk - 2 for every trip of the pass.
+    // Request and cut are INTERLEAVED: two loads of the new block in front of every quarter of the cut.  Issued as one burst the 8 loads keep the
+    // wave at the vector-memory queue until most of them have been taken (a CU's address path takes ~30 clocks per 1 KB wave load: measured, the
+    // loads of a block cost the CU ~1000 clocks), and the address path then idles while the wave splits: loads + cut ran as long as their sum.
+    auto fused = [&](auto LS, int lblk, auto CS, int stage_) __attribute__((always_inline)) {
+        constexpr int ls = decltype(LS)::value, cs = decltype(CS)::value;
+        const float* p0 = P + ((long)kbeg + 32 * lblk + 8 * lg) * pld + pcol;
+        u32x4* dst = lds + stage_ * X6W_STAGE + ps * X6W_SET + lane;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#ifndef X6W_EXP_NOLOAD
+            fa[ls][2 * a] = x6w_ld(p0 + (2 * a) * pld);
+            fa[ls][2 * a + 1] = x6w_ld(p0 + (2 * a + 1) * pld);
+#endif
+            bf16x8 h, m, l;
+            fn_split8<RN>(fa[cs], a, h, m, l);
+            dst[(a * 3 + 0) * 64] = __builtin_bit_cast(u32x4, h);
+            dst[(a * 3 + 1) * 64] = __builtin_bit_cast(u32x4, m);
+            dst[(a * 3 + 2) * 64] = __builtin_bit_cast(u32x4, l);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
 #pragma unroll 1
     for (; t + 2 * NS + 1 < nblk; t += NS) {
         x6w_for<NS>([&](auto R) __attribute__((always_inline)) {
             constexpr int r = decltype(R)::value;
-            gload(x6w_ic<(r + 1) % NS>{}, t + r + NS + 1);
-            cut(x6w_ic<(r + 2) % NS>{}, t + r + 2, stage, false);
+            if (X6W_INTERLEAVE) {
+                fused(x6w_ic<(r + 1) % NS>{}, t + r + NS + 1, x6w_ic<(r + 2) % NS>{}, stage);
+            } else {
+                gload(x6w_ic<(r + 1) % NS>{}, t + r + NS + 1);
+                cut(x6w_ic<(r + 2) % NS>{}, t + r + 2, stage, false);
+            }
             stage = stage == 2 ? 0 : stage + 1;
             x6w_barrier_p();
         });
@@ -820,12 +848,45 @@ FN_DEVINL void x6w_produce_nt(u32x4* __restrict__ lds, const float* __restrict__
     if (nblk > NS) gload(x6w_ic<0>{}, NS);
     x6w_barrier_p();
     int stage = 2, t = 0;
+    // request and cut interleaved (see x6w_produce): the two loads of row 4 r + e of the new block in front of the cut of tile e
+    auto fused = [&](auto LS, int lblk, auto CS, int stage_) __attribute__((always_inline)) {
+        constexpr int ls = decltype(LS)::value, cs = decltype(CS)::value;
+        const float* p0 = base + 32 * lblk;
+        u32x4* dst = lds + stage_ * X6W_STAGE + ps * X6W_SET + r + 16 * q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            fa[ls][2 * e] = x6w_ld(p0 + e * pld);
+            fa[ls][2 * e + 1] = x6w_ld(p0 + e * pld + 4);
+            float x[8], hi[8], r1[8], mi[8], r2[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = fa[cs][2 * e + (j >> 2)][j & 3];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { hi[j] = RN ? fn_rn16(x[j]) : fn_top16(x[j]); r1[j] = x[j] - hi[j]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { mi[j] = RN ? fn_rn16(r1[j]) : fn_top16(r1[j]); r2[j] = r1[j] - mi[j]; }
+            u32x4 Hh, Mm, Ll;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                Hh[j] = fn_pack_top16(hi[2 * j], hi[2 * j + 1]);
+                Mm[j] = fn_pack_top16(mi[2 * j], mi[2 * j + 1]);
+                Ll[j] = fn_pack_top16(r2[2 * j], r2[2 * j + 1]);
+            }
+            dst[(e * 3 + 0) * 64] = Hh;
+            dst[(e * 3 + 1) * 64] = Mm;
+            dst[(e * 3 + 2) * 64] = Ll;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
 #pragma unroll 1
     for (; t + 2 * NS < nblk; t += NS) {
         x6w_for<NS>([&](auto R) __attribute__((always_inline)) {
             constexpr int rr = decltype(R)::value;
-            gload(x6w_ic<(rr + 1) % NS>{}, t + rr + NS + 1);
-            cut(x6w_ic<(rr + 2) % NS>{}, stage);
+            if (X6W_INTERLEAVE) {
+                fused(x6w_ic<(rr + 1) % NS>{}, t + rr + NS + 1, x6w_ic<(rr + 2) % NS>{}, stage);
+            } else {
+                gload(x6w_ic<(rr + 1) % NS>{}, t + rr + NS + 1);
+                cut(x6w_ic<(rr + 2) % NS>{}, stage);
+            }
             stage = stage == 2 ? 0 : stage + 1;
             x6w_barrier_p();
         });
@@ -974,13 +1035,41 @@ FN_DEVINL void x6v_produce(u32x4* __restrict__ lds, const float* __restrict__ Pf
             }
         }
 #ifdef X6W_EXP_NOCUT
-        if (blk > 0) return;
+        if (blk > 0) {                                   // experiment: the loads stay (their registers are "used"), no split, no LDS write
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fn_keep(fa[set][j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fn_keep(fh[set][j]);
+            return;
+        }
 #endif
         u32x4* dst = lds + stage * X6V_STAGE + fs * X6W_SET + lane;
+#ifdef X6W_EXP_NOVALU
+        if (blk > 0) {                                   // experiment: the same LDS writes without the split arithmetic
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                dst[(a * 3 + 0) * 64] = __builtin_bit_cast(u32x4, fa[set][2 * a]);
+                dst[(a * 3 + 1) * 64] = __builtin_bit_cast(u32x4, fa[set][2 * a + 1]);
+                dst[(a * 3 + 2) * 64] = __builtin_bit_cast(u32x4, fa[set][(2 * a + 2) & 7]);
+            }
+            u32x2* dh0 = reinterpret_cast<u32x2*>(lds + stage * X6V_STAGE + hs * X6W_SET + li + 16 * (2 * kh + (lg >> 1))) + (lg & 1);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const u32x4 w = __builtin_bit_cast(u32x4, fh[set][a]);
+                dh0[((a * 3 + 0) * 64) * 2] = (u32x2){w[0], w[1]};
+                dh0[((a * 3 + 1) * 64) * 2] = (u32x2){w[2], w[3]};
+                dh0[((a * 3 + 2) * 64) * 2] = (u32x2){w[1], w[2]};
+            }
+            return;
+        }
+#endif
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             bf16x8 h, m, l;
             fn_split8<RNF>(fa[set], a, h, m, l);
+#ifdef X6W_EXP_NODSW
+            if (blk > 0) { asm volatile("" ::"v"(h), "v"(m), "v"(l)); continue; }
+#endif
             dst[(a * 3 + 0) * 64] = __builtin_bit_cast(u32x4, h);
             dst[(a * 3 + 1) * 64] = __builtin_bit_cast(u32x4, m);
             dst[(a * 3 + 2) * 64] = __builtin_bit_cast(u32x4, l);
@@ -991,6 +1080,9 @@ FN_DEVINL void x6v_produce(u32x4* __restrict__ lds, const float* __restrict__ Pf
         for (int a = 0; a < 4; ++a) {
             u32x2 h, m, l;
             fn_split4<true>(fh[set], a, h, m, l);
+#ifdef X6W_EXP_NODSW
+            if (blk > 0) { asm volatile("" ::"v"(h), "v"(m), "v"(l)); continue; }
+#endif
             dh[((a * 3 + 0) * 64) * 2] = h;
             dh[((a * 3 + 1) * 64) * 2] = m;
             dh[((a * 3 + 2) * 64) * 2] = l;
@@ -1004,12 +1096,50 @@ FN_DEVINL void x6v_produce(u32x4* __restrict__ lds, const float* __restrict__ Pf
     x6w_barrier_p();
     int t = 0;
     // steady state: trip t (t % NS == r) requests block t + NS -> set r and cuts block t + 1 (set (r + 1) % NS, stage (t + 1) & 1); whole blocks only
+    // request and cut interleaved (see x6w_produce): two loads in front of every quarter of the full set's cut, one in front of every quarter of the half set's
+    auto fused = [&](auto LS, int lblk, auto CS, int stage) __attribute__((always_inline)) {
+        constexpr int ls = decltype(LS)::value, cs = decltype(CS)::value;
+        const long kb = (long)kbeg + 32 * lblk;
+        const float* p0 = Pf + (kb + 8 * lg) * ldf + colf;
+        const float* p1 = Ph + (kb + hrow) * ldh + colh;
+        u32x4* dst = lds + stage * X6V_STAGE + fs * X6W_SET + lane;
+        u32x2* dh = reinterpret_cast<u32x2*>(lds + stage * X6V_STAGE + hs * X6W_SET + li + 16 * (2 * kh + (lg >> 1))) + (lg & 1);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#ifndef X6W_EXP_NOLOAD
+            fa[ls][2 * a] = x6w_ld(p0 + (2 * a) * ldf);
+            fa[ls][2 * a + 1] = x6w_ld(p0 + (2 * a + 1) * ldf);
+#endif
+            bf16x8 h, m, l;
+            fn_split8<RNF>(fa[cs], a, h, m, l);
+            dst[(a * 3 + 0) * 64] = __builtin_bit_cast(u32x4, h);
+            dst[(a * 3 + 1) * 64] = __builtin_bit_cast(u32x4, m);
+            dst[(a * 3 + 2) * 64] = __builtin_bit_cast(u32x4, l);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#ifndef X6W_EXP_NOLOAD
+            fh[ls][a] = x6w_ld(p1 + a * ldh);
+#endif
+            u32x2 h, m, l;
+            fn_split4<true>(fh[cs], a, h, m, l);
+            dh[((a * 3 + 0) * 64) * 2] = h;
+            dh[((a * 3 + 1) * 64) * 2] = m;
+            dh[((a * 3 + 2) * 64) * 2] = l;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
 #pragma unroll 1
     for (; t + 2 * NS < nblk; t += NS) {
         x6w_for<NS>([&](auto R) __attribute__((always_inline)) {
             constexpr int r = decltype(R)::value;
-            gload(R, t + r + NS);
-            cut(x6w_ic<(r + 1) % NS>{}, t + r + 1, (t + r + 1) & 1, false);
+            if (X6W_INTERLEAVE) {
+                fused(R, t + r + NS, x6w_ic<(r + 1) % NS>{}, (t + r + 1) & 1);
+            } else {
+                gload(R, t + r + NS);
+                cut(x6w_ic<(r + 1) % NS>{}, t + r + 1, (t + r + 1) & 1, false);
+            }
             x6w_barrier_p();
         });
     }
