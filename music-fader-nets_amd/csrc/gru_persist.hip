@@ -2027,7 +2027,8 @@ int x6_bwd_tiles(const FnGruBwd* scans, int n_scans, int cus) {
     // 256 rows x 32 steps) measured SLOWER than the fp32 kernel (353 against 322-337 us: both are bound by the exchange stream through the XCD's L2, which
     // the triples make 1.5 x wider, and the 12-unit K loops are too short for the store -> arrival -> counter chain): only on request (variant bit 15)
     const bool th1_ok = (scans[0].variant & 0x8000) != 0;
-    return (d64 && g64 > 8 && g64 <= 16 && g64 * 16 <= cus) ? 2 : (th1_ok && d32 && g32 > 8 && g32 <= 16 && g32 * 16 <= cus) ? 1 : 0;
+    // (g64 * 16 == cus: the caller asked for exactly this with a CU budget - the half-chip launches of the decoder pipeline's backward, 8 groups on 128 CUs)
+    return (d64 && (g64 > 8 || g64 * 16 == cus) && g64 <= 16 && g64 * 16 <= cus) ? 2 : (th1_ok && d32 && g32 > 8 && g32 <= 16 && g32 * 16 <= cus) ? 1 : 0;
 }
 
 }  // namespace

@@ -45,6 +45,13 @@ class Engine:
         self.saved = None
         self.splitk_big = 16            # K ranges of the T*B-deep weight-gradient products (see _splitk)
         self.chunk = 32                 # time steps per pipeline chunk of the two decoder layers (layer 2 lags layer 1 by two chunks)
+        # compute-unit budget of the decoder pipeline's launches (FnGruFwd / FnGruBwd.cu_budget; 0 = the whole chip).  With 128 a launch of two 256-row scans
+        # takes the bf16 x 6 kernels in their 128-row (forward) / 64-row (backward) group forms on HALF of the compute units of every XCD, and the lane's
+        # projection / state-gradient GEMM - which needs whole CUs (144 KB of LDS) and otherwise runs between the whole-chip launches - runs BESIDE the scan.
+        # Measured (round 6): one launch + its GEMM in isolation 442 -> 396 us (backward), 365 -> 353 us (forward), but the captured step gets SLOWER
+        # (17.28 - 17.57 -> 17.80 - 17.83 ms backward, 17.93 both): off.  EXPERIMENTS.md R6.3.
+        self.dec_bwd_budget = 0
+        self.dec_fwd_budget = 0
         self.persist_dec = True         # decoder scans as weight-stationary launches (False: per-step kernels; debug / tests)
         self.fill_edges = True          # the attribute decoders' chunks ride in the half-empty head / tail launches of the global decoder's
                                         # two-layer pipeline (same results; False: one launch of their own)
@@ -414,6 +421,8 @@ class Engine:
         # every launch on the fp32 MFMA
         x6 = bool(pd and getattr(ops, "gru_fwd_x6_ok", None) and all(ops.gru_fwd_x6_ok(part) for part in launches if part))
         xkw = {"x6": x6} if hasattr(ops, "gru_fwd_x6_ok") else {}
+        if x6 and self.dec_fwd_budget and all(ops.gru_fwd_x6_ok(part, self.dec_fwd_budget) for part in launches if part):
+            xkw["cu_budget"] = self.dec_fwd_budget
         for k, part in enumerate(launches):
             if k >= 2:
                 self.lane_wait("main", "aux%d" % (k & 1))            # the projection of chunk k-2 (issued two launches ago)
@@ -576,7 +585,11 @@ class Engine:
             if k >= nch and "r" in fch and k - nch < len(fch["r"]):
                 part.append(fch["r"][k - nch])
             if part:
-                ops.gru_seq_bwd(part, persistent=pd)
+                bkw = {}
+                if pd and self.dec_bwd_budget and getattr(ops, "dw_x6", False) and getattr(ops, "bwd_x6", False) and len(part) == 2 \
+                        and ops.gru_bwd_x6_ok(part, self.dec_bwd_budget):
+                    bkw = {"cu_budget": self.dec_bwd_budget}
+                ops.gru_seq_bwd(part, persistent=pd, **bkw)
             if k < nch:
                 t0, t1 = js[k], min(T, js[k] + CH)
                 lane = "auxb%d" % (k & 1)
