@@ -508,6 +508,18 @@ def test_gemm_nt_bf16x6(ops, M, N, K):
         ops.dw_x6, ops.nt_x6 = _x6_default(), True
 
 
+def test_gemm_bf16x6_kernels_random_shapes():
+    """scratch/r6_fuzz_gemm.py (the randomised sweep behind profiles/r06_gemm_fuzz.txt) with a small case count: ragged M / N, K tails, every split depth,
+    padded leading dimensions, the two-source form, the Linear-forward form with alpha / beta / bias - the three weight-gradient kernels agree bit for bit
+    on whole-block K ranges (the two producer / consumer kernels always) and every result stays within the fp32 kernels' float64 error bound"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scratch", "r6_fuzz_gemm.py"), "60", "7"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "TN: 60 cases, 0 mismatches" in r.stdout and "NT: 30 cases, 0 mismatches" in r.stdout, r.stdout[-1000:]
+
+
 @pytest.mark.parametrize("n,B,T", [(4, 256, 14), (2, 256, 9), (1, 128, 6), (3, 64, 5)])
 def test_forward_scan_bf16x6(ops, n, B, T):
     """the opt-in forward scan with exact split products on the bf16 MFMA (FnGruFwd.variant bit 14: weights and exchanged state as bf16 triples,
