@@ -253,7 +253,9 @@ typedef struct FnGruCell {
     int32_t variant;          /* 0 = automatic.  Tuning / tests: 1-3, 8 force a staged tiling (8 = its default: 64 rows x 32 units), 4-7 the LDS-free
                                  loop (4, 6: 128 rows x 32 units per workgroup, 1 / 2 k steps in flight; 5, 7: 64 rows, 4 / 2), 9-12 the loop with
                                  the weight slice in LDS (9, 11: 256 rows x 16 units, 2 steps; 10, 12: 128 rows, 4 / 8; 13, 14: 192 rows, 4 / 2), 15-18 the same with
-                                 the slice fills under the K loops (K1 = H = 512; 15, 18: 128 rows, 4 / 2 steps; 16: 192 rows; 17: 256 rows) where eligible */
+                                 the slice fills under the K loops (K1 = H = 512; 15, 18: 128 rows, 4 / 2 steps; 16: 192 rows; 17: 256 rows) where eligible.
+                                 | 0x4000 (bit 14, as in FnGruFwd): the cell on the bf16 MFMA with exact triple splits (gru.hip: gru_cell_x6_kernel) where
+                                 B % 128 == 0, H % 32 == 0, K1 % 32 == 0 and the operands are 16-byte aligned; other shapes run as without the bit */
     const uint64_t* idx_best; /* NULL, or the packed argmax words of the previous token (fn_out_argmax_f32): the token of row b is
                                  best_v - 1 - (uint32_t)idx_best[b]; takes precedence over idx                                */
     int32_t best_v;           /* vocabulary size the words were packed with                                                   */

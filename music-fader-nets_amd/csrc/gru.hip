@@ -26,6 +26,7 @@
 #include <atomic>
 
 #include "gru_layout.h"
+#include "x6w_core.h"
 
 #ifdef FN_TIMING
 __device__ unsigned long long fn_dbg[64 * 8];
@@ -1496,6 +1497,229 @@ int launch_cell_wlds(const CellArgs& a, hipStream_t st) {
     return launch_cell_wlds_inst<RT, PF, false, false>(a, kmax, lds, st);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// One GRUCell step of a large batch on the bf16 MFMA with exact triple splits (round 6; FnGruCell.variant bit 14): the producer / consumer form of the
+// round-6 GEMMs (x6w_core.h, gemm.hip) with the gate epilogue behind it.  Workgroup = 128 rows x 32 hidden units; its "N tile" is 128 columns:
+// [r | z | n_x | n_h] of those 32 units, where r and z accumulate the dense-input part x W_ih^T AND the recurrent part h W_hh^T (one K loop over
+// K1 + H), n_x only the input part and n_h only the recurrent part (their weight rows count as zeros in the other part: a quarter of the MFMAs multiply
+// zeros - the cell is bound by its prologue / epilogue and the loads, not by the matrix pipe, so the uniform loop wins).  Waves 4-7 load + split
+// (A: rows of x then of h_prev, truncated pieces; B: weight rows, rounded pieces) into LDS, waves 0-3 multiply; the four 64 x 64 accumulator
+// tiles then meet in LDS (the stages are free by then) and every thread finishes four (row, 4 units) items: biases, token row, row bias, gates,
+// new state.  B % 128 == 0, H % 32 == 0, K1 % 32 == 0, 16-byte aligned operands.  Same gate arithmetic as the fp32 cells; the products are summed
+// in another order (fp32-class): greedy tokens agree up to the reference's own near-ties (tests/test_gpu_parity.py).
+// ---------------------------------------------------------------------------------------------------------------
+template <bool RN>
+FN_DEVINL void cell_x6_produce(u32x4* __restrict__ lds, const float* const (&px)[4], const float* const (&ph)[4], bool zero_x, bool zero_h, int nbx, int ps, int lane,
+                               int nblk) {
+    constexpr int NS = X6W_NS;
+    const int r = lane >> 2, q = lane & 3;
+    f32x4 fa[NS][8];                                     // [set][2 e + j]: set row 4 r + e, k = 8 q + 4 j ..
+    auto gload = [&](auto SET, int blk) __attribute__((always_inline)) {
+        constexpr int set = decltype(SET)::value;
+        const bool xp = blk < nbx;
+        const long off = xp ? 32L * blk : 32L * (blk - nbx);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float* p0 = (xp ? px[e] : ph[e]) + off;
+            fa[set][2 * e] = x6w_ld(p0);
+            fa[set][2 * e + 1] = x6w_ld(p0 + 4);
+        }
+    };
+    auto cut = [&](auto SET, int blk, int stage) __attribute__((always_inline)) {
+        constexpr int set = decltype(SET)::value;
+        const bool zero = blk < nbx ? zero_x : zero_h;   // this lane's rows do not take part in this K part: zeros (the loads above fetched legal rows)
+        u32x4* dst = lds + stage * X6W_STAGE + ps * X6W_SET + r + 16 * q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x[8], hi[8], r1[8], mi[8], r2[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = zero ? 0.f : fa[set][2 * e + (j >> 2)][j & 3];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { hi[j] = RN ? fn_rn16(x[j]) : fn_top16(x[j]); r1[j] = x[j] - hi[j]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { mi[j] = RN ? fn_rn16(r1[j]) : fn_top16(r1[j]); r2[j] = r1[j] - mi[j]; }
+            u32x4 Hh, Mm, Ll;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                Hh[j] = fn_pack_top16(hi[2 * j], hi[2 * j + 1]);
+                Mm[j] = fn_pack_top16(mi[2 * j], mi[2 * j + 1]);
+                Ll[j] = fn_pack_top16(r2[2 * j], r2[2 * j + 1]);
+            }
+            dst[(e * 3 + 0) * 64] = Hh;
+            dst[(e * 3 + 1) * 64] = Mm;
+            dst[(e * 3 + 2) * 64] = Ll;
+        }
+    };
+    // the trip structure of x6w_produce_nt (gemm.hip): blocks 0, 1 cut and 2 .. NS requested, then per trip request t + NS + 1 | cut t + 2 | barrier
+    x6w_for<NS>([&](auto I) __attribute__((always_inline)) {
+        if (decltype(I)::value < nblk) gload(I, decltype(I)::value);
+    });
+    cut(x6w_ic<0>{}, 0, 0);
+    if (nblk > 1) cut(x6w_ic<1>{}, 1, 1);
+    if (nblk > NS) gload(x6w_ic<0>{}, NS);
+    x6w_barrier_p();
+    int stage = 2, t = 0;
+#pragma unroll 1
+    for (; t + 2 * NS < nblk; t += NS) {
+        x6w_for<NS>([&](auto R) __attribute__((always_inline)) {
+            constexpr int rr = decltype(R)::value;
+            gload(x6w_ic<(rr + 1) % NS>{}, t + rr + NS + 1);
+            cut(x6w_ic<(rr + 2) % NS>{}, t + rr + 2, stage);
+            stage = stage == 2 ? 0 : stage + 1;
+            x6w_barrier_p();
+        });
+    }
+    x6w_for<2 * NS>([&](auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value, rr = i % NS;
+        if (t + i < nblk) {
+            if (t + i + NS + 1 < nblk) gload(x6w_ic<(rr + 1) % NS>{}, t + i + NS + 1);
+            if (t + i + 2 < nblk) cut(x6w_ic<(rr + 2) % NS>{}, t + i + 2, stage);
+            stage = stage == 2 ? 0 : stage + 1;
+            x6w_barrier_p();
+        }
+    });
+}
+
+constexpr int CX_LDT = 68;                           // floats per row of an accumulator tile in LDS (64 + 4: 16-byte rows, conflict-free column reads)
+template <bool HAS_TAB, bool HAS_RB>
+__global__ __launch_bounds__(X6W_NT) void gru_cell_x6_kernel(const CellArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 cx_lds[];       // [3 stages][4 sets][4 tiles][3 pieces][64 lanes]; epilogue: float [2][2][64][CX_LDT]
+    const int nut = a.H >> 5;
+    const int v = fn_xcd_remap(blockIdx.x, gridDim.x);                   // consecutive unit tiles of one row panel on one XCD (they share the rows of x / h_prev)
+    const int m0 = (v / nut) * 128, u0 = (v % nut) * 32;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nbx = a.x ? a.K1 >> 5 : 0, nblk = nbx + (a.H >> 5);
+    if (wave >= 4) {
+        const int ps = wave & 3, r = lane >> 2, q = lane & 3;
+        const float* px[4];
+        const float* ph[4];
+        bool zx = false, zh = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int s_ = 4 * r + e;                                    // row of the 64-row set
+            if (ps < 2) {                                                // A: batch rows m0 + 64 ps + s_
+                const long row = m0 + 64 * ps + s_;
+                px[e] = (a.x ? a.x + row * a.ldx : a.h_prev + row * a.ldh) + 8 * q;
+                ph[e] = a.h_prev + row * a.ldh + 8 * q;
+            } else {                                                     // B: set 2 = [r | z], set 3 = [n_x | n_h] of units u0 .. u0 + 31
+                const int half = s_ >> 5, u = u0 + (s_ & 31);
+                const int gate = ps == 2 ? half : 2;
+                px[e] = (a.x ? a.w_ih + (long)(gate * a.H + u) * a.ldw_ih : a.w_hh + (long)(gate * a.H + u) * a.ldw_hh) + 8 * q;
+                ph[e] = a.w_hh + (long)(gate * a.H + u) * a.ldw_hh + 8 * q;
+                if (ps == 3) { zx = half == 1; zh = half == 0; }        // n_x takes the input part only, n_h the recurrent part only
+            }
+        }
+        if (ps < 2) cell_x6_produce<false>(cx_lds, px, ph, zx, zh, nbx, ps, lane, nblk);
+        else cell_x6_produce<true>(cx_lds, px, ph, zx, zh, nbx, ps, lane, nblk);
+        // ---- the producers are done two blocks before the consumers: they fetch the epilogue's operands meanwhile and finish the cell.
+        //      Thread = four (row, 4 units) items: rows m0 + tid / 8 + 32 k, units u0 + 4 (tid % 8) ----
+        const int tid = threadIdx.x - 256;
+        const int uq = tid & 7, eu = u0 + 4 * uq;
+        const long H3 = 3L * a.H;
+        f32x4 bi[3], bh[3], hv[4], tv[4][3], rv[4][3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            bh[g] = *reinterpret_cast<const f32x4*>(a.b_hh + g * a.H + eu);
+            bi[g] = a.b_ih ? *reinterpret_cast<const f32x4*>(a.b_ih + g * a.H + eu) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = m0 + (tid >> 3) + 32 * k;
+            hv[k] = *reinterpret_cast<const f32x4*>(a.h_prev + (long)row * a.ldh + eu);
+            if (HAS_TAB) {
+                const int tok = a.token(row);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) tv[k][g] = *reinterpret_cast<const f32x4*>(a.gx_table + (long)tok * H3 + g * a.H + eu);
+            }
+            if (HAS_RB) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) rv[k][g] = *reinterpret_cast<const f32x4*>(a.gx_rowbias + (long)row * H3 + g * a.H + eu);
+            }
+        }
+        x6w_barrier_p();                                 // E0: every consumer has read its last operands - the stages may be overwritten
+        x6w_barrier_p();                                 // E1: the four accumulator tiles are in LDS
+        const float* T = reinterpret_cast<const float*>(cx_lds);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int lr = (tid >> 3) + 32 * k;          // row inside the 128-row panel
+            const float* t0 = T + ((lr >> 6) * 2 + 0) * 64 * CX_LDT + (lr & 63) * CX_LDT;      // [r | z] tile of this row's panel half
+            const float* t1 = t0 + 64 * CX_LDT;                                                   // [n_x | n_h]
+            const f32x4 g_r = *reinterpret_cast<const f32x4*>(t0 + 4 * uq), g_z = *reinterpret_cast<const f32x4*>(t0 + 32 + 4 * uq);
+            const f32x4 g_nx = *reinterpret_cast<const f32x4*>(t1 + 4 * uq), g_nh = *reinterpret_cast<const f32x4*>(t1 + 32 + 4 * uq);
+            f32x4 o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float gi[3];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    float e = bi[g][c];
+                    if (HAS_TAB) e += tv[k][g][c];
+                    if (HAS_RB) e += rv[k][g][c];
+                    gi[g] = e;
+                }
+                const float rg = fn_sigmoid((gi[0] + bh[0][c]) + g_r[c]);
+                const float zg = fn_sigmoid((gi[1] + bh[1][c]) + g_z[c]);
+                const float ng = fn_tanh((gi[2] + g_nx[c]) + rg * (g_nh[c] + bh[2][c]));
+                o[c] = (1.0f - zg) * ng + zg * hv[k][c];
+            }
+            *reinterpret_cast<f32x4*>(a.h_out + (long)(m0 + lr) * a.ldo + eu) = o;
+        }
+        return;
+    }
+    const int wm = (wave >> 1) & 1, wn = wave & 1;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[i][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    x6w_consume(cx_lds, wm, wn, lane, nblk, acc);
+    x6w_barrier_p();                                     // E0
+    {
+        float* tw = reinterpret_cast<float*>(cx_lds) + (wm * 2 + wn) * 64 * CX_LDT;
+        const int li = lane & 15, lg = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const f32x4 o = {acc[i][0][rr], acc[i][1][rr], acc[i][2][rr], acc[i][3][rr]};
+                *reinterpret_cast<f32x4*>(tw + (4 * (lg * 4 + rr) + i) * CX_LDT + 4 * li) = o;      // row 4 (lg 4 + rr) + i, columns 4 li .. of the wave's 64
+            }
+    }
+    x6w_barrier_p();                                     // E1: the producers take it from here
+}
+
+static bool cell_x6_ok(const CellArgs& a) {
+    const uintptr_t al = (uintptr_t)a.x | (uintptr_t)a.w_ih | (uintptr_t)a.h_prev | (uintptr_t)a.w_hh | (uintptr_t)a.h_out | (uintptr_t)a.b_hh | (uintptr_t)a.b_ih |
+                         (uintptr_t)a.gx_table | (uintptr_t)a.gx_rowbias;
+    return (a.B % 128) == 0 && (a.H % 32) == 0 && a.H >= 64 && (!a.x || ((a.K1 % 32) == 0 && (a.ldx & 3) == 0 && (a.ldw_ih & 3) == 0)) && (a.ldh & 3) == 0 &&
+           (a.ldw_hh & 3) == 0 && (a.ldo & 3) == 0 && (al & 15) == 0;
+}
+
+template <bool HAS_TAB, bool HAS_RB>
+int launch_cell_x6_inst(const CellArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)X6W_STAGES * X6W_STAGE * 16;
+    static std::atomic<bool> attr_set[32];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return FN_E_SHAPE;
+    auto k = gru_cell_x6_kernel<HAS_TAB, HAS_RB>;
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set[dev].store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(k, dim3((a.B / 128) * (a.H / 32)), dim3(X6W_NT), lds, st, a);
+    FN_CHECK_LAUNCH();
+    return FN_OK;
+}
+
+int launch_cell_x6(const CellArgs& a, hipStream_t st) {
+    const bool tab = a.gx_table != nullptr, rb = a.gx_rowbias != nullptr;
+    if (tab && rb) return launch_cell_x6_inst<true, true>(a, st);
+    if (tab) return launch_cell_x6_inst<true, false>(a, st);
+    if (rb) return launch_cell_x6_inst<false, true>(a, st);
+    return launch_cell_x6_inst<false, false>(a, st);
+}
+
 FN_DEVINL void fn_wait_vm_n(int n) {                // n folds to a constant in fully unrolled loops
     switch (n) {
 #define FN_WV(k) case k: fn_wait_vm<k>(); break;
@@ -1773,20 +1997,23 @@ int fn_gru_cell_f32(const FnGruCell* c, void* stream) {
     a.h_out = c->h_out; a.ldo = c->ldo; a.B = c->B; a.H = c->H;
     a.best = reinterpret_cast<const unsigned long long*>(c->idx_best); a.best_v = c->best_v;
     if (c->idx_best && (c->best_v <= 0 || !c->gx_table)) return FN_E_SHAPE;
+    // variant bit 14 (as in FnGruFwd): the cell on the bf16 MFMA with exact triple splits where the shape allows it (else the fp32 cells below, as if the bit were clear)
+    const int variant = c->variant & ~0x4000;
+    if ((c->variant & 0x4000) && cell_x6_ok(a)) return launch_cell_x6(a, (hipStream_t)stream);
     // measured (scratch/prof_decode_cells.sh, us per token of the tokens-only decode, profiles/r04_decode_cells_lds_free.txt): the form with the weight slice in
     // LDS wants ONE workgroup per CU: 64 RT rows x 16 units with RT = ceil(rows / 512) - 1024 rows 71.5 (staged 82, LDS-free 77), 1152-1536 rows 88-89 (LDS-free 101-102);
     // at 2048 rows (RT = 4) it is behind the LDS-free 128-row form (108 against 103)
-    if (c->variant == 0 && c->B > 512 && c->B <= 2048 && cell_direct_ok(a) && cell_wlds_ovl_ok(a)) {
+    if (variant == 0 && c->B > 512 && c->B <= 2048 && cell_direct_ok(a) && cell_wlds_ovl_ok(a)) {
         // K1 = H = 512: the slice fills under the K loops - 640-1024 rows 60 (71), 1280-1536 rows 78-80 (88), 2048 rows 99.8 (102.9 LDS-free)
         if (c->B <= 1024) return launch_cell_wlds_ovl<2, 2>(a, (hipStream_t)stream);
         if (c->B <= 1536) return launch_cell_wlds_ovl<3, 2>(a, (hipStream_t)stream);
         return launch_cell_wlds_ovl<4, 2>(a, (hipStream_t)stream);
     }
-    if (c->variant == 0 && c->B > 512 && cell_direct_ok(a)) {
+    if (variant == 0 && c->B > 512 && cell_direct_ok(a)) {
         if (c->B > 1536 || !cell_wlds_ok(a)) return c->B > 1024 ? launch_cell_direct<4, 2>(a, (hipStream_t)stream) : launch_cell_direct<2, 4>(a, (hipStream_t)stream);
         return c->B > 1024 ? launch_cell_wlds<3, 2>(a, (hipStream_t)stream) : launch_cell_wlds<2, 4>(a, (hipStream_t)stream);
     }
-    switch (c->variant) {                                  // tuning / tests: the staged forms agree bit for bit, the LDS-free forms 4-7 among themselves (another k order)
+    switch (variant) {                                  // tuning / tests: the staged forms agree bit for bit, the LDS-free forms 4-7 among themselves (another k order)
         case 15: if (cell_direct_ok(a) && cell_wlds_ovl_ok(a)) return launch_cell_wlds_ovl<2, 4>(a, (hipStream_t)stream); break;
         case 16: if (cell_direct_ok(a) && cell_wlds_ovl_ok(a)) return launch_cell_wlds_ovl<3, 2>(a, (hipStream_t)stream); break;
         case 17: if (cell_direct_ok(a) && cell_wlds_ovl_ok(a)) return launch_cell_wlds_ovl<4, 2>(a, (hipStream_t)stream); break;
@@ -1803,7 +2030,7 @@ int fn_gru_cell_f32(const FnGruCell* c, void* stream) {
         case 7: if (cell_direct_ok(a)) return launch_cell_direct<2, 2>(a, (hipStream_t)stream); break;
         default: break;
     }
-    switch (c->variant) {
+    switch (variant) {
         case 1: return launch_cell<128, 4, 1>(a, (hipStream_t)stream);
         case 2: return launch_cell<128, 2, 2>(a, (hipStream_t)stream);
         case 3: return launch_cell<64, 4, 1>(a, (hipStream_t)stream);

@@ -33,7 +33,8 @@ def greedy_decode(model, z, steps, want_logp=True, use_graph=None):
     if not use_graph:
         return _decode_body(eng, z, steps, want_logp, None, None)
     cache = eng.__dict__.setdefault("_decode_graphs", {})
-    key = (z.shape[0], steps, bool(want_logp), z.shape[0] >= eng.cell_decode_rows, bool(getattr(eng, "fused_argmax", True)))     # the captured launches depend on the path taken
+    key = (z.shape[0], steps, bool(want_logp), z.shape[0] >= eng.cell_decode_rows, bool(getattr(eng, "fused_argmax", True)),
+           bool(getattr(eng.ops, "dw_x6", False) and getattr(eng.ops, "cell_x6", False)))     # the captured launches depend on the path taken (and on the cells' arithmetic)
     ent = cache.get(key)
     if ent is None:
         zs = z.clone()

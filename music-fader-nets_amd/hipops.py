@@ -57,6 +57,8 @@ class HipOps:
         self.dw_x6 = arith.default() == arith.BF16X6        # arithmetic of the deep products (the package default; a model sets its own choice: arith.py): True = exact bf16 triple splits on the bf16 MFMA (FN_GEMM_BF16X6, FnGruFwd.variant bit 14), False = fp32 MFMA
         self.x6_wide = True       # with dw_x6: 128 x 256 output tiles (FN_GEMM_X6_WIDE) where the product has >= 256 columns - with TWICE the K ranges the caller asked for (the same number of workgroups); False: 128 x 128 tiles
         self.nt_x6 = True         # with dw_x6: the big Linear-forward / dX products (whole 128 x 128 tiles, K % 32 == 0) on the bf16 x 6 kernel too; False: fp32 MFMA (A/B measurements)
+        self.cell_x6_rows = 2048  # ... from this many rows on (tests: 0 = wherever the kernel takes the shape)
+        self.cell_x6 = True       # with dw_x6: the large-batch decode cells (fn_gru_cell_f32) on the bf16 x 6 producer / consumer kernel (gru_cell_x6_kernel); False: fp32 MFMA cells
         self.x6_perwave = False   # with dw_x6: the round-5 weight-gradient kernel in which every wavefront splits its own operands (FN_GEMM_X6_PERWAVE; A/B measurements, tests)
         self.bwd_x6 = True        # with dw_x6: the backward scans on the bf16 x 6 kernel too (False: fp32 MFMA backward scans; A/B measurements, tests)
         self.variant = 0          # FnGruFwd.variant of every scan launch (tuning / tests only; results do not depend on it)
@@ -349,6 +351,12 @@ class HipOps:
             c.x, c.ldx, c.K1, c.w_ih, c.ldw_ih = px, ldx, K1, pwi, ldwi
         c.gx_table, c.gx_rowbias, c.start_token = _p(gx_table), _p(gx_rowbias), int(start_token)
         c.variant = int(self.cell_variant if variant is None else variant)
+        if self.dw_x6 and self.cell_x6 and variant is None and B >= self.cell_x6_rows:
+            # FnGruCell.variant bit 14: the cell on the bf16 MFMA with exact triple splits where the shape allows it (B % 128 == 0, H % 32 == 0, K1 % 32 == 0), else
+            # the fp32 cells.  Measured (scratch/r6_bench_decode_cells.py, us per token of the tokens-only decode): 2048 rows 90.0 against 95.7, 1536 rows 87.2
+            # against 76.6, 1024 rows 87.2 against 59.5 - one 128-row workgroup per CU takes ~28 / 48 us for the 16 / 32 blocks of the two cells whatever the row
+            # count, so it only pays where the fp32 cells need every CU: from 2048 rows on
+            c.variant |= 0x4000
         if idx is not None:
             if idx.dtype != torch.int32 or idx.dim() != 1 or idx.shape[0] != B:
                 raise RuntimeError("gru_cell: idx must be a [B] int32 column")

@@ -144,6 +144,50 @@ def test_gru_cell_dense(ops, B, H, K1, mode, variant):
     close(out, ref, 2e-5, "gru_cell")
 
 
+@pytest.mark.parametrize("B,H,K1,mode", [(2048, 512, 512, "dense"), (1024, 512, 0, "table"), (768, 512, 0, "table0"), (128, 64, 32, "dense"), (256, 96, 64, "dense"),
+                                         (1280, 512, 512, "dense_rb")])
+def test_gru_cell_bf16x6(ops, B, H, K1, mode):
+    """gru_cell_x6_kernel (round 6; FnGruCell.variant bit 14): one GRUCell step of a large batch on the bf16 MFMA with exact triple splits - producer / consumer
+    form, [r | z | n_x | n_h] column tiles, gate epilogue on the producer wavefronts - against tests/fake_ops.py (torch nn.GRUCell semantics) at the fp32
+    cells' tolerance and against the fp32 cell itself (agreement to fp32 rounding: the products are exact, the sums run in another order); dense input,
+    token row + row bias, start token, both; repeated launches bit-identical; a shape it does not take (B % 128 != 0) falls back to the fp32 cells."""
+    from fake_ops import FakeOps
+    torch.manual_seed(B + H + K1)
+    V = 50
+    hp = torch.randn(B, H) * 0.5
+    whh, bhh, bih = torch.randn(3 * H, H) / H ** 0.5, torch.randn(3 * H) * 0.1, torch.randn(3 * H) * 0.1
+    kw = dict(b_ih=bih)
+    toks = torch.randint(0, V, (B, 7), dtype=torch.int32)
+    if mode.startswith("dense"):
+        kw.update(x=torch.randn(B, K1), w_ih=torch.randn(3 * H, K1) / K1 ** 0.5)
+        if mode == "dense_rb":
+            kw.update(gx_rowbias=torch.randn(B, 3 * H) * 0.3)
+    else:
+        kw.update(gx_table=torch.randn(V, 3 * H) * 0.3, gx_rowbias=torch.randn(B, 3 * H) * 0.3, start_token=V - 1, idx=toks[:, 3] if mode == "table" else None)
+    ref = torch.zeros(B, H)
+    FakeOps().gru_cell(hp, whh, bhh, ref, **kw)
+    dkw = {k: (g(v) if torch.is_tensor(v) and k != "idx" else v) for k, v in kw.items() if k != "idx"}
+    dkw["idx"] = g(toks)[:, 3] if mode == "table" else None
+    outs = {}
+    try:
+        for x6 in (False, True, True):
+            ops.dw_x6, ops.cell_x6, ops.cell_x6_rows = x6, x6, 0
+            out = torch.full((B, H), float("nan"), device=DEV)
+            ops.gru_cell(g(hp), g(whh), g(bhh), out, **dkw)
+            close(out, ref, 2e-5, "gru_cell x6=%s" % x6)
+            if x6 in outs:
+                assert torch.equal(out, outs[x6])
+            outs[x6] = out
+        assert float((outs[True] - outs[False]).abs().max()) < 5e-6
+        if B > 128:                                       # ragged batch: the bf16 x 6 kernel does not take it, the call must still work
+            out = torch.zeros(B - 3, H, device=DEV)
+            rk = {k: (v[:B - 3] if torch.is_tensor(v) and v.shape[0] == B else v) for k, v in dkw.items()}
+            ops.gru_cell(g(hp)[:B - 3], g(whh), g(bhh), out, **rk)
+            close(out, ref[:B - 3], 2e-5, "ragged")
+    finally:
+        ops.dw_x6, ops.cell_x6, ops.cell_x6_rows = _x6_default(), True, 2048
+
+
 def test_gemm_tn_column_view_at_the_end_of_its_allocation(ops):
     """weight-gradient form on a COLUMN-OFFSET view whose last row ends with the allocation (dpre[:, Z:2Z] of the latent block, K = batch rows):
     the operand loads must stay inside the view's columns - clamped to the leading dimension they ran 128 bytes past the buffer (a memory fault
