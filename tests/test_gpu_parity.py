@@ -789,7 +789,7 @@ def test_bf16x6_adversarial_operands_vs_float64(ops, lo, hi, K, splitk):
     tied so that the PRODUCTS stay within 2^-20 .. 2^20 - the sum must not overflow -, i.e. tiny a meet huge b: every piece of the split
     travels the full exponent range; (-120, -90): lo pieces of values below 2^-103 are subnormal as bf16), heavy cancellation (every
     product has a partner of opposite sign that differs in its last bits only, the exact sum is ~1e-7 of sum |a||b|), K = 65 536.  Bound:
-    the error in units of sum |a||b| - maximum and root mean square over the 65 536 outputs - is at most 1.6 x the fp32-MFMA kernel's own."""
+    the error in units of sum |a||b| - maximum and root mean square over the 65 536 outputs - is at most 1.25 x the fp32-MFMA kernel's own."""
     M = N = 256
     g = torch.Generator(device="cpu").manual_seed(1000 * K + hi - lo)
     half = K // 2
@@ -827,9 +827,133 @@ def test_bf16x6_adversarial_operands_vs_float64(ops, lo, hi, K, splitk):
     # 1e-8 .. 1e-7 of sum |a||b|, a fraction of an fp32 ulp of that sum); the review's 1.25 x is met by the maximum in most cases and not by
     # the root mean square.  With rounded pieces the DROPPED products are zero-mean and ~2^-26 |a b| each - what remains is how a
     # 16x16x32 MFMA adds its 32 exact products (one rounding per MFMA, addends aligned to the largest) against 32 chained fp32 FMAs.
-    assert rms[True] <= 1.6 * rms[False] + 2.0 ** -32, (lo, hi, K, rms, err)
-    assert err[True] <= 1.6 * err[False] + 2.0 ** -30, (lo, hi, K, err)
+    # Round 6 (128 x 256 tiles, twice the K ranges - same products, 32 instead of 16 partial sums): 0.79 - 1.11 x in all six cases (profiles/r06_bf16x6_adversarial.txt):
+    # the bar is the round-4 review's 1.25 x again
+    assert rms[True] <= 1.25 * rms[False] + 2.0 ** -32, (lo, hi, K, rms, err)
+    assert err[True] <= 1.25 * err[False] + 2.0 ** -30, (lo, hi, K, err)
     assert err[True] < 2e-6, err
+
+
+def _block_gates(gt, B, H, n_floats):
+    """[T][B][4][H] -> the HIP kernels' private gate layout (inverse of _unblock_gates)"""
+    T = gt.shape[0]
+    nrt = (B + 15) // 16
+    b = torch.arange(B).view(B, 1, 1)
+    q = torch.arange(4).view(1, 4, 1)
+    u = torch.arange(H).view(1, 1, H)
+    off = ((((u // 16) * nrt + (b // 16)) * 4 + q) * 4 + (b % 4)) * 64 + ((b % 16) // 4) * 16 + (u % 16)
+    g = torch.zeros(T, n_floats, dtype=gt.dtype, device=gt.device)
+    g[:, off.reshape(-1).to(gt.device)] = gt.reshape(T, -1)
+    return g
+
+
+def _adversarial_pairs(rows, K, lo, hi, gen):
+    """[rows][K] x [cols = rows][K] operand pair as in test_bf16x6_adversarial_operands_vs_float64, along K: magnitudes spread over 2^lo .. 2^hi with the
+    partner's exponent tied (products within 2^-10 .. 2^10), every product with a partner of opposite sign that differs in its last bits"""
+    half = K // 2
+    ea = torch.randint(lo, hi + 1, (1, half), generator=gen).double()
+    a = (torch.where(torch.rand(rows, half, generator=gen) < 0.5, -1.0, 1.0).double() * (1.0 + torch.rand(rows, half, generator=gen, dtype=torch.float64)) * 2.0 ** ea).float()
+    eb = -ea + torch.randint(-10, 11, (1, half), generator=gen).double()
+    b = (torch.where(torch.rand(rows, half, generator=gen) < 0.5, -1.0, 1.0).double() * (1.0 + torch.rand(rows, half, generator=gen, dtype=torch.float64)) * 2.0 ** eb).float()
+    a2 = (-(a.double() * (1.0 + torch.randint(-3, 4, (rows, half), generator=gen).double() * 2.0 ** -23))).float()
+    perm = torch.randperm(K, generator=gen)
+    return torch.cat([a, a2], 1)[:, perm].contiguous(), torch.cat([b, b], 1)[:, perm].contiguous()
+
+
+@pytest.mark.parametrize("n,lo,hi", [(4, -30, 10), (2, -30, 10), (4, -6, 6)])
+def test_bf16x6_forward_scan_adversarial_operands_vs_float64(ops, n, lo, hi):
+    """review r5: the bf16 x 6 SCANS had no adversarial test.  The forward scan saves W_hn h_{t-1} + b_hn - a RAW product of its recurrent GEMM - with the gates
+    (slot 3 of the saved gates): step 0 of a scan started from an initial state h0 therefore exposes h0 W_hn^T.  h0 and W_hn are the adversarial pair of the
+    GEMM test along K = 512 (magnitudes over 2^lo .. 2^hi, every product with a cancelling partner); the error against float64 in units of sum |h||w| must be
+    within 1.6 x the fp32-MFMA scan's own (maximum and rms), on the 128-row-group kernel (n = 4: gru_fwd_x6pp_kernel<1>) and the 64-row-group one with its
+    K split (n = 2: <2>).  Step 1 checks the same product on the state the kernel itself produced (|h| <= ~2^hi, no engineered cancellation)."""
+    H, B, T = 512, 256, 2
+    gen = torch.Generator(device="cpu").manual_seed(100 * n + hi - lo)
+    scans, W, H0 = [], [], []
+    for s_ in range(n):
+        h0, whn = _adversarial_pairs(max(B, H), H, lo, hi, gen)
+        h0, whn = h0[:B].contiguous(), whn[:H].contiguous()
+        w = torch.cat([torch.randn(2 * H, H, generator=gen) / H ** 0.5, whn], 0).contiguous().to(DEV)
+        wf = torch.zeros(ops.frag_floats(3 * H, H), device=DEV); ops.frag_pack(w, wf)
+        wf3 = torch.zeros(ops.frag_floats(3 * H, H) * 3 // 2, device=DEV); ops.frag3_pack(w, wf3)
+        scans.append(dict(B=B, T=T, H=H, reverse=0, w_hh_frag=wf, w_hh_frag3=wf3, b_hh=torch.zeros(3 * H, device=DEV), b_ih=torch.zeros(3 * H, device=DEV), h0=h0.to(DEV),
+                          gx_dense=torch.zeros(T, B, 3 * H, device=DEV), h_all=torch.zeros(T, B, H, device=DEV), gates=torch.zeros(T, ops.gates_floats(B, H), device=DEV)))
+        W.append(w[2 * H:].double()); H0.append(h0.to(DEV).double())
+    err = {}
+    try:
+        for x6 in (False, True):
+            ops.dw_x6 = x6
+            if x6:
+                assert ops.gru_fwd_x6_ok(scans)
+            ops.gru_seq_fwd(scans)
+            torch.cuda.synchronize()
+            assert not ops.gru_sync_error()
+            e0, e1 = [], []
+            for d, w, h0 in zip(scans, W, H0):
+                ghn = _unblock_gates(d["gates"].cpu(), B, H)[:, :, 3, :].to(DEV).double()
+                for t, hin, acc in ((0, h0, e0), (1, d["h_all"][0].double(), e1)):
+                    ref, scale = hin @ w.t(), hin.abs() @ w.abs().t()
+                    if t == 0:
+                        assert float((ref.abs() / scale).median()) < 1e-4          # heavy cancellation indeed
+                    acc.append(((ghn[t] - ref).abs() / scale).flatten())
+            e0, e1 = torch.cat(e0), torch.cat(e1)
+            err[x6] = (float(e0.max()), float((e0 * e0).mean().sqrt()), float(e1.max()), float((e1 * e1).mean().sqrt()))
+    finally:
+        ops.dw_x6 = _x6_default()
+    print("x6 forward scan adversarial n=%d 2^%d..2^%d: step 0 max / rms fp32 %.3e %.3e x6 %.3e %.3e; step 1 fp32 %.3e %.3e x6 %.3e %.3e" % ((n, lo, hi) + err[False][:2] + err[True][:2] + err[False][2:] + err[True][2:]))
+    for i in range(4):
+        assert err[True][i] <= 1.6 * err[False][i] + 2.0 ** -30, (i, err)
+    assert err[True][0] < 2e-6 and err[True][2] < 2e-6, err
+
+
+def test_bf16x6_backward_scan_wide_operands_vs_float64(ops):
+    """the backward scan's recurrent product dh = [dr' dz' | dn' r] W_hh on bf16 x 6 (gru_bwd_x6_kernel<2>, the encoder shape) against float64: with z = 0 in
+    the saved gates of step 0 the gradient wrt the initial state IS that product of the gate gradients the kernel itself wrote (dgx_all / dghn_all of step 0:
+    exact fp32 operands, magnitudes spread over ~2^40 by the incoming gradient's scales), so dh0 can be checked against a float64 evaluation - error in
+    units of sum |dg||w| within 1.6 x the fp32 kernel's own"""
+    H, B, T, n = 512, 256, 2, 4
+    gen = torch.Generator(device="cpu").manual_seed(77)
+    bwd, W = [], []
+    for s_ in range(n):
+        w = (torch.randn(3 * H, H, generator=gen) * 2.0 ** torch.randint(-12, 5, (3 * H, 1), generator=gen).float()).contiguous().to(DEV)
+        wt = torch.zeros(ops.frag_floats(H, 3 * H), device=DEV)
+        wt3 = torch.zeros(ops.frag_floats(H, 3 * H) * 3 // 2, device=DEV)
+        ops.weight_images([("frag_t", w, wt), ("frag3_t", w, wt3)])
+        gt = torch.rand(T, B, 4, H, generator=gen)
+        gt[:, :, 2] = gt[:, :, 2] * 2 - 1                  # n in (-1, 1)
+        gt[:, :, 3] = torch.randn(T, B, H, generator=gen)  # W_hn h + b_hn
+        gt[0, :, 1] = 0.0                                  # z = 0 at step 0: nothing of dh flows past the gates into dh0
+        gates = _block_gates(gt, B, H, ops.gates_floats(B, H)).to(DEV)
+        scale_u = 2.0 ** torch.randint(-25, 15, (1, H), generator=gen).float()
+        bwd.append(dict(B=B, T=T, H=H, w_hh_t_frag=wt, w_hh_t_frag3=wt3, h0=(torch.rand(B, H, generator=gen) * 2 - 1).to(DEV),
+                        h_all=(torch.rand(T, B, H, generator=gen) * 2 - 1).to(DEV), gates=gates, dh_last=(torch.randn(B, H, generator=gen) * scale_u).to(DEV), dh_ext=None,
+                        dgx_all=torch.zeros(T, B, 3 * H, device=DEV), dghn_all=torch.zeros(T, B, H, device=DEV), dh0=torch.zeros(B, H, device=DEV),
+                        dgx_rowsum=torch.zeros(B, 3 * H, device=DEV), dghn_rowsum=torch.zeros(B, H, device=DEV), scratch=torch.zeros(B, H, device=DEV)))
+        W.append(w.double())
+    err = {}
+    try:
+        for x6 in (False, True):
+            ops.dw_x6 = x6
+            if x6:
+                assert ops.gru_bwd_x6_ok(bwd)
+            for b in bwd:
+                b["dgx_rowsum"].zero_(); b["dghn_rowsum"].zero_()
+            ops.gru_seq_bwd(bwd)
+            torch.cuda.synchronize()
+            assert not ops.gru_sync_error()
+            es = []
+            for b, w in zip(bwd, W):
+                dg = torch.cat([b["dgx_all"][0][:, :2 * H], b["dghn_all"][0]], 1).double()
+                ref, scale = dg @ w, dg.abs() @ w.abs()
+                assert torch.isfinite(ref).all() and float(scale.min()) > 0
+                es.append(((b["dh0"].double() - ref).abs() / scale).flatten())
+            e = torch.cat(es)
+            err[x6] = (float(e.max()), float((e * e).mean().sqrt()))
+    finally:
+        ops.dw_x6 = _x6_default()
+    print("x6 backward scan wide operands: max / rms error in units of sum |dg||w|: fp32 %.3e %.3e  x6 %.3e %.3e" % (err[False] + err[True]))
+    assert err[True][0] <= 1.6 * err[False][0] + 2.0 ** -30 and err[True][1] <= 1.6 * err[False][1] + 2.0 ** -32, err
+    assert err[True][0] < 2e-6, err
 
 
 @pytest.mark.parametrize("B,T,Tr,fill", [(64, 33, 9, True), (128, 65, 33, True), (1024, 96, 8, False), (192, 64, 16, True)])
