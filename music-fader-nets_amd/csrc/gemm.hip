@@ -128,7 +128,9 @@ __global__ __launch_bounds__(NT) void gemm_multi_kernel(const GmArgs args) {
         const int K = S.K, nk = (K + BK - 1) / BK;
         auto loadA = [&](int k0, SA& st) { st.load_checked(A, lda, ra, k0, K); };
         auto loadB = [&](int k0, SB& st) { st.load_checked(B, ldb, rb, k0, K); };
-        fn_kloop<PF_DEPTH, TM, TN, BK, SA, SB>(smem, nk, loadA, loadB, wm * TM * 16, wn * TN * 16, lane, acc);
+        // 4 K tiles in flight: these launches are a handful of workgroups walking K = 512 .. 2048 on the critical path between two scans, bound by the
+        // latency of a 16-k tile's loads (1.3 us per tile with 2 in flight: 82 us for the encoder heads' 64 tiles)
+        fn_kloop<4, TM, TN, BK, SA, SB>(smem, nk, loadA, loadB, wm * TM * 16, wn * TN * 16, lane, acc);
     }
     const int cj = lane & 15, rq = (lane >> 4) * 4;
 #pragma unroll

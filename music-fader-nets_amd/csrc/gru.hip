@@ -433,9 +433,13 @@ __global__ void frag_pack_kernel(const float* __restrict__ src, int rows, int K,
 // lane (i, g) = row 16 t + i, k values 32 b + 8 g .. + 7; piece 0 / 1 / 2 = hi / mid / lo with hi + mid + lo == src exactly (rounded pieces: fn_rn16);
 // rows padded to a multiple of 16 with zeros.  One thread per (row, 8 k).
 // item i = (row, 8 k) of the triple image of a [rows][K] matrix whose element (row, k) lives at src[row * sr + k * sk]
+// ROWFAST: consecutive items walk the ROWS of one 8-k group (the transposed source, sr == 1: a wavefront's loads are 256 contiguous bytes per k
+// instead of 64 lines of 4 bytes)
+template <bool ROWFAST = false>
 FN_DEVINL void frag3_item(const float* __restrict__ src, int rows, int K, long sr, long sk, unsigned* __restrict__ dst, long i) {
     const int nb = K >> 5;
-    const int row = (int)(i / (K >> 3)), k8 = (int)(i % (K >> 3));
+    const int rows16 = (rows + 15) & ~15;
+    const int row = ROWFAST ? (int)(i % rows16) : (int)(i / (K >> 3)), k8 = ROWFAST ? (int)(i / rows16) : (int)(i % (K >> 3));
     float x[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[j] = row < rows ? src[(long)row * sr + (long)(8 * k8 + j) * sk] : 0.f;
@@ -507,8 +511,12 @@ __global__ __launch_bounds__(256) void weight_images_kernel(const WiArgs a) {
     if (J.kind >= 3) {
         const int rows = J.kind == 3 ? J.R : J.C, K = J.kind == 3 ? J.C : J.R;
         const long total = (long)((rows + 15) & ~15) * (K >> 3);
-        for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L)
-            frag3_item(J.src, rows, K, J.kind == 3 ? (long)J.ld : 1L, J.kind == 3 ? 1L : (long)J.ld, reinterpret_cast<unsigned*>(J.dst), i);
+        if (J.kind == 3)
+            for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L)
+                frag3_item<false>(J.src, rows, K, (long)J.ld, 1L, reinterpret_cast<unsigned*>(J.dst), i);
+        else
+            for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L)
+                frag3_item<true>(J.src, rows, K, 1L, (long)J.ld, reinterpret_cast<unsigned*>(J.dst), i);
         return;
     }
     const int rows = J.kind == 1 ? J.R : J.C, K = J.kind == 1 ? J.C : J.R;

@@ -64,7 +64,9 @@ class Engine:
         self.fused_head = True          # trainers: output projection + log-softmax + NLL + gradient seed as ONE kernel (fn_out_head_f32); False: GEMM -> logits in HBM -> fn_vocab_logsoftmax
         self.lean_dw = False            # decoder-side weight-gradient GEMMs as the <= 128-register instance.  Paid while an encoder-scan wavefront left 138 of a SIMD's 512 registers free (round 2: 9 % packing gain); the hand-placed K loops hold all of them, the side lane's GEMMs run once the scan has ended and the 194-register instance is the faster one (A/B in one session, scratch/ab_dw.py: 23.65 vs 24.29 ms per step)
         self.lean_proj = True           # layer-2 input projection beside the decoder pipeline's forward launches as the <= 128-register instance of the LDS-free NT kernel: 4 workgroups per CU (768 tiles = one round) and one of its wavefronts fits a SIMD beside a forward-scan wavefront (377 registers): 107 us beside a 351 us launch (the 248-register instance: 125 us in front of the launch)
-        self.dw_order = "side"          # decoder-side weight-gradient GEMMs: "side" = side stream, issued in front of the encoder backward; "before" / "after" = caller's stream, in front of / behind the encoder block
+        self.proj_x6 = False            # layer-2 input projection beside the decoder pipeline's FORWARD launches: True = the bf16x6 producer / consumer kernel (78 us, but its 144 KB / 512-thread workgroups cannot share a CU with a scan wavefront: the launch serialises with the scans), False = the lean fp32 instance above, which does (a bf16x6 forward-scan wavefront holds 328 of a SIMD's 512 registers)
+        self.dw_order = "side+aux"      # decoder-side weight-gradient GEMMs: "side+aux" = the global decoder's on the side stream, issued in front of the encoder backward, the attribute decoders' on the aux stream behind the encoder scans; "side" = all of them on the side stream; "before" / "after" = caller's stream, in front of / behind the encoder block
+        self.losses_early = False       # trainer: True = the side lane's loss-term launches start in FRONT of the fused output head (they need nothing from it) instead of behind it; measured: the graph runs them behind the head's and the dhx1 product's workgroups either way (17.70 vs 17.68 ms), and with 16 hardware queues they land beside the first backward launch (20.4 ms): off
         self.losses_on_side = True      # trainer: the small loss-term launches run on the side lane beside the decoder backward's first launches
         self.buf_ns = ""                # namespace of buf(): a second decoder pass (GLSR) must not overwrite the saved activations of the first
         self.serialize_lanes = False    # True: every lane runs on the caller's stream (per-kernel measurements: each kernel alone)
@@ -324,12 +326,13 @@ class Engine:
             scans.append(dict(B=B, T=Tr, H=H, w_hh_frag=self.whh_f["d_" + e], w_hh_frag3=self.whh_f3.get("d_" + e), b_hh=P["gru_d_%s.bias_hh_l0" % e],
                               b_ih=P["gru_d_%s.bias_ih_l0" % e], h0=h0, gx_table=self.tab["d_" + e], idx=attr, gx_rowbias=rb,
                               h_all=sd[e]["h_all"], gates=sd[e]["gates"]))
-        ops.gemm_multi(jobs)                                     # initial states + per-sequence input parts of both decoders: one launch
-        if defer:
+        if defer:                                                # (the four products ride in global_decoder_tf's launch of its own two)
             for e, sc in zip(("r", "n"), scans):
                 sc["tag"] = "sd_" + e
                 sd[e]["scan"] = sc
+            sd["init_jobs"] = jobs
             return sd
+        ops.gemm_multi(jobs)                                     # initial states + per-sequence input parts of both decoders: one launch
         ops.gru_seq_fwd(scans)
         return self._sub_decoder_logits(sd, Tr, B)
 
@@ -355,7 +358,7 @@ class Engine:
         CH = self.chunk
         return bool(self.fill_edges and self.persist_dec and Tr <= 2 * CH and T >= 2 * CH and Tr > 1)
 
-    def global_decoder_tf(self, d, zc, save=True, head=True, fill=None):
+    def global_decoder_tf(self, d, zc, save=True, head=True, fill=None, more_jobs=()):
         """gmm_model.py:119-149 in train mode (teacher forced with d, start token 341, input shifted by one step) up to the
         pre-softmax logits [T*B][LOGIT_LD].  head=False: the output projection is left to the caller's fused head
         (ops.out_head on dec['hx1'], which writes the gradient seed into dec['logits']); the buffer is returned unwritten."""
@@ -364,7 +367,7 @@ class Engine:
         h0g = self.buf("g_h0", (B, H))
         rbg = self.buf("g_rb", (B, 3 * H))
         ops.gemm_multi([dict(C=h0g, segs=[(zc, P["linear_init_global.weight"])], bias=P["linear_init_global.bias"]),
-                        dict(C=rbg, segs=[(zc, P["grucell_g.weight_ih"][:, E_VOCAB:])])])
+                        dict(C=rbg, segs=[(zc, P["grucell_g.weight_ih"][:, E_VOCAB:])])] + list(more_jobs))
         hx0 = self.buf("g_hx0", (T, B, H))
         g1 = self.buf("g_gates1", (T, ops.gates_floats(B, H))) if save else None
         l1 = dict(B=B, T=T, H=H, w_hh_frag=self.whh_f["g"], w_hh_frag3=self.whh_f3.get("g"), b_hh=P["grucell_g.bias_hh"], b_ih=P["grucell_g.bias_ih"],
@@ -434,18 +437,20 @@ class Engine:
                 self.lane_wait(lane, "main")
                 with Engine._Lane(self, True, lane):
                     ops.gemm(hx0[t0:t1].view(-1, H), P["grucell_g_2.weight_ih"], gx2[t0:t1].view(-1, 3 * H), bias=P["grucell_g_2.bias_ih"],
-                             lean=self.lean_proj)
+                             lean=self.lean_proj, **({} if self.proj_x6 else {"nt_x6": False}))
         logits = self.buf("g_logits", (T * B, LOGIT_LD), zero_init=True)     # columns [342, 352) stay zero: every writer leaves them alone or writes zeros
         if head:
             ops.gemm(hx1.view(T * B, H), P["linear_out_g.weight"], logits[:, :E_VOCAB], bias=P["linear_out_g.bias"])
         return dict(zc=zc, h0g=h0g, rbg=rbg, hx0=hx0, g1=g1, gx2=gx2, hx1=hx1, g2=g2, logits=logits)
 
-    def decoders(self, d, r, n, c, z_r, z_n, save=True, head=True):
-        """sub-decoders + teacher-forced global decoder up to the (pre-softmax) logits."""
+    def decoders(self, d, r, n, c, z_r, z_n, save=True, head=True, sd_logits=True):
+        """sub-decoders + teacher-forced global decoder up to the (pre-softmax) logits.  sd_logits=False: the attribute decoders' output
+        layers are left to the caller (``sub_decoder_logits(S)``: the trainer issues them on the side lane, beside its fused head)."""
         if self._fill_ok(d.shape[1], r.shape[1]):
             sd = self.sub_decoders_fwd(r, n, z_r, z_n, save, defer=True)
-            dec = self.global_decoder_tf(d, self.pack_zc(z_r, z_n, c), save, head, fill={e: sd[e].pop("scan") for e in ("r", "n")})
-            self._sub_decoder_logits(sd, r.shape[1], r.shape[0])
+            dec = self.global_decoder_tf(d, self.pack_zc(z_r, z_n, c), save, head, fill={e: sd[e].pop("scan") for e in ("r", "n")}, more_jobs=sd.pop("init_jobs"))
+            if sd_logits:
+                self._sub_decoder_logits(sd, r.shape[1], r.shape[0])
         else:
             sd = self.sub_decoders_fwd(r, n, z_r, z_n, save)
             dec = self.global_decoder_tf(d, self.pack_zc(z_r, z_n, c), save, head)
@@ -483,9 +488,16 @@ class Engine:
         c["dh0"] = carry_out
         return c
 
-    def forward(self, d, r, n, c, eps_r, eps_n, labels=None, save=True, head=True):
+    def sub_decoder_logits(self, S):
+        """the output layers forward(sd_logits=False) left out (no-op when they were not deferred)"""
+        sd = S["dec"]["sd"]
+        if "logits" not in sd["r"]:
+            self._sub_decoder_logits(sd, S["r"].shape[1], S["r"].shape[0])
+        return sd
+
+    def forward(self, d, r, n, c, eps_r, eps_n, labels=None, save=True, head=True, sd_logits=True):
         """Full training-mode forward up to logits; everything backward needs stays in named buffers (save=False: forward only,
-        the gate tensors are not written).  head=False: see global_decoder_tf."""
+        the gate tensors are not written).  head=False: see global_decoder_tf; sd_logits=False: see decoders()."""
         sort = None
         if save:
             # token sorts for the backward's segment sums (embed.hip): tiny kernels, side stream, beside the encoder scans
@@ -494,7 +506,7 @@ class Engine:
                 sort = {k: ops_sort(self, k, t, V) for k, t, V in (("d", d, E_VOCAB), ("r", r, R_DIMS), ("n", n, N_DIMS))}
         pre = self.encode(d, save)
         lat = self.latent(pre, {"r": eps_r, "n": eps_n}, labels)
-        dec = self.decoders(d, r, n, c, lat["r"]["z"], lat["n"]["z"], save, head)
+        dec = self.decoders(d, r, n, c, lat["r"]["z"], lat["n"]["z"], save, head, sd_logits)
         self.main_wait_side()
         S = dict(d=d, r=r, n=n, c=c, eps={"r": eps_r, "n": eps_n}, labels=labels, pre=pre, lat=lat, dec=dec, sort=sort)
         self.saved = S if save else None
@@ -525,7 +537,7 @@ class Engine:
         # peak against 210 us = 0.78 with 16; scratch/sweep_dwhh_splitk.py)
         return self.splitk_big if rows >= 8192 else (8 if rows >= 4096 else (4 if rows >= 1024 else 1))
 
-    def _bwd_global_decoder_scans(self, S, fill=None):
+    def _bwd_global_decoder_scans(self, S, fill=None, before_first_launch=None):
         """Backward of global_decoder_tf up to the gate gradients (dlogits must already be in S['dec']['logits'], in place):
         output layer dX, then the two cells, chunk-pipelined.  Returns the gate-gradient buffers, the per-sequence row sums
         (drb_g = d(W_ih[:, V:] z) rows, i.e. the gradient wrt the conditioning projection) and dh0_g = dL/d(linear_init_global(z))."""
@@ -535,6 +547,8 @@ class Engine:
         dlog = dec["logits"]                                   # [T*B][LOGIT_LD], holds dlogits
         dhx1 = self.buf("g_dhx1", (T, B, H))
         ops.gemm(dlog, self.wout_t, dhx1.view(T * B, H), a_k=True, b_k=True)         # K = LOGIT_LD incl. the zero pad columns: whole K tiles
+        if before_first_launch is not None:
+            before_first_launch()          # backward(): joins the side lane (loss terms, the attribute decoders' gradient seeds) behind this GEMM
         dgx2 = self.buf("g_dgx2", (T, B, 3 * H))
         dghn2 = self.buf("g_dghn2", (T, B, H))
         dhx0 = self.buf("g_dhx0", (T, B, H))
@@ -653,9 +667,12 @@ class Engine:
         sd = dec["sd"]
         if self._fill_ok(T, Tr):
             # ---- both attribute decoders ride in the half-empty launches of the global decoder's pipeline ------------------------
-            self.main_wait_side()        # the caller's loss terms / gradient seeds of the sub-decoders and of z (side lane)
-            sdb, sds = self._bwd_sub_decoder_scans(sd, dlogits_sd, B, Tr, defer=True)
-            gd = self._bwd_global_decoder_scans(S, fill={e: (sds[e], sdb[e]["dh0"]) for e in ("r", "n")})
+            # the caller's loss terms / gradient seeds of the sub-decoders and of z sit on the side lane (beside the fused head): the two
+            # output-layer products of the attribute decoders follow them THERE, and the lane is joined behind the dhx1 product
+            self.side_wait_main()        # (a caller that wrote the seeds on its own stream)
+            with self.on_side():
+                sdb, sds = self._bwd_sub_decoder_scans(sd, dlogits_sd, B, Tr, defer=True)
+            gd = self._bwd_global_decoder_scans(S, fill={e: (sds[e], sdb[e]["dh0"]) for e in ("r", "n")}, before_first_launch=self.main_wait_side)
         else:
             gd = self._bwd_global_decoder_scans(S)
             self.main_wait_side()
@@ -688,14 +705,36 @@ class Engine:
         ops.gemm_multi(jobs, a_k=True, b_k=False)
         ops.colsum_multi(sums)
         # ---- decoder-side PARAMETER gradients (dw_order: where they run relative to the latent block and the encoder scans) ---
-        def decoder_params():
-            self._bwd_global_decoder_params(G, S, gd, flush=False)
+        def sub_decoder_params():
             self._bwd_sub_decoder_params(G, sd, sdb, dlogits_sd, S["sort"], {"r": lat["r"]["z"], "n": lat["n"]["z"]}, B, Tr)
             self.flush_colsums()
+
+        def decoder_params():
+            self._bwd_global_decoder_params(G, S, gd, flush=False)
+            sub_decoder_params()
             if after_decoders is not None:
                 after_decoders()           # data parallel: this bucket's all-reduce is ordered behind these launches
 
-        if self.dw_order in ("side", "side_late"):
+        if self.dw_order == "side+aux":
+            # three lanes: the global decoder's deep products on the side lane (issued in front of the encoder block, they run once its
+            # scans have ended); the attribute decoders' ~25 small launches (K = Tr*B products, segment sums, column sums: a 0.6 ms
+            # dependent chain that fills a fraction of the chip) on the aux lane, issued BEHIND the encoder scans so that they run in
+            # the gaps of the deep products instead of alone at the end of the step
+            self.side_wait_main()
+            with self.on_side():
+                self._bwd_global_decoder_params(G, S, gd, flush=True)
+
+            def after_scans():
+                self.lane_wait("aux", "main")
+                with self.on_aux():
+                    sub_decoder_params()
+                self.lane_wait("side", "aux")
+                if after_decoders is not None:
+                    with self.on_side():
+                        after_decoders()
+            self.backward_encoder(G, S, lat_up, w3, after_encoder_r, after_scans=after_scans)
+            self.main_wait_side()
+        elif self.dw_order in ("side", "side_late"):
             def on_side_lane():
                 self.side_wait_main()
                 with self.on_side():
@@ -750,7 +789,7 @@ class Engine:
             ops.gemm(sdb[e]["dh0"], z[e], G["linear_init_%s.weight" % e], a_k=False, b_k=False)
             self.colsum(sdb[e]["dh0"], G["linear_init_%s.bias" % e])
 
-    def backward_encoder(self, G, S, lat_up, w3=None, after_encoder_r=None, before_scans=None):
+    def backward_encoder(self, G, S, lat_up, w3=None, after_encoder_r=None, before_scans=None, after_scans=None):
         """latent block + heads + the four encoder scans and their parameter gradients (the last third of backward(); also the whole
         backward of a direct ``model.encode(x)`` call: S then holds d, pre, lat, eps, labels, sort['d'] only)"""
         ops, P, H, Z, K = self.ops, self.p, self.H, self.Z, self.K
@@ -760,6 +799,7 @@ class Engine:
         # ---- latent block + heads -----------------------------------------------------------------
         scans = []
         encb = {}
+        dh_jobs, head_jobs, head_bias = [], [], []
         for e in ("r", "n"):
             up = lat_up[e]
             dpre = self.buf("dpre_" + e, (B, 2 * Z))
@@ -774,21 +814,27 @@ class Engine:
             dhf, dhb = self.buf("enc_dhf_" + e, (B, H)), self.buf("enc_dhb_" + e, (B, H))
             Wm, Wv = P["mu_" + e + ".weight"], P["var_" + e + ".weight"]      # [Z][2H]
             dpm, dpv = dpre[:, :Z], dpre[:, Z:]
-            ops.gemm_multi([dict(C=dhf, segs=[(dpm, Wm[:, :H]), (dpv, Wv[:, :H])]), dict(C=dhb, segs=[(dpm, Wm[:, H:]), (dpv, Wv[:, H:])])],
-                           a_k=True, b_k=False)
-            ops.gemm_multi([dict(C=G[head + e + ".weight"][:, c0:c0 + H], segs=[(dp, hh)])
-                            for head, dp in (("mu_", dpm), ("var_", dpv)) for c0, hh in ((0, hf), (H, hb))], a_k=False, b_k=False)
-            for head, dp in (("mu_", dpm), ("var_", dpv)):
-                self.colsum(dp, G[head + e + ".bias"])
+            # the scans wait for dhf / dhb only: both encoders' four products are ONE launch behind the two latent launches, the heads'
+            # own parameter gradients follow the scan launch (they used to sit in front of it, 2 x 20 us of the critical path)
+            dh_jobs += [dict(C=dhf, segs=[(dpm, Wm[:, :H]), (dpv, Wv[:, :H])]), dict(C=dhb, segs=[(dpm, Wm[:, H:]), (dpv, Wv[:, H:])])]
+            head_jobs += [dict(C=G[head + e + ".weight"][:, c0:c0 + H], segs=[(dp, hh)])
+                          for head, dp in (("mu_", dpm), ("var_", dpv)) for c0, hh in ((0, hf), (H, hb))]
+            head_bias += [(dp, G[head + e + ".bias"]) for head, dp in (("mu_", dpm), ("var_", dpv))]
             for key, dh in ((e, dhf), (e + "_reverse", dhb)):
                 encb[key] = dict(dgx=self.buf("enc_dgx_" + key, (T, B, 3 * H)), dghn=self.buf("enc_dghn_" + key, (T, B, H)),
                                  rs=self.zbuf("enc_rs_" + key, (B, 3 * H)), rsn=self.zbuf("enc_rsn_" + key, (B, H)))
                 scans.append(dict(B=B, T=T, H=H, w_hh_t_frag=self.whh_t[key], w_hh_t_frag3=self.whh_t3.get(key), h0=None, h_all=pre["h_all"][key],
                                   gates=pre["gates"][key], dh_last=dh, dgx_all=encb[key]["dgx"], dghn_all=encb[key]["dghn"],
                                   scratch=self.buf("enc_scr_" + key, (B, H)), dgx_rowsum=encb[key]["rs"], dghn_rowsum=encb[key]["rsn"]))
+        ops.gemm_multi(dh_jobs, a_k=True, b_k=False)
         if before_scans is not None:
             before_scans()
-        ops.gru_seq_bwd(scans)        # 4 concurrent reverse scans, one weight-stationary launch (the side lane's GEMMs run beside it)
+        ops.gru_seq_bwd(scans)        # 4 concurrent reverse scans, one weight-stationary launch (the side lane's GEMMs run once it has ended)
+        if after_scans is not None:
+            after_scans()
+        ops.gemm_multi(head_jobs, a_k=False, b_k=False)
+        for dp, gb in head_bias:
+            self.colsum(dp, gb)
         enc_keys = [(e, "gru_%s." % e, key, sfx, rev) for e in ("r", "n") for key, sfx, rev in ((e, "_l0", 0), (e + "_reverse", "_l0_reverse", 1))]
         # one-hot columns of the four W_ih: token-segment sums of the gate gradients (ONE launch pair, the batch's token sort is shared)
         ops.embed_grad_sorted(S["sort"]["d"], [dict(dgx=encb[key]["dgx"], out=G[pfx + "weight_ih" + sfx], transposed=True, reverse=rev)

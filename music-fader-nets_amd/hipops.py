@@ -82,7 +82,7 @@ class HipOps:
         return cur
 
     # -- dense ----------------------------------------------------------------------------------
-    def gemm(self, A, B, Cm, a_k=True, b_k=True, alpha=1.0, beta=0.0, bias=None, splitk=1, lean=False):
+    def gemm(self, A, B, Cm, a_k=True, b_k=True, alpha=1.0, beta=0.0, bias=None, splitk=1, lean=False, nt_x6=True):
         pa, ar, ac, lda = _mat(A, "A")
         pb, br, bc, ldb = _mat(B, "B")
         pc, M, N, ldc = _mat(Cm, "C")
@@ -94,7 +94,7 @@ class HipOps:
         x6 = _lib.GEMM_BF16X6 if (self.dw_x6 and not a_k and not b_k and K >= 1024) else 0
         if x6:
             splitk, x6 = self._x6_mode(splitk, N, K, x6)
-        elif self.dw_x6 and self.nt_x6 and a_k and b_k and splitk <= 1 and M % 128 == 0 and N % 128 == 0 and K % 32 == 0 and K >= 128 and (M // 128) * (N // 128) >= 128:
+        elif self.dw_x6 and self.nt_x6 and nt_x6 and a_k and b_k and splitk <= 1 and M % 128 == 0 and N % 128 == 0 and K % 32 == 0 and K >= 128 and (M // 128) * (N // 128) >= 128:
             x6 = _lib.GEMM_BF16X6                  # Linear forward / dX of the decoder pipeline on the bf16 MFMA (gemm_nt_x6w_kernel; the lean instance is then moot)
         if splitk > 1:
             wsb = self.lib.fn_gemm_ws_bytes(M, N, splitk & 0xffff)

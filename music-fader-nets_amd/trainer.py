@@ -151,9 +151,12 @@ class GMVAETrainer:
         fused = eng.fused_head
         if want_grads:
             eng.begin_step()                       # one fill for every zero-initialised accumulator of the step
-        S = eng.forward(d, r, n, c, eps[0], eps[1], labels, head=not fused)
+        side = eng.losses_on_side
+        S = eng.forward(d, r, n, c, eps[0], eps[1], labels, head=not fused, sd_logits=not side)
         dec, lat = S["dec"], S["lat"]
         st = self.stats
+        if side and eng.losses_early:
+            eng.side_wait_main()                   # the side lane starts HERE: its ~25 small launches run beside the output head below
         # reconstruction terms; the gradient seeds land where the logits would be (fused head: the logits are never written)
         nll = eng.buf("nll_rows", (T * B,))
         gs = 5.0 / (Bg * T) if want_grads else 0.0
@@ -162,12 +165,14 @@ class GMVAETrainer:
                          grad_scale=gs, dlogits=dec["logits"] if want_grads else None)
         else:
             ops.vocab_logsoftmax(dec["logits"], B, T, E_VOCAB, target=d, nll_rows=nll, grad_scale=gs, dlogits=dec["logits"] if want_grads else None)
-        # Everything below is ~20 dependent launches of a few microseconds each; the decoder backward only needs the dlogits written
-        # above, so the rest runs on the side lane beside its first launches (Engine.backward joins the lane before it reads these).
-        if eng.losses_on_side:
-            eng.side_wait_main()
-        with (eng.on_side() if eng.losses_on_side else contextlib.nullcontext()):
-            ops.sum(nll, st[S_CE_X:S_CE_X + 1], 1.0 / (Bg * T))
+        ops.sum(nll, st[S_CE_X:S_CE_X + 1], 1.0 / (Bg * T))
+        # Everything below is ~25 dependent launches of a few microseconds each that need nothing from the output head: the attribute
+        # decoders' output layers and loss terms, the latent terms, the regulariser.  They run on the side lane beside the head and the
+        # first product of the decoder backward (Engine.backward joins the lane in front of its first scan launch).
+        if side and not eng.losses_early:
+            eng.side_wait_main()                   # (A/B switch: the lane starts behind the head, as up to round 5)
+        with (eng.on_side() if side else contextlib.nullcontext()):
+            eng.sub_decoder_logits(S)
             dl_sd = {}
             for slot, e, attr, Ce in ((S_CE_R, "r", r, 3), (S_CE_N, "n", n, 16)):
                 nbc = eng.buf("nll_bc_" + e, (B, Ce))

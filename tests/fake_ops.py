@@ -20,7 +20,7 @@ class FakeOps:
         self.lane = ""
 
     # -- dense --------------------------------------------------------------------------------------
-    def gemm(self, A, B, Cm, a_k=True, b_k=True, alpha=1.0, beta=0.0, bias=None, splitk=1, lean=False):
+    def gemm(self, A, B, Cm, a_k=True, b_k=True, alpha=1.0, beta=0.0, bias=None, splitk=1, lean=False, nt_x6=True):
         self.calls.append("gemm")
         a = A if a_k else A.t()
         b = B.t() if b_k else B
