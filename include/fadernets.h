@@ -201,6 +201,7 @@ int fn_frag_pack(const float* src, int rows, int K, int ld, float* dst, void* st
  *   kind 2: dst = fn_frag_pack image of src^T, the [cols][K = rows] matrix (rows % 32 == 0): W_hh^T for the backward scans
  *   kind 3: dst = fn_frag3_pack image (bf16 triples) of src [rows][K = cols]            (bf16 x 6 forward scans, variant bit 14)
  *   kind 4: dst = fn_frag3_pack image of src^T, the [cols][K = rows] matrix              (bf16 x 6 backward scans: W_hh^T)
+ *   kind 5: dst [rows][cols] dense = src [rows][cols] (leading dim ld)                   (round 6: 16-byte aligned image of a column slice, W_ih[:, V:])
  * up to 56 jobs; dst of kinds 1 / 2 16-byte aligned with fn_frag_floats(...) floats, of kinds 3 / 4 with 3/2 of that. */
 typedef struct FnWeightImage {
     const float* src;

@@ -126,11 +126,19 @@ __global__ __launch_bounds__(NT) void gemm_multi_kernel(const GmArgs args) {
         const float* B = S.B;
         const long lda = S.lda, ldb = S.ldb;
         const int K = S.K, nk = (K + BK - 1) / BK;
-        auto loadA = [&](int k0, SA& st) { st.load_checked(A, lda, ra, k0, K); };
-        auto loadB = [&](int k0, SB& st) { st.load_checked(B, ldb, rb, k0, K); };
-        // 4 K tiles in flight: these launches are a handful of workgroups walking K = 512 .. 2048 on the critical path between two scans, bound by the
-        // latency of a 16-k tile's loads (1.3 us per tile with 2 in flight: 82 us for the encoder heads' 64 tiles)
-        fn_kloop<4, TM, TN, BK, SA, SB>(smem, nk, loadA, loadB, wm * TM * 16, wn * TN * 16, lane, acc);
+        // These launches are a handful of workgroups walking K = 128 .. 2048 on the critical path between two scans.  Up to round 6 every segment
+        // took the element-wise checked loads, whose selects consume a tile's registers right behind the loads: no prefetch at all, one exposed memory
+        // latency per 16-k tile (1.2 us: 82 us for the encoder heads' 64 tiles).  Aligned segments of whole tiles (all of the step's) take the
+        // unconditional 16-byte loads, 4 tiles in flight; the order of the summation is the same.
+        if (SA::can_fast(A, lda, ra, K) && SB::can_fast(B, ldb, rb, K)) {
+            auto loadA = [&](int k0, SA& st) { st.load_fast(A, lda, ra, k0); };
+            auto loadB = [&](int k0, SB& st) { st.load_fast(B, ldb, rb, k0); };
+            fn_kloop<4, TM, TN, BK, SA, SB>(smem, nk, loadA, loadB, wm * TM * 16, wn * TN * 16, lane, acc);
+        } else {
+            auto loadA = [&](int k0, SA& st) { st.load_checked(A, lda, ra, k0, K); };
+            auto loadB = [&](int k0, SB& st) { st.load_checked(B, ldb, rb, k0, K); };
+            fn_kloop<PF_DEPTH, TM, TN, BK, SA, SB>(smem, nk, loadA, loadB, wm * TM * 16, wn * TN * 16, lane, acc);
+        }
     }
     const int cj = lane & 15, rq = (lane >> 4) * 4;
 #pragma unroll

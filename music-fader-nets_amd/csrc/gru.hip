@@ -475,6 +475,7 @@ __global__ void frag3_pack_kernel(const float* __restrict__ src, int rows, int K
 //            2 = fragment-major image of src^T, i.e. of the [rows = C][K = R] matrix    (backward scans: W_hh^T) - no intermediate
 //            3 = bf16 triple image (fn_frag3_pack layout) of src [rows = R][K = C]       (bf16 x 6 forward scans)
 //            4 = bf16 triple image of src^T, the [rows = C][K = R] matrix                (bf16 x 6 backward scans: W_hh^T)
+//            5 = dst [R][C] dense = src [R][C] (leading dimension ld): aligned image of a column slice (W_ih[:, V:], the z part of a cell's input matrix)
 // The refresh after every Adam update used to be ~40 dependent launches of a few microseconds of work each (0.5 ms of the step).
 constexpr int WI_MAX_JOBS = 56;
 struct WiJob {
@@ -506,6 +507,12 @@ __global__ __launch_bounds__(256) void weight_images_kernel(const WiArgs a) {
             }
             __syncthreads();
         }
+        return;
+    }
+    if (J.kind == 5) {
+        // dense copy dst [R][C] of a column slice src [R][C] (leading dimension ld): a 16-byte aligned operand for the products that read the slice
+        const long total = (long)J.R * J.C;
+        for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) J.dst[i] = J.src[(i / J.C) * J.ld + (i % J.C)];
         return;
     }
     if (J.kind >= 3) {
@@ -1922,7 +1929,7 @@ extern "C" int fn_weight_images(const FnWeightImage* jobs, int n_jobs, void* str
     for (int j = 0; j < n_jobs; ++j) {
         const FnWeightImage& d = jobs[j];
         if (!d.src || !d.dst) return FN_E_NULL;
-        if (d.rows <= 0 || d.cols <= 0 || d.ld < d.cols || d.kind < 0 || d.kind > 4) return FN_E_SHAPE;
+        if (d.rows <= 0 || d.cols <= 0 || d.ld < d.cols || d.kind < 0 || d.kind > 5) return FN_E_SHAPE;
         if ((d.kind == 1 || d.kind == 3) && (d.cols % 32)) return FN_E_SHAPE;
         if ((d.kind == 2 || d.kind == 4) && (d.rows % 32)) return FN_E_SHAPE;
         if (d.kind != 0 && (((uintptr_t)d.dst) & 15)) return FN_E_ALIGN;

@@ -252,6 +252,15 @@ class Engine:
             if w2 is not None:
                 self.wih2_t = self.buf("wih2_t", (w2.shape[1], w2.shape[0]))
                 jobs.append(("transpose", w2, self.wih2_t))
+        if need_backward:
+            # the z columns of the three cells' input matrices W_ih[:, V:] as dense, 16-byte aligned matrices: dz = drb W_ih[:, V:] sits on the critical
+            # path between the decoder and the encoder backward, and a slice that starts at column 342 / 3 takes fn_gemm_multi's element-wise loads
+            self.wz = {}
+            for key, name, V in (("g", "grucell_g.weight_ih", E_VOCAB), ("d_r", "gru_d_r.weight_ih_l0", R_DIMS), ("d_n", "gru_d_n.weight_ih_l0", N_DIMS)):
+                w = self.p.get(name)
+                if w is not None and hasattr(self.ops, "weight_images"):
+                    self.wz[key] = self.buf("wz_" + key, (w.shape[0], w.shape[1] - V))
+                    jobs.append(("copy", w[:, V:], self.wz[key]))
         if getattr(self.ops, "dw_x6", False) and H == 512:
             # bf16 x 6 arithmetic: bf16 triple images of the recurrent matrices (forward scans) and of their transposes (backward scans)
             for key, (pfx, sfx, V) in self._gru_sets().items():
@@ -690,8 +699,9 @@ class Engine:
         part = self.buf("gz_part", (2, NP, B, Z))
         jobs, sums = [], []
         for ei, (e, c0, Ce) in enumerate((("r", 0, R_DIMS), ("n", Z, N_DIMS))):
-            prods = [(drb_g, Wz_g[:, E_VOCAB + c0:E_VOCAB + c0 + Z]), (dh0_g, Wig[:, c0:c0 + Z]),
-                     (sdb[e]["drb"], P["gru_d_%s.weight_ih_l0" % e][:, Ce:]), (sdb[e]["dh0"], P["linear_init_%s.weight" % e])]
+            wz = getattr(self, "wz", {})          # aligned images of the z columns (refresh_weights)
+            prods = [(drb_g, wz["g"][:, c0:c0 + Z] if "g" in wz else Wz_g[:, E_VOCAB + c0:E_VOCAB + c0 + Z]), (dh0_g, Wig[:, c0:c0 + Z]),
+                     (sdb[e]["drb"], wz.get("d_" + e, P["gru_d_%s.weight_ih_l0" % e][:, Ce:])), (sdb[e]["dh0"], P["linear_init_%s.weight" % e])]
             pieces = []
             for A, W in prods:
                 Kp = A.shape[1]

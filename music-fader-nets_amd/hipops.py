@@ -201,15 +201,16 @@ class HipOps:
 
     def weight_images(self, jobs):
         """jobs: (kind, src 2-D view, dst) with kind "transpose" (dst [C][R] contiguous), "frag" (fragment-major image of src), "frag_t"
-        (fragment-major image of src^T), "frag3" / "frag3_t" (the same two as bf16 triple images) - all in ONE launch (fn_weight_images)"""
-        kinds = {"transpose": 0, "frag": 1, "frag_t": 2, "frag3": 3, "frag3_t": 4}
+        (fragment-major image of src^T), "frag3" / "frag3_t" (the same two as bf16 triple images), "copy" (dst [R][C] dense: an aligned image of a
+        column slice) - all in ONE launch (fn_weight_images)"""
+        kinds = {"transpose": 0, "frag": 1, "frag_t": 2, "frag3": 3, "frag3_t": 4, "copy": 5}
         for i0 in range(0, len(jobs), 56):
             part = jobs[i0:i0 + 56]
             arr = (_lib.FnWeightImage * len(part))()
             for d, (kind, src, dst) in zip(arr, part):
                 ps, R, Cc, ld = _mat(src, "src")
                 _dense(dst, name="dst")
-                need = {"transpose": lambda: R * Cc, "frag": lambda: self.frag_floats(R, Cc), "frag_t": lambda: self.frag_floats(Cc, R),
+                need = {"transpose": lambda: R * Cc, "copy": lambda: R * Cc, "frag": lambda: self.frag_floats(R, Cc), "frag_t": lambda: self.frag_floats(Cc, R),
                         "frag3": lambda: self.frag_floats(R, Cc) * 3 // 2, "frag3_t": lambda: self.frag_floats(Cc, R) * 3 // 2}[kind]()
                 if dst.numel() < need:
                     raise RuntimeError("weight_images: dst too small for %s of %s" % (kind, tuple(src.shape)))

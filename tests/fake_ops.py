@@ -187,6 +187,8 @@ class FakeOps:
         for kind, src, dst in jobs:
             if kind == "transpose":
                 dst.view(src.shape[1], src.shape[0]).copy_(src.t())
+            elif kind == "copy":
+                dst.view(src.shape).copy_(src)
             elif kind == "frag":
                 self.frag_pack(src, dst)
             else:

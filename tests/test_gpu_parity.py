@@ -1049,15 +1049,18 @@ def test_head_kernels(ops):
     fake.vocab_logsoftmax_bwd(lp_c, gout, d1c)
     ops.vocab_logsoftmax_bwd(lp_d, g(gout), d1d)
     close(d1d[:, :E], d1c[:, :E], 2e-5)
-    # time axis
-    Tr, Cc = 8, 16
-    lg = torch.randn(Tr, B, Cc) * 2
-    tg = torch.randint(0, Cc, (B, Tr), dtype=torch.int32)
-    lpc, nc, dc = torch.zeros(B, Tr, Cc), torch.zeros(B, Cc), torch.zeros(Tr, B, Cc)
-    lpd, nd, dd = (torch.zeros_like(x, device=DEV) for x in (lpc, nc, dc))
-    fake.time_logsoftmax(lg, lpc, tg, nc, 0.11, dc)
-    ops.time_logsoftmax(g(lg), lpd, g(tg), nd, 0.11, dd)
-    close(lpd, lpc), close(nd, nc), close(dd, dc, 2e-5)
+    # time axis (Tr <= 64: the column's logits in registers; longer: the loop kernel; 3 classes = the rhythm decoder's width)
+    for Tr, Cc in ((64, 3), (33, 16), (70, 5), (8, 16)):
+        lg = torch.randn(Tr, B, Cc) * 2
+        tg = torch.randint(0, Cc, (B, Tr), dtype=torch.int32)
+        lpc, nc, dc = torch.zeros(B, Tr, Cc), torch.zeros(B, Cc), torch.zeros(Tr, B, Cc)
+        lpd, nd, dd = (torch.zeros_like(x, device=DEV) for x in (lpc, nc, dc))
+        fake.time_logsoftmax(lg, lpc, tg, nc, 0.11, dc)
+        ops.time_logsoftmax(g(lg), lpd, g(tg), nd, 0.11, dd)
+        close(lpd, lpc), close(nd, nc), close(dd, dc, 2e-5)
+        lp_only = torch.zeros_like(lpd)
+        ops.time_logsoftmax(g(lg), logp_bt=lp_only)             # eval form: no target, no gradient
+        assert torch.equal(lp_only, lpd)
     go = torch.randn(B, Tr, Cc)
     d2c, d2d = torch.zeros(Tr, B, Cc), torch.zeros(Tr, B, Cc, device=DEV)
     fake.time_logsoftmax_bwd(lpc, go, d2c)
@@ -2022,8 +2025,10 @@ def test_weight_images_one_launch(ops):
     tab = torch.zeros(V, 3 * H, device=DEV)
     f1, f2 = torch.zeros(ops.frag_floats(3 * H, H), device=DEV), torch.zeros(ops.frag_floats(H, 3 * H), device=DEV)
     f3 = torch.zeros(ops.frag_floats(V, H), device=DEV)
-    ops.weight_images([("transpose", w_ih[:, :V], tab), ("frag", w_hh, f1), ("frag_t", w_hh, f2), ("frag", w_out, f3)])
+    wz = torch.zeros(3 * H, 40, device=DEV)
+    ops.weight_images([("transpose", w_ih[:, :V], tab), ("frag", w_hh, f1), ("frag_t", w_hh, f2), ("frag", w_out, f3), ("copy", w_ih[:, V:], wz)])
     assert torch.equal(tab, w_ih[:, :V].t())
+    assert torch.equal(wz, w_ih[:, V:])                         # kind 5: the dense image of a column slice
     r1, r2, r3 = torch.zeros_like(f1), torch.zeros_like(f2), torch.zeros_like(f3)
     ops.frag_pack(w_hh, r1)
     ops.frag_pack(w_hh.t().contiguous(), r2)
@@ -2036,7 +2041,9 @@ def test_gemm_multi(ops, a_k, b_k):
     """several small GEMMs, each a sum of products over separate operands, in one launch (odd sizes, strided views, beta, bias)"""
     torch.manual_seed(77)
     jobs_d, refs = [], []
-    for M, N, Ks in ((256, 128, (512, 512)), (37, 70, (33,)), (256, 1536, (128,)), (130, 64, (20, 48, 16, 100))):
+    # (aligned segments of whole 16-k tiles take the unconditional 16-byte loads with 4 tiles in flight, the others the element-wise checked loads:
+    # the fifth job mixes both inside one accumulation, the last one walks 5 tiles - not a multiple of the prefetch depth)
+    for M, N, Ks in ((256, 128, (512, 512)), (37, 70, (33,)), (256, 1536, (128,)), (130, 64, (20, 48, 16, 100)), (128, 64, (64, 20, 256)), (64, 192, (80,))):
         C0 = torch.randn(M, N + 6)
         bias = torch.randn(N)
         beta = 0.0 if len(Ks) == 1 else 1.0
