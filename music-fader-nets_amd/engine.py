@@ -64,7 +64,8 @@ class Engine:
         self.fused_head = True          # trainers: output projection + log-softmax + NLL + gradient seed as ONE kernel (fn_out_head_f32); False: GEMM -> logits in HBM -> fn_vocab_logsoftmax
         self.lean_dw = False            # decoder-side weight-gradient GEMMs as the <= 128-register instance.  Paid while an encoder-scan wavefront left 138 of a SIMD's 512 registers free (round 2: 9 % packing gain); the hand-placed K loops hold all of them, the side lane's GEMMs run once the scan has ended and the 194-register instance is the faster one (A/B in one session, scratch/ab_dw.py: 23.65 vs 24.29 ms per step)
         self.lean_proj = True           # layer-2 input projection beside the decoder pipeline's forward launches as the <= 128-register instance of the LDS-free NT kernel: 4 workgroups per CU (768 tiles = one round) and one of its wavefronts fits a SIMD beside a forward-scan wavefront (377 registers): 107 us beside a 351 us launch (the 248-register instance: 125 us in front of the launch)
-        self.proj_x6 = False            # layer-2 input projection beside the decoder pipeline's FORWARD launches: True = the bf16x6 producer / consumer kernel (78 us, but its 144 KB / 512-thread workgroups cannot share a CU with a scan wavefront: the launch serialises with the scans), False = the lean fp32 instance above, which does (a bf16x6 forward-scan wavefront holds 328 of a SIMD's 512 registers)
+        self.prepack_h0 = True          # global_decoder_tf: operand images of the initial states of later launches are packed on the aux lane after launch 0 (False: by fn_gru_seq_fwd in front of the launch)
+        self.proj_x6 = True             # layer-2 input projection beside the decoder pipeline's FORWARD launches: True = the bf16x6 producer / consumer kernel (78 us, but its 144 KB / 512-thread workgroups cannot share a CU with a scan wavefront: the launch serialises with the scans), False = the lean fp32 instance above, which does (a bf16x6 forward-scan wavefront holds 328 of a SIMD's 512 registers)
         self.dw_order = "side+aux"      # decoder-side weight-gradient GEMMs: "side+aux" = the global decoder's on the side stream, issued in front of the encoder backward, the attribute decoders' on the aux stream behind the encoder scans; "side" = all of them on the side stream; "before" / "after" = caller's stream, in front of / behind the encoder block
         self.losses_early = False       # trainer: True = the side lane's loss-term launches start in FRONT of the fused output head (they need nothing from it) instead of behind it; measured: the graph runs them behind the head's and the dhx1 product's workgroups either way (17.70 vs 17.68 ms), and with 16 hardware queues they land beside the first backward launch (20.4 ms): off
         self.losses_on_side = True      # trainer: the small loss-term launches run on the side lane beside the decoder backward's first launches
@@ -435,6 +436,17 @@ class Engine:
         xkw = {"x6": x6} if hasattr(ops, "gru_fwd_x6_ok") else {}
         if x6 and self.dec_fwd_budget and all(ops.gru_fwd_x6_ok(part, self.dec_fwd_budget) for part in launches if part):
             xkw["cu_budget"] = self.dec_fwd_budget
+        # Initial states that a LATER launch starts from (layer 2: hx0[0], known after launch 0; the 'n' attribute decoder in the tail) are
+        # turned into operand images here, on the aux lane in front of the first projection - left to fn_gru_seq_fwd the packing launch
+        # sits between two scan launches beside a projection that saturates the memory pipes: 109 us instead of 6, twice per step
+        prepack = []
+        if self.prepack_h0 and pd and nch >= 2 and hasattr(ops, "frag3_pack"):
+            for k, part in enumerate(launches):
+                for c in part:
+                    if k >= 2 and c.get("h0") is not None and c.get("h0_frag") is None:
+                        img = self.buf("g_h0img_%s" % c["tag"], (nf,))
+                        prepack.append((c["h0"], img))
+                        c["h0_frag"] = img
         for k, part in enumerate(launches):
             if k >= 2:
                 self.lane_wait("main", "aux%d" % (k & 1))            # the projection of chunk k-2 (issued two launches ago)
@@ -445,6 +457,9 @@ class Engine:
                 lane = "aux%d" % (k & 1)
                 self.lane_wait(lane, "main")
                 with Engine._Lane(self, True, lane):
+                    if k == 0:
+                        for src, img in prepack:
+                            (ops.frag3_pack if x6 else ops.frag_pack)(src, img)
                     ops.gemm(hx0[t0:t1].view(-1, H), P["grucell_g_2.weight_ih"], gx2[t0:t1].view(-1, 3 * H), bias=P["grucell_g_2.bias_ih"],
                              lean=self.lean_proj, **({} if self.proj_x6 else {"nt_x6": False}))
         logits = self.buf("g_logits", (T * B, LOGIT_LD), zero_init=True)     # columns [342, 352) stay zero: every writer leaves them alone or writes zeros

@@ -1049,7 +1049,7 @@ def test_head_kernels(ops):
     fake.vocab_logsoftmax_bwd(lp_c, gout, d1c)
     ops.vocab_logsoftmax_bwd(lp_d, g(gout), d1d)
     close(d1d[:, :E], d1c[:, :E], 2e-5)
-    # time axis (Tr <= 64: the column's logits in registers; longer: the loop kernel; 3 classes = the rhythm decoder's width)
+    # time axis (Tr <= 64: one wavefront per column, lane = time step; longer: the loop kernel; 3 classes = the rhythm decoder's width)
     for Tr, Cc in ((64, 3), (33, 16), (70, 5), (8, 16)):
         lg = torch.randn(Tr, B, Cc) * 2
         tg = torch.randint(0, Cc, (B, Tr), dtype=torch.int32)
