@@ -782,15 +782,17 @@ class Engine:
         drb = per-sequence sums of the gate gradients (= gradient wrt the z projection), rsn, dh0 = dL/d linear_init(z))"""
         ops, P, H = self.ops, self.p, self.H
         dh_sd, sdb, sds = {}, {}, {}
+        jobs = []
         for e, Ce in (("r", R_DIMS), ("n", N_DIMS)):
             dl = dlogits_sd[e].view(Tr * B, Ce)
             dh_sd[e] = self.buf("sd_dh_" + e, (Tr, B, H))
-            ops.gemm(dl, P["linear_out_%s.weight" % e], dh_sd[e].view(Tr * B, H), a_k=True, b_k=False)
+            jobs.append(dict(C=dh_sd[e].view(Tr * B, H), segs=[(dl, P["linear_out_%s.weight" % e])]))
             sdb[e] = dict(dgx=self.buf("sd_dgx_" + e, (Tr, B, 3 * H)), dghn=self.buf("sd_dghn_" + e, (Tr, B, H)),
                           drb=self.zbuf("sd_drb_" + e, (B, 3 * H)), rsn=self.zbuf("sd_rsn_" + e, (B, H)), dh0=self.buf("sd_dh0_" + e, (B, H)))
             sds[e] = dict(B=B, T=Tr, H=H, w_hh_t_frag=self.whh_t["d_" + e], w_hh_t_frag3=self.whh_t3.get("d_" + e), h0=sd[e]["h0"], h_all=sd[e]["h_all"], gates=sd[e]["gates"],
                           dh_ext=dh_sd[e], dgx_all=sdb[e]["dgx"], dghn_all=sdb[e]["dghn"], scratch=self.buf("sd_scr_" + e, (B, H)),
                           dgx_rowsum=sdb[e]["drb"], dghn_rowsum=sdb[e]["rsn"], tag="sd_" + e)
+        ops.gemm_multi(jobs, a_k=True, b_k=False)                # both output layers' input gradients (K = 3 / 16): one launch
         if defer:                                                # the scans are left to _bwd_global_decoder_scans(fill=...)
             return sdb, sds
         ops.gru_seq_bwd([self._bwd_chunk(sds[e], 0, Tr, None, sdb[e]["dh0"]) for e in ("r", "n")], persistent=self.persist_dec)

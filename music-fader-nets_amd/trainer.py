@@ -345,9 +345,20 @@ class GMVAETrainer:
         if st is None:                              # first call with these shapes: static input buffers + one eager run
             st = dict(batch=[None if t is None else t.clone() for t in batch], eps=[None if e is None else e.clone() for e in eps], runs=0)
             self._static[key] = st
+        # the batch into the captured step's input buffers: one multi-tensor copy per dtype (3 launches instead of 9 in front of every replay)
+        groups = {}
         for dst, src in zip(st["batch"] + st["eps"], list(batch) + list(eps)):
             if dst is not None and dst.data_ptr() != src.data_ptr():
-                dst.copy_(src, non_blocking=True)
+                if src.device == dst.device and src.dtype == dst.dtype and src.shape == dst.shape:
+                    g = groups.setdefault(dst.dtype, ([], []))
+                    g[0].append(dst), g[1].append(src)
+                else:
+                    dst.copy_(src, non_blocking=True)
+        for dsts, srcs in groups.values():
+            if len(dsts) > 1:
+                torch._foreach_copy_(dsts, srcs, non_blocking=True)
+            else:
+                dsts[0].copy_(srcs[0], non_blocking=True)
         sbatch, seps = tuple(st["batch"]), tuple(st["eps"])
         m.engine()                                  # (re)builds the engine / weight images outside of any capture
         self._gather_densities(sbatch, st)          # per-batch constants: gathered eagerly into static buffers, outside of the graph
