@@ -762,45 +762,57 @@ __global__ __launch_bounds__(X6W_NT) void gemm_nt_x6w_kernel(int M, int N, int K
                                                               const float* __restrict__ B, long ldb, float beta, float* __restrict__ C, long ldc,
                                                               const float* __restrict__ bias) {
     extern __shared__ __attribute__((aligned(16))) u32x4 x6w_lds[];      // [3 stages][4 sets][4 tiles][3 pieces][64 lanes]
-    const int ntn = N >> 7;
-    const int tile = fn_xcd_remap(blockIdx.x, ntn * (M >> 7));           // consecutive tiles (same rows of A) on one XCD
+    const int ntn = N >> 7, ntiles = ntn * (M >> 7);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int mb = (tile / ntn) * 128, nb = (tile % ntn) * 128;
     const int nblk = K >> 5;
+    // A workgroup walks tiles blockIdx.x, + gridDim.x, ... (the launch takes one workgroup per CU when there are more tiles than CUs): both roles run
+    // 1 + nblk barriers per tile, and the producers' last barrier of a tile is the one behind the consumers' last read of it - every stage is free when
+    // they start on the next tile, whose first blocks are requested and cut while the consumers still store the finished tile (the prologue and the
+    // epilogue of a tile were ~8 us of the 22 - 28 us a 11 / 16-block tile takes).  gridDim.x is a multiple of 8 then: a workgroup's tiles stay on its XCD.
     if (wave >= 4) {
         const int ps = wave & 3;
-        if (ps < 2) x6w_produce_nt<false>(x6w_lds, A + (long)(mb + 64 * ps) * lda, lda, ps, lane, nblk);
-        else x6w_produce_nt<true>(x6w_lds, B + (long)(nb + 64 * (ps - 2)) * ldb, ldb, ps, lane, nblk);
+#pragma unroll 1
+        for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+            const int tile = fn_xcd_remap(v, ntiles);                    // consecutive tiles (same rows of A) on one XCD
+            const int mb = (tile / ntn) * 128, nb = (tile % ntn) * 128;
+            if (ps < 2) x6w_produce_nt<false>(x6w_lds, A + (long)(mb + 64 * ps) * lda, lda, ps, lane, nblk);
+            else x6w_produce_nt<true>(x6w_lds, B + (long)(nb + 64 * (ps - 2)) * ldb, ldb, ps, lane, nblk);
+        }
         return;
     }
     const int wm = (wave >> 1) & 1, wn = wave & 1;
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    x6w_consume(x6w_lds, wm, wn, lane, nblk, acc);
-    // D[(l >> 4) * 4 + rr][l & 15] of tile (a, b) = row mb + 64 wm + 4 ((l >> 4) * 4 + rr) + a, column nb + 64 wn + 4 (l & 15) + b
     const int li = lane & 15, lg = lane >> 4;
-    const int col = nb + 64 * wn + 4 * li;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + col);
+#pragma unroll 1
+    for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+        const int tile = fn_xcd_remap(v, ntiles);
+        const int mb = (tile / ntn) * 128, nb = (tile % ntn) * 128;
+        f32x4 acc[4][4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int row = mb + 64 * wm + 4 * (lg * 4 + rr) + a;
-            float* cp = C + (long)row * ldc + col;
-            f32x4 o;
+            for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        x6w_consume(x6w_lds, wm, wn, lane, nblk, acc);
+        // D[(l >> 4) * 4 + rr][l & 15] of tile (a, b) = row mb + 64 wm + 4 ((l >> 4) * 4 + rr) + a, column nb + 64 wn + 4 (l & 15) + b
+        const int col = nb + 64 * wn + 4 * li;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (bias) bv = *reinterpret_cast<const f32x4*>(bias + col);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) o[b] = alpha * acc[a][b][rr] + bv[b];
-            if (beta != 0.f) {
-                const f32x4 old = *reinterpret_cast<const f32x4*>(cp);
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) o[b] += beta * old[b];
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = mb + 64 * wm + 4 * (lg * 4 + rr) + a;
+                float* cp = C + (long)row * ldc + col;
+                f32x4 o;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) o[b] = alpha * acc[a][b][rr] + bv[b];
+                if (beta != 0.f) {
+                    const f32x4 old = *reinterpret_cast<const f32x4*>(cp);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) o[b] += beta * old[b];
+                }
+                *reinterpret_cast<f32x4*>(cp) = o;
             }
-            *reinterpret_cast<f32x4*>(cp) = o;
-        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1736,6 +1748,21 @@ int fn_gemm_multi(int a_kmajor, int b_kmajor, const FnGemmJob* jobs, int n_jobs,
 }
 
 // grid of a TN launch: 1-D (K ranges dealt to the XCDs, see gemm_tn_body) when the K ranges divide by 8, else tiles x 1 x K ranges
+// compute units of the current device (write-once per device, as gru_persist.hip's cu_count)
+static int gemm_cu_count() {
+    static std::atomic<int> n[32];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return 0;
+    int c = n[dev].load(std::memory_order_acquire);
+    if (c == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        c = prop.multiProcessorCount;
+        n[dev].store(c, std::memory_order_release);
+    }
+    return c;
+}
+
 static dim3 tn_grid(int tiles, int splitk) {
     return splitk > 1 && (splitk & 7) == 0 ? dim3(tiles * splitk, 1, 1) : dim3(tiles, 1, splitk > 1 ? splitk : 1);
 }
@@ -1818,7 +1845,11 @@ int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha, co
             if (e != hipSuccess) return (int)e;
             attr_set[dev].store(true, std::memory_order_release);
         }
-        hipLaunchKernelGGL(gemm_nt_x6w_kernel, dim3((M / 128) * (N / 128)), dim3(X6W_NT), lds, st, M, N, K, alpha, A, (long)lda, B, (long)ldb, beta, C, (long)ldc, bias);
+        // one workgroup per CU (144 KB of LDS each) walking its tiles, unless asked for one workgroup per tile (FN_GEMM_X6_PERWAVE: the A/B switch of the TN
+        // form doubles as "no persistent tiles" here) or the CU count is not a multiple of the 8 XCDs
+        const int ntiles = (M / 128) * (N / 128), cus = gemm_cu_count();
+        const int grid = (ntiles > cus && cus >= 8 && (cus & 7) == 0 && !(x6_mode & FN_GEMM_X6_PERWAVE)) ? cus : ntiles;
+        hipLaunchKernelGGL(gemm_nt_x6w_kernel, dim3(grid), dim3(X6W_NT), lds, st, M, N, K, alpha, A, (long)lda, B, (long)ldb, beta, C, (long)ldc, bias);
         FN_CHECK_LAUNCH();
         return FN_OK;
     }

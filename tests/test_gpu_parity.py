@@ -518,7 +518,8 @@ def test_gemm_tn_x6_producer_consumer_vs_per_wave_kernel(ops, M, N, K, splitk):
         ops.dw_x6, ops.x6_perwave, ops.x6_wide = _x6_default(), False, True
 
 
-@pytest.mark.parametrize("M,N,K", [(8192, 1536, 512), (8192, 512, 1536), (65536, 512, 352), (2048, 1024, 128), (2048, 1024, 160), (4096, 512, 32 * 7)])
+@pytest.mark.parametrize("M,N,K", [(8192, 1536, 512), (8192, 512, 1536), (65536, 512, 352), (2048, 1024, 128), (2048, 1024, 160), (4096, 512, 32 * 7),
+                                   (8192, 1024, 160), (4096, 1152, 32 * 7), (16384, 256, 128)])      # (the last three: 512 / 288 / 256 tiles of 5 / 7 / 4 blocks - a workgroup walks 2, 1 or 2, 1 tiles)
 def test_gemm_nt_bf16x6(ops, M, N, K):
     """gemm_nt_x6w_kernel (round 6): the Linear-forward form C = alpha A B^T + bias + beta C with both operands K-contiguous, exact bf16 triple splits
     on the bf16 MFMA - the decoder pipeline's layer-2 input projection and the state-gradient products.  Against float64 it is as accurate as the fp32
@@ -548,8 +549,13 @@ def test_gemm_nt_bf16x6(ops, M, N, K):
         C = torch.empty(M, N, device=DEV)
         ops.gemm(A, W, C, a_k=True, b_k=True)
         assert torch.equal(C, outs[True])
+        # one workgroup per CU walking its tiles (more tiles than CUs) == one workgroup per tile, bit for bit
+        ops.x6_perwave = True
+        C = torch.full((M, N), float("nan"), device=DEV)
+        ops.gemm(A, W, C, a_k=True, b_k=True)
+        assert torch.equal(C, outs[True])
     finally:
-        ops.dw_x6, ops.nt_x6 = _x6_default(), True
+        ops.dw_x6, ops.nt_x6, ops.x6_perwave = _x6_default(), True, False
 
 
 def test_gemm_bf16x6_kernels_random_shapes():
