@@ -81,6 +81,10 @@ const char* fn_strerror(int code);    /* static string for FN_E_* / hipError_t *
  * 128 x 128 tiles (the same number of workgroups).  Same products in the same order per accumulator: bit-identical to the other two kernels on the
  * same K ranges. */
 #define FN_GEMM_X6_WIDE 0x80000
+/* ... | FN_GEMM_X6_PERTILE (only with FN_GEMM_BF16X6; tests / A-B measurements): one workgroup per output tile (Linear-forward form) or per (tile, K range)
+ * item (weight-gradient form with K ranges in multiples of 8).  Default (round 6): one workgroup per CU walks its items, the next item's first blocks
+ * are requested and cut while the finished one is stored.  Same arithmetic per item: bit-identical. */
+#define FN_GEMM_X6_PERTILE 0x100000
 size_t fn_gemm_ws_bytes(int M, int N, int splitk);
 int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha,
                 const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc,

@@ -14,6 +14,7 @@ ABI_VERSION = 5
 GEMM_LEAN = 0x10000          # FN_GEMM_LEAN
 GEMM_BF16X6 = 0x20000        # FN_GEMM_BF16X6 (exact bf16 triple split on the bf16 MFMA)
 GEMM_X6_WIDE = 0x80000       # FN_GEMM_X6_WIDE (128 x 256 output tiles per workgroup)
+GEMM_X6_PERTILE = 0x100000   # FN_GEMM_X6_PERTILE (tests / A-B: one workgroup per tile / (tile, K range) item instead of one per CU walking its items)
 GEMM_X6_PERWAVE = 0x40000    # FN_GEMM_X6_PERWAVE (tests / A-B: the round-5 kernel, every wavefront splits its own operands)
 FN_E_NULL, FN_E_SHAPE, FN_E_ALIGN, FN_E_WORKSPACE, FN_E_COUNT = -1, -2, -3, -4, -5
 FN_E_UNSUPPORTED = -6

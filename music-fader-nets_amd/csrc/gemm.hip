@@ -557,21 +557,12 @@ FN_DEVINL void x6w_produce(u32x4* __restrict__ lds, const float* __restrict__ P,
     });
 }
 
-__global__ __launch_bounds__(X6W_NT) void gemm_tn_x6w_kernel(int M, int N, int K, float alpha, const float* __restrict__ A, long lda,
+// one (output tile, K range) of gemm_tn_x6w_kernel: both roles run 1 + nblk barriers, and behind the last one no stage is read any more (the reads in flight fetch
+// values nobody uses): the next item of a workgroup that walks several of them may be cut into the stages at once
+FN_DEVINL void gemm_tn_x6w_kernel_item(int M, int N, int K, float alpha, const float* __restrict__ A, long lda,
                                                               const float* __restrict__ B, long ldb, float beta, float* __restrict__ C, long ldc,
                                                               const float* __restrict__ bias, int ksplit_len, float* __restrict__ slabs,
-                                                              const float* __restrict__ A2, long lda2, int msplit) {
-    extern __shared__ __attribute__((aligned(16))) u32x4 x6w_lds[];      // [3 stages][4 sets][4 tiles][3 pieces][64 lanes]
-    const int ntn = (N + 127) / 128, ntm = (M + 127) / 128;
-    int tile, zk;
-    if (gridDim.z == 1 && slabs != nullptr) {            // K ranges dealt to the XCDs (see gemm_tn_body)
-        const int S = (K + ksplit_len - 1) / ksplit_len, c = blockIdx.x & 7, q = blockIdx.x >> 3;
-        zk = c * (S >> 3) + q / (ntn * ntm);
-        tile = q % (ntn * ntm);
-    } else {
-        tile = fn_xcd_remap(blockIdx.x, ntn * ntm);
-        zk = blockIdx.z;
-    }
+                                                              const float* __restrict__ A2, long lda2, int msplit, u32x4* __restrict__ x6w_lds, int ntn, int tile, int zk) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int mb = (tile / ntn) * 128, nb = (tile % ntn) * 128;          // the workgroup's output tile
     const int li = lane & 15, lg = lane >> 4;
@@ -644,6 +635,24 @@ __global__ __launch_bounds__(X6W_NT) void gemm_tn_x6w_kernel(int M, int N, int K
                 }
             }
         }
+}
+
+__global__ __launch_bounds__(X6W_NT) void gemm_tn_x6w_kernel(int M, int N, int K, float alpha, const float* __restrict__ A, long lda,
+                                                              const float* __restrict__ B, long ldb, float beta, float* __restrict__ C, long ldc,
+                                                              const float* __restrict__ bias, int ksplit_len, float* __restrict__ slabs,
+                                                              const float* __restrict__ A2, long lda2, int msplit) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 x6w_lds[];      // [3 stages][4 sets][4 tiles][3 pieces][64 lanes]
+    const int ntn = (N + 127) / 128, ntm = (M + 127) / 128;
+    if (gridDim.z == 1 && slabs != nullptr) {            // K ranges dealt to the XCDs (see gemm_tn_body); a workgroup walks items blockIdx.x, + gridDim.x, ...
+        const int S = (K + ksplit_len - 1) / ksplit_len, items = S * ntn * ntm;      // (gridDim.x < items only when it is a multiple of 8: the items of a workgroup stay on its XCD)
+#pragma unroll 1
+        for (int v = blockIdx.x; v < items; v += gridDim.x) {
+            const int c = v & 7, q = v >> 3;
+            gemm_tn_x6w_kernel_item(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, ksplit_len, slabs, A2, lda2, msplit, x6w_lds, ntn, q % (ntn * ntm), c * (S >> 3) + q / (ntn * ntm));
+        }
+    } else {
+        gemm_tn_x6w_kernel_item(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, ksplit_len, slabs, A2, lda2, msplit, x6w_lds, ntn, fn_xcd_remap(blockIdx.x, ntn * ntm), blockIdx.z);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1022,21 +1031,12 @@ FN_DEVINL void x6v_produce(u32x4* __restrict__ lds, const float* __restrict__ Pf
     });
 }
 
-__global__ __launch_bounds__(X6W_NT) void gemm_tn_x6v_kernel(int M, int N, int K, float alpha, const float* __restrict__ A, long lda,
+// one (output tile, K range) of gemm_tn_x6v_kernel: both roles run 1 + nblk barriers, and behind the last one no stage is read any more (the reads in flight fetch
+// values nobody uses): the next item of a workgroup that walks several of them may be cut into the stages at once
+FN_DEVINL void gemm_tn_x6v_kernel_item(int M, int N, int K, float alpha, const float* __restrict__ A, long lda,
                                                               const float* __restrict__ B, long ldb, float beta, float* __restrict__ C, long ldc,
                                                               const float* __restrict__ bias, int ksplit_len, float* __restrict__ slabs,
-                                                              const float* __restrict__ A2, long lda2, int msplit) {
-    extern __shared__ __attribute__((aligned(16))) u32x4 x6v_lds[];      // [2 stages][6 sets][4 tiles][3 pieces][64 lanes]
-    const int ntn = (N + 255) / 256, ntm = (M + 127) / 128;
-    int tile, zk;
-    if (gridDim.z == 1 && slabs != nullptr) {            // K ranges dealt to the XCDs (see gemm_tn_body)
-        const int S = (K + ksplit_len - 1) / ksplit_len, c = blockIdx.x & 7, q = blockIdx.x >> 3;
-        zk = c * (S >> 3) + q / (ntn * ntm);
-        tile = q % (ntn * ntm);
-    } else {
-        tile = fn_xcd_remap(blockIdx.x, ntn * ntm);
-        zk = blockIdx.z;
-    }
+                                                              const float* __restrict__ A2, long lda2, int msplit, u32x4* __restrict__ x6v_lds, int ntn, int tile, int zk) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int mb = (tile / ntn) * 128, nb = (tile % ntn) * 256;          // the workgroup's output tile
     const int li = lane & 15, lg = lane >> 4;
@@ -1207,6 +1207,24 @@ __global__ __launch_bounds__(X6W_NT) void gemm_tn_x6v_kernel(int M, int N, int K
                 }
             }
         }
+}
+
+__global__ __launch_bounds__(X6W_NT) void gemm_tn_x6v_kernel(int M, int N, int K, float alpha, const float* __restrict__ A, long lda,
+                                                              const float* __restrict__ B, long ldb, float beta, float* __restrict__ C, long ldc,
+                                                              const float* __restrict__ bias, int ksplit_len, float* __restrict__ slabs,
+                                                              const float* __restrict__ A2, long lda2, int msplit) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 x6v_lds[];      // [2 stages][6 sets][4 tiles][3 pieces][64 lanes]
+    const int ntn = (N + 255) / 256, ntm = (M + 127) / 128;
+    if (gridDim.z == 1 && slabs != nullptr) {            // K ranges dealt to the XCDs (see gemm_tn_body); a workgroup walks items blockIdx.x, + gridDim.x, ...
+        const int S = (K + ksplit_len - 1) / ksplit_len, items = S * ntn * ntm;      // (gridDim.x < items only when it is a multiple of 8: the items of a workgroup stay on its XCD)
+#pragma unroll 1
+        for (int v = blockIdx.x; v < items; v += gridDim.x) {
+            const int c = v & 7, q = v >> 3;
+            gemm_tn_x6v_kernel_item(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, ksplit_len, slabs, A2, lda2, msplit, x6v_lds, ntn, q % (ntn * ntm), c * (S >> 3) + q / (ntn * ntm));
+        }
+    } else {
+        gemm_tn_x6v_kernel_item(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, ksplit_len, slabs, A2, lda2, msplit, x6v_lds, ntn, fn_xcd_remap(blockIdx.x, ntn * ntm), blockIdx.z);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1786,11 +1804,16 @@ static int launch_tn_x6(int mode, int tiles, int splitk, hipStream_t st, int M, 
         if (e != hipSuccess) return (int)e;
         attr_set[wide][dev].store(true, std::memory_order_release);
     }
+    // 1-D launches (K ranges dealt to the XCDs): one workgroup per CU walking its (tile, K range) items instead of one workgroup per item - the next
+    // item's first blocks are requested and cut while the consumers store the finished one (FN_GEMM_X6_PERTILE: one workgroup per item, A/B and tests)
+    const int wtiles = wide ? ((M + 127) / 128) * ((N + 255) / 256) : tiles;
+    dim3 grid = tn_grid(wtiles, splitk);
+    const int cus = gemm_cu_count();
+    if (grid.y == 1 && grid.z == 1 && slabs != nullptr && !(mode & FN_GEMM_X6_PERTILE) && cus >= 8 && (cus & 7) == 0 && (int)grid.x > cus) grid.x = cus;
     if (wide) {
-        const int wtiles = ((M + 127) / 128) * ((N + 255) / 256);
-        hipLaunchKernelGGL(gemm_tn_x6v_kernel, tn_grid(wtiles, splitk), dim3(X6W_NT), lds, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, klen, slabs, A2, lda2, msplit);
+        hipLaunchKernelGGL(gemm_tn_x6v_kernel, grid, dim3(X6W_NT), lds, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, klen, slabs, A2, lda2, msplit);
     } else {
-        hipLaunchKernelGGL(gemm_tn_x6w_kernel, tn_grid(tiles, splitk), dim3(X6W_NT), lds, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, klen, slabs, A2, lda2, msplit);
+        hipLaunchKernelGGL(gemm_tn_x6w_kernel, grid, dim3(X6W_NT), lds, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, klen, slabs, A2, lda2, msplit);
     }
     return FN_OK;
 }
@@ -1803,8 +1826,8 @@ int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha, co
     if (M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return FN_E_SHAPE;
     const bool lean = (splitk & FN_GEMM_LEAN) != 0;
     const bool x6 = (splitk & FN_GEMM_BF16X6) != 0;
-    const int x6_mode = splitk & (FN_GEMM_X6_PERWAVE | FN_GEMM_X6_WIDE);
-    splitk &= ~(FN_GEMM_LEAN | FN_GEMM_BF16X6 | FN_GEMM_X6_PERWAVE | FN_GEMM_X6_WIDE);
+    const int x6_mode = splitk & (FN_GEMM_X6_PERWAVE | FN_GEMM_X6_WIDE | FN_GEMM_X6_PERTILE);
+    splitk &= ~(FN_GEMM_LEAN | FN_GEMM_BF16X6 | FN_GEMM_X6_PERWAVE | FN_GEMM_X6_WIDE | FN_GEMM_X6_PERTILE);
     if (splitk > 1 && (!ws || ws_bytes < fn_gemm_ws_bytes(M, N, splitk))) return FN_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (!a_kmajor && !b_kmajor && (lda % 4) == 0 && (ldb % 4) == 0 && lda >= 4 && ldb >= 4 &&
@@ -1845,10 +1868,10 @@ int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha, co
             if (e != hipSuccess) return (int)e;
             attr_set[dev].store(true, std::memory_order_release);
         }
-        // one workgroup per CU (144 KB of LDS each) walking its tiles, unless asked for one workgroup per tile (FN_GEMM_X6_PERWAVE: the A/B switch of the TN
-        // form doubles as "no persistent tiles" here) or the CU count is not a multiple of the 8 XCDs
+        // one workgroup per CU (144 KB of LDS each) walking its tiles, unless asked for one workgroup per tile (FN_GEMM_X6_PERTILE) or the CU count is not a
+        // multiple of the 8 XCDs
         const int ntiles = (M / 128) * (N / 128), cus = gemm_cu_count();
-        const int grid = (ntiles > cus && cus >= 8 && (cus & 7) == 0 && !(x6_mode & FN_GEMM_X6_PERWAVE)) ? cus : ntiles;
+        const int grid = (ntiles > cus && cus >= 8 && (cus & 7) == 0 && !(x6_mode & FN_GEMM_X6_PERTILE)) ? cus : ntiles;
         hipLaunchKernelGGL(gemm_nt_x6w_kernel, dim3(grid), dim3(X6W_NT), lds, st, M, N, K, alpha, A, (long)lda, B, (long)ldb, beta, C, (long)ldc, bias);
         FN_CHECK_LAUNCH();
         return FN_OK;
@@ -1892,9 +1915,9 @@ int fn_gru_dwhh_f32(const float* dgx, const float* dghn, const float* hprev, int
     if (rows <= 0 || rows > 0x7fffffff || H <= 0) return FN_E_SHAPE;
     const bool lean = (splitk & FN_GEMM_LEAN) != 0;
     const bool x6 = (splitk & FN_GEMM_BF16X6) != 0;
-    const int x6_mode = splitk & (FN_GEMM_X6_PERWAVE | FN_GEMM_X6_WIDE);
-    const int xflags = splitk & (FN_GEMM_BF16X6 | FN_GEMM_X6_PERWAVE | FN_GEMM_X6_WIDE);
-    splitk &= ~(FN_GEMM_LEAN | FN_GEMM_BF16X6 | FN_GEMM_X6_PERWAVE | FN_GEMM_X6_WIDE);
+    const int x6_mode = splitk & (FN_GEMM_X6_PERWAVE | FN_GEMM_X6_WIDE | FN_GEMM_X6_PERTILE);
+    const int xflags = splitk & (FN_GEMM_BF16X6 | FN_GEMM_X6_PERWAVE | FN_GEMM_X6_WIDE | FN_GEMM_X6_PERTILE);
+    splitk &= ~(FN_GEMM_LEAN | FN_GEMM_BF16X6 | FN_GEMM_X6_PERWAVE | FN_GEMM_X6_WIDE | FN_GEMM_X6_PERTILE);
     if (splitk > 1 && (!ws || ws_bytes < fn_gru_dwhh_ws_bytes(H, splitk))) return FN_E_WORKSPACE;
     const int M = 3 * H, N = H, K = (int)rows;
     const bool one_launch = (2 * H) % 128 == 0 && (H % 4) == 0 && (((((uintptr_t)dgx) | ((uintptr_t)dghn) | ((uintptr_t)hprev)) & 15) == 0);

@@ -57,7 +57,7 @@ class HipOps:
         self.dw_x6 = arith.default() == arith.BF16X6        # arithmetic of the deep products (the package default; a model sets its own choice: arith.py): True = exact bf16 triple splits on the bf16 MFMA (FN_GEMM_BF16X6, FnGruFwd.variant bit 14), False = fp32 MFMA
         self.x6_wide = True       # with dw_x6: 128 x 256 output tiles (FN_GEMM_X6_WIDE) where the product has >= 256 columns - with TWICE the K ranges the caller asked for (the same number of workgroups); False: 128 x 128 tiles
         self.nt_x6 = True         # with dw_x6: the big Linear-forward / dX products (whole 128 x 128 tiles, K % 32 == 0) on the bf16 x 6 kernel too; False: fp32 MFMA (A/B measurements)
-        self.nt_per_tile = False       # A/B: gemm_nt_x6w_kernel as one workgroup per output tile (round 6: one per CU walking its tiles)
+        self.x6_per_tile = False  # A/B, tests: the producer / consumer bf16 x 6 kernels as one workgroup per output tile / (tile, K range) item (round 6: one per CU walking its items)
         self.cell_x6_rows = 2048  # ... from this many rows on (tests: 0 = wherever the kernel takes the shape)
         self.cell_x6 = True       # with dw_x6: the large-batch decode cells (fn_gru_cell_f32) on the bf16 x 6 producer / consumer kernel (gru_cell_x6_kernel); False: fp32 MFMA cells
         self.x6_perwave = False   # with dw_x6: the round-5 weight-gradient kernel in which every wavefront splits its own operands (FN_GEMM_X6_PERWAVE; A/B measurements, tests)
@@ -97,8 +97,8 @@ class HipOps:
             splitk, x6 = self._x6_mode(splitk, N, K, x6)
         elif self.dw_x6 and self.nt_x6 and nt_x6 and a_k and b_k and splitk <= 1 and M % 128 == 0 and N % 128 == 0 and K % 32 == 0 and K >= 128 and (M // 128) * (N // 128) >= 128:
             x6 = _lib.GEMM_BF16X6                  # Linear forward / dX of the decoder pipeline on the bf16 MFMA (gemm_nt_x6w_kernel; the lean instance is then moot)
-            if self.x6_perwave or self.nt_per_tile:     # (A/B, tests: one workgroup per tile instead of one per CU walking its tiles)
-                x6 |= _lib.GEMM_X6_PERWAVE
+            if self.x6_per_tile:                   # (A/B, tests: one workgroup per tile instead of one per CU walking its tiles)
+                x6 |= _lib.GEMM_X6_PERTILE
         if splitk > 1:
             wsb = self.lib.fn_gemm_ws_bytes(M, N, splitk & 0xffff)
             ws = self.workspace(wsb, "gemm")
@@ -118,6 +118,8 @@ class HipOps:
                 x6 |= _lib.GEMM_X6_WIDE
         if self.x6_perwave:
             x6 |= _lib.GEMM_X6_PERWAVE
+        if self.x6_per_tile:
+            x6 |= _lib.GEMM_X6_PERTILE
         return splitk, x6
 
     def gemm_multi(self, jobs, a_k=True, b_k=True):

@@ -10,7 +10,7 @@ torch.manual_seed(0)
 for tag, M, N, K in (("gx2 = hx0 W_ih2^T (chunk)", 8192, 1536, 512), ("dhx0 = dgx2 W_ih2 (chunk)", 8192, 512, 1536), ("dhx1 = dlogits W_out", 65536, 512, 352)):
     A, W, C = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev) * 0.1, torch.empty(M, N, device=dev)
     for x6, per_tile in ((False, False), (True, True), (True, False)):
-        ops.dw_x6, ops.nt_x6, ops.nt_per_tile = x6, x6, per_tile
+        ops.dw_x6, ops.nt_x6, ops.x6_per_tile = x6, x6, per_tile
         ms = []
         for _ in range(12):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -452,14 +452,18 @@ def test_gemm_tn_x6_producer_consumer_vs_per_wave_kernel(ops, M, N, K, splitk):
     B = torch.randn(K, N, device=DEV) * 0.3
     ref = (A.double().t() @ B.double())
     scale = float((A.double().abs().t() @ B.double().abs()).max())
-    MODES = (("perwave", False, True), ("tile128", False, False), ("tile256", "force", False))
+    # (the two producer / consumer kernels both as one workgroup per CU walking its (tile, K range) items - the default - and as one workgroup per item)
+    MODES = (("perwave", False, True, False), ("tile128", False, False, False), ("tile256", "force", False, False),
+             ("tile128_item", False, False, True), ("tile256_item", "force", False, True))
     ops.dw_x6 = True
 
     def run(fn):
         out = {}
-        for name, wide, pw in MODES:
-            ops.x6_wide, ops.x6_perwave = wide, pw
+        for name, wide, pw, item in MODES:
+            ops.x6_wide, ops.x6_perwave, ops.x6_per_tile = wide, pw, item
             out[name] = fn()
+        ops.x6_per_tile = False
+        assert torch.equal(out["tile128"], out["tile128_item"]) and torch.equal(out["tile256"], out["tile256_item"])
         return out
     try:
         def plain():
@@ -515,7 +519,7 @@ def test_gemm_tn_x6_producer_consumer_vs_per_wave_kernel(ops, M, N, K, splitk):
             if K % 32 == 0 and splitk > 1 and (K // (2 * splitk)) % 32 == 0:
                 assert torch.equal(auto[True], auto[False])
     finally:
-        ops.dw_x6, ops.x6_perwave, ops.x6_wide = _x6_default(), False, True
+        ops.dw_x6, ops.x6_perwave, ops.x6_wide, ops.x6_per_tile = _x6_default(), False, True, False
 
 
 @pytest.mark.parametrize("M,N,K", [(8192, 1536, 512), (8192, 512, 1536), (65536, 512, 352), (2048, 1024, 128), (2048, 1024, 160), (4096, 512, 32 * 7),
@@ -550,12 +554,12 @@ def test_gemm_nt_bf16x6(ops, M, N, K):
         ops.gemm(A, W, C, a_k=True, b_k=True)
         assert torch.equal(C, outs[True])
         # one workgroup per CU walking its tiles (more tiles than CUs) == one workgroup per tile, bit for bit
-        ops.x6_perwave = True
+        ops.x6_per_tile = True
         C = torch.full((M, N), float("nan"), device=DEV)
         ops.gemm(A, W, C, a_k=True, b_k=True)
         assert torch.equal(C, outs[True])
     finally:
-        ops.dw_x6, ops.nt_x6, ops.x6_perwave = _x6_default(), True, False
+        ops.dw_x6, ops.nt_x6, ops.x6_per_tile = _x6_default(), True, False
 
 
 def test_gemm_bf16x6_kernels_random_shapes():
