@@ -41,7 +41,8 @@ extern "C" {
 
 #define FN_MAX_SCANS 8
 
-int fn_version(void);                 /* ABI version, currently 5 (round 5: fn_gru_fwd_x6_ok, fn_gru_bwd_x6_ok, fn_comm_count / fn_comm_rank, fn_weight_images kinds 3 / 4, FnGruBwd.variant bit 14) */
+int fn_version(void);                 /* ABI version, currently 6 (round 5: fn_gru_fwd_x6_ok, fn_gru_bwd_x6_ok, fn_comm_count / fn_comm_rank, fn_weight_images kinds 3 / 4, FnGruBwd.variant bit 14;
+                                         round 6: FN_GEMM_X6_PERWAVE / _WIDE / _PERTILE, FN_GEMM_BF16X6 on the Linear-forward form, FnGruCell.variant bit 14, fn_weight_images kind 5) */
 const char* fn_strerror(int code);    /* static string for FN_E_* / hipError_t */
 
 /* ------------------------------------------------------------------------------------------

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfadernets_hip.so")
 
 FN_MAX_SCANS = 8
-ABI_VERSION = 5
+ABI_VERSION = 6
 GEMM_LEAN = 0x10000          # FN_GEMM_LEAN
 GEMM_BF16X6 = 0x20000        # FN_GEMM_BF16X6 (exact bf16 triple split on the bf16 MFMA)
 GEMM_X6_WIDE = 0x80000       # FN_GEMM_X6_WIDE (128 x 256 output tiles per workgroup)

@@ -3,7 +3,7 @@
 
 extern "C" {
 
-int fn_version(void) { return 5; }
+int fn_version(void) { return 6; }
 
 const char* fn_strerror(int code) {
     switch (code) {

@@ -15,7 +15,7 @@ def test_header_symbols_exported():
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.fn_version() == 5
+    assert lib.fn_version() == 6
     assert lib.fn_strerror(-2) == b"unsupported or inconsistent sizes"
 
 
