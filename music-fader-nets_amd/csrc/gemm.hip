@@ -1889,6 +1889,10 @@ int fn_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, float alpha, co
         FN_CHECK_LAUNCH();
         return FN_OK;
     }
+    // skinny outputs (the attribute decoders' output layers: 16384 x 3 / 16 x 512): 64 x 16 tiles, 12.8 KB of LDS - a workgroup fits a CU beside one of the
+    // bf16 x 6 producer / consumer kernels (144 of 160 KB), so the loss chain of the step runs beside the dhx1 product instead of behind it; same k order
+    if (N <= 16 && a_kmajor && b_kmajor && splitk <= 1 && M >= 64)
+        return launch_gemm<64, 16, 16, 4, 1>(a_kmajor, b_kmajor, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, splitk, ws, st);
     const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     // 128 x 128 tiles only when they fill the chip (one workgroup per CU); below that the 64 x 64 kernel's 4x more workgroups win
     // (decode at 2048 rows: 192 big tiles -> 55 us, 768 small ones -> 40 us per W_ih2 projection)

@@ -172,6 +172,11 @@ class GMVAETrainer:
         if side and not eng.losses_early:
             eng.side_wait_main()                   # (A/B switch: the lane starts behind the head, as up to round 5)
         with (eng.on_side() if side else contextlib.nullcontext()):
+            # first the launches that hold no LDS (column sums of the latent terms, regulariser): they fit a CU beside a workgroup of the dhx1 product that
+            # Engine.backward issues next (144 of 160 KB); the two output-layer products of the attribute decoders (37 KB of LDS) only start once it has ended
+            for slot, e in ((S_TERMS_R, "r"), (S_TERMS_N, "n")):
+                ops.colsum(lat[e]["terms"], st[slot:slot + 4])      # latent terms: column sums of the per-row terms written by fn_latent_fwd
+            lat_up = self._regulariser(eng, S, batch, Bg, want_grads)
             eng.sub_decoder_logits(S)
             dl_sd = {}
             for slot, e, attr, Ce in ((S_CE_R, "r", r, 3), (S_CE_N, "n", n, 16)):
@@ -179,10 +184,6 @@ class GMVAETrainer:
                 dl_sd[e] = eng.buf("sd_dlogits_" + e, (Tr, B, Ce)) if want_grads else None
                 ops.time_logsoftmax(dec["sd"][e]["logits"], target=attr, nll_bc=nbc, grad_scale=1.0 / (Bg * Tr), dlogits=dl_sd[e])
                 ops.sum(nbc, st[slot:slot + 1], 1.0 / (Bg * Tr))
-            # latent terms: column sums of the per-row terms written by fn_latent_fwd
-            for slot, e in ((S_TERMS_R, "r"), (S_TERMS_N, "n")):
-                ops.colsum(lat[e]["terms"], st[slot:slot + 4])
-            lat_up = self._regulariser(eng, S, batch, Bg, want_grads)
         if not want_grads:
             eng.main_wait_side()
         return dl_sd, lat_up, self.sp[0:3], beta0, Bg

@@ -59,7 +59,8 @@ def close(a, b, tol=2e-5, msg=""):
 @pytest.mark.parametrize("a_k,b_k", [(True, True), (True, False), (False, False), (False, True)])
 @pytest.mark.parametrize("M,N,K,splitk", [(64, 48, 32, 1), (256, 1536, 512, 1), (130, 342, 75, 1), (7, 3, 513, 1),
                                           (300, 200, 4100, 8), (1536, 512, 2048, 4), (1536, 512, 4104, 16), (136, 392, 1031, 24), (384, 128, 999, 42),
-                                          (2048, 2048, 80, 1), (4096, 1024, 512, 1), (8192, 512, 48, 1)])
+                                          (2048, 2048, 80, 1), (4096, 1024, 512, 1), (8192, 512, 48, 1),
+                                          (16384, 3, 512, 1), (16384, 16, 512, 1), (200, 13, 70, 1)])      # (the last three: skinny outputs, 64 x 16 tiles)
 def test_gemm(ops, a_k, b_k, M, N, K, splitk):
     torch.manual_seed(M * 7 + N * 3 + K)
     A = torch.randn((M, K) if a_k else (K, M))
