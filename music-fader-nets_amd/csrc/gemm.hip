@@ -1358,9 +1358,15 @@ void gemm_tn_lean_kernel(int M, int N, int K, float alpha, const float* __restri
 // wave needs 25 and was LDS-bound: 60 TFLOP/s); the row maximum / sum of the two column halves meet through LDS.  Same k order as
 // gemm_kernel in the staged path; the LDS-free path (aligned operands, K % 16 == 0) permutes k inside a 16-k step.  The gradient rows leave through LDS as aligned float4 rows.
 constexpr int OH_BM = 64, OH_BN = 384, OH_BK = 16, OH_LDT = OH_BN + 4;
+// wave layout of a 64-row x 384-column workgroup: OH_WN column groups x (4 / OH_WN) row groups.  1 x 4 (round 6): a wave = 64 rows x 96 columns loads 4 + 6
+// operand tiles per 96 MFMAs, 2 x 2 (up to round 5: 32 rows x 192 columns) 2 + 12 - the LDS-free loop is bound by what a CU's L1 keeps in flight
+#ifndef OH_WN
+#define OH_WN 4
+#endif
+constexpr int OH_WM = 4 / OH_WN;
 size_t out_head_lds_bytes() {
     const size_t stage = (size_t)2 * (Stage<OH_BM, OH_BK, true, NT>::WORDS + Stage<OH_BN, OH_BK, true, NT>::WORDS) * sizeof(float);
-    const size_t rows = (size_t)(OH_BM / 2) * OH_LDT * sizeof(float) + 4 * OH_BM * sizeof(float);      // half the rows at a time + row statistics
+    const size_t rows = (size_t)(OH_BM / 2) * OH_LDT * sizeof(float) + 2 * OH_WN * OH_BM * sizeof(float);      // half the rows at a time + row statistics
     return stage > rows ? stage : rows;
 }
 
@@ -1368,13 +1374,13 @@ __global__ __launch_bounds__(NT, 2) void out_head_kernel(const float* __restrict
                                                          const float* __restrict__ bias, int R, int V, int K, int B, int T,
                                                          const int* __restrict__ target, float grad_scale, float* __restrict__ nll_rows,
                                                          float* __restrict__ dlogits, long ld) {
-    constexpr int TM = 2, TN = OH_BN / 2 / 16;
+    constexpr int TM = OH_BM / OH_WM / 16, TN = OH_BN / OH_WN / 16;
     using SA = Stage<OH_BM, OH_BK, true, NT>;
     using SB = Stage<OH_BN, OH_BK, true, NT>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int m0 = blockIdx.x * OH_BM;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / OH_WN, wn = wave % OH_WN;
     const RowsPlain ra{m0, R}, rb{0, V};
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -1389,9 +1395,9 @@ __global__ __launch_bounds__(NT, 2) void out_head_kernel(const float* __restrict
         const int li = lane & 15, lg = lane >> 4;
         unsigned oa[TM], ob[TN];
 #pragma unroll
-        for (int m = 0; m < TM; ++m) oa[m] = (unsigned)(((long)min(m0 + wm * 32 + 16 * m + li, R - 1) * ldh + 4 * lg) * 4);
+        for (int m = 0; m < TM; ++m) oa[m] = (unsigned)(((long)min(m0 + wm * (TM * 16) + 16 * m + li, R - 1) * ldh + 4 * lg) * 4);
 #pragma unroll
-        for (int n = 0; n < TN; ++n) ob[n] = (unsigned)(((long)min(wn * (OH_BN / 2) + 16 * n + li, V - 1) * ldw + 4 * lg) * 4);
+        for (int n = 0; n < TN; ++n) ob[n] = (unsigned)(((long)min(wn * (TN * 16) + 16 * n + li, V - 1) * ldw + 4 * lg) * 4);
         constexpr int PFD = 2, NL = TM + TN;
         f32x4 fa[PFD][TM], fb[PFD][TN];
         const float* pa = h;
@@ -1446,16 +1452,16 @@ __global__ __launch_bounds__(NT, 2) void out_head_kernel(const float* __restrict
     } else if (SA::can_fast(h, ldh, ra, K) && SB::can_fast(W, ldw, rb, K)) {
         auto loadA = [&](int k0, SA& st) { st.load_fast(h, ldh, ra, k0); };
         auto loadB = [&](int k0, SB& st) { st.load_fast(W, ldw, rb, k0); };
-        fn_kloop<PF_DEPTH, TM, TN, OH_BK, SA, SB>(smem, nk, loadA, loadB, wm * 32, wn * (OH_BN / 2), lane, acc);
+        fn_kloop<PF_DEPTH, TM, TN, OH_BK, SA, SB>(smem, nk, loadA, loadB, wm * (TM * 16), wn * (TN * 16), lane, acc);
     } else {
         auto loadA = [&](int k0, SA& st) { st.load_checked(h, ldh, ra, k0, K); };
         auto loadB = [&](int k0, SB& st) { st.load_checked(W, ldw, rb, k0, K); };
-        fn_kloop<PF_DEPTH, TM, TN, OH_BK, SA, SB>(smem, nk, loadA, loadB, wm * 32, wn * (OH_BN / 2), lane, acc);
+        fn_kloop<PF_DEPTH, TM, TN, OH_BK, SA, SB>(smem, nk, loadA, loadB, wm * (TM * 16), wn * (TN * 16), lane, acc);
     }
     // (the K loop ended with a barrier: the staging buffers are free)
-    // D[row = 16 m + (lane>>4)*4 + i][col = 192 wn + 16 n + (lane&15)]; row statistics of the two column halves meet in stat[]
-    float* stat = smem + (OH_BM / 2) * OH_LDT;          // [2 halves][64 rows] maxima, then [2][64] sums
-    const int cj = lane & 15, rq = (lane >> 4) * 4, c0 = wn * (OH_BN / 2);
+    // D[row = 16 m + (lane>>4)*4 + i][col = 16 TN wn + 16 n + (lane&15)]; row statistics of the OH_WN column groups meet in stat[]
+    float* stat = smem + (OH_BM / 2) * OH_LDT;          // [OH_WN groups][64 rows] maxima, then [OH_WN][64] sums
+    const int cj = lane & 15, rq = (lane >> 4) * 4, c0 = wn * (TN * 16), r0 = wm * (TM * 16);
     float mxr[TM][4], lser[TM][4];
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
@@ -1476,15 +1482,17 @@ __global__ __launch_bounds__(NT, 2) void out_head_kernel(const float* __restrict
                 if (c0 + 16 * n + cj < V) mx = fmaxf(mx, acc[m][n][i]);
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-            if (cj == 0) stat[wn * OH_BM + wm * 32 + 16 * m + rq + i] = mx;
+            if (cj == 0) stat[wn * OH_BM + r0 + 16 * m + rq + i] = mx;
         }
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < TM; ++m)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int rl = wm * 32 + 16 * m + rq + i;
-            const float mx = fmaxf(stat[rl], stat[OH_BM + rl]);
+            const int rl = r0 + 16 * m + rq + i;
+            float mx = stat[rl];
+#pragma unroll
+            for (int g = 1; g < OH_WN; ++g) mx = fmaxf(mx, stat[g * OH_BM + rl]);
             mxr[m][i] = mx;
             float sum = 0.f;
 #pragma unroll
@@ -1492,16 +1500,19 @@ __global__ __launch_bounds__(NT, 2) void out_head_kernel(const float* __restrict
                 if (c0 + 16 * n + cj < V) sum += expf(acc[m][n][i] - mx);
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
-            if (cj == 0) stat[2 * OH_BM + wn * OH_BM + rl] = sum;
+            if (cj == 0) stat[(OH_WN + wn) * OH_BM + rl] = sum;
         }
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < TM; ++m)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int rl = wm * 32 + 16 * m + rq + i;
+            const int rl = r0 + 16 * m + rq + i;
             const int row = m0 + rl;
-            const float lse = mxr[m][i] + logf(stat[2 * OH_BM + rl] + stat[3 * OH_BM + rl]);    // half 0 + half 1: the same order in both waves
+            float tot = stat[OH_WN * OH_BM + rl];                                               // group 0 + 1 + ...: the same order in every wave
+#pragma unroll
+            for (int g = 1; g < OH_WN; ++g) tot += stat[(OH_WN + g) * OH_BM + rl];
+            const float lse = mxr[m][i] + logf(tot);
             lser[m][i] = lse;
             const int rc = min(row, R - 1);
             const int tg = target[(long)(rc % B) * T + rc / B];
@@ -1519,13 +1530,14 @@ __global__ __launch_bounds__(NT, 2) void out_head_kernel(const float* __restrict
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         __syncthreads();                                // statistics read / previous half written out
-        if (wm == half) {
 #pragma unroll
-            for (int m = 0; m < TM; ++m)
+        for (int m = 0; m < TM; ++m) {
+            const int rb0 = r0 + 16 * m;                 // this row tile's first row inside the 64-row panel (a multiple of 16: one half or the other)
+            if ((rb0 >> 5) != half) continue;
 #pragma unroll
-                for (int n = 0; n < TN; ++n)
+            for (int n = 0; n < TN; ++n)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) smem[(16 * m + rq + i) * OH_LDT + c0 + 16 * n + cj] = acc[m][n][i];
+                for (int i = 0; i < 4; ++i) smem[((rb0 & 31) + rq + i) * OH_LDT + c0 + 16 * n + cj] = acc[m][n][i];
         }
         __syncthreads();
         for (int idx = threadIdx.x; idx < 32 * nq; idx += NT) {
